@@ -1,0 +1,121 @@
+/*
+ * bn254_pairing.h -- C ABI of the MI355X-native batched BN254 pairing engine.
+ *
+ * Drop-in boundary for the native witness path of qope/plonky2-bn254-pairing.  The
+ * reference has no FFI of its own: its boundary is a set of plain Rust `pub fn`s.  Each
+ * entry point below names the reference function it replaces (file:line relative to the
+ * reference repository); rust-shim/ and INTEGRATION.md show the Rust side that keeps the
+ * original signatures on top of this header.
+ *
+ * DATA FORMAT (all entry points)
+ *   Fq      4 x u64 little-endian limbs, Montgomery form, R = 2^256 -- bit-identical to
+ *           ark-ff's `Fp.0.0` for ark_bn254::Fq, so the shim does no conversion.
+ *   Batches are struct-of-arrays, limb-major:   elem(c, l, i) = buf[(c*4 + l)*n + i]
+ *     G1      c in {x, y}                                  ->  8*n u64
+ *     G2      c in {x.c0, x.c1, y.c0, y.c1}                -> 16*n u64
+ *     MyFq12  c = MyFq12.coeffs index 0..11                -> 48*n u64
+ *             (coeffs[i] + coeffs[i+6] u is the Fq2 coefficient of w^i, w^6 = 9+u)
+ *   For n = 1 SoA and AoS coincide, which is what the scalar Rust signatures use.
+ *
+ * POINTERS   `*_dev` entry points take DEVICE pointers (HBM-resident inputs/outputs; the
+ *            timed path).  The un-suffixed entry points take HOST pointers and stage
+ *            through the device (PCIe inclusive).
+ * STREAM     `stream` is a hipStream_t (NULL = default stream).  `_dev` calls are enqueued
+ *            on it and return after the launch; status words are read with a stream sync
+ *            only inside bn254_last_status().  Host-pointer calls synchronise before
+ *            returning.
+ * ERRORS     0 = success, negative = failure (bn254_strerror).  The reference panics on
+ *            the same conditions (division by zero in ark's `/`); the Rust shim turns a
+ *            negative status back into a panic.  Points at infinity are outside the
+ *            reference's contract (it reads raw x/y) and outside this one.
+ * THREADING  Re-entrant; no global state except lazily created per-device scratch
+ *            buffers guarded by a mutex.
+ */
+#ifndef BN254_PAIRING_H
+#define BN254_PAIRING_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BN254_OK 0
+#define BN254_ERR_INVALID_ARG (-1)
+#define BN254_ERR_NO_DEVICE (-2)
+#define BN254_ERR_HIP (-3)
+#define BN254_ERR_ZERO_DIVISOR (-4) /* reference: ark `/` panics (final_exp_native.rs:74,200) */
+#define BN254_ERR_NAF_CARRY (-5)    /* reference: get_naf assert at final_exp_native.rs:123 */
+#define BN254_ERR_ALLOC (-6)
+
+/* number of visible HIP devices (0 when none / no driver) */
+int bn254_device_count(void);
+const char* bn254_strerror(int status);
+/* Synchronises `stream` on `device` and returns the sticky status of the device-side
+ * checks (zero divisor) accumulated since the last call; clears it. */
+int bn254_last_status(int device, void* stream);
+/* Bytes of device scratch a call over n lanes will use (informational). */
+size_t bn254_scratch_bytes(size_t n, size_t k);
+
+/* ---- the hot path -------------------------------------------------------------------- */
+
+/* pairing(p, q) = final_exp_native(miller_loop_native(&q, &p))      src/pairing.rs:20-22
+ * out: MyFq12 coefficient order (apply bn254_myfq12_to_ark_index for ark Fq12 order). */
+int bn254_pairing_batch_dev(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n, int device, void* stream);
+int bn254_pairing_batch(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n, int device, void* stream);
+
+/* miller_loop_native(Q, P)                                   src/miller_loop_native.rs:320-322
+ * bit-exact un-normalised affine-line value of the reference. */
+int bn254_miller_loop_batch_dev(const uint64_t* g1, const uint64_t* g2, uint64_t* f_out, size_t n, int device, void* stream);
+int bn254_miller_loop_batch(const uint64_t* g1, const uint64_t* g2, uint64_t* f_out, size_t n, int device, void* stream);
+
+/* final_exp_native(a)                                        src/final_exp_native.rs:209-213
+ * arbitrary non-zero Fq12 input (T4, final_exp_native.rs:274-285). */
+int bn254_final_exp_batch_dev(const uint64_t* f_in, uint64_t* out, size_t n, int device, void* stream);
+int bn254_final_exp_batch(const uint64_t* f_in, uint64_t* out, size_t n, int device, void* stream);
+
+/* multi_miller_loop_native(pairs)                            src/miller_loop_native.rs:324-326
+ * n_groups independent groups of k pairs (G1 then G2, the reference's argument order);
+ * pair j of group g is element g*k + j of the g1/g2 batches (batch length n_groups*k).
+ * do_final_exp != 0 applies final_exp_native to each group's shared-f Miller value
+ * (the Groth16 shape). */
+int bn254_multi_pairing_batch_dev(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_groups, size_t k,
+                                  int do_final_exp, int device, void* stream);
+int bn254_multi_pairing_batch(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_groups, size_t k,
+                              int do_final_exp, int device, void* stream);
+
+/* ---- batched public helpers of the reference ------------------------------------------ */
+
+/* MyFq12 `Mul` (plonky2-bn254 fields::native::MyFq12; call sites miller_loop_native.rs:153,239,345) */
+int bn254_fq12_mul_batch_dev(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, int device, void* stream);
+int bn254_fq12_mul_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, int device, void* stream);
+/* frobenius_map_native(a, power)                             src/final_exp_native.rs:17-54 */
+int bn254_frobenius_map_batch_dev(const uint64_t* a, size_t power, uint64_t* out, size_t n, int device, void* stream);
+int bn254_frobenius_map_batch(const uint64_t* a, size_t power, uint64_t* out, size_t n, int device, void* stream);
+/* pow_native(a, exp)                                         src/final_exp_native.rs:56-84
+ * exp: exp_limbs u64 limbs, least significant first (the reference's Vec<u64>), shared by the batch. */
+int bn254_pow_batch_dev(const uint64_t* a, const uint64_t* exp, size_t exp_limbs, uint64_t* out, size_t n, int device, void* stream);
+int bn254_pow_batch(const uint64_t* a, const uint64_t* exp, size_t exp_limbs, uint64_t* out, size_t n, int device, void* stream);
+/* get_naf(exp)                                               src/final_exp_native.rs:86-128
+ * host-side; naf must hold 64*exp_limbs + 1 entries; returns the length or BN254_ERR_NAF_CARRY. */
+long bn254_get_naf(const uint64_t* exp, size_t exp_limbs, int8_t* naf);
+/* frob_coeffs(index) -> Fq2 as 8 u64 (c0 limbs, c1 limbs)     src/final_exp_native.rs:183-192
+ * index 0..11 (the only values frobenius_map_native uses, :22). */
+int bn254_frob_coeffs(size_t index, uint64_t* out8);
+/* SIX_U_PLUS_2_NAF (miller_loop_native.rs:314-318) and BN_X (final_exp_native.rs:15) */
+const int8_t* bn254_six_u_plus_2_naf(void); /* 65 entries */
+uint64_t bn254_bn_x(void);
+/* index map MyFq12 -> ark Fq12 flat order (`.into()` at src/pairing.rs:21):
+ * ark_flat[j] = myfq12.coeffs[bn254_myfq12_to_ark_index(j)], j = 0..11 */
+int bn254_myfq12_to_ark_index(int j);
+
+/* ---- synthetic inputs (bench / tests): on-device subgroup points ------------------------ */
+/* P_i = [s_i] G1, Q_i = [t_i] G2 with s_i, t_i from SplitMix64(seed, i) (non-zero, < 2^128);
+ * affine, Montgomery, SoA.  Device pointers. */
+int bn254_generate_pairs_dev(uint64_t seed, uint64_t* g1_out, uint64_t* g2_out, size_t n, int device, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BN254_PAIRING_H */

@@ -1,0 +1,338 @@
+"""plonky2-bn254-pairing_amd -- MI355X-native batched BN254 pairing engine (host-side plumbing).
+
+This package is a thin ctypes binding over the C ABI in include/bn254_pairing.h
+(libbn254_pairing_hip.so, built in-tree by __graft_entry__.build()).  It mirrors the
+names of the reference's public native functions
+(/root/reference/src/{pairing,miller_loop_native,final_exp_native}.rs):
+
+    pairing, miller_loop_native, multi_miller_loop_native, final_exp_native,
+    frobenius_map_native, pow_native, get_naf, frob_coeffs,
+    conjugate_fp2, neg_conjugate_fp2, SIX_U_PLUS_2_NAF, BN_X
+
+plus `*_batch` forms over struct-of-arrays numpy / torch buffers.  All field data is
+u64 little-endian limbs in Montgomery form (R = 2^256), i.e. ark-ff's in-memory
+representation; see `layout` below.  There is NO CPU fallback: every compute entry point
+raises if the HIP library is missing or no GPU is visible.
+
+The directory name contains hyphens, so import it with
+    importlib.import_module("plonky2-bn254-pairing_amd")
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbn254_pairing_hip.so")
+
+BN254_OK = 0
+ERR_INVALID_ARG = -1
+ERR_NO_DEVICE = -2
+ERR_HIP = -3
+ERR_ZERO_DIVISOR = -4
+ERR_NAF_CARRY = -5
+ERR_ALLOC = -6
+
+P = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+R_ORDER = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+BN_X = 4965661367192848881  # src/final_exp_native.rs:15
+# src/miller_loop_native.rs:314-318
+SIX_U_PLUS_2_NAF = [
+    0, 0, 0, 1, 0, 1, 0, -1, 0, 0, 1, -1, 0, 0, 1, 0, 0, 1, 1, 0, -1, 0, 0, 1, 0, -1, 0, 0, 0, 0,
+    1, 1, 1, 0, 0, -1, 0, 0, 1, 0, 0, 0, 0, 0, -1, 0, 0, 1, 1, 0, 0, -1, 0, 0, 0, 1, 1, 0, -1, 0,
+    0, 1, 0, 1, 1,
+]
+
+G1_WORDS, G2_WORDS, FQ12_WORDS = 8, 16, 48
+
+
+class Bn254Error(RuntimeError):
+    """Raised where the reference panics (or the device/library is unusable)."""
+
+    def __init__(self, status, what=""):
+        self.status = status
+        msg = _strerror(status)
+        super().__init__(f"{what}: {msg} (status {status})" if what else f"{msg} (status {status})")
+
+
+_lib = None
+
+_PROTOS = {
+    "bn254_device_count": (ctypes.c_int, []),
+    "bn254_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+    "bn254_last_status": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p]),
+    "bn254_scratch_bytes": (ctypes.c_size_t, [ctypes.c_size_t, ctypes.c_size_t]),
+    "bn254_pairing_batch_dev": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_pairing_batch": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_miller_loop_batch_dev": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_miller_loop_batch": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_final_exp_batch_dev": (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_final_exp_batch": (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_multi_pairing_batch_dev": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_multi_pairing_batch": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_fq12_mul_batch_dev": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_fq12_mul_batch": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_frobenius_map_batch_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_frobenius_map_batch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_pow_batch_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_pow_batch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_get_naf": (ctypes.c_long, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "bn254_frob_coeffs": (ctypes.c_int, [ctypes.c_size_t, ctypes.c_void_p]),
+    "bn254_six_u_plus_2_naf": (ctypes.POINTER(ctypes.c_int8), []),
+    "bn254_bn_x": (ctypes.c_uint64, []),
+    "bn254_myfq12_to_ark_index": (ctypes.c_int, [ctypes.c_int]),
+    "bn254_generate_pairs_dev": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+}
+# symbols include/bn254_pairing.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = sorted(_PROTOS)
+
+
+def load_library(path=None):
+    """Loads the HIP library; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise Bn254Error(ERR_NO_DEVICE, f"HIP extension {p} not built (run __graft_entry__.build())")
+    lib = ctypes.CDLL(p)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _strerror(status):
+    try:
+        return load_library().bn254_strerror(status).decode()
+    except Exception:  # library unavailable: still produce a message
+        return {ERR_NO_DEVICE: "no HIP device / library"}.get(status, "error")
+
+
+def device_count():
+    return load_library().bn254_device_count()
+
+
+def _check(rc, what):
+    if rc != BN254_OK:
+        raise Bn254Error(rc, what)
+
+
+# ----------------------------------------------------------------------------- layout helpers
+class layout:
+    """SoA (limb-major) <-> AoS conversions.  SoA: elem(c, l, i) = buf[(c*4 + l)*n + i]."""
+
+    @staticmethod
+    def to_soa(aos, words):
+        a = np.ascontiguousarray(aos, dtype=np.uint64).reshape(-1, words)
+        return np.ascontiguousarray(a.T).reshape(-1)
+
+    @staticmethod
+    def to_aos(soa, words):
+        s = np.ascontiguousarray(soa, dtype=np.uint64).reshape(words, -1)
+        return np.ascontiguousarray(s.T).reshape(-1)
+
+    @staticmethod
+    def fq_to_limbs(mont_int):
+        return [(mont_int >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+
+    @staticmethod
+    def limbs_to_int(limbs):
+        return sum(int(w) << (64 * i) for i, w in enumerate(limbs))
+
+    @staticmethod
+    def to_mont(x):
+        return (x << 256) % P
+
+    @staticmethod
+    def from_mont(x):
+        return (x * pow(1 << 256, -1, P)) % P
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _np_in(a, words, n):
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1)
+    if a.size != words * n:
+        raise Bn254Error(ERR_INVALID_ARG, f"expected {words * n} u64 words, got {a.size}")
+    return a
+
+
+# ----------------------------------------------------------------------------- batch API (host numpy buffers, SoA)
+def pairing_batch(g1, g2, n, device=0):
+    """n x pairing(p, q)  (src/pairing.rs:20-22), MyFq12 coefficient order, SoA."""
+    lib = load_library()
+    g1, g2 = _np_in(g1, G1_WORDS, n), _np_in(g2, G2_WORDS, n)
+    out = np.empty(FQ12_WORDS * n, dtype=np.uint64)
+    _check(lib.bn254_pairing_batch(_ptr(g1), _ptr(g2), _ptr(out), n, device, None), "pairing")
+    return out
+
+
+def miller_loop_batch(g1, g2, n, device=0):
+    """n x miller_loop_native(Q, P)  (src/miller_loop_native.rs:320-322)."""
+    lib = load_library()
+    g1, g2 = _np_in(g1, G1_WORDS, n), _np_in(g2, G2_WORDS, n)
+    out = np.empty(FQ12_WORDS * n, dtype=np.uint64)
+    _check(lib.bn254_miller_loop_batch(_ptr(g1), _ptr(g2), _ptr(out), n, device, None), "miller_loop_native")
+    return out
+
+
+def final_exp_batch(f, n, device=0):
+    """n x final_exp_native(a)  (src/final_exp_native.rs:209-213)."""
+    lib = load_library()
+    f = _np_in(f, FQ12_WORDS, n)
+    out = np.empty(FQ12_WORDS * n, dtype=np.uint64)
+    _check(lib.bn254_final_exp_batch(_ptr(f), _ptr(out), n, device, None), "final_exp_native")
+    return out
+
+
+def multi_pairing_batch(g1, g2, n_groups, k, do_final_exp=True, device=0):
+    """n_groups x multi_miller_loop_native(k pairs) [+ final_exp_native]  (:324-326)."""
+    lib = load_library()
+    g1, g2 = _np_in(g1, G1_WORDS, n_groups * k), _np_in(g2, G2_WORDS, n_groups * k)
+    out = np.empty(FQ12_WORDS * n_groups, dtype=np.uint64)
+    _check(lib.bn254_multi_pairing_batch(_ptr(g1), _ptr(g2), _ptr(out), n_groups, k, 1 if do_final_exp else 0, device, None),
+           "multi_miller_loop_native")
+    return out
+
+
+def fq12_mul_batch(a, b, n, device=0):
+    lib = load_library()
+    a, b = _np_in(a, FQ12_WORDS, n), _np_in(b, FQ12_WORDS, n)
+    out = np.empty(FQ12_WORDS * n, dtype=np.uint64)
+    _check(lib.bn254_fq12_mul_batch(_ptr(a), _ptr(b), _ptr(out), n, device, None), "MyFq12 mul")
+    return out
+
+
+def frobenius_map_batch(a, power, n, device=0):
+    lib = load_library()
+    a = _np_in(a, FQ12_WORDS, n)
+    out = np.empty(FQ12_WORDS * n, dtype=np.uint64)
+    _check(lib.bn254_frobenius_map_batch(_ptr(a), power, _ptr(out), n, device, None), "frobenius_map_native")
+    return out
+
+
+def pow_batch(a, exp, n, device=0):
+    lib = load_library()
+    a = _np_in(a, FQ12_WORDS, n)
+    e = np.ascontiguousarray(exp, dtype=np.uint64)
+    out = np.empty(FQ12_WORDS * n, dtype=np.uint64)
+    _check(lib.bn254_pow_batch(_ptr(a), _ptr(e), e.size, _ptr(out), n, device, None), "pow_native")
+    return out
+
+
+# ----------------------------------------------------------------------------- device-pointer API (torch tensors / raw pointers)
+def _dev(t):
+    return ctypes.c_void_p(t.data_ptr()) if hasattr(t, "data_ptr") else ctypes.c_void_p(int(t))
+
+
+def _stream(stream):
+    if stream is None:
+        return None
+    return ctypes.c_void_p(getattr(stream, "cuda_stream", stream))
+
+
+def pairing_batch_dev(g1, g2, out, n, device=0, stream=None):
+    _check(load_library().bn254_pairing_batch_dev(_dev(g1), _dev(g2), _dev(out), n, device, _stream(stream)), "pairing")
+
+
+def miller_loop_batch_dev(g1, g2, out, n, device=0, stream=None):
+    _check(load_library().bn254_miller_loop_batch_dev(_dev(g1), _dev(g2), _dev(out), n, device, _stream(stream)), "miller_loop_native")
+
+
+def final_exp_batch_dev(f, out, n, device=0, stream=None):
+    _check(load_library().bn254_final_exp_batch_dev(_dev(f), _dev(out), n, device, _stream(stream)), "final_exp_native")
+
+
+def multi_pairing_batch_dev(g1, g2, out, n_groups, k, do_final_exp=True, device=0, stream=None):
+    _check(load_library().bn254_multi_pairing_batch_dev(_dev(g1), _dev(g2), _dev(out), n_groups, k, 1 if do_final_exp else 0, device,
+                                                        _stream(stream)), "multi_miller_loop_native")
+
+
+def generate_pairs_dev(seed, g1_out, g2_out, n, device=0, stream=None):
+    _check(load_library().bn254_generate_pairs_dev(seed, _dev(g1_out), _dev(g2_out), n, device, _stream(stream)), "generate_pairs")
+
+
+def last_status(device=0, stream=None):
+    """Synchronises the stream and raises where the reference would have panicked."""
+    _check(load_library().bn254_last_status(device, _stream(stream)), "device status")
+
+
+# ----------------------------------------------------------------------------- scalar mirrors of the reference's functions
+# Points / field elements are flat numpy uint64 arrays in the AoS order of include/bn254_pairing.h
+# (for n = 1 AoS == SoA): G1 = x,y (8 words); G2 = x.c0,x.c1,y.c0,y.c1 (16); MyFq12 = coeffs[0..12] (48).
+def miller_loop_native(Q, P_):
+    """miller_loop_native(Q: &G2Affine, P: &G1Affine) -> MyFq12   (src/miller_loop_native.rs:320)"""
+    return miller_loop_batch(P_, Q, 1)
+
+
+def multi_miller_loop_native(pairs):
+    """multi_miller_loop_native(pairs: Vec<(&G1Affine, &G2Affine)>) -> MyFq12   (:324)"""
+    k = len(pairs)
+    if k == 0:
+        raise Bn254Error(ERR_INVALID_ARG, "multi_miller_loop_native: empty pair list (the reference panics: pairs[0])")
+    g1 = layout.to_soa(np.concatenate([np.asarray(a, dtype=np.uint64) for a, _ in pairs]), G1_WORDS)
+    g2 = layout.to_soa(np.concatenate([np.asarray(b, dtype=np.uint64) for _, b in pairs]), G2_WORDS)
+    return multi_pairing_batch(g1, g2, 1, k, do_final_exp=False)
+
+
+def final_exp_native(a):
+    """final_exp_native(a: MyFq12) -> MyFq12   (src/final_exp_native.rs:209)"""
+    return final_exp_batch(a, 1)
+
+
+def pairing(p, q):
+    """pairing(p: G1Affine, q: G2Affine) -> Fq12 in ark's flat order (src/pairing.rs:20-22)"""
+    my = pairing_batch(p, q, 1).reshape(12, 4)
+    lib = load_library()
+    return np.concatenate([my[lib.bn254_myfq12_to_ark_index(j)] for j in range(12)])
+
+
+def frobenius_map_native(a, power):
+    """frobenius_map_native(a: MyFq12, power: usize)   (src/final_exp_native.rs:17)"""
+    return frobenius_map_batch(a, power, 1)
+
+
+def pow_native(a, exp):
+    """pow_native(a: MyFq12, exp: Vec<u64>)   (src/final_exp_native.rs:56)"""
+    return pow_batch(a, exp, 1)
+
+
+def get_naf(exp):
+    """get_naf(exp: Vec<u64>) -> Vec<i8>   (src/final_exp_native.rs:86) -- host logic in the C++ library."""
+    lib = load_library()
+    e = np.ascontiguousarray(exp, dtype=np.uint64)
+    naf = np.zeros(64 * max(e.size, 1) + 1, dtype=np.int8)
+    n = lib.bn254_get_naf(_ptr(e), e.size, _ptr(naf))
+    if n < 0:
+        raise Bn254Error(int(n), "get_naf")
+    return naf[:n].tolist()
+
+
+def frob_coeffs(index):
+    """frob_coeffs(index: usize) -> Fq2 as 8 u64 (c0, c1)   (src/final_exp_native.rs:183)"""
+    out = np.zeros(8, dtype=np.uint64)
+    _check(load_library().bn254_frob_coeffs(index % 12 if index >= 12 else index, _ptr(out)), "frob_coeffs")
+    return out
+
+
+def _fq_neg_limbs(l4):
+    v = layout.limbs_to_int(l4)
+    return np.array(layout.fq_to_limbs((P - v) % P), dtype=np.uint64)
+
+
+def conjugate_fp2(x):
+    """conjugate_fp2(x: Fq2) -> Fq2 = (c0, -c1)   (src/miller_loop_native.rs:284)"""
+    x = np.asarray(x, dtype=np.uint64)
+    return np.concatenate([x[:4], _fq_neg_limbs(x[4:8])])
+
+
+def neg_conjugate_fp2(x):
+    """neg_conjugate_fp2(x: Fq2) -> Fq2 = (-c0, c1)   (src/miller_loop_native.rs:291)"""
+    x = np.asarray(x, dtype=np.uint64)
+    return np.concatenate([_fq_neg_limbs(x[:4]), x[4:8]])
