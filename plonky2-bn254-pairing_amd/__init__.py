@@ -93,6 +93,10 @@ def load_library(path=None):
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    try:  # PyTorch (device memory / streams plumbing) bundles its own HIP runtime: let it load first so
+        import torch  # noqa: F401  -- the process ends up with exactly one libamdhip64
+    except Exception:
+        pass
     if not os.path.exists(p):
         raise Bn254Error(ERR_NO_DEVICE, f"HIP extension {p} not built (run __graft_entry__.build())")
     lib = ctypes.CDLL(p)
