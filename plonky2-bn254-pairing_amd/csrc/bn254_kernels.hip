@@ -12,6 +12,7 @@
 #include <mutex>
 #include <vector>
 #include "bn254_dev.h"
+#include "pairing_asm_gen.h"
 #include "../../include/bn254_pairing.h"
 
 using namespace bn254;
@@ -206,6 +207,24 @@ k_pairing(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in, uint64_t
     }
 }
 
+// ------------------------------------------------------------------ v2: generated whole-kernel assembly (tools/kgen*.py)
+// hipcc contributes the kernel descriptor and the argument SGPRs; the body is one asm statement.
+#define BN254_ASM_KERNEL(NAME, BLOB)                                                                                       \
+    __global__ void __launch_bounds__(BLOCK, 1)                                                                            \
+    NAME(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in, uint64_t* out, uint32_t n, uint32_t k, uint4* scratch, \
+         uint32_t gslot_stride, int* status) {                                                                             \
+        uint32_t tid = threadIdx.x, bid = blockIdx.x, grid = gridDim.x;                                                    \
+        asm volatile(BLOB                                                                                                  \
+                     :                                                                                                     \
+                     : "s"(g1), "s"(g2), "s"(f_in), "s"(out), "s"(n), "s"(k), "s"(scratch), "s"(gslot_stride), "s"(status), \
+                       "v"(tid), "s"(bid), "s"(grid)                                                                       \
+                     : BN254_ASM_CLOBBERS);                                                                                \
+    }
+BN254_ASM_KERNEL(k2_pairing, BN254_ASM_PAIRING)
+BN254_ASM_KERNEL(k2_miller, BN254_ASM_MILLER)
+BN254_ASM_KERNEL(k2_fexp, BN254_ASM_FEXP)
+constexpr int V2_GSLOTS = 48;   // eight Fq12 registers of the final exponentiation, 64 B per lane each
+
 enum { OP_MUL = 0, OP_FROB = 1, OP_POW = 2, OP_INV = 3, OP_SQR = 4, OP_CYC_SQR = 5 };
 
 // Batched MyFq12 helpers: Mul, frobenius_map_native, pow_native (general: true inverse on -1 digits).
@@ -365,6 +384,9 @@ int ctx_get(int device, size_t k, DeviceCtx** out, uint32_t* grid_out, size_t n_
         HIPCHK(hipFuncSetAttribute((const void*)k_pairing<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
         HIPCHK(hipFuncSetAttribute((const void*)k_fq12_op, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
         HIPCHK(hipFuncSetAttribute((const void*)k_generate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k2_pairing, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k2_miller, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k2_fexp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
         c.init = true;
     }
     uint32_t grid = (uint32_t)(n_items < (size_t)c.n_cu ? n_items : (size_t)c.n_cu);
@@ -389,6 +411,19 @@ int launch_pairing(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in,
     size_t n_items = (n_groups + BLOCK - 1) / BLOCK;
     int rc = ctx_get(device, k, &c, &grid, n_items);
     if (rc) return rc;
+    static const bool use_v1 = (getenv("BN254_FORCE_V1") != nullptr);
+    if (k == 1 && !use_v1) {
+        if (n_groups >= (1ull << 29)) return BN254_ERR_INVALID_ARG;   // 32-bit element offsets in the asm kernels
+        uint32_t stride = grid * BLOCK * 64;                            // bytes between scratch slots
+        if (M && F) hipLaunchKernelGGL(k2_pairing, dim3(grid), dim3(BLOCK), LDS_BYTES, (hipStream_t)stream, g1, g2, f_in, out,
+                                       (uint32_t)n_groups, 1u, c->scratch, stride, c->status);
+        else if (M) hipLaunchKernelGGL(k2_miller, dim3(grid), dim3(BLOCK), LDS_BYTES, (hipStream_t)stream, g1, g2, f_in, out,
+                                       (uint32_t)n_groups, 1u, c->scratch, stride, c->status);
+        else hipLaunchKernelGGL(k2_fexp, dim3(grid), dim3(BLOCK), LDS_BYTES, (hipStream_t)stream, g1, g2, f_in, out,
+                                (uint32_t)n_groups, 1u, c->scratch, stride, c->status);
+        HIPCHK(hipGetLastError());
+        return BN254_OK;
+    }
     hipLaunchKernelGGL((k_pairing<M, F>), dim3(grid), dim3(BLOCK), LDS_BYTES, (hipStream_t)stream,
                        g1, g2, f_in, out, n_groups, (int)k, c->scratch, (uint32_t)(c->n_cu * BLOCK), c->status);
     HIPCHK(hipGetLastError());

@@ -1,0 +1,382 @@
+#!/usr/bin/env python3
+"""ksim.py -- single-lane interpreter for the gfx950 instruction subset tools/kgen.py emits.
+
+Runs the generated kernels (text after the hazard post-pass) on one lane with Python integers:
+VGPR/AGPR/SGPR files, LDS and global memory as byte-addressed dicts of dwords, labels, branches,
+s_call_b64 / s_setpc_b64.  Besides computing, it re-checks what the generator must guarantee:
+  * VALU read of an SGPR/VCC written by a VALU < 2 instructions earlier (gfx940/950 hazard)
+  * even alignment of 64-bit VGPR operands, 16-bit DS offsets, 13-bit global offsets
+  * every register read was written before (catches allocation bugs)
+It is test infrastructure (tests/test_kgen.py), not part of the product.
+"""
+import re
+
+M32 = 0xFFFFFFFF
+M64 = 0xFFFFFFFFFFFFFFFF
+
+
+class SimError(Exception):
+    pass
+
+
+def _split_args(rest):
+    return [a.strip() for a in re.split(r",\s*(?![^\[]*\])", rest)] if rest else []
+
+
+class Machine:
+    def __init__(self, check_uninit=True):
+        self.v = [None] * 256
+        self.a = [None] * 256
+        self.s = {}
+        self.vcc = 0
+        self.scc = 0
+        self.exec = 1
+        self.lds = {}
+        self.gmem = {}
+        self.check_uninit = check_uninit
+        self.valu_w = {}      # sgpr name -> dyn. instruction counter of the last VALU write
+        self.count = 0        # dynamic instruction count
+        self.count_valu = 0
+        self.count_nop = 0
+
+    # ---------------------------------------------------------------- scalar register helpers
+    def sget(self, name):
+        if name == "vcc":
+            return self.vcc
+        if name == "exec":
+            return self.exec
+        m = re.match(r"s\[(\d+):(\d+)\]", name)
+        if m:
+            lo = int(m.group(1))
+            a, b = self.s.get(lo), self.s.get(lo + 1)
+            if a is None or b is None:
+                raise SimError(f"uninitialised {name}")
+            return a | (b << 32)
+        m = re.match(r"s(\d+)$", name)
+        if m:
+            x = self.s.get(int(m.group(1)))
+            if x is None:
+                raise SimError(f"uninitialised {name}")
+            return x
+        raise SimError("bad sgpr " + name)
+
+    def sset(self, name, val):
+        if name == "vcc":
+            self.vcc = val & M64
+            return
+        if name == "exec":
+            self.exec = val & M64
+            return
+        m = re.match(r"s\[(\d+):(\d+)\]", name)
+        if m:
+            lo = int(m.group(1))
+            self.s[lo] = val & M32
+            self.s[lo + 1] = (val >> 32) & M32
+            return
+        m = re.match(r"s(\d+)$", name)
+        if m:
+            self.s[int(m.group(1))] = val & M32
+            return
+        raise SimError("bad sgpr " + name)
+
+    def vsrc(self, tok, valu=True):
+        """32-bit source operand of a VALU instruction."""
+        if tok[0] == "v" and tok[1].isdigit():
+            x = self.v[int(tok[1:])]
+            if x is None:
+                if self.check_uninit:
+                    raise SimError(f"read of uninitialised {tok}")
+                return 0
+            return x
+        if tok[0] == "s" or tok == "vcc":
+            if valu:
+                self._hazard(tok)
+            return self.sget(tok) & M32
+        if tok == "-1":
+            return M32
+        return int(tok, 0) & M32
+
+    def vsrc64(self, tok):
+        m = re.match(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            lo = int(m.group(1))
+            if lo % 2:
+                raise SimError("odd-aligned 64-bit VGPR operand " + tok)
+            a, b = self.v[lo], self.v[lo + 1]
+            if a is None or b is None:
+                if self.check_uninit:
+                    raise SimError(f"read of uninitialised {tok}")
+                a, b = a or 0, b or 0
+            return a | (b << 32)
+        return int(tok, 0) & M64
+
+    def _hazard(self, reg):
+        w = self.valu_w.get(reg)
+        if w is not None and self.count - w - 1 < 2:
+            raise SimError(f"hazard: VALU reads {reg} {self.count - w - 1} wait states after a VALU write (dyn #{self.count})")
+
+    def carry_in(self, reg):
+        self._hazard(reg)
+        return self.sget(reg) & 1
+
+    def carry_out(self, reg, bit):
+        self.sset(reg, bit)
+        self.valu_w[reg] = self.count
+
+    def vset(self, tok, val):
+        self.v[int(tok[1:])] = val & M32
+
+
+def run(lines, m, entry=None, max_steps=200_000_000, trace=None):
+    """Execute `lines` on machine `m` until s_endpgm."""
+    prog = []
+    labels = {}
+    for ln in lines:
+        ln = ln.strip()
+        if not ln or ln.startswith(";") or ln.startswith("//"):
+            continue
+        if ln.endswith(":"):
+            labels[ln[:-1]] = len(prog)
+            continue
+        op, _, rest = ln.partition(" ")
+        prog.append((op, _split_args(rest.strip()), ln))
+    pc = labels[entry] if entry else 0
+    v = m.v
+    steps = 0
+    while True:
+        if pc >= len(prog):
+            raise SimError("fell off the end of the program")
+        op, a, text = prog[pc]
+        pc += 1
+        steps += 1
+        if steps > max_steps:
+            raise SimError("step limit")
+        try:
+            if op == "v_mad_u64_u32":
+                r = m.vsrc(a[2]) * m.vsrc(a[3]) + m.vsrc64(a[4])
+                lo = int(re.match(r"v\[(\d+):", a[0]).group(1))
+                if lo % 2:
+                    raise SimError("odd-aligned 64-bit VGPR dest")
+                v[lo] = r & M32
+                v[lo + 1] = (r >> 32) & M32
+                m.carry_out(a[1], (r >> 64) & 1)
+                m.count_valu += 1
+            elif op in ("v_addc_co_u32_e64", "v_addc_co_u32_e32"):
+                r = m.vsrc(a[2]) + m.vsrc(a[3]) + m.carry_in(a[4])
+                m.vset(a[0], r)
+                m.carry_out(a[1], r >> 32)
+                m.count_valu += 1
+            elif op in ("v_add_co_u32_e32", "v_add_co_u32_e64"):
+                r = m.vsrc(a[2]) + m.vsrc(a[3])
+                m.vset(a[0], r)
+                m.carry_out(a[1], r >> 32)
+                m.count_valu += 1
+            elif op in ("v_sub_co_u32_e32", "v_sub_co_u32_e64"):
+                r = m.vsrc(a[2]) - m.vsrc(a[3])
+                m.vset(a[0], r)
+                m.carry_out(a[1], 1 if r < 0 else 0)
+                m.count_valu += 1
+            elif op in ("v_subb_co_u32_e32", "v_subb_co_u32_e64"):
+                r = m.vsrc(a[2]) - m.vsrc(a[3]) - m.carry_in(a[4])
+                m.vset(a[0], r)
+                m.carry_out(a[1], 1 if r < 0 else 0)
+                m.count_valu += 1
+            elif op == "v_mov_b32_e32":
+                m.vset(a[0], m.vsrc(a[1]))
+                m.count_valu += 1
+            elif op == "v_mul_lo_u32":
+                m.vset(a[0], m.vsrc(a[1]) * m.vsrc(a[2]))
+                m.count_valu += 1
+            elif op == "v_mul_u32_u24_e32":
+                m.vset(a[0], (m.vsrc(a[1]) & 0xFFFFFF) * (m.vsrc(a[2]) & 0xFFFFFF))
+                m.count_valu += 1
+            elif op == "v_cndmask_b32_e32" or op == "v_cndmask_b32_e64":
+                c = m.carry_in(a[3])
+                m.vset(a[0], m.vsrc(a[2]) if c else m.vsrc(a[1]))
+                m.count_valu += 1
+            elif op == "v_and_b32_e32":
+                m.vset(a[0], m.vsrc(a[1]) & m.vsrc(a[2]))
+                m.count_valu += 1
+            elif op == "v_or_b32_e32":
+                m.vset(a[0], m.vsrc(a[1]) | m.vsrc(a[2]))
+                m.count_valu += 1
+            elif op == "v_or3_b32":
+                m.vset(a[0], m.vsrc(a[1]) | m.vsrc(a[2]) | m.vsrc(a[3]))
+                m.count_valu += 1
+            elif op == "v_alignbit_b32":
+                x = ((m.vsrc(a[1]) << 32) | m.vsrc(a[2])) >> (m.vsrc(a[3]) & 31)
+                m.vset(a[0], x)
+                m.count_valu += 1
+            elif op == "v_lshlrev_b32_e32":
+                m.vset(a[0], m.vsrc(a[2]) << (m.vsrc(a[1]) & 31))
+                m.count_valu += 1
+            elif op == "v_lshrrev_b32_e32":
+                m.vset(a[0], m.vsrc(a[2]) >> (m.vsrc(a[1]) & 31))
+                m.count_valu += 1
+            elif op == "v_add_u32_e32":
+                m.vset(a[0], m.vsrc(a[1]) + m.vsrc(a[2]))
+                m.count_valu += 1
+            elif op == "v_min_u32_e32":
+                m.vset(a[0], min(m.vsrc(a[1]), m.vsrc(a[2])))
+                m.count_valu += 1
+            elif op == "v_cmp_eq_u32_e32":
+                m.carry_out(a[0], 1 if m.vsrc(a[1]) == m.vsrc(a[2]) else 0)
+                m.count_valu += 1
+            elif op == "v_cmp_ne_u32_e32":
+                m.carry_out(a[0], 1 if m.vsrc(a[1]) != m.vsrc(a[2]) else 0)
+                m.count_valu += 1
+            elif op == "v_cmp_lt_u32_e32":
+                m.carry_out(a[0], 1 if m.vsrc(a[1]) < m.vsrc(a[2]) else 0)
+                m.count_valu += 1
+            elif op == "v_cmp_gt_u32_e32":
+                m.carry_out(a[0], 1 if m.vsrc(a[1]) > m.vsrc(a[2]) else 0)
+                m.count_valu += 1
+            elif op == "v_accvgpr_write_b32":
+                m.a[int(a[0][1:])] = m.vsrc(a[1])
+                m.count_valu += 1
+            elif op == "v_accvgpr_read_b32":
+                x = m.a[int(a[1][1:])]
+                if x is None:
+                    if m.check_uninit:
+                        raise SimError("read of uninitialised " + a[1])
+                    x = 0
+                m.vset(a[0], x)
+                m.count_valu += 1
+            # ------------------------------------------------------------ SALU
+            elif op == "s_nop":
+                m.count += int(a[0], 0)
+                m.count_nop += 1
+            elif op == "s_mov_b32":
+                m.sset(a[0], m.vsrc(a[1], valu=False))
+            elif op == "s_mov_b64":
+                m.sset(a[0], m.sget(a[1]) if (a[1][0] in "sve") else int(a[1], 0))
+            elif op == "s_add_u32":
+                r = m.vsrc(a[1], False) + m.vsrc(a[2], False)
+                m.sset(a[0], r)
+                m.scc = r >> 32
+            elif op == "s_addc_u32":
+                r = m.vsrc(a[1], False) + m.vsrc(a[2], False) + m.scc
+                m.sset(a[0], r)
+                m.scc = r >> 32
+            elif op == "s_sub_u32":
+                r = m.vsrc(a[1], False) - m.vsrc(a[2], False)
+                m.sset(a[0], r)
+                m.scc = 1 if r < 0 else 0
+            elif op == "s_mul_i32":
+                m.sset(a[0], m.vsrc(a[1], False) * m.vsrc(a[2], False))
+            elif op == "s_lshl_b32":
+                r = (m.vsrc(a[1], False) << (m.vsrc(a[2], False) & 31)) & M32
+                m.sset(a[0], r)
+                m.scc = 1 if r else 0
+            elif op == "s_lshr_b32":
+                r = m.vsrc(a[1], False) >> (m.vsrc(a[2], False) & 31)
+                m.sset(a[0], r)
+                m.scc = 1 if r else 0
+            elif op == "s_and_b32":
+                r = m.vsrc(a[1], False) & m.vsrc(a[2], False)
+                m.sset(a[0], r)
+                m.scc = 1 if r else 0
+            elif op == "s_cmp_eq_u32":
+                m.scc = 1 if m.vsrc(a[0], False) == m.vsrc(a[1], False) else 0
+            elif op == "s_cmp_lg_u32":
+                m.scc = 1 if m.vsrc(a[0], False) != m.vsrc(a[1], False) else 0
+            elif op == "s_cmp_lt_u32":
+                m.scc = 1 if m.vsrc(a[0], False) < m.vsrc(a[1], False) else 0
+            elif op == "s_cmp_ge_u32":
+                m.scc = 1 if m.vsrc(a[0], False) >= m.vsrc(a[1], False) else 0
+            elif op == "s_bitcmp1_b64":
+                m.scc = (m.sget(a[0]) >> (m.vsrc(a[1], False) & 63)) & 1
+            elif op == "s_bitcmp1_b32":
+                m.scc = (m.vsrc(a[0], False) >> (m.vsrc(a[1], False) & 31)) & 1
+            elif op == "s_cbranch_scc1":
+                if m.scc:
+                    pc = labels[a[0]]
+            elif op == "s_cbranch_scc0":
+                if not m.scc:
+                    pc = labels[a[0]]
+            elif op == "s_branch":
+                pc = labels[a[0]]
+            elif op == "s_call_b64":
+                m.sset(a[0], pc)          # "return address" = next instruction index
+                pc = labels[a[1]]
+            elif op == "s_setpc_b64":
+                pc = m.sget(a[0])
+            elif op == "s_waitcnt":
+                pass
+            elif op == "s_and_saveexec_b64":
+                old = m.exec
+                m.sset(a[0], old)
+                m.exec = old & (m.sget(a[1]) & 1)
+            elif op == "s_endpgm":
+                m.count += 1
+                return
+            # ------------------------------------------------------------ memory
+            elif op in ("ds_read_b128", "ds_write_b128"):
+                off = 0
+                regs = None
+                addr = None
+                for t in a:
+                    for part in t.split():
+                        if part.startswith("offset:"):
+                            off = int(part[7:], 0)
+                toks = [t.split()[0] for t in a]
+                if off < 0 or off > 65535:
+                    raise SimError("DS offset out of range: " + text)
+                if op == "ds_read_b128":
+                    lo = int(re.match(r"v\[(\d+):", toks[0]).group(1))
+                    base = m.vsrc(toks[1])
+                    for k in range(4):
+                        x = m.lds.get(base + off + 4 * k)
+                        if x is None:
+                            raise SimError(f"LDS read of unwritten address {base + off + 4 * k}: {text}")
+                        v[lo + k] = x
+                else:
+                    base = m.vsrc(toks[0])
+                    lo = int(re.match(r"v\[(\d+):", toks[1]).group(1))
+                    if (base + off) % 16:
+                        raise SimError("misaligned ds_write_b128")
+                    for k in range(4):
+                        if v[lo + k] is None:
+                            raise SimError("store of uninitialised register: " + text)
+                        if m.exec:
+                            m.lds[base + off + 4 * k] = v[lo + k]
+            elif op.startswith("global_load_dword") or op.startswith("global_store_dword"):
+                n = {"": 1, "x2": 2, "x4": 4}[op.split("dword")[1]]
+                off = 0
+                toks = []
+                for t in a:
+                    parts = t.split()
+                    toks.append(parts[0])
+                    for part in parts[1:]:
+                        if part.startswith("offset:"):
+                            off = int(part[7:], 0)
+                if off < -4096 or off > 4095:
+                    raise SimError("global offset out of range: " + text)
+                if op.startswith("global_load"):
+                    dst, voff, sbase = toks[0], toks[1], toks[2]
+                    addr = m.sget(sbase) + m.vsrc(voff) + off
+                    lo = int(re.match(r"v\[?(\d+)", dst).group(1))
+                    for k in range(n):
+                        x = m.gmem.get(addr + 4 * k)
+                        if x is None:
+                            raise SimError(f"global read of unwritten address {hex(addr + 4 * k)}: {text}")
+                        v[lo + k] = x
+                else:
+                    voff, src, sbase = toks[0], toks[1], toks[2]
+                    addr = m.sget(sbase) + m.vsrc(voff) + off
+                    lo = int(re.match(r"v\[?(\d+)", src).group(1))
+                    for k in range(n):
+                        if v[lo + k] is None:
+                            raise SimError("store of uninitialised register: " + text)
+                        if m.exec:
+                            m.gmem[addr + 4 * k] = v[lo + k]
+            else:
+                raise SimError("unknown instruction: " + text)
+        except SimError as ex:
+            raise SimError(f"{ex} @ `{text}`") from None
+        m.count += 1
+
+
+def run_block(lines, m):
+    """Run a straight-line routine body (no s_endpgm): appends one."""
+    run(list(lines) + ["s_endpgm"], m)
