@@ -1,0 +1,131 @@
+// bn254_pairing.hpp -- C++ host-side mirror of the reference's native API on top of the C ABI
+// (include/bn254_pairing.h).  Same names, argument order and error behaviour as the Rust
+// functions it replaces; the reference panics where these throw.
+//
+//   reference                                               here
+//   pairing(p, q) -> Fq12                 pairing.rs:20      bn254::pairing(p, q)
+//   miller_loop_native(&Q, &P) -> MyFq12  miller_loop_native.rs:320   bn254::miller_loop_native(Q, P)
+//   multi_miller_loop_native(pairs)       :324               bn254::multi_miller_loop_native(pairs)
+//   final_exp_native(a) -> MyFq12         final_exp_native.rs:209     bn254::final_exp_native(a)
+//   frobenius_map_native / pow_native / get_naf / frob_coeffs / conjugate_fp2 / neg_conjugate_fp2
+//   SIX_U_PLUS_2_NAF, BN_X
+#pragma once
+#include <array>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "bn254_pairing.h"
+
+namespace bn254 {
+
+using Fq = std::array<uint64_t, 4>;                 // Montgomery limbs == ark Fp.0.0
+struct Fq2 { Fq c0, c1; };
+struct G1Affine { Fq x, y; };                       // (ark's `infinity` flag is outside the contract)
+struct G2Affine { Fq2 x, y; };
+struct MyFq12 { std::array<Fq, 12> coeffs; bool operator==(const MyFq12& o) const { return coeffs == o.coeffs; } };
+struct Fq12 { std::array<Fq, 12> flat; };           // ark order c0.c0.c0, c0.c0.c1, c0.c1.c0, ...
+
+struct Panic : std::runtime_error {                 // the reference panics here
+    int status;
+    explicit Panic(int s) : std::runtime_error(bn254_strerror(s)), status(s) {}
+};
+inline void check(int rc) { if (rc != BN254_OK) throw Panic(rc); }
+
+constexpr uint64_t BN_X = 4965661367192848881ull;   // final_exp_native.rs:15
+inline const int8_t* SIX_U_PLUS_2_NAF() { return bn254_six_u_plus_2_naf(); }  // miller_loop_native.rs:314-318 (65 digits)
+
+namespace detail {
+inline void put(const Fq& f, uint64_t* dst, size_t stride) { for (int l = 0; l < 4; l++) dst[l * stride] = f[l]; }
+inline void get(Fq& f, const uint64_t* src, size_t stride) { for (int l = 0; l < 4; l++) f[l] = src[l * stride]; }
+// SoA batch of n elements: elem(c, l, i) = buf[(c*4 + l)*n + i]
+inline void pack_g1(const G1Affine& p, uint64_t* buf, size_t n, size_t i) { put(p.x, buf + i, n); put(p.y, buf + 4 * n + i, n); }
+inline void pack_g2(const G2Affine& q, uint64_t* buf, size_t n, size_t i) {
+    put(q.x.c0, buf + i, n); put(q.x.c1, buf + 4 * n + i, n); put(q.y.c0, buf + 8 * n + i, n); put(q.y.c1, buf + 12 * n + i, n);
+}
+inline void pack_fq12(const MyFq12& a, uint64_t* buf, size_t n, size_t i) { for (int c = 0; c < 12; c++) put(a.coeffs[c], buf + 4 * c * n + i, n); }
+inline MyFq12 unpack_fq12(const uint64_t* buf, size_t n, size_t i) { MyFq12 r; for (int c = 0; c < 12; c++) get(r.coeffs[c], buf + 4 * c * n + i, n); return r; }
+}  // namespace detail
+
+inline MyFq12 miller_loop_native(const G2Affine& Q, const G1Affine& P, int device = 0) {
+    uint64_t g1[8], g2[16], out[48];
+    detail::pack_g1(P, g1, 1, 0); detail::pack_g2(Q, g2, 1, 0);
+    check(bn254_miller_loop_batch(g1, g2, out, 1, device, nullptr));
+    return detail::unpack_fq12(out, 1, 0);
+}
+inline MyFq12 multi_miller_loop_native(const std::vector<std::pair<const G1Affine*, const G2Affine*>>& pairs, int device = 0) {
+    const size_t k = pairs.size();
+    if (k == 0) throw Panic(BN254_ERR_INVALID_ARG);          // reference: pairs[0] panics
+    std::vector<uint64_t> g1(8 * k), g2(16 * k);
+    uint64_t out[48];
+    for (size_t j = 0; j < k; j++) { detail::pack_g1(*pairs[j].first, g1.data(), k, j); detail::pack_g2(*pairs[j].second, g2.data(), k, j); }
+    check(bn254_multi_pairing_batch(g1.data(), g2.data(), out, 1, k, 0, device, nullptr));
+    return detail::unpack_fq12(out, 1, 0);
+}
+inline MyFq12 final_exp_native(const MyFq12& a, int device = 0) {
+    uint64_t in[48], out[48];
+    detail::pack_fq12(a, in, 1, 0);
+    check(bn254_final_exp_batch(in, out, 1, device, nullptr));
+    return detail::unpack_fq12(out, 1, 0);
+}
+inline Fq12 pairing(const G1Affine& p, const G2Affine& q, int device = 0) {
+    uint64_t g1[8], g2[16], out[48];
+    detail::pack_g1(p, g1, 1, 0); detail::pack_g2(q, g2, 1, 0);
+    check(bn254_pairing_batch(g1, g2, out, 1, device, nullptr));
+    MyFq12 m = detail::unpack_fq12(out, 1, 0);
+    Fq12 r;
+    for (int j = 0; j < 12; j++) r.flat[j] = m.coeffs[bn254_myfq12_to_ark_index(j)];   // `.into()` at pairing.rs:21
+    return r;
+}
+inline MyFq12 frobenius_map_native(const MyFq12& a, size_t power, int device = 0) {
+    uint64_t in[48], out[48];
+    detail::pack_fq12(a, in, 1, 0);
+    check(bn254_frobenius_map_batch(in, power, out, 1, device, nullptr));
+    return detail::unpack_fq12(out, 1, 0);
+}
+inline MyFq12 pow_native(const MyFq12& a, const std::vector<uint64_t>& exp, int device = 0) {
+    uint64_t in[48], out[48];
+    detail::pack_fq12(a, in, 1, 0);
+    check(bn254_pow_batch(in, exp.data(), exp.size(), out, 1, device, nullptr));
+    return detail::unpack_fq12(out, 1, 0);
+}
+inline std::vector<int8_t> get_naf(const std::vector<uint64_t>& exp) {
+    std::vector<int8_t> naf(64 * exp.size() + 1);
+    long n = bn254_get_naf(exp.data(), exp.size(), naf.data());
+    if (n < 0) throw Panic((int)n);
+    naf.resize((size_t)n);
+    return naf;
+}
+inline Fq2 frob_coeffs(size_t index) {
+    uint64_t o[8];
+    check(bn254_frob_coeffs(index % 12, o));     // frobenius_map_native reduces the power mod 12 (:22)
+    Fq2 r;
+    for (int l = 0; l < 4; l++) { r.c0[l] = o[l]; r.c1[l] = o[4 + l]; }
+    return r;
+}
+// conjugate_fp2 / neg_conjugate_fp2 (miller_loop_native.rs:284-296): p - x on one component
+inline Fq fq_neg(const Fq& a) {
+    static const Fq P = {0x3c208c16d87cfd47ull, 0x97816a916871ca8dull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+    if ((a[0] | a[1] | a[2] | a[3]) == 0) return a;
+    Fq r; unsigned __int128 br = 0;
+    for (int i = 0; i < 4; i++) { unsigned __int128 d = (unsigned __int128)P[i] - a[i] - (uint64_t)br; r[i] = (uint64_t)d; br = (d >> 64) & 1; }
+    return r;
+}
+inline Fq2 conjugate_fp2(const Fq2& x) { return Fq2{x.c0, fq_neg(x.c1)}; }
+inline Fq2 neg_conjugate_fp2(const Fq2& x) { return Fq2{fq_neg(x.c0), x.c1}; }
+
+// ---- batch forms (the reason the engine exists): SoA buffers, see bn254_pairing.h ------------
+inline std::vector<MyFq12> pairing_batch(const std::vector<G1Affine>& ps, const std::vector<G2Affine>& qs, int device = 0) {
+    const size_t n = ps.size();
+    if (qs.size() != n) throw Panic(BN254_ERR_INVALID_ARG);
+    std::vector<uint64_t> g1(8 * n), g2(16 * n), out(48 * n);
+    for (size_t i = 0; i < n; i++) { detail::pack_g1(ps[i], g1.data(), n, i); detail::pack_g2(qs[i], g2.data(), n, i); }
+    check(bn254_pairing_batch(g1.data(), g2.data(), out.data(), n, device, nullptr));
+    std::vector<MyFq12> r(n);
+    for (size_t i = 0; i < n; i++) r[i] = detail::unpack_fq12(out.data(), n, i);
+    return r;
+}
+
+}  // namespace bn254

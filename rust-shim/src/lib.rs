@@ -1,0 +1,105 @@
+//! Rust shim over `include/bn254_pairing.h`: the reference's native functions with their original
+//! signatures (src/pairing.rs:20, src/miller_loop_native.rs:320,324, src/final_exp_native.rs:17,56,86,183,209),
+//! executed by the MI355X engine.  `repr(Rust)` structs are never transmuted: fields are copied limb by
+//! limb (`Fp.0.0` is the Montgomery representation the C ABI uses, so no conversion happens).
+//! NOT compiled in the build image (no Rust toolchain there); kept as the binding a maintainer adds.
+#![allow(non_snake_case)]
+use ark_bn254::{Fq, Fq12, Fq2, G1Affine, G2Affine};
+use ark_ff::{BigInt, Fp};
+use plonky2_bn254::fields::native::MyFq12;
+use std::os::raw::{c_int, c_long, c_void};
+
+extern "C" {
+    fn bn254_pairing_batch(g1: *const u64, g2: *const u64, out: *mut u64, n: usize, device: c_int, stream: *mut c_void) -> c_int;
+    fn bn254_miller_loop_batch(g1: *const u64, g2: *const u64, out: *mut u64, n: usize, device: c_int, stream: *mut c_void) -> c_int;
+    fn bn254_final_exp_batch(f: *const u64, out: *mut u64, n: usize, device: c_int, stream: *mut c_void) -> c_int;
+    fn bn254_multi_pairing_batch(g1: *const u64, g2: *const u64, out: *mut u64, n_groups: usize, k: usize, do_final_exp: c_int,
+                                 device: c_int, stream: *mut c_void) -> c_int;
+    fn bn254_frobenius_map_batch(a: *const u64, power: usize, out: *mut u64, n: usize, device: c_int, stream: *mut c_void) -> c_int;
+    fn bn254_pow_batch(a: *const u64, exp: *const u64, exp_limbs: usize, out: *mut u64, n: usize, device: c_int, stream: *mut c_void) -> c_int;
+    fn bn254_get_naf(exp: *const u64, exp_limbs: usize, naf: *mut i8) -> c_long;
+    fn bn254_frob_coeffs(index: usize, out8: *mut u64) -> c_int;
+    fn bn254_myfq12_to_ark_index(j: c_int) -> c_int;
+}
+
+pub const BN_X: u64 = 4965661367192848881;
+pub const SIX_U_PLUS_2_NAF: [i8; 65] = [
+    0, 0, 0, 1, 0, 1, 0, -1, 0, 0, 1, -1, 0, 0, 1, 0, 0, 1, 1, 0, -1, 0, 0, 1, 0, -1, 0, 0, 0, 0, 1, 1, 1, 0, 0, -1, 0, 0, 1, 0, 0, 0, 0, 0,
+    -1, 0, 0, 1, 1, 0, 0, -1, 0, 0, 0, 1, 1, 0, -1, 0, 0, 1, 0, 1, 1,
+];
+
+fn limbs(x: &Fq) -> [u64; 4] { (x.0).0 }
+fn from_limbs(l: &[u64]) -> Fq { Fp(BigInt([l[0], l[1], l[2], l[3]]), core::marker::PhantomData) }
+fn ok(rc: c_int) { if rc != 0 { panic!("bn254 engine status {}", rc) } } // the reference panics in the same places
+
+/// SoA batch writers (elem(c, l, i) = buf[(c*4 + l)*n + i]).
+pub fn pack_g1(ps: &[G1Affine]) -> Vec<u64> {
+    let n = ps.len(); let mut b = vec![0u64; 8 * n];
+    for (i, p) in ps.iter().enumerate() { for l in 0..4 { b[l * n + i] = limbs(&p.x)[l]; b[(4 + l) * n + i] = limbs(&p.y)[l]; } }
+    b
+}
+pub fn pack_g2(qs: &[G2Affine]) -> Vec<u64> {
+    let n = qs.len(); let mut b = vec![0u64; 16 * n];
+    for (i, q) in qs.iter().enumerate() {
+        for l in 0..4 {
+            b[l * n + i] = limbs(&q.x.c0)[l]; b[(4 + l) * n + i] = limbs(&q.x.c1)[l];
+            b[(8 + l) * n + i] = limbs(&q.y.c0)[l]; b[(12 + l) * n + i] = limbs(&q.y.c1)[l];
+        }
+    }
+    b
+}
+fn pack_fq12(a: &MyFq12) -> [u64; 48] { let mut b = [0u64; 48]; for c in 0..12 { b[4 * c..4 * c + 4].copy_from_slice(&limbs(&a.coeffs[c])); } b }
+fn unpack_fq12(b: &[u64]) -> MyFq12 { let mut c = [Fq::from(0u64); 12]; for i in 0..12 { c[i] = from_limbs(&b[4 * i..4 * i + 4]); } MyFq12 { coeffs: c } }
+
+pub fn miller_loop_native(Q: &G2Affine, P: &G1Affine) -> MyFq12 {
+    let (g1, g2) = (pack_g1(&[*P]), pack_g2(&[*Q])); let mut out = [0u64; 48];
+    ok(unsafe { bn254_miller_loop_batch(g1.as_ptr(), g2.as_ptr(), out.as_mut_ptr(), 1, 0, core::ptr::null_mut()) });
+    unpack_fq12(&out)
+}
+pub fn multi_miller_loop_native(pairs: Vec<(&G1Affine, &G2Affine)>) -> MyFq12 {
+    let ps: Vec<G1Affine> = pairs.iter().map(|p| *p.0).collect(); let qs: Vec<G2Affine> = pairs.iter().map(|p| *p.1).collect();
+    let (g1, g2) = (pack_g1(&ps), pack_g2(&qs)); let mut out = [0u64; 48];
+    ok(unsafe { bn254_multi_pairing_batch(g1.as_ptr(), g2.as_ptr(), out.as_mut_ptr(), 1, pairs.len(), 0, 0, core::ptr::null_mut()) });
+    unpack_fq12(&out)
+}
+pub fn final_exp_native(a: MyFq12) -> MyFq12 {
+    let inp = pack_fq12(&a); let mut out = [0u64; 48];
+    ok(unsafe { bn254_final_exp_batch(inp.as_ptr(), out.as_mut_ptr(), 1, 0, core::ptr::null_mut()) });
+    unpack_fq12(&out)
+}
+pub fn pairing(p: G1Affine, q: G2Affine) -> Fq12 {
+    let (g1, g2) = (pack_g1(&[p]), pack_g2(&[q])); let mut out = [0u64; 48];
+    ok(unsafe { bn254_pairing_batch(g1.as_ptr(), g2.as_ptr(), out.as_mut_ptr(), 1, 0, core::ptr::null_mut()) });
+    unpack_fq12(&out).into() // MyFq12 -> Fq12, as at src/pairing.rs:21 (or use bn254_myfq12_to_ark_index)
+}
+pub fn frobenius_map_native(a: MyFq12, power: usize) -> MyFq12 {
+    let inp = pack_fq12(&a); let mut out = [0u64; 48];
+    ok(unsafe { bn254_frobenius_map_batch(inp.as_ptr(), power, out.as_mut_ptr(), 1, 0, core::ptr::null_mut()) });
+    unpack_fq12(&out)
+}
+pub fn pow_native(a: MyFq12, exp: Vec<u64>) -> MyFq12 {
+    let inp = pack_fq12(&a); let mut out = [0u64; 48];
+    ok(unsafe { bn254_pow_batch(inp.as_ptr(), exp.as_ptr(), exp.len(), out.as_mut_ptr(), 1, 0, core::ptr::null_mut()) });
+    unpack_fq12(&out)
+}
+pub fn get_naf(exp: Vec<u64>) -> Vec<i8> {
+    let mut naf = vec![0i8; 64 * exp.len() + 1];
+    let n = unsafe { bn254_get_naf(exp.as_ptr(), exp.len(), naf.as_mut_ptr()) };
+    if n < 0 { panic!("get_naf: carry out of the top limb") }
+    naf.truncate(n as usize); naf
+}
+pub fn frob_coeffs(index: usize) -> Fq2 {
+    let mut o = [0u64; 8]; ok(unsafe { bn254_frob_coeffs(index % 12, o.as_mut_ptr()) });
+    Fq2::new(from_limbs(&o[0..4]), from_limbs(&o[4..8]))
+}
+pub fn conjugate_fp2(x: Fq2) -> Fq2 { Fq2::new(x.c0, -x.c1) }
+pub fn neg_conjugate_fp2(x: Fq2) -> Fq2 { Fq2::new(-x.c0, x.c1) }
+
+/// New: whole batches in one launch (what the engine is for).  Output: MyFq12 per pairing.
+pub fn pairing_batch(ps: &[G1Affine], qs: &[G2Affine]) -> Vec<MyFq12> {
+    assert_eq!(ps.len(), qs.len()); let n = ps.len();
+    let (g1, g2) = (pack_g1(ps), pack_g2(qs)); let mut out = vec![0u64; 48 * n];
+    ok(unsafe { bn254_pairing_batch(g1.as_ptr(), g2.as_ptr(), out.as_mut_ptr(), n, 0, core::ptr::null_mut()) });
+    (0..n).map(|i| { let mut c = [0u64; 48]; for w in 0..48 { c[w] = out[w * n + i]; } unpack_fq12(&c) }).collect()
+}
+#[allow(dead_code)] fn _ark_index(j: i32) -> i32 { unsafe { bn254_myfq12_to_ark_index(j) } }

@@ -86,3 +86,10 @@ def test_bad_arguments(pk):
         pk.pairing_batch(np.zeros(7, dtype=np.uint64), np.zeros(16, dtype=np.uint64), 1)
     with pytest.raises(pk.Bn254Error):
         pk.multi_miller_loop_native([])
+
+
+def test_cpp_host_header_compiles():
+    """include/bn254_pairing.hpp (C++ mirror of the reference's function names) is valid C++17."""
+    import subprocess
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(H.ROOT, "include"), "-x", "c++",
+                           os.path.join(H.ROOT, "include", "bn254_pairing.hpp")])
