@@ -223,7 +223,12 @@ k_pairing(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in, uint64_t
 BN254_ASM_KERNEL(k2_pairing, BN254_ASM_PAIRING)
 BN254_ASM_KERNEL(k2_miller, BN254_ASM_MILLER)
 BN254_ASM_KERNEL(k2_fexp, BN254_ASM_FEXP)
-constexpr int V2_GSLOTS = 48;   // eight Fq12 registers of the final exponentiation, 64 B per lane each
+// v3: carry-free signed radix-2^27 limbs (tools/kgen3*.py); 80-byte scratch slots
+BN254_ASM_KERNEL(k3_pairing, BN254_ASM3_PAIRING)
+BN254_ASM_KERNEL(k3_miller, BN254_ASM3_MILLER)
+BN254_ASM_KERNEL(k3_fexp, BN254_ASM3_FEXP)
+constexpr int V3_GSLOTS = 56;         // eight Fq12 registers + eight overflow temporaries
+constexpr int V3_SLOT_BYTES = 80;
 
 enum { OP_MUL = 0, OP_FROB = 1, OP_POW = 2, OP_INV = 3, OP_SQR = 4, OP_CYC_SQR = 5 };
 
@@ -387,12 +392,17 @@ int ctx_get(int device, size_t k, DeviceCtx** out, uint32_t* grid_out, size_t n_
         HIPCHK(hipFuncSetAttribute((const void*)k2_pairing, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
         HIPCHK(hipFuncSetAttribute((const void*)k2_miller, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
         HIPCHK(hipFuncSetAttribute((const void*)k2_fexp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k3_pairing, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k3_miller, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k3_fexp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
         c.init = true;
     }
     uint32_t grid = (uint32_t)(n_items < (size_t)c.n_cu ? n_items : (size_t)c.n_cu);
     if (grid == 0) grid = 1;
     size_t slots = N_GSLOTS_BASE + 3 * (k > 1 ? k : 0);
     size_t need = slots * 64 * (size_t)c.n_cu * BLOCK;   // sized for a full grid so the buffer is stable
+    size_t need3 = (size_t)V3_GSLOTS * V3_SLOT_BYTES * (size_t)c.n_cu * BLOCK;
+    if (need3 > need) need = need3;
     if (need > c.scratch_bytes) {
         if (c.scratch) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(c.scratch)); c.scratch = nullptr; c.scratch_bytes = 0; }
         if (hipMalloc(&c.scratch, need) != hipSuccess) return BN254_ERR_ALLOC;
@@ -412,6 +422,19 @@ int launch_pairing(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in,
     int rc = ctx_get(device, k, &c, &grid, n_items);
     if (rc) return rc;
     static const bool use_v1 = (getenv("BN254_FORCE_V1") != nullptr);
+    static const bool use_v2 = (getenv("BN254_FORCE_V2") != nullptr);
+    if (k == 1 && !use_v1 && !use_v2) {
+        if (n_groups >= (1ull << 29)) return BN254_ERR_INVALID_ARG;   // 32-bit element offsets in the asm kernels
+        uint32_t stride = grid * BLOCK * V3_SLOT_BYTES;                 // bytes between scratch slots
+        if (M && F) hipLaunchKernelGGL(k3_pairing, dim3(grid), dim3(BLOCK), LDS_BYTES, (hipStream_t)stream, g1, g2, f_in, out,
+                                       (uint32_t)n_groups, 1u, c->scratch, stride, c->status);
+        else if (M) hipLaunchKernelGGL(k3_miller, dim3(grid), dim3(BLOCK), LDS_BYTES, (hipStream_t)stream, g1, g2, f_in, out,
+                                       (uint32_t)n_groups, 1u, c->scratch, stride, c->status);
+        else hipLaunchKernelGGL(k3_fexp, dim3(grid), dim3(BLOCK), LDS_BYTES, (hipStream_t)stream, g1, g2, f_in, out,
+                                (uint32_t)n_groups, 1u, c->scratch, stride, c->status);
+        HIPCHK(hipGetLastError());
+        return BN254_OK;
+    }
     if (k == 1 && !use_v1) {
         if (n_groups >= (1ull << 29)) return BN254_ERR_INVALID_ARG;   // 32-bit element offsets in the asm kernels
         uint32_t stride = grid * BLOCK * 64;                            // bytes between scratch slots
@@ -537,7 +560,9 @@ int bn254_last_status(int device, void* stream) {
 
 size_t bn254_scratch_bytes(size_t n, size_t k) {
     (void)n;
-    return (size_t)(N_GSLOTS_BASE + 3 * (k > 1 ? k : 0)) * 64 * 256 * BLOCK;
+    size_t v1 = (size_t)(N_GSLOTS_BASE + 3 * (k > 1 ? k : 0)) * 64 * 256 * BLOCK;
+    size_t v3 = (size_t)V3_GSLOTS * V3_SLOT_BYTES * 256 * BLOCK;
+    return v1 > v3 ? v1 : v3;
 }
 
 int bn254_pairing_batch_dev(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n, int device, void* stream) {

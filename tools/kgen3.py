@@ -1,0 +1,362 @@
+#!/usr/bin/env python3
+"""kgen3.py -- L1 field routines of the v3 kernels: carry-free signed reduced-radix limbs.
+
+gfx950 has no cheap carries (v_addc costs a full issue slot and a VALU may not read a carry a VALU
+wrote < 2 instructions earlier), so v3 drops 32-bit limbs + carry chains:
+
+  * an Fq element is NL = 10 signed 32-bit limbs in radix 2^27 (value = sum l_i 2^(27 i)), kept in
+    Montgomery form with R' = 2^270; limbs and values are REDUNDANT (limbs may exceed 27 bits by a
+    few bits and be negative, values are any representative), bounds are tracked by the generator;
+  * a limb product is ONE instruction: v_mad_i64_i32 acc64 += a_i * b_j -- column sums of up to
+    ~40 products of 28-bit limbs fit a signed 64-bit accumulator, so there is no carry handling inside
+    a column; one arithmetic 64-bit shift per column moves on;
+  * Montgomery reduction is fused column-wise (FIPS): m_k = (lo(S) * n0') mod 2^27, S += m_k p_0, S >>= 27;
+  * an Fq2 product is two fused two-product columns passes (a0 b0 + (-a1) b1, a0 b1 + a1 b0): no Karatsuba
+    recombination, no wide subtraction;
+  * add / sub / neg are NL independent v_add_u32 / v_sub_u32; x(9+u) is v_lshl_add_u32 + add/sub;
+    `norm` is one carry-propagation pass (shift, mask, add per limb).
+  * R'/p = 2^16.4, so every reduction contracts values to < ~2p whatever the operands' slack.
+
+Blocks: A = v[0:19] (c0 = v0..9, c1 = v10..19), B = v[20:39]; temporaries v[40:79].
+At the kernel boundary values are converted from/to ark's 4 x u64 Montgomery (R = 2^256) form.
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kgen import Emitter, Pool, P_INT  # noqa: E402
+
+NL = 10
+LB = 27
+MASK = (1 << LB) - 1
+RP = 1 << (NL * LB)                       # R' = 2^270
+N0P = (-pow(P_INT, -1, 1 << LB)) % (1 << LB)
+P_L = [(P_INT >> (LB * i)) & MASK for i in range(NL)]
+
+A0, B0 = 0, 20
+TMP_FIRST, TMP_LAST = 40, 79
+V_LDS = 80          # v80, v81, v82: LDS byte address of the lane (+0, +64 KiB, +128 KiB)
+V_GOFF = 83         # lane * 80 (byte offset inside a global scratch slot)
+V_IDX8 = 84
+V_IDX = 85
+V_TID = 86
+V_FLAG = 87
+HOME0 = 88          # homes: v[88:247] = 8 x 20
+N_HOME = 8
+N_AGPR_SLOTS = 12   # a[0:239]
+N_LDS_SLOTS = 8     # 8 x 80 B x 256 lanes = 160 KiB
+SLOT_DW = 20
+S_P = 36            # s36..s45: modulus limbs (radix 2^27)
+S_N0 = 46
+S_RET1 = "s[54:55]"
+S_RET2 = "s[56:57]"
+S_RET3 = "s[58:59]"
+
+
+def to_limbs(x):
+    """Canonical non-negative integer -> NL limbs."""
+    return [(x >> (LB * i)) & MASK for i in range(NL - 1)] + [x >> (LB * (NL - 1))]
+
+
+def from_limbs(l):
+    return sum(int(v) << (LB * i) for i, v in enumerate(l))
+
+
+def mont3(x):
+    return x * RP % P_INT
+
+
+class L1v3:
+    def __init__(self, e):
+        self.e = e
+        self.pool = Pool(TMP_FIRST, TMP_LAST)
+        self.p = [f"s{S_P + i}" for i in range(NL)]
+        self.n0 = f"s{S_N0}"
+
+    # ------------------------------------------------------------------ fused Montgomery column pass
+    def fips(self, prods, out):
+        """out[0..NL-1] <- (sum over (a, b) in prods of a*b) / R' mod p   (redundant result: limbs 0..NL-2 in
+        [0, 2^27), top limb signed).  a, b: lists of NL VGPR numbers.  out registers may alias inputs only
+        if those inputs are dead (they are written while later columns still read inputs -> use temps)."""
+        acc = self.pool.alloc_pair()
+        P = f"v[{acc}:{acc + 1}]"
+        m = [self.pool.alloc() for _ in range(NL)]
+        res = [self.pool.alloc() for _ in range(NL)]
+        first = True
+
+        def mad(x, y):
+            nonlocal first
+            X = f"v{x}" if isinstance(x, int) else x
+            Y = f"v{y}" if isinstance(y, int) else y
+            if first:
+                self.e.emit(f"v_mad_i64_i32 {P}, vcc, {X}, {Y}, 0", w=["vcc"], vw=[acc, acc + 1])
+                first = False
+            else:
+                self.e.emit(f"v_mad_i64_i32 {P}, vcc, {X}, {Y}, {P}", w=["vcc"], vw=[acc, acc + 1])
+
+        for k in range(2 * NL - 1):
+            lo_i, hi_i = max(0, k - (NL - 1)), min(NL - 1, k)
+            for (a, b) in prods:
+                for i in range(lo_i, hi_i + 1):
+                    mad(a[i], b[k - i])
+            if k < NL:
+                for i in range(k):
+                    mad(m[i], self.p[k - i])
+                self.e.emit(f"v_mul_lo_u32 v{m[k]}, v{acc}, {self.n0}", vw=[m[k]])
+                self.e.emit(f"v_and_b32_e32 v{m[k]}, 0x{MASK:x}, v{m[k]}", vw=[m[k]])
+                mad(m[k], self.p[0])
+                self.e.emit(f"v_ashrrev_i64 {P}, {LB}, {P}", vw=[acc, acc + 1])
+            else:
+                for i in range(k - (NL - 1), NL):
+                    mad(m[i], self.p[k - i])
+                self.e.emit(f"v_and_b32_e32 v{res[k - NL]}, 0x{MASK:x}, v{acc}", vw=[res[k - NL]])
+                self.e.emit(f"v_ashrrev_i64 {P}, {LB}, {P}", vw=[acc, acc + 1])
+        self.e.emit(f"v_mov_b32_e32 v{res[NL - 1]}, v{acc}", vw=[res[NL - 1]])
+        for i in range(NL):
+            self.e.emit(f"v_mov_b32_e32 v{out[i]}, v{res[i]}", vw=[out[i]])
+        self.pool.free(acc, acc + 1, *m)
+        self.pool.free(*res)
+
+    def fips_direct(self, prods, out):
+        """Same, writing result limbs straight into `out` (out must not overlap any input)."""
+        acc = self.pool.alloc_pair()
+        P = f"v[{acc}:{acc + 1}]"
+        m = [self.pool.alloc() for _ in range(NL)]
+        first = True
+
+        def mad(x, y):
+            nonlocal first
+            X = f"v{x}" if isinstance(x, int) else x
+            Y = f"v{y}" if isinstance(y, int) else y
+            if first:
+                self.e.emit(f"v_mad_i64_i32 {P}, vcc, {X}, {Y}, 0", w=["vcc"], vw=[acc, acc + 1])
+                first = False
+            else:
+                self.e.emit(f"v_mad_i64_i32 {P}, vcc, {X}, {Y}, {P}", w=["vcc"], vw=[acc, acc + 1])
+
+        for k in range(2 * NL - 1):
+            lo_i, hi_i = max(0, k - (NL - 1)), min(NL - 1, k)
+            for (a, b) in prods:
+                for i in range(lo_i, hi_i + 1):
+                    mad(a[i], b[k - i])
+            if k < NL:
+                for i in range(k):
+                    mad(m[i], self.p[k - i])
+                self.e.emit(f"v_mul_lo_u32 v{m[k]}, v{acc}, {self.n0}", vw=[m[k]])
+                self.e.emit(f"v_and_b32_e32 v{m[k]}, 0x{MASK:x}, v{m[k]}", vw=[m[k]])
+                mad(m[k], self.p[0])
+                self.e.emit(f"v_ashrrev_i64 {P}, {LB}, {P}", vw=[acc, acc + 1])
+            else:
+                for i in range(k - (NL - 1), NL):
+                    mad(m[i], self.p[k - i])
+                self.e.emit(f"v_and_b32_e32 v{out[k - NL]}, 0x{MASK:x}, v{acc}", vw=[out[k - NL]])
+                self.e.emit(f"v_ashrrev_i64 {P}, {LB}, {P}", vw=[acc, acc + 1])
+        self.e.emit(f"v_mov_b32_e32 v{out[NL - 1]}, v{acc}", vw=[out[NL - 1]])
+        self.pool.free(acc, acc + 1, *m)
+
+    # ------------------------------------------------------------------ blocks
+    @staticmethod
+    def blk(base, half):
+        return list(range(base + NL * half, base + NL * half + NL))
+
+    def limbwise(self, op, dst, a, b):
+        for i in range(NL):
+            self.e.emit(f"{op} v{dst[i]}, v{a[i]}, v{b[i]}", vw=[dst[i]])
+
+    # ------------------------------------------------------------------ routines: A <- op(A, B)
+    def r_mul(self):
+        a0, a1, b0, b1 = self.blk(A0, 0), self.blk(A0, 1), self.blk(B0, 0), self.blk(B0, 1)
+        na1 = [self.pool.alloc() for _ in range(NL)]
+        for i in range(NL):
+            self.e.emit(f"v_sub_u32_e32 v{na1[i]}, 0, v{a1[i]}", vw=[na1[i]])
+        c0 = [self.pool.alloc() for _ in range(NL)]
+        self.fips_direct([(a0, b0), (na1, b1)], c0)
+        self.pool.free(*na1)
+        c1 = [self.pool.alloc() for _ in range(NL)]
+        self.fips_direct([(a0, b1), (a1, b0)], c1)
+        for i in range(NL):
+            self.e.emit(f"v_mov_b32_e32 v{a0[i]}, v{c0[i]}", vw=[a0[i]])
+            self.e.emit(f"v_mov_b32_e32 v{a1[i]}, v{c1[i]}", vw=[a1[i]])
+        self.pool.free(*c0)
+        self.pool.free(*c1)
+
+    def r_sqr(self):
+        """(a0 + a1 u)^2 = (a0+a1)(a0-a1) + 2 a0 a1 u"""
+        a0, a1 = self.blk(A0, 0), self.blk(A0, 1)
+        d = [self.pool.alloc() for _ in range(NL)]
+        self.limbwise("v_add_u32_e32", d, a0, a0)
+        c1 = [self.pool.alloc() for _ in range(NL)]
+        self.fips_direct([(d, a1)], c1)
+        t = d                                               # d is dead: reuse for a0 + a1
+        self.limbwise("v_add_u32_e32", t, a0, a1)
+        self.limbwise("v_sub_u32_e32", a1, a0, a1)          # u = a0 - a1 in place of a1
+        self.fips_direct([(t, a1)], a0)                     # a0 is dead (t and u hold what is needed)
+        for i in range(NL):
+            self.e.emit(f"v_mov_b32_e32 v{a1[i]}, v{c1[i]}", vw=[a1[i]])
+        self.pool.free(*d)
+        self.pool.free(*c1)
+
+    def r_mulfq(self):
+        """A <- (A.c0 * B.c0, A.c1 * B.c0)"""
+        a0, a1, k = self.blk(A0, 0), self.blk(A0, 1), self.blk(B0, 0)
+        c0 = [self.pool.alloc() for _ in range(NL)]
+        self.fips_direct([(a0, k)], c0)
+        c1 = [self.pool.alloc() for _ in range(NL)]
+        self.fips_direct([(a1, k)], c1)
+        for i in range(NL):
+            self.e.emit(f"v_mov_b32_e32 v{a0[i]}, v{c0[i]}", vw=[a0[i]])
+            self.e.emit(f"v_mov_b32_e32 v{a1[i]}, v{c1[i]}", vw=[a1[i]])
+        self.pool.free(*c0)
+        self.pool.free(*c1)
+
+    def r_fqmul(self):
+        a0, k = self.blk(A0, 0), self.blk(B0, 0)
+        c0 = [self.pool.alloc() for _ in range(NL)]
+        self.fips_direct([(a0, k)], c0)
+        for i in range(NL):
+            self.e.emit(f"v_mov_b32_e32 v{a0[i]}, v{c0[i]}", vw=[a0[i]])
+        self.pool.free(*c0)
+
+    def r_fqsqr(self):
+        a0 = self.blk(A0, 0)
+        c0 = [self.pool.alloc() for _ in range(NL)]
+        self.fips_direct([(a0, a0)], c0)
+        for i in range(NL):
+            self.e.emit(f"v_mov_b32_e32 v{a0[i]}, v{c0[i]}", vw=[a0[i]])
+        self.pool.free(*c0)
+
+    def r_add(self):
+        for h in range(2):
+            self.limbwise("v_add_u32_e32", self.blk(A0, h), self.blk(A0, h), self.blk(B0, h))
+
+    def r_sub(self):
+        for h in range(2):
+            self.limbwise("v_sub_u32_e32", self.blk(A0, h), self.blk(A0, h), self.blk(B0, h))
+
+    def r_rsub(self):
+        for h in range(2):
+            self.limbwise("v_sub_u32_e32", self.blk(A0, h), self.blk(B0, h), self.blk(A0, h))
+
+    def r_dbl(self):
+        for h in range(2):
+            for r in self.blk(A0, h):
+                self.e.emit(f"v_lshlrev_b32_e32 v{r}, 1, v{r}", vw=[r])
+
+    def r_neg(self):
+        for h in range(2):
+            for r in self.blk(A0, h):
+                self.e.emit(f"v_sub_u32_e32 v{r}, 0, v{r}", vw=[r])
+
+    def r_negc1(self):
+        for r in self.blk(A0, 1):
+            self.e.emit(f"v_sub_u32_e32 v{r}, 0, v{r}", vw=[r])
+
+    def r_mulxi(self):
+        """A <- (9 a0 - a1, a0 + 9 a1)"""
+        a0, a1 = self.blk(A0, 0), self.blk(A0, 1)
+        t = self.pool.alloc()
+        for i in range(NL):
+            self.e.emit(f"v_lshl_add_u32 v{t}, v{a0[i]}, 3, v{a0[i]}", vw=[t])             # 9 a0
+            self.e.emit(f"v_sub_u32_e32 v{t}, v{t}, v{a1[i]}", vw=[t])                      # 9 a0 - a1
+            self.e.emit(f"v_lshl_add_u32 v{a1[i]}, v{a1[i]}, 3, v{a1[i]}", vw=[a1[i]])      # 9 a1
+            self.e.emit(f"v_add_u32_e32 v{a1[i]}, v{a1[i]}, v{a0[i]}", vw=[a1[i]])          # 9 a1 + a0
+            self.e.emit(f"v_mov_b32_e32 v{a0[i]}, v{t}", vw=[a0[i]])
+        self.pool.free(t)
+
+    def norm_limbs(self, a):
+        """One carry pass: limbs 0..NL-2 -> [0, 2^27), excess pushed up (top limb keeps the sign)."""
+        c = self.pool.alloc()
+        for i in range(NL - 1):
+            self.e.emit(f"v_ashrrev_i32_e32 v{c}, {LB}, v{a[i]}", vw=[c])
+            self.e.emit(f"v_and_b32_e32 v{a[i]}, 0x{MASK:x}, v{a[i]}", vw=[a[i]])
+            self.e.emit(f"v_add_u32_e32 v{a[i + 1]}, v{a[i + 1]}, v{c}", vw=[a[i + 1]])
+        self.pool.free(c)
+
+    def r_norm(self):
+        self.norm_limbs(self.blk(A0, 0))
+        self.norm_limbs(self.blk(A0, 1))
+
+    # ------------------------------------------------------------------ boundary conversions
+    def r_cvtin(self):
+        """A.c0 <- internal form of the packed external value in v[0:7] (8 x u32, canonical, Montgomery R = 2^256).
+        unpack to 27-bit limbs, then one Montgomery multiplication by 2^284 mod p (x 2^256 * 2^284 / 2^270 = x 2^270)."""
+        w = list(range(A0, A0 + 8))
+        l = [self.pool.alloc() for _ in range(NL)]
+        for i in range(NL):
+            bit = LB * i
+            j, s = bit // 32, bit % 32
+            if i == NL - 1:
+                self.e.emit(f"v_lshrrev_b32_e32 v{l[i]}, {s}, v{w[j]}", vw=[l[i]])
+                continue
+            if s + LB <= 32:
+                self.e.emit(f"v_bfe_u32 v{l[i]}, v{w[j]}, {s}, {LB}", vw=[l[i]])
+            else:
+                self.e.emit(f"v_alignbit_b32 v{l[i]}, v{w[j + 1]}, v{w[j]}, {s}", vw=[l[i]])
+                self.e.emit(f"v_and_b32_e32 v{l[i]}, 0x{MASK:x}, v{l[i]}", vw=[l[i]])
+        c = [self.pool.alloc() for _ in range(NL)]
+        cin = to_limbs(pow(2, 284, P_INT))
+        for i in range(NL):
+            self.e.emit(f"v_mov_b32_e32 v{c[i]}, 0x{cin[i]:x}", vw=[c[i]])
+        self.fips_direct([(l, c)], self.blk(A0, 0))      # A.c0 region (v0..v9) overlaps w only after w is dead
+        self.pool.free(*l)
+        self.pool.free(*c)
+
+    def r_cvtout(self):
+        """v[0:7] <- canonical external form (8 x u32, Montgomery R = 2^256, in [0,p)) of internal A.c0."""
+        a0 = self.blk(A0, 0)
+        c = [self.pool.alloc() for _ in range(NL)]
+        cout = to_limbs(pow(2, 256, P_INT))
+        for i in range(NL):
+            self.e.emit(f"v_mov_b32_e32 v{c[i]}, 0x{cout[i]:x}", vw=[c[i]])
+        w = [self.pool.alloc() for _ in range(NL)]
+        self.fips_direct([(a0, c)], w)                    # w == y 2^256 mod p, in (-p, 2p), limbs 0..8 normalised
+        self.pool.free(*c)
+        # w += p if negative (top limb < 0)
+        msk = self.pool.alloc()
+        t = self.pool.alloc()
+        self.e.emit(f"v_ashrrev_i32_e32 v{msk}, 31, v{w[NL - 1]}", vw=[msk])
+        for i in range(NL):
+            self.e.emit(f"v_and_b32_e32 v{t}, {self.p[i]}, v{msk}", vw=[t])
+            self.e.emit(f"v_add_u32_e32 v{w[i]}, v{w[i]}, v{t}", vw=[w[i]])
+        self.norm_limbs(w)
+        # d = w - p ; take d if d >= 0
+        d = [self.pool.alloc() for _ in range(NL)]
+        for i in range(NL):
+            self.e.emit(f"v_subrev_u32_e32 v{d[i]}, {self.p[i]}, v{w[i]}", vw=[d[i]])
+        self.norm_limbs(d)
+        self.e.emit(f"v_cmp_gt_i32_e32 vcc, 0, v{d[NL - 1]}", w=["vcc"])      # vcc = (d < 0)
+        for i in range(NL):
+            self.e.emit(f"v_cndmask_b32_e32 v{w[i]}, v{d[i]}, v{w[i]}, vcc", r=["vcc"], vw=[w[i]])
+        # the same once more (w was < 2p + p)
+        for i in range(NL):
+            self.e.emit(f"v_subrev_u32_e32 v{d[i]}, {self.p[i]}, v{w[i]}", vw=[d[i]])
+        self.norm_limbs(d)
+        self.e.emit(f"v_cmp_gt_i32_e32 vcc, 0, v{d[NL - 1]}", w=["vcc"])
+        for i in range(NL):
+            self.e.emit(f"v_cndmask_b32_e32 v{w[i]}, v{d[i]}, v{w[i]}, vcc", r=["vcc"], vw=[w[i]])
+        # repack 10 x 27 -> 8 x 32
+        for j in range(8):
+            lo_bit = 32 * j
+            i, s = lo_bit // LB, lo_bit % LB
+            dst = A0 + j
+            # word j = (l_i >> s) | (l_{i+1} << (27 - s)) | (l_{i+2} << (54 - s))
+            self.e.emit(f"v_lshrrev_b32_e32 v{dst}, {s}, v{w[i]}", vw=[dst])
+            sh1 = LB - s
+            if i + 1 < NL and sh1 < 32:
+                self.e.emit(f"v_lshl_or_b32 v{dst}, v{w[i + 1]}, {sh1}, v{dst}", vw=[dst])
+            sh2 = 2 * LB - s
+            if i + 2 < NL and sh2 < 32:
+                self.e.emit(f"v_lshl_or_b32 v{dst}, v{w[i + 2]}, {sh2}, v{dst}", vw=[dst])
+        self.pool.free(msk, t, *w)
+        self.pool.free(*d)
+
+
+L1V3_NAMES = ["mul", "sqr", "mulfq", "add", "sub", "rsub", "dbl", "neg", "negc1", "mulxi", "norm", "fqmul", "fqsqr", "cvtin", "cvtout"]
+
+if __name__ == "__main__":
+    for n in L1V3_NAMES:
+        e = Emitter()
+        g = L1v3(e)
+        getattr(g, "r_" + n)()
+        lines = e.finalize()
+        print(n, len(lines), "nops", sum(1 for l in lines if l.startswith("s_nop")), "max tmp", max(g.pool.used) if g.pool.used else None)

@@ -1,0 +1,625 @@
+#!/usr/bin/env python3
+"""kgen3_prog.py -- L2/L3 of the v3 kernels (signed radix-2^27 limbs, see tools/kgen3.py).
+
+Re-uses the accumulator-machine algorithms of tools/kgen_prog.py (Fq6/Fq12 arithmetic, line
+multiplications, G2 steps, Miller loop, final exponentiation) on the v3 register map and adds
+  * 20-dword slots (LDS 8, VGPR homes 8, AGPR 12, global scratch),
+  * a static BOUND TRACKER: every value carries log2 of its largest limb; multiplications assert that
+    their signed 64-bit column sums cannot overflow and `norm` (one carry pass) is inserted exactly
+    where a bound would be exceeded (before x(9+u), before stores of values with > 28-bit limbs, ...),
+  * conversion from/to ark's 4 x u64 Montgomery (R = 2^256) limbs at the kernel boundary (bit-exact
+    canonical output).
+"""
+import math
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import kgen_prog as KP  # noqa: E402
+from kgen import Emitter, P_INT, SIX_U_PLUS_2_NAF  # noqa: E402
+from kgen3 import (A0, B0, HOME0, L1V3_NAMES, L1v3, LB, MASK, N0P, N_AGPR_SLOTS, N_HOME, N_LDS_SLOTS, NL, P_L, S_N0, S_P, S_RET1, S_RET2,  # noqa: E402
+                   S_RET3, SLOT_DW, V_FLAG, V_GOFF, V_IDX, V_IDX8, V_LDS, V_TID, mont3, to_limbs)
+from kgen_prog import (AGPR, GLOB, HOME, LDS, Const, GlobDyn, Slot, S_FIN, S_G1, S_G2, S_GADDR, S_GBASE, S_GRID, S_GSTRIDE, S_I, S_IOADDR,  # noqa: E402
+                       S_ITEM, S_J, S_K, S_N, S_NAF_NEG, S_NAF_NZ, S_NITEMS, S_NSTRIDE, S_OUT, S_SAVE_EXEC, S_SCRATCH, S_STATUS, S_TMP0, S_TMP1,
+                       S_XNAF_NEG, S_XNAF_NZ, f2mul, f2pow, naf_masks, x_naf)
+
+E_NORM = float(LB)          # limb exponent of a normalised value
+E_STORE_MAX = 28.01         # stored values keep at most one addition of slack
+E_MULXI_MAX = 27.6          # 10 * 2^e must stay below 2^31
+E_LIMIT = 30.9              # int32 limbs
+COL_LIMIT = 62.5            # signed 64-bit column sums (margin 0.5 bit)
+N_CHUNK = SLOT_DW // 4      # 16-byte chunks per slot
+
+
+def lsum(a, b):
+    return math.log2(2.0 ** a + 2.0 ** b)
+
+
+class Prog3(KP.Prog):
+    def __init__(self, e, l1_labels):
+        super().__init__(e, l1_labels)
+        self.eA = None
+        self.slot_e = {}
+
+    # ---------------------------------------------------------------- bounds
+    @staticmethod
+    def key(slot):
+        if slot.kind == "globdyn":
+            return ("globdyn", slot.k)
+        if slot.kind == "const":
+            return ("const", slot.name)
+        return (slot.kind, slot.idx)
+
+    def e_of(self, slot):
+        if slot.kind == "const":
+            return E_NORM
+        return self.slot_e.get(self.key(slot), E_STORE_MAX)     # contract at routine boundaries
+
+    def reset_tags(self):
+        super().reset_tags()
+        self.eA = None
+
+    # ---------------------------------------------------------------- data movement (20-dword slots)
+    def _lds_addr(self, slot, c):
+        ci = slot.idx * N_CHUNK + c
+        return V_LDS + ci // 16, (ci % 16) * 4096
+
+    def _glob_base(self, slot):
+        if slot.kind == "glob":
+            self.e.salu(f"s_mul_i32 s{S_TMP0}, s{S_GSTRIDE}, {slot.idx}")
+        else:
+            self.e.salu(f"s_mul_i32 s{S_TMP0}, s{S_GSTRIDE}, {slot.k}")
+            self.e.salu(f"s_add_u32 s{S_TMP0}, s{S_TMP0}, s{S_GBASE}")
+        self.e.salu(f"s_add_u32 s62, s64, s{S_TMP0}")
+        self.e.salu("s_addc_u32 s63, s65, 0")
+
+    def load(self, blk, slot):
+        if slot.kind == "lds":
+            for c in range(N_CHUNK):
+                base, off = self._lds_addr(slot, c)
+                self.e.emit(f"ds_read_b128 v[{blk + 4 * c}:{blk + 4 * c + 3}], v{base} offset:{off}", kind="lds", vw=range(blk + 4 * c, blk + 4 * c + 4))
+            self.lds_pending = True
+        elif slot.kind == "home":
+            r0 = HOME0 + SLOT_DW * slot.idx
+            for i in range(SLOT_DW):
+                self.e.emit(f"v_mov_b32_e32 v{blk + i}, v{r0 + i}", vw=[blk + i])
+        elif slot.kind == "agpr":
+            for i in range(SLOT_DW):
+                self.e.emit(f"v_accvgpr_read_b32 v{blk + i}, a{SLOT_DW * slot.idx + i}", vw=[blk + i])
+        elif slot.kind == "const":
+            w = to_limbs(mont3(slot.c0)) + to_limbs(mont3(slot.c1))
+            for i in range(SLOT_DW):
+                self.e.emit(f"v_mov_b32_e32 v{blk + i}, 0x{w[i]:x}", vw=[blk + i])
+        elif slot.kind in ("glob", "globdyn"):
+            self._glob_base(slot)
+            for c in range(N_CHUNK):
+                self.e.emit(f"global_load_dwordx4 v[{blk + 4 * c}:{blk + 4 * c + 3}], v{V_GOFF}, {S_GADDR} offset:{16 * c}", kind="vmem",
+                            vw=range(blk + 4 * c, blk + 4 * c + 4))
+            self.vm_pending = True
+        else:
+            raise ValueError(slot.kind)
+        self._count("ld_" + slot.kind)
+
+    def store(self, blk, slot):
+        assert blk == A0
+        if slot.kind == "lds":
+            for c in range(N_CHUNK):
+                base, off = self._lds_addr(slot, c)
+                self.e.emit(f"ds_write_b128 v{base}, v[{blk + 4 * c}:{blk + 4 * c + 3}] offset:{off}", kind="lds")
+        elif slot.kind == "home":
+            r0 = HOME0 + SLOT_DW * slot.idx
+            for i in range(SLOT_DW):
+                self.e.emit(f"v_mov_b32_e32 v{r0 + i}, v{blk + i}", vw=[r0 + i])
+        elif slot.kind == "agpr":
+            for i in range(SLOT_DW):
+                self.e.emit(f"v_accvgpr_write_b32 a{SLOT_DW * slot.idx + i}, v{blk + i}")
+        elif slot.kind in ("glob", "globdyn"):
+            self._glob_base(slot)
+            for c in range(N_CHUNK):
+                self.e.emit(f"global_store_dwordx4 v{V_GOFF}, v[{blk + 4 * c}:{blk + 4 * c + 3}], {S_GADDR} offset:{16 * c}", kind="vmem",
+                            store=range(blk + 4 * c, blk + 4 * c + 4))
+            self.e.raw("s_nop 1")
+        else:
+            raise ValueError(slot.kind)
+        self._count("st_" + slot.kind)
+
+    # ---------------------------------------------------------------- accumulator machine with bound tracking
+    def A(self, x):
+        if self.tagA is not x:
+            self.load(A0, x)
+            self.tagA = x
+            self.eA = self.e_of(x)
+        return self
+
+    def _B(self, y):
+        if self.tagB is not y:
+            self.load(B0, y)
+            self.tagB = y
+
+    def set_A_fresh(self, e=E_NORM):
+        """A was filled by hand-written code with a value whose limbs are < 2^e."""
+        self.tagA = None
+        self.eA = e
+
+    def _raw_call(self, name):
+        self.wait()
+        self.e.salu(f"s_call_b64 {S_RET1}, {self.l1[name]}")
+        self.tagA = None
+        self._count(name)
+
+    def norm(self):
+        self._raw_call("norm")
+        self.eA = E_NORM
+        return self
+
+    def _need(self, ok, what):
+        if not ok:
+            raise AssertionError("bound violated: " + what)
+
+    def call(self, name, eB=None):
+        eA = self.eA if self.eA is not None else E_STORE_MAX
+        if name == "mul":
+            if math.log2(2 * NL) + eA + eB > COL_LIMIT:
+                self.norm()
+                eA = E_NORM
+            self._need(math.log2(2 * NL) + eA + eB <= COL_LIMIT, f"mul {eA} {eB}")
+            out = E_NORM
+        elif name == "mulfq" or name == "fqmul":
+            if math.log2(NL) + eA + eB > COL_LIMIT:
+                self.norm()
+                eA = E_NORM
+            self._need(math.log2(NL) + eA + eB <= COL_LIMIT, f"{name} {eA} {eB}")
+            out = E_NORM
+        elif name in ("sqr", "fqsqr"):
+            if math.log2(NL) + 2 * (eA + 1) > COL_LIMIT or eA + 1 > E_LIMIT:
+                self.norm()
+                eA = E_NORM
+            out = E_NORM
+        elif name in ("add", "sub", "rsub"):
+            if lsum(eA, eB) > E_LIMIT:
+                self.norm()
+                eA = E_NORM
+            out = lsum(eA, eB)
+            self._need(out <= E_LIMIT, f"{name} {eA} {eB}")
+        elif name == "dbl":
+            if eA + 1 > E_LIMIT:
+                self.norm()
+                eA = E_NORM
+            out = eA + 1
+        elif name in ("neg", "negc1"):
+            out = eA
+        elif name == "mulxi":
+            if eA > E_MULXI_MAX:
+                self.norm()
+                eA = E_NORM
+            out = eA + math.log2(10)
+        elif name == "norm":
+            out = E_NORM
+        else:
+            raise ValueError(name)
+        self._raw_call(name)
+        self.eA = out
+        return self
+
+    def _bin(self, name, y):
+        self._B(y)
+        return self.call(name, self.e_of(y))
+
+    def to(self, dst):
+        eA = self.eA if self.eA is not None else E_STORE_MAX
+        if eA > E_STORE_MAX:
+            self.norm()
+        self.wait()
+        self.store(A0, dst)
+        self.slot_e[self.key(dst)] = self.eA if self.eA is not None else E_STORE_MAX
+        self.tagA = dst
+        if self.tagB is dst:
+            self.tagB = None
+        return self
+
+
+class KernelBuilder3(KP.KernelBuilder):
+    F = [LDS(i, f"F{i}") for i in range(6)]
+    R = [LDS(6, "RX"), LDS(7, "RY"), HOME(7, "RZ")]
+    SCALE = AGPR(11, "scale")
+    QX, QY, PX, PY = AGPR(0, "QX"), AGPR(1, "QY"), AGPR(2, "PX"), AGPR(3, "PY")
+    SX, SY = AGPR(4, "SX"), AGPR(5, "SY")
+    LINE = [AGPR(6, "La"), AGPR(7, "Lb"), AGPR(8, "Lc")]
+    FQINV_BASE = AGPR(9, "fqinv_base")
+    BOP = [AGPR(i, f"B{i}") for i in (0, 1, 2, 3, 4, 5)]      # fq12_mul operand copy (final exponentiation only)
+
+    def __init__(self, do_miller=True, do_fexp=True, track=False):
+        super().__init__(do_miller, do_fexp, track)
+        self.labels = {n: f"L1_{n}_%=" for n in L1V3_NAMES}
+
+    def new_prog(self, temps):
+        e = Emitter()
+        p = Prog3(e, self.labels)
+        p.set_temps(temps)
+        return e, p
+
+    def miller_temps(self, extra=()):
+        """Fast temporaries of the Miller-loop routines: homes 0..6, AGPR 10 (11 when no scale is tracked),
+        plus routine-specific dead slots; global scratch slots only as overflow."""
+        return ([HOME(i) for i in range(7)] + [AGPR(10)] + ([] if self.track else [AGPR(11)]) + [AGPR(i) for i in extra]
+                + [GLOB(48 + i) for i in range(8)])
+
+    def fexp_temps(self):
+        # LDS 6,7 ; homes ; AGPR 6..11 (0..5 hold the multiplication operand)
+        return [HOME(i) for i in range(8)] + [LDS(6), LDS(7)] + [AGPR(i) for i in (6, 7, 8, 10, 11)] + [GLOB(48 + i) for i in range(8)]
+
+    # ---------------------------------------------------------------------------------------------
+    def build(self):
+        main = Emitter()
+        self.prologue(main)
+        l1e = Emitter()
+        for n in L1V3_NAMES:
+            g = L1v3(l1e)
+            l1e.label(self.labels[n])
+            getattr(g, "r_" + n)()
+            l1e.salu(f"s_setpc_b64 {S_RET1}")
+        self.sections = []
+        if self.do_miller:
+            sc = self.SCALE if self.track else None
+            # during f^2 the line (AGPR 6..8) and the addition point (AGPR 4, 5) are dead
+            self.l2_routine("L2_sqr", lambda p: p.fq12_sqr(self.F), self.miller_temps(extra=(4, 5, 6, 7, 8)))
+            self.l2_routine("L2_dblmul", lambda p: (p.dbl_step(self.R, (self.PX, self.PY), self.LINE, scale=sc),
+                                                    p.mul_by_034(self.F, *self.LINE)), self.miller_temps())
+            self.l2_routine("L2_dblfirst", lambda p: self._dbl_first(p), self.miller_temps())
+            self.l2_routine("L2_addmul", lambda p: (p.add_step(self.R, (self.SX, self.SY), (self.PX, self.PY), self.LINE, scale=sc, update=True),
+                                                    p.mul_by_235(self.F, *self.LINE)), self.miller_temps())
+            self.l2_routine("L2_addmul_last", lambda p: (p.add_step(self.R, (self.SX, self.SY), (self.PX, self.PY), self.LINE, scale=sc, update=False),
+                                                         p.mul_by_235(self.F, *self.LINE)), self.miller_temps())
+            if self.track:
+                self.l2_routine("L2_fqinv", self._fq_inv, self.miller_temps())
+                self.l2_routine("L2_descale", self._descale, self.miller_temps())
+                self.l2_routine("L2_sqscale", lambda p: p.A(self.SCALE).sqr().to(self.SCALE), self.miller_temps())
+        if self.do_fexp:
+            if not (self.do_miller and self.track):
+                self.l2_routine("L2_fqinv", self._fq_inv, self.fexp_temps())
+            self.l2_routine("L2_cyc", lambda p: p.fq12_cyc_sqr(self.F), self.fexp_temps())
+            self._mulG_routines()
+            for k in (1, 2, 3):
+                self.l2_routine(f"L2_frob{k}", lambda p, k=k: self._frobenius(p, k), self.fexp_temps())
+            self.l2_routine("L2_inv", self._fq12_inv, self.fexp_temps())
+            self.l2_routine("L2_stG", lambda p: [p.A(self.F[i]).to(GlobDyn(i)) for i in range(6)], self.fexp_temps())
+            self.l2_routine("L2_ldG", lambda p: [p.A(GlobDyn(i)).to(self.F[i]) for i in range(6)], self.fexp_temps())
+            self.l2_routine("L2_ldGc", lambda p: [(p.A(GlobDyn(i)).neg().to(self.F[i]) if i % 2 else p.A(GlobDyn(i)).to(self.F[i])) for i in range(6)],
+                            self.fexp_temps())
+            self.l2_routine("L2_conjF", lambda p: [p.A(self.F[i]).neg().to(self.F[i]) for i in (1, 3, 5)], self.fexp_temps())
+            self._powx_routine()
+        self.main_body(main)
+        out = []
+        for e in [self._pro, l1e] + self.sections + [main]:
+            out.extend(e.finalize())
+        return out
+
+    def _mulG_routines(self):
+        e, p = self.new_prog(self.fexp_temps())
+        e.label(self.lab("L2_mulGc"))
+        for i in range(6):
+            if i % 2:
+                p.A(GlobDyn(i)).neg().to(self.BOP[i])
+            else:
+                p.A(GlobDyn(i)).to(self.BOP[i])
+        p.wait()
+        e.salu(f"s_branch {self.lab('L2_mul_body')}")
+        e.label(self.lab("L2_mulG"))
+        p.reset_tags()
+        for i in range(6):
+            p.A(GlobDyn(i)).to(self.BOP[i])
+        p.wait()
+        e.label(self.lab("L2_mul_body"))
+        p.reset_tags()
+        p.fq12_mul(self.F, self.BOP)
+        p.wait()
+        e.salu(f"s_setpc_b64 {S_RET2}")
+        self.sections.append(e)
+
+    # ---------------------------------------------------------------------------------------------
+    def prologue(self, main):
+        e = Emitter()
+        self._pro = e
+        e.salu(f"s_mov_b64 {S_G1}, %0")
+        e.salu(f"s_mov_b64 {S_G2}, %1")
+        e.salu(f"s_mov_b64 {S_FIN}, %2")
+        e.salu(f"s_mov_b64 {S_OUT}, %3")
+        e.salu(f"s_mov_b32 s{S_N}, %4")
+        e.salu(f"s_mov_b32 s{S_K}, %5")
+        e.salu(f"s_mov_b32 s{S_GSTRIDE}, %7")
+        e.salu(f"s_mov_b64 {S_STATUS}, %8")
+        e.salu(f"s_mov_b32 s{S_ITEM}, %10")
+        e.salu(f"s_mov_b32 s{S_GRID}, %11")
+        # scratch base of this workgroup: scratch + block * 256 * 80 ; lane offset = tid * 80
+        e.salu(f"s_mul_i32 s{S_TMP0}, %10, {256 * 4 * SLOT_DW}")
+        e.salu(f"s_mov_b64 {S_SCRATCH}, %6")
+        e.salu(f"s_add_u32 s64, s64, s{S_TMP0}")
+        e.salu("s_addc_u32 s65, s65, 0")
+        e.emit(f"v_mul_u32_u24_e32 v{V_GOFF}, {4 * SLOT_DW}, %9", vw=[V_GOFF])
+        e.emit(f"v_lshlrev_b32_e32 v{V_LDS}, 4, %9", vw=[V_LDS])
+        e.emit(f"v_add_u32_e32 v{V_LDS + 1}, 0x10000, v{V_LDS}", vw=[V_LDS + 1])
+        e.emit(f"v_add_u32_e32 v{V_LDS + 2}, 0x20000, v{V_LDS}", vw=[V_LDS + 2])
+        e.emit(f"v_mov_b32_e32 v{V_TID}, %9", vw=[V_TID])
+        for i in range(NL):
+            e.salu(f"s_mov_b32 s{S_P + i}, 0x{P_L[i]:x}")
+        e.salu(f"s_mov_b32 s{S_N0}, 0x{N0P:x}")
+        nz, neg = naf_masks(SIX_U_PLUS_2_NAF[:64])
+        e.salu(f"s_mov_b32 s68, 0x{nz & 0xFFFFFFFF:x}")
+        e.salu(f"s_mov_b32 s69, 0x{nz >> 32:x}")
+        e.salu(f"s_mov_b32 s70, 0x{neg & 0xFFFFFFFF:x}")
+        e.salu(f"s_mov_b32 s71, 0x{neg >> 32:x}")
+        xn = x_naf()
+        nz, neg = naf_masks(xn[:-1])
+        self.x_top = len(xn) - 1
+        e.salu(f"s_mov_b32 s72, 0x{nz & 0xFFFFFFFF:x}")
+        e.salu(f"s_mov_b32 s73, 0x{nz >> 32:x}")
+        e.salu(f"s_mov_b32 s74, 0x{neg & 0xFFFFFFFF:x}")
+        e.salu(f"s_mov_b32 s75, 0x{neg >> 32:x}")
+        e.salu(f"s_lshl_b32 s{S_NSTRIDE}, s{S_N}, 3")
+        e.salu(f"s_add_u32 s{S_NITEMS}, s{S_N}, 255")
+        e.salu(f"s_lshr_b32 s{S_NITEMS}, s{S_NITEMS}, 8")
+        e.emit(f"v_mov_b32_e32 v{V_FLAG}, 0", vw=[V_FLAG])
+        e.salu(f"s_branch {self.lab('L_main')}")
+
+    # ---------------------------------------------------------------------------------------------
+    def io_load_fq(self, e, reg0):
+        for l in range(4):
+            e.emit(f"global_load_dwordx2 v[{reg0 + 2 * l}:{reg0 + 2 * l + 1}], v{V_IDX8}, {S_IOADDR}", kind="vmem", vw=[reg0 + 2 * l, reg0 + 2 * l + 1])
+            self.io_walk_next(e)
+
+    def io_store_fq(self, e, reg0):
+        for l in range(4):
+            e.emit(f"global_store_dwordx2 v{V_IDX8}, v[{reg0 + 2 * l}:{reg0 + 2 * l + 1}], {S_IOADDR}", kind="vmem")
+            self.io_walk_next(e)
+
+    def zero_block(self, e, blk, n=SLOT_DW):
+        for i in range(n):
+            e.emit(f"v_mov_b32_e32 v{blk + i}, 0", vw=[blk + i])
+
+    def one_into_A(self, e):
+        w = to_limbs(mont3(1))
+        for i in range(NL):
+            e.emit(f"v_mov_b32_e32 v{A0 + i}, 0x{w[i]:x}", vw=[A0 + i])
+        self.zero_block(e, A0 + NL, NL)
+
+    def cvt_call(self, e, name):
+        e.salu(f"s_call_b64 {S_RET1}, {self.labels[name]}")
+
+    def io_load_fq2_into_A(self, e, p, c1_present=True):
+        """Loads c0 (and c1) of the SoA batch at the walking address, converts to internal form -> block A."""
+        if c1_present:
+            self.io_load_fq(e, 20)                 # c0 packed -> v[20:27] (block B as staging)
+            self.io_load_fq(e, A0)                 # c1 packed -> v[0:7]
+            e.raw("s_waitcnt vmcnt(0)")
+            self.cvt_call(e, "cvtin")              # A.c0 <- internal(c1)
+            for i in range(NL):
+                e.emit(f"v_mov_b32_e32 v{A0 + NL + i}, v{A0 + i}", vw=[A0 + NL + i])
+            for i in range(8):
+                e.emit(f"v_mov_b32_e32 v{A0 + i}, v{20 + i}", vw=[A0 + i])
+            self.cvt_call(e, "cvtin")
+        else:
+            self.io_load_fq(e, A0)
+            e.raw("s_waitcnt vmcnt(0)")
+            self.cvt_call(e, "cvtin")
+            self.zero_block(e, A0 + NL, NL)
+        p.set_A_fresh()
+        p.tagB = None
+
+    def _dbl_first(self, p):
+        p.dbl_step(self.R, (self.PX, self.PY), self.LINE, scale=None)
+        p.mov(self.F[0], self.LINE[0])
+        p.mov(self.F[3], self.LINE[1])
+        p.mov(self.F[4], self.LINE[2])
+        p.wait()
+        self.zero_block(p.e, A0)
+        p.set_A_fresh()
+        for k in (1, 2, 5):
+            p.store(A0, self.F[k])
+            p.slot_e[p.key(self.F[k])] = E_NORM
+
+    def _fq_inv(self, p):
+        """A.c0 <- A.c0^(p-2) (Fermat; fixed exponent).  Input/outputs normalised."""
+        e = p.e
+        base = self.FQINV_BASE
+        p.wait()
+        p.store(A0, base)
+        p.load(B0, base)
+        p.tagA = p.tagB = None
+        # exponent p - 2, canonical 32-bit words as literals in SGPR s61 per word
+        ex = P_INT - 2
+        words = [(ex >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
+        for limb in range(7, -1, -1):
+            top = 28 if limb == 7 else 31
+            lbl = self.lab(f"L_fqinv_{limb}_{id(p) & 0xffff}")
+            skip = self.lab(f"L_fqinv_skip_{limb}_{id(p) & 0xffff}")
+            e.salu(f"s_mov_b32 s{S_TMP1}, 0x{words[limb]:x}")
+            e.salu(f"s_mov_b32 s{S_TMP0}, {top}")
+            e.label(lbl)
+            e.salu(f"s_call_b64 {S_RET1}, {self.labels['fqsqr']}")
+            e.salu(f"s_bitcmp1_b32 s{S_TMP1}, s{S_TMP0}")
+            e.salu(f"s_cbranch_scc0 {skip}")
+            e.salu(f"s_call_b64 {S_RET1}, {self.labels['fqmul']}")
+            e.label(skip)
+            e.salu(f"s_sub_u32 s{S_TMP0}, s{S_TMP0}, 1")
+            e.salu(f"s_cbranch_scc0 {lbl}")
+        p.set_A_fresh()
+
+    def _fq2_inv_inline(self, p, src, dst):
+        e = p.e
+        n0, tmp = p.tmp(), p.tmp()
+        p.A(src)
+        if p.eA > E_NORM:
+            p.norm()
+        p._raw_call("fqsqr")
+        p.set_A_fresh()
+        p.to(n0)
+        p.A(src)
+        p.wait()
+        for i in range(NL):
+            e.emit(f"v_mov_b32_e32 v{A0 + i}, v{A0 + NL + i}", vw=[A0 + i])
+        eS = p.eA
+        p.tagA = None
+        p.eA = eS
+        if p.eA > E_NORM + 0.5:
+            p.norm()
+        p._raw_call("fqsqr")
+        p.set_A_fresh()
+        p.add(n0).norm()                                         # A.c0 = c0^2 + c1^2
+        # zero test needs the canonical representative: convert a copy out (value zero <-> all words zero)
+        p.to(tmp)
+        p.wait()
+        self.cvt_call(e, "cvtout")
+        e.emit(f"v_or3_b32 v{V_TID}, v{A0}, v{A0 + 1}, v{A0 + 2}", vw=[V_TID])
+        e.emit(f"v_or3_b32 v{V_TID}, v{V_TID}, v{A0 + 3}, v{A0 + 4}", vw=[V_TID])
+        e.emit(f"v_or3_b32 v{V_TID}, v{V_TID}, v{A0 + 5}, v{A0 + 6}", vw=[V_TID])
+        e.emit(f"v_or_b32_e32 v{V_TID}, v{V_TID}, v{A0 + 7}", vw=[V_TID])
+        e.emit(f"v_cmp_eq_u32_e32 vcc, 0, v{V_TID}", w=["vcc"])
+        e.emit(f"v_cndmask_b32_e64 v{V_TID}, 0, 1, vcc", r=["vcc"], vw=[V_TID])
+        e.emit(f"v_or_b32_e32 v{V_FLAG}, v{V_FLAG}, v{V_TID}", vw=[V_FLAG])
+        p.tagA = None
+        p.A(tmp)
+        p.wait()
+        e.salu(f"s_mov_b64 {S_RET3}, {S_RET2}")
+        e.salu(f"s_call_b64 {S_RET2}, {self.lab('L2_fqinv')}")
+        e.salu(f"s_mov_b64 {S_RET2}, {S_RET3}")
+        p.set_A_fresh()
+        p.tagB = None
+        p.to(tmp)
+        p.A(src).mulfq(tmp).conj().to(dst)
+        p.rel(n0, tmp)
+
+    # ---------------------------------------------------------------------------------------------
+    def main_body(self, e):
+        L = self.lab
+        e.label(L("L_main"))
+        e.label(L("L_item"))
+        e.salu(f"s_cmp_ge_u32 s{S_ITEM}, s{S_NITEMS}")
+        e.salu(f"s_cbranch_scc1 {L('L_done')}")
+        e.salu(f"s_lshl_b32 s{S_TMP0}, s{S_ITEM}, 8")
+        e.emit(f"v_add_u32_e32 v{V_IDX}, s{S_TMP0}, v{V_TID}", vw=[V_IDX])
+        e.salu(f"s_sub_u32 s{S_TMP1}, s{S_N}, 1")
+        e.emit(f"v_min_u32_e32 v{V_IDX8}, s{S_TMP1}, v{V_IDX}", vw=[V_IDX8])
+        e.emit(f"v_lshlrev_b32_e32 v{V_IDX8}, 3, v{V_IDX8}", vw=[V_IDX8])
+        e.emit(f"v_mov_b32_e32 v{V_FLAG}, 0", vw=[V_FLAG])
+        p = Prog3(e, self.labels)
+        p.set_temps(self.miller_temps())
+        if self.do_miller:
+            self.miller_main(e, p)
+        else:
+            # f_in (MyFq12, SoA): components 0..5 are the c0 parts of w^0..w^5, 6..11 the c1 parts.
+            # two passes over the batch: c1 parts first into AGPR staging, then c0 parts
+            self.io_walk_begin(e, S_FIN)
+            for k in range(6):
+                self.io_load_fq(e, A0)
+                e.raw("s_waitcnt vmcnt(0)")
+                self.cvt_call(e, "cvtin")
+                for i in range(NL):
+                    e.emit(f"v_accvgpr_write_b32 a{NL * k + i}, v{A0 + i}")       # c0 of coefficient k
+            for k in range(6):
+                self.io_load_fq(e, A0)
+                e.raw("s_waitcnt vmcnt(0)")
+                self.cvt_call(e, "cvtin")
+                for i in range(NL):
+                    e.emit(f"v_mov_b32_e32 v{A0 + NL + i}, v{A0 + i}", vw=[A0 + NL + i])
+                for i in range(NL):
+                    e.emit(f"v_accvgpr_read_b32 v{A0 + i}, a{NL * k + i}", vw=[A0 + i])
+                p.set_A_fresh()
+                p.to(self.F[k])
+            p.reset_tags()
+        if self.do_fexp:
+            self.fexp_main(e, p)
+        self.store_out(e, p)
+        e.salu(f"s_add_u32 s{S_ITEM}, s{S_ITEM}, s{S_GRID}")
+        e.salu(f"s_branch {L('L_item')}")
+        e.label(L("L_done"))
+
+    def miller_main(self, e, p):
+        L = self.lab
+        self.io_walk_begin(e, S_G1)
+        self.io_load_fq2_into_A(e, p, c1_present=False)          # Px
+        p.to(self.PX)
+        self.io_load_fq2_into_A(e, p, c1_present=False)          # Py
+        p.to(self.PY)
+        self.io_walk_begin(e, S_G2)
+        self.io_load_fq2_into_A(e, p)                            # Q.x
+        p.to(self.QX)
+        p.store(A0, self.R[0])
+        p.slot_e[p.key(self.R[0])] = E_NORM
+        self.io_load_fq2_into_A(e, p)                            # Q.y
+        p.to(self.QY)
+        p.store(A0, self.R[1])
+        p.slot_e[p.key(self.R[1])] = E_NORM
+        self.one_into_A(e)
+        p.set_A_fresh()
+        p.to(self.R[2])
+        if self.track:
+            p.store(A0, self.SCALE)
+        p.reset_tags()
+        self.call2(e, "L2_dblfirst")
+        e.salu(f"s_mov_b32 s{S_I}, 63")
+        e.label(L("L_mloop"))
+        e.salu(f"s_cmp_eq_u32 s{S_I}, 63")
+        e.salu(f"s_cbranch_scc1 {L('L_mskip')}")
+        self.call2(e, "L2_sqr")
+        if self.track:
+            self.call2(e, "L2_sqscale")
+        self.call2(e, "L2_dblmul")
+        e.label(L("L_mskip"))
+        e.salu(f"s_bitcmp1_b64 {S_NAF_NZ}, s{S_I}")
+        e.salu(f"s_cbranch_scc0 {L('L_mnoadd')}")
+        p.reset_tags()
+        p.mov(self.SX, self.QX)
+        p.A(self.QY)
+        p.wait()
+        e.salu(f"s_bitcmp1_b64 {S_NAF_NEG}, s{S_I}")
+        e.salu(f"s_cbranch_scc0 {L('L_mpos')}")
+        e.salu(f"s_call_b64 {S_RET1}, {self.labels['neg']}")
+        e.label(L("L_mpos"))
+        p.tagA = None
+        p.to(self.SY)
+        self.call2(e, "L2_addmul")
+        e.label(L("L_mnoadd"))
+        e.salu(f"s_sub_u32 s{S_I}, s{S_I}, 1")
+        e.salu(f"s_cbranch_scc0 {L('L_mloop')}")
+        xi = (9, 1)
+        c = f2pow(xi, (P_INT - 1) // 6)
+        c2 = f2mul(c, c)
+        c3 = f2mul(c2, c)
+        C2, C3 = Const(c2[0], c2[1], "c2"), Const(c3[0], c3[1], "c3")
+        p.reset_tags()
+        p.A(self.QX).conj().mul(C2).to(self.SX)
+        p.A(self.QY).conj().mul(C3).to(self.SY)
+        self.call2(e, "L2_addmul")
+        p.reset_tags()
+        p.A(self.SX).conj().mul(C2).to(self.SX)
+        p.A(self.SY).conj().neg().mul(C3).to(self.SY)
+        self.call2(e, "L2_addmul_last")
+        if self.track:
+            self.call2(e, "L2_descale")
+        p.reset_tags()
+
+    def store_out(self, e, p):
+        p.reset_tags()
+        e.emit(f"v_cmp_gt_u32_e32 vcc, s{S_N}, v{V_IDX}", w=["vcc"])
+        e.raw("s_nop 1")
+        e.salu(f"s_and_saveexec_b64 {S_SAVE_EXEC}, vcc")
+        self.io_walk_begin(e, S_OUT)
+        for half in range(2):
+            for k in range(6):
+                p.load(A0, self.F[k])
+                p.wait()
+                if half == 1:
+                    for i in range(NL):
+                        e.emit(f"v_mov_b32_e32 v{A0 + i}, v{A0 + NL + i}", vw=[A0 + i])
+                self.cvt_call(e, "cvtout")
+                self.io_store_fq(e, A0)
+                e.raw("s_nop 1")
+        e.emit(f"v_cmp_ne_u32_e32 vcc, 0, v{V_FLAG}", w=["vcc"])
+        e.raw("s_nop 1")
+        e.salu("s_and_saveexec_b64 s[60:61], vcc")
+        e.emit(f"v_mov_b32_e32 v{V_IDX8}, 1", vw=[V_IDX8])
+        e.emit("v_mov_b32_e32 v40, 0", vw=[40])
+        e.emit(f"global_store_dword v40, v{V_IDX8}, {S_STATUS}", kind="vmem")
+        e.salu(f"s_mov_b64 exec, {S_SAVE_EXEC}")
+        e.raw("s_waitcnt vmcnt(0)")
+        e.emit(f"v_lshrrev_b32_e32 v{V_TID}, 4, v{V_LDS}", vw=[V_TID])

@@ -287,56 +287,48 @@ class Prog:
         self.rel(V0, V1, V2, S)
 
     def fq12_sqr(self, F):
-        """F <- F^2 in place (complex squaring over Fq6)."""
+        """F <- F^2 in place (complex squaring over Fq6: t = A0 A1, u = (A0 + A1)(A0 + v A1))."""
         T = [self.tmp() for _ in range(3)]
-        SA = [self.tmp() for _ in range(3)]
         SB = [self.tmp() for _ in range(3)]
         A_0, A_1 = [F[0], F[2], F[4]], [F[1], F[3], F[5]]
         self.fq6_mul(A_0, A_1, T)
-        for i in range(3):
-            self.A(A_0[i]).add(A_1[i]).to(SA[i])
         self.A(F[5]).mulxi().add(F[0]).to(SB[0])
         self.A(F[2]).add(F[1]).to(SB[1])
         self.A(F[4]).add(F[3]).to(SB[2])
-        U = [F[0], F[2], F[4]]
-        self.fq6_mul(SA, SB, U)
-        for s in SA + SB:
+        for i in range(3):
+            self.A(A_0[i]).add(A_1[i]).to(A_0[i])          # SA in place of A0 (A0 is dead from here)
+        U = A_1                                            # A1 is dead too: u lands in the odd slots
+        self.fq6_mul(A_0, SB, U)
+        for s in SB:
             self.rel(s)
         X = self.tmp()
         self.A(T[2]).mulxi().to(X)
-        self.A(F[0]).sub(T[0]).sub(X).to(F[0])
-        self.A(F[2]).sub(T[1]).sub(T[0]).to(F[2])
-        self.A(F[4]).sub(T[2]).sub(T[1]).to(F[4])
+        self.A(U[0]).sub(T[0]).sub(X).to(F[0])
+        self.A(U[1]).sub(T[1]).sub(T[0]).to(F[2])
+        self.A(U[2]).sub(T[2]).sub(T[1]).to(F[4])
         self.A(T[0]).dbl().to(F[1])
         self.A(T[1]).dbl().to(F[3])
         self.A(T[2]).dbl().to(F[5])
         self.rel(X, *T)
 
     def fq12_mul(self, F, Bs, conj_b=False):
-        """F <- F * B (B: six slots, left intact).  conj_b: use conjugate_fp12(B) (odd coefficients negated)."""
+        """F <- F * B.  B (six slots) is a private copy and is DESTROYED (its even slots end up holding B0 + B1).
+        conj_b: use conjugate_fp12(B) (odd coefficients negated in place first)."""
         b = list(Bs)
-        neg_tmp = []
         if conj_b:
             for k in (1, 3, 5):
-                t = self.tmp()
-                self.A(Bs[k]).neg().to(t)
-                b[k] = t
-                neg_tmp.append(t)
+                self.A(Bs[k]).neg().to(Bs[k])
         A_0, A_1 = [F[0], F[2], F[4]], [F[1], F[3], F[5]]
         B_0, B_1 = [b[0], b[2], b[4]], [b[1], b[3], b[5]]
         T0 = [self.tmp() for _ in range(3)]
         T1 = [self.tmp() for _ in range(3)]
-        SA = [self.tmp() for _ in range(3)]
-        SB = [self.tmp() for _ in range(3)]
         self.fq6_mul(A_0, B_0, T0)
         self.fq6_mul(A_1, B_1, T1)
         for i in range(3):
-            self.A(A_0[i]).add(A_1[i]).to(SA[i])
-            self.A(B_0[i]).add(B_1[i]).to(SB[i])
-        M = [F[1], F[3], F[5]]
-        self.fq6_mul(SA, SB, M)
-        for s in SA + SB:
-            self.rel(s)
+            self.A(A_0[i]).add(A_1[i]).to(A_0[i])          # SA in place of A0
+            self.A(B_0[i]).add(B_1[i]).to(B_0[i])          # SB in place of B0
+        M = A_1
+        self.fq6_mul(A_0, B_0, M)
         for i in range(3):
             self.A(M[i]).sub(T0[i]).sub(T1[i]).to(M[i])
         self.A(T1[2]).mulxi().add(T0[0]).to(F[0])
@@ -344,7 +336,6 @@ class Prog:
         self.A(T0[2]).add(T1[1]).to(F[4])
         self.rel(*T0)
         self.rel(*T1)
-        self.rel(*neg_tmp)
 
     def fq4_sqr(self, a, b, r0, r1):
         """(a + b y)^2, y^2 = xi -> r0 = a^2 + xi b^2, r1 = 2ab (r0, r1 temp slots distinct from a, b)."""

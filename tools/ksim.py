@@ -38,6 +38,7 @@ class Machine:
         self.count = 0        # dynamic instruction count
         self.count_valu = 0
         self.count_nop = 0
+        self.max_acc = 0      # largest |column accumulator| seen (v3 kernels)
 
     # ---------------------------------------------------------------- scalar register helpers
     def sget(self, name):
@@ -160,6 +161,58 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None):
                 v[lo] = r & M32
                 v[lo + 1] = (r >> 32) & M32
                 m.carry_out(a[1], (r >> 64) & 1)
+                m.count_valu += 1
+            elif op == "v_mad_i64_i32":
+                x, y = m.vsrc(a[2]), m.vsrc(a[3])
+                x = x - (1 << 32) if x >> 31 else x
+                y = y - (1 << 32) if y >> 31 else y
+                c = m.vsrc64(a[4])
+                c = c - (1 << 64) if c >> 63 else c
+                r = x * y + c
+                if not (-(1 << 63) <= r < (1 << 63)):
+                    raise SimError("signed 64-bit column accumulator overflow")
+                m.max_acc = max(m.max_acc, abs(r))
+                lo = int(re.match(r"v\[(\d+):", a[0]).group(1))
+                if lo % 2:
+                    raise SimError("odd-aligned 64-bit VGPR dest")
+                v[lo] = r & M32
+                v[lo + 1] = (r >> 32) & M32
+                m.carry_out(a[1], 0)
+                m.count_valu += 1
+            elif op == "v_ashrrev_i64":
+                sh = m.vsrc(a[1]) & 63
+                c = m.vsrc64(a[2])
+                c = c - (1 << 64) if c >> 63 else c
+                r = c >> sh
+                lo = int(re.match(r"v\[(\d+):", a[0]).group(1))
+                v[lo] = r & M32
+                v[lo + 1] = (r >> 32) & M32
+                m.count_valu += 1
+            elif op == "v_ashrrev_i32_e32":
+                x = m.vsrc(a[2])
+                x = x - (1 << 32) if x >> 31 else x
+                m.vset(a[0], x >> (m.vsrc(a[1]) & 31))
+                m.count_valu += 1
+            elif op == "v_lshl_add_u32":
+                m.vset(a[0], (m.vsrc(a[1]) << (m.vsrc(a[2]) & 31)) + m.vsrc(a[3]))
+                m.count_valu += 1
+            elif op == "v_lshl_or_b32":
+                m.vset(a[0], (m.vsrc(a[1]) << (m.vsrc(a[2]) & 31)) | m.vsrc(a[3]))
+                m.count_valu += 1
+            elif op == "v_sub_u32_e32":
+                m.vset(a[0], m.vsrc(a[1]) - m.vsrc(a[2]))
+                m.count_valu += 1
+            elif op == "v_subrev_u32_e32":
+                m.vset(a[0], m.vsrc(a[2]) - m.vsrc(a[1]))
+                m.count_valu += 1
+            elif op == "v_bfe_u32":
+                m.vset(a[0], (m.vsrc(a[1]) >> (m.vsrc(a[2]) & 31)) & ((1 << (m.vsrc(a[3]) & 31)) - 1))
+                m.count_valu += 1
+            elif op == "v_cmp_gt_i32_e32":
+                x, y = m.vsrc(a[1]), m.vsrc(a[2])
+                x = x - (1 << 32) if x >> 31 else x
+                y = y - (1 << 32) if y >> 31 else y
+                m.carry_out(a[0], 1 if x > y else 0)
                 m.count_valu += 1
             elif op in ("v_addc_co_u32_e64", "v_addc_co_u32_e32"):
                 r = m.vsrc(a[2]) + m.vsrc(a[3]) + m.carry_in(a[4])
