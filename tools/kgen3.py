@@ -165,65 +165,48 @@ class L1v3:
 
     # ------------------------------------------------------------------ routines: A <- op(A, B)
     def r_mul(self):
+        """(a0 + a1 u)(b0 + b1 u): two fused two-product passes.  Result limb j of a pass is produced after
+        column j + NL, when operand limb a_j is dead, so each pass writes its result in place: c1 over a1
+        (pass 1: a0 b1 + a1 b0), then c0 over a0 (pass 2: a0 b0 + (-a1) b1 with -a1 kept in temporaries)."""
         a0, a1, b0, b1 = self.blk(A0, 0), self.blk(A0, 1), self.blk(B0, 0), self.blk(B0, 1)
         na1 = [self.pool.alloc() for _ in range(NL)]
         for i in range(NL):
             self.e.emit(f"v_sub_u32_e32 v{na1[i]}, 0, v{a1[i]}", vw=[na1[i]])
-        c0 = [self.pool.alloc() for _ in range(NL)]
-        self.fips_direct([(a0, b0), (na1, b1)], c0)
+        self.fips_direct([(a1, b0), (a0, b1)], a1)
+        self.fips_direct([(a0, b0), (na1, b1)], a0)
         self.pool.free(*na1)
-        c1 = [self.pool.alloc() for _ in range(NL)]
-        self.fips_direct([(a0, b1), (a1, b0)], c1)
-        for i in range(NL):
-            self.e.emit(f"v_mov_b32_e32 v{a0[i]}, v{c0[i]}", vw=[a0[i]])
-            self.e.emit(f"v_mov_b32_e32 v{a1[i]}, v{c1[i]}", vw=[a1[i]])
-        self.pool.free(*c0)
-        self.pool.free(*c1)
 
     def r_sqr(self):
-        """(a0 + a1 u)^2 = (a0+a1)(a0-a1) + 2 a0 a1 u"""
+        """(a0 + a1 u)^2 = (a0+a1)(a0-a1) + 2 a0 a1 u ; both passes write in place."""
         a0, a1 = self.blk(A0, 0), self.blk(A0, 1)
-        d = [self.pool.alloc() for _ in range(NL)]
-        self.limbwise("v_add_u32_e32", d, a0, a0)
-        c1 = [self.pool.alloc() for _ in range(NL)]
-        self.fips_direct([(d, a1)], c1)
-        t = d                                               # d is dead: reuse for a0 + a1
+        t = [self.pool.alloc() for _ in range(NL)]
+        u = [self.pool.alloc() for _ in range(NL)]
         self.limbwise("v_add_u32_e32", t, a0, a1)
-        self.limbwise("v_sub_u32_e32", a1, a0, a1)          # u = a0 - a1 in place of a1
-        self.fips_direct([(t, a1)], a0)                     # a0 is dead (t and u hold what is needed)
-        for i in range(NL):
-            self.e.emit(f"v_mov_b32_e32 v{a1[i]}, v{c1[i]}", vw=[a1[i]])
-        self.pool.free(*d)
-        self.pool.free(*c1)
+        self.limbwise("v_sub_u32_e32", u, a0, a1)
+        for r in a0:
+            self.e.emit(f"v_lshlrev_b32_e32 v{r}, 1, v{r}", vw=[r])     # a0 <- 2 a0 (t, u already hold what c0 needs)
+        self.fips_direct([(a1, a0)], a1)                                # c1 = a1 * 2a0, in place over a1
+        self.fips_direct([(t, u)], a0)                                  # c0 over (dead) a0; t, u are temporaries
+        self.pool.free(*t)
+        self.pool.free(*u)
 
     def r_mulfq(self):
-        """A <- (A.c0 * B.c0, A.c1 * B.c0)"""
+        """A <- (A.c0 * B.c0, A.c1 * B.c0), in place"""
         a0, a1, k = self.blk(A0, 0), self.blk(A0, 1), self.blk(B0, 0)
-        c0 = [self.pool.alloc() for _ in range(NL)]
-        self.fips_direct([(a0, k)], c0)
-        c1 = [self.pool.alloc() for _ in range(NL)]
-        self.fips_direct([(a1, k)], c1)
-        for i in range(NL):
-            self.e.emit(f"v_mov_b32_e32 v{a0[i]}, v{c0[i]}", vw=[a0[i]])
-            self.e.emit(f"v_mov_b32_e32 v{a1[i]}, v{c1[i]}", vw=[a1[i]])
-        self.pool.free(*c0)
-        self.pool.free(*c1)
+        self.fips_direct([(a0, k)], a0)
+        self.fips_direct([(a1, k)], a1)
 
     def r_fqmul(self):
         a0, k = self.blk(A0, 0), self.blk(B0, 0)
-        c0 = [self.pool.alloc() for _ in range(NL)]
-        self.fips_direct([(a0, k)], c0)
-        for i in range(NL):
-            self.e.emit(f"v_mov_b32_e32 v{a0[i]}, v{c0[i]}", vw=[a0[i]])
-        self.pool.free(*c0)
+        self.fips_direct([(a0, k)], a0)
 
     def r_fqsqr(self):
         a0 = self.blk(A0, 0)
-        c0 = [self.pool.alloc() for _ in range(NL)]
-        self.fips_direct([(a0, a0)], c0)
+        t = [self.pool.alloc() for _ in range(NL)]
         for i in range(NL):
-            self.e.emit(f"v_mov_b32_e32 v{a0[i]}, v{c0[i]}", vw=[a0[i]])
-        self.pool.free(*c0)
+            self.e.emit(f"v_mov_b32_e32 v{t[i]}, v{a0[i]}", vw=[t[i]])
+        self.fips_direct([(a0, t)], a0)
+        self.pool.free(*t)
 
     def r_add(self):
         for h in range(2):
@@ -236,6 +219,19 @@ class L1v3:
     def r_rsub(self):
         for h in range(2):
             self.limbwise("v_sub_u32_e32", self.blk(A0, h), self.blk(B0, h), self.blk(A0, h))
+
+    def home_variant(self, op, idx):
+        """A <- A op HOME[idx] with the operand read straight from its home registers (no marshalling)."""
+        h0 = HOME0 + SLOT_DW * idx
+        for half in range(2):
+            a = self.blk(A0, half)
+            h = list(range(h0 + NL * half, h0 + NL * half + NL))
+            if op == "add":
+                self.limbwise("v_add_u32_e32", a, a, h)
+            elif op == "sub":
+                self.limbwise("v_sub_u32_e32", a, a, h)
+            else:
+                self.limbwise("v_sub_u32_e32", a, h, a)
 
     def r_dbl(self):
         for h in range(2):

@@ -156,7 +156,7 @@ class Prog3(KP.Prog):
         if not ok:
             raise AssertionError("bound violated: " + what)
 
-    def call(self, name, eB=None):
+    def call(self, name, eB=None, direct=None):
         eA = self.eA if self.eA is not None else E_STORE_MAX
         if name == "mul":
             if math.log2(2 * NL) + eA + eB > COL_LIMIT:
@@ -197,11 +197,13 @@ class Prog3(KP.Prog):
             out = E_NORM
         else:
             raise ValueError(name)
-        self._raw_call(name)
+        self._raw_call(direct or name)
         self.eA = out
         return self
 
     def _bin(self, name, y):
+        if y.kind == "home" and name in ("add", "sub", "rsub"):
+            return self.call(name, self.e_of(y), direct=f"{name}_h{y.idx}")
         self._B(y)
         return self.call(name, self.e_of(y))
 
@@ -231,6 +233,9 @@ class KernelBuilder3(KP.KernelBuilder):
     def __init__(self, do_miller=True, do_fexp=True, track=False):
         super().__init__(do_miller, do_fexp, track)
         self.labels = {n: f"L1_{n}_%=" for n in L1V3_NAMES}
+        for op in ("add", "sub", "rsub"):
+            for i in range(N_HOME):
+                self.labels[f"{op}_h{i}"] = f"L1_{op}_h{i}_%="
 
     def new_prog(self, temps):
         e = Emitter()
@@ -258,6 +263,12 @@ class KernelBuilder3(KP.KernelBuilder):
             l1e.label(self.labels[n])
             getattr(g, "r_" + n)()
             l1e.salu(f"s_setpc_b64 {S_RET1}")
+        for op in ("add", "sub", "rsub"):
+            for i in range(N_HOME):
+                g = L1v3(l1e)
+                l1e.label(self.labels[f"{op}_h{i}"])
+                g.home_variant(op, i)
+                l1e.salu(f"s_setpc_b64 {S_RET1}")
         self.sections = []
         if self.do_miller:
             sc = self.SCALE if self.track else None
