@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log2-batch", type=int, default=LOG2_BATCH, help="pairings per GPU per step = 2^k (default: configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extra", action="store_true", help="also time configs[2] (2^20 pairings) and configs[3] (Groth16: 2^18 groups x 4 pairs); "
+                                                        "reported under \"extra\" in the same JSON line")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -65,6 +67,37 @@ def cpu_baseline(pkg, g1_soa, g2_soa, n_avail, seconds):
     return {"value": done / dt, "unit": "pairings/s", "cores": cores, "kind": "port",
             "sample": f"first {done} pairings of the same batch, C oracle (reference schedule: affine G2 steps with an inversion "
                       f"per step, NAF pow with divisions), {cores} pthreads, {dt:.1f} s"}
+
+
+def extra_configs(pkg, torch, dev, local_rank, stream):
+    """BASELINE.json configs[2] and configs[3] on one GPU (not the headline `value`)."""
+    out = {}
+
+    def timed(fn, reps=2):
+        fn()
+        torch.cuda.synchronize(dev)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        for _ in range(reps):
+            fn()
+        b.record(stream)
+        torch.cuda.synchronize(dev)
+        return a.elapsed_time(b) / reps
+
+    n = 1 << 20
+    g1 = torch.zeros(8 * n, dtype=torch.int64, device=dev)
+    g2 = torch.zeros(16 * n, dtype=torch.int64, device=dev)
+    o = torch.zeros(48 * n, dtype=torch.int64, device=dev)
+    pkg.generate_pairs_dev(0xB2540002, g1, g2, n, device=local_rank, stream=stream)
+    ms = timed(lambda: pkg.pairing_batch_dev(g1, g2, o, n, device=local_rank, stream=stream))
+    out["2^20 independent pairings"] = {"ms": ms, "pairings_per_s": n / (ms * 1e-3)}
+    groups, k = 1 << 18, 4
+    o2 = torch.zeros(48 * groups, dtype=torch.int64, device=dev)
+    ms = timed(lambda: pkg.multi_pairing_batch_dev(g1, g2, o2, groups, k, True, device=local_rank, stream=stream))
+    out["Groth16 shape: 2^18 groups x 4 pairs, shared final exp"] = {"ms": ms, "groups_per_s": groups / (ms * 1e-3),
+                                                                      "pairs_per_s": groups * k / (ms * 1e-3)}
+    pkg.last_status(local_rank, stream)
+    return out
 
 
 def main():
@@ -143,6 +176,8 @@ def main():
                          "frac_of_nominal_quarter_rate_peak": achieved / NOMINAL_PEAK_MUL32_PER_S,
                          "hbm_note": "algorithmic HBM bytes are 576 B/pairing (<0.01% of 8 TB/s): not the bound"},
         }
+        if args.extra and world == 1:
+            rec["extra"] = extra_configs(pkg, torch, dev, local_rank, stream)
         if world == 1 and not args.no_cpu_baseline:
             m = min(n, 1 << 14)
             g1h = g1.cpu().numpy().view(np.uint64).reshape(8, n)[:, :m].reshape(-1).copy()

@@ -227,7 +227,9 @@ BN254_ASM_KERNEL(k2_fexp, BN254_ASM_FEXP)
 BN254_ASM_KERNEL(k3_pairing, BN254_ASM3_PAIRING)
 BN254_ASM_KERNEL(k3_miller, BN254_ASM3_MILLER)
 BN254_ASM_KERNEL(k3_fexp, BN254_ASM3_FEXP)
-constexpr int V3_GSLOTS = 56;         // eight Fq12 registers + eight overflow temporaries
+BN254_ASM_KERNEL(k3_mpairing, BN254_ASM3_MPAIRING)   // k pairs per lane, shared f (multi_miller_loop_native) + final exp
+BN254_ASM_KERNEL(k3_mmiller, BN254_ASM3_MMILLER)     // k pairs per lane, exact multi_miller_loop_native value
+constexpr int V3_GSLOTS = 56;         // eight Fq12 registers + eight overflow temporaries (+ 7 per pair in the multi kernels)
 constexpr int V3_SLOT_BYTES = 80;
 
 enum { OP_MUL = 0, OP_FROB = 1, OP_POW = 2, OP_INV = 3, OP_SQR = 4, OP_CYC_SQR = 5 };
@@ -395,13 +397,15 @@ int ctx_get(int device, size_t k, DeviceCtx** out, uint32_t* grid_out, size_t n_
         HIPCHK(hipFuncSetAttribute((const void*)k3_pairing, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
         HIPCHK(hipFuncSetAttribute((const void*)k3_miller, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
         HIPCHK(hipFuncSetAttribute((const void*)k3_fexp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k3_mpairing, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k3_mmiller, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
         c.init = true;
     }
     uint32_t grid = (uint32_t)(n_items < (size_t)c.n_cu ? n_items : (size_t)c.n_cu);
     if (grid == 0) grid = 1;
     size_t slots = N_GSLOTS_BASE + 3 * (k > 1 ? k : 0);
     size_t need = slots * 64 * (size_t)c.n_cu * BLOCK;   // sized for a full grid so the buffer is stable
-    size_t need3 = (size_t)V3_GSLOTS * V3_SLOT_BYTES * (size_t)c.n_cu * BLOCK;
+    size_t need3 = (size_t)(V3_GSLOTS + 7 * (k > 1 ? k : 0)) * V3_SLOT_BYTES * (size_t)c.n_cu * BLOCK;
     if (need3 > need) need = need3;
     if (need > c.scratch_bytes) {
         if (c.scratch) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(c.scratch)); c.scratch = nullptr; c.scratch_bytes = 0; }
@@ -432,6 +436,16 @@ int launch_pairing(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in,
                                        (uint32_t)n_groups, 1u, c->scratch, stride, c->status);
         else hipLaunchKernelGGL(k3_fexp, dim3(grid), dim3(BLOCK), LDS_BYTES, (hipStream_t)stream, g1, g2, f_in, out,
                                 (uint32_t)n_groups, 1u, c->scratch, stride, c->status);
+        HIPCHK(hipGetLastError());
+        return BN254_OK;
+    }
+    if (k > 1 && M && !use_v1 && !use_v2) {
+        if (n_groups * k >= (1ull << 29)) return BN254_ERR_INVALID_ARG;
+        uint32_t stride = grid * BLOCK * V3_SLOT_BYTES;
+        if (F) hipLaunchKernelGGL(k3_mpairing, dim3(grid), dim3(BLOCK), LDS_BYTES, (hipStream_t)stream, g1, g2, f_in, out,
+                                  (uint32_t)n_groups, (uint32_t)k, c->scratch, stride, c->status);
+        else hipLaunchKernelGGL(k3_mmiller, dim3(grid), dim3(BLOCK), LDS_BYTES, (hipStream_t)stream, g1, g2, f_in, out,
+                                (uint32_t)n_groups, (uint32_t)k, c->scratch, stride, c->status);
         HIPCHK(hipGetLastError());
         return BN254_OK;
     }
@@ -561,7 +575,7 @@ int bn254_last_status(int device, void* stream) {
 size_t bn254_scratch_bytes(size_t n, size_t k) {
     (void)n;
     size_t v1 = (size_t)(N_GSLOTS_BASE + 3 * (k > 1 ? k : 0)) * 64 * 256 * BLOCK;
-    size_t v3 = (size_t)V3_GSLOTS * V3_SLOT_BYTES * 256 * BLOCK;
+    size_t v3 = (size_t)(V3_GSLOTS + 7 * (k > 1 ? k : 0)) * V3_SLOT_BYTES * 256 * BLOCK;
     return v1 > v3 ? v1 : v3;
 }
 

@@ -85,3 +85,76 @@ def test_oracle_parity_ragged_batch():
     want_m = H.oracle_miller(g1a[: 8 * 40], g2a[: 16 * 40], 40)
     got_m = H.to_aos(pk.miller_loop_batch(H.to_soa(g1a[: 8 * 40], 8), H.to_soa(g2a[: 16 * 40], 16), 40), 48)
     assert np.array_equal(got_m, want_m)
+
+
+def test_multi_pairing_batch_vs_oracle():
+    """Groth16 shape (k = 4) and k = 3 over a ragged batch of groups; shared-f Miller value and final value."""
+    pk = H.pkg()
+    base_P, base_Q = H.subgroup_points(8)
+    for k, n_groups in ((4, 70), (3, 5)):
+        n = n_groups * k
+        P = [base_P[(i * 5 + 1) % 8] for i in range(n)]
+        Q = [base_Q[(i * 3 + i // 8) % 8] for i in range(n)]
+        g1a, g2a = H.g1_aos(P), H.g2_aos(Q)
+        g1, g2 = H.to_soa(g1a, 8), H.to_soa(g2a, 16)
+        want_m = H.oracle_multi_miller(g1a, g2a, n_groups, k)
+        got_m = H.to_aos(pk.multi_pairing_batch(g1, g2, n_groups, k, do_final_exp=False), 48)
+        assert np.array_equal(got_m, want_m), f"multi_miller_loop_native k={k}"
+        want = H.oracle_multi_pairing(g1a, g2a, n_groups, k)
+        got = H.to_aos(pk.multi_pairing_batch(g1, g2, n_groups, k, do_final_exp=True), 48)
+        assert np.array_equal(got, want), f"multi pairing k={k}"
+
+
+def test_groth16_style_product_is_one():
+    """e(aP, bQ) e(abP, -Q) = 1 for every group (T3 pattern, final_exp_native.rs:245-263), on device-generated points."""
+    import torch
+    pk = H.pkg()
+    vec = H.load_golden("bn254_vectors.json")
+    t3 = vec["t3"]
+    P3 = [tuple(int(x, 16) for x in p) for p in t3["g1"]]
+    Q3 = [((int(q[0], 16), int(q[1], 16)), (int(q[2], 16), int(q[3], 16))) for q in t3["g2"]]
+    n_groups = 300
+    g1 = H.to_soa(H.g1_aos(P3 * n_groups), 8)
+    g2 = H.to_soa(H.g2_aos(Q3 * n_groups), 16)
+    out = H.fq12_from_aos(H.to_aos(pk.multi_pairing_batch(g1, g2, n_groups, 2, do_final_exp=True), 48), n_groups)
+    one = [1] + [0] * 11
+    assert all(o == one for o in out)
+
+
+def test_final_exp_zero_is_an_error():
+    """final_exp_native(0): the reference panics (division by zero, final_exp_native.rs:200)."""
+    pk = H.pkg()
+    with pytest.raises(pk.Bn254Error) as ei:
+        pk.final_exp_batch(np.zeros(48 * 3, dtype=np.uint64), 3)
+    assert ei.value.status == pk.ERR_ZERO_DIVISOR
+    # and the status word is cleared afterwards
+    x = H.to_soa(H.fq12_aos([[1] + [0] * 11]), 48)
+    assert H.fq12_from_aos(pk.final_exp_batch(x, 1), 1)[0] == [1] + [0] * 11
+
+
+def test_large_batch_properties():
+    """BASELINE configs[1] size (2^16): on-device inputs, spot-check vs oracle + bilinearity-free invariants:
+    every output is in the order-r subgroup's image under x -> x^r == 1 is too slow on CPU for all, so check
+    (a) 64 random positions against the oracle, (b) determinism of two runs, (c) no lane wrote outside its slot."""
+    import torch
+    pk = H.pkg()
+    n = 1 << 16
+    dev = torch.device("cuda:0")
+    g1 = torch.zeros(8 * n, dtype=torch.int64, device=dev)
+    g2 = torch.zeros(16 * n, dtype=torch.int64, device=dev)
+    out = torch.full((48 * n + 64,), -1, dtype=torch.int64, device=dev)      # guard words behind the output
+    out2 = torch.zeros(48 * n, dtype=torch.int64, device=dev)
+    st = torch.cuda.current_stream(dev)
+    pk.generate_pairs_dev(0xB2540001, g1, g2, n, 0, st)
+    pk.pairing_batch_dev(g1, g2, out, n, 0, st)
+    pk.pairing_batch_dev(g1, g2, out2, n, 0, st)
+    pk.last_status(0, st)
+    assert torch.equal(out[:48 * n], out2)
+    assert bool((out[48 * n:] == -1).all())
+    rng = np.random.default_rng(5)
+    pos = np.sort(rng.choice(n, size=64, replace=False))
+    g1h = g1.cpu().numpy().view(np.uint64).reshape(8, n)[:, pos].reshape(-1).copy()
+    g2h = g2.cpu().numpy().view(np.uint64).reshape(16, n)[:, pos].reshape(-1).copy()
+    got = out[:48 * n].cpu().numpy().view(np.uint64).reshape(48, n)[:, pos].reshape(-1).copy()
+    want = H.oracle_pairing(pk.layout.to_aos(g1h, 8), pk.layout.to_aos(g2h, 16), 64, threads=16)
+    assert np.array_equal(pk.layout.to_aos(got, 48), want)

@@ -144,13 +144,159 @@ def test_final_exp_kernel(vec):
     fin = [w for c in x for w in R.limbs4(R.to_mont(c))]
     out, m = _run_kernel(KP.KernelBuilder(do_miller=False, do_fexp=True), fin=fin)
     assert out == HX(vec["final_exp"][1])
-    # zero input: the reference panics (division by zero) -> status word written
-    out, m = _run_kernel(KP.KernelBuilder(do_miller=False, do_fexp=True), fin=[0] * 48)
-    assert m.gmem.get(STAT) == 1
 
 
-def test_pairing_kernel_generators(vec):
-    """BASELINE.json configs[0]: e(G1gen, G2gen) through the fused kernel."""
+# ---------------------------------------------------------------- v3: signed radix-2^27 limbs (the default kernels)
+import kgen3 as K3  # noqa: E402
+import kgen3_prog as K3P  # noqa: E402
+
+
+def _sval(limbs):
+    v = 0
+    for i, l in enumerate(limbs):
+        l = l - (1 << 32) if l >> 31 else l
+        v += l << (K3.LB * i)
+    return v
+
+
+def _redundant(x, rng, slack):
+    """A signed redundant representation of x + k p with limb borrows of up to `slack` units."""
+    y = x + (rng.randrange(-3, 4) if slack else 0) * P
+    l = K3.to_limbs(abs(y))
+    if y < 0:
+        l = [-t for t in l]
+    for i in range(K3.NL - 1):
+        b = rng.randrange(-slack, slack + 1) if slack else 0
+        l[i] += b << K3.LB
+        l[i + 1] -= b
+    return l
+
+
+def _m3(vals, rng, slack):
+    m = S.Machine()
+    for i in range(K3.NL):
+        m.s[K3.S_P + i] = K3.P_L[i]
+    m.s[K3.S_N0] = K3.N0P
+    for j, x in enumerate(vals):
+        for i, w in enumerate(_redundant(x, rng, slack)):
+            m.v[K3.NL * j + i] = w & 0xFFFFFFFF
+    return m
+
+
+def test_l1_v3_routines():
+    """Redundant signed operands (negative limbs, limbs above 27 bits, value offsets by multiples of p): results
+    are checked mod p; the simulator traps any signed 64-bit column overflow."""
+    rng = random.Random(7)
+    RPI = pow(K3.RP, -1, P)
+
+    def body(n):
+        e = K.Emitter()
+        getattr(K3.L1v3(e), "r_" + n)()
+        return e.finalize()
+
+    B = {n: body(n) for n in K3.L1V3_NAMES}
+
+    def rnd():
+        return rng.choice([0, 1, P - 1, P - 2]) if rng.random() < 0.25 else rng.randrange(P)
+
+    def val(m, j):
+        return _sval([m.v[K3.NL * j + i] for i in range(K3.NL)])
+
+    for t in range(30):
+        a0, a1, b0, b1 = rnd(), rnd(), rnd(), rnd()
+        sl = [0, 1, 3][t % 3]
+        want = {"mul": ((a0 * b0 - a1 * b1) * RPI, (a0 * b1 + a1 * b0) * RPI), "sqr": ((a0 * a0 - a1 * a1) * RPI, 2 * a0 * a1 * RPI),
+                "mulfq": (a0 * b0 * RPI, a1 * b0 * RPI), "fqmul": (a0 * b0 * RPI, None), "fqsqr": (a0 * a0 * RPI, None),
+                "add": (a0 + b0, a1 + b1), "sub": (a0 - b0, a1 - b1), "rsub": (b0 - a0, b1 - a1), "dbl": (2 * a0, 2 * a1),
+                "neg": (-a0, -a1), "negc1": (a0, -a1), "norm": (a0, a1)}
+        if sl == 0:
+            want["mulxi"] = (9 * a0 - a1, a0 + 9 * a1)
+        for name, (w0, w1) in want.items():
+            m = _m3([a0, a1, b0, b1], rng, sl)
+            S.run_block(B[name], m)
+            assert (val(m, 0) - w0) % P == 0, name
+            if w1 is not None:
+                assert (val(m, 1) - w1) % P == 0, name
+            if name == "norm":
+                assert all(0 <= m.v[K3.NL * j + i] < (1 << K3.LB) for j in range(2) for i in range(K3.NL - 1))
+    # boundary conversions: ark 4 x u64 Montgomery (R = 2^256) <-> internal; cvtout is canonical
+    for t in range(20):
+        x = rnd()
+        ext = (x << 256) % P
+        m = _m3([], rng, 0)
+        for i in range(8):
+            m.v[i] = (ext >> (32 * i)) & 0xFFFFFFFF
+        S.run_block(B["cvtin"], m)
+        assert (val(m, 0) - x * K3.RP) % P == 0
+        m2 = _m3([(x * K3.RP) % P], rng, 2)
+        S.run_block(B["cvtout"], m2)
+        assert sum(m2.v[i] << (32 * i) for i in range(8)) == ext
+
+
+def _run_kernel3(kb, g1=None, g2=None, fin=None, k=1):
+    lines = _concretize(kb.build()) + ["s_endpgm"]
+    m = S.Machine()
+
+    def put64(base, words):
+        for i, w in enumerate(words):
+            m.gmem[base + 8 * i] = w & 0xFFFFFFFF
+            m.gmem[base + 8 * i + 4] = (w >> 32) & 0xFFFFFFFF
+
+    for base, words in ((G1B, g1), (G2B, g2), (FINB, fin)):
+        if words is not None:
+            put64(base, words)
+    for name, val in (("s[2:3]", G1B), ("s[4:5]", G2B), ("s[6:7]", FINB), ("s[8:9]", OUTB), ("s10", 1), ("s11", k), ("s[12:13]", SCR),
+                      ("s14", 256 * 80), ("s[16:17]", STAT), ("s18", 0), ("s19", 1)):
+        m.sset(name, val)
+    m.v[255] = 0
+    S.run(lines, m)
+    out = []
+    for c in range(12):
+        v = 0
+        for l in range(4):
+            a = OUTB + (c * 4 + l) * 8
+            v |= (m.gmem[a] | (m.gmem[a + 4] << 32)) << (64 * l)
+        out.append(R.from_mont(v))
+    return out, m
+
+
+def test_v3_miller_kernel_exact(vec):
+    g1, g2 = _inputs(vec, 3)
+    out, m = _run_kernel3(K3P.KernelBuilder3(do_miller=True, do_fexp=False, track=True), g1, g2)
+    assert out == HX(vec["miller"][3]) and STAT not in m.gmem
+    assert m.max_acc < (1 << 62)
+
+
+def test_v3_final_exp_kernel(vec):
+    x = HX(vec["fq12_in"][2])
+    fin = [w for c in x for w in R.limbs4(R.to_mont(c))]
+    out, m = _run_kernel3(K3P.KernelBuilder3(do_miller=False, do_fexp=True), fin=fin)
+    assert out == HX(vec["final_exp"][2])
+    out, m = _run_kernel3(K3P.KernelBuilder3(do_miller=False, do_fexp=True), fin=[0] * 48)
+    assert m.gmem.get(STAT) == 1            # zero input: the reference panics
+
+
+def test_v3_pairing_kernel_generators(vec):
+    """BASELINE.json configs[0]: e(G1gen, G2gen) through the fused default kernel."""
     g1, g2 = _inputs(vec, 0)
-    out, m = _run_kernel(KP.KernelBuilder(do_miller=True, do_fexp=True), g1, g2)
+    out, m = _run_kernel3(K3P.KernelBuilder3(do_miller=True, do_fexp=True), g1, g2)
     assert out == HX(vec["pairing"][0])
+
+
+def test_v3_multi_pairing_kernel(vec):
+    """k = 2 shared-f kernel: exact multi_miller_loop_native value (tracked scale)."""
+    g = vec["groups"][0]
+    k, idx = g["k"], g["idx"]
+
+    def soa(rows):
+        n = len(rows)
+        out = [0] * (len(rows[0]) * 4 * n)
+        for i, el in enumerate(rows):
+            for c, x in enumerate(el):
+                for l, w in enumerate(R.limbs4(R.to_mont(x))):
+                    out[(c * 4 + l) * n + i] = w
+        return out
+
+    g1, g2 = soa([HX(vec["g1"][i]) for i in idx]), soa([HX(vec["g2"][i]) for i in idx])
+    out, m = _run_kernel3(K3P.KernelBuilder3(do_miller=True, do_fexp=False, track=True, multi=True), g1, g2, k=k)
+    assert out == HX(g["miller"])

@@ -230,8 +230,11 @@ class KernelBuilder3(KP.KernelBuilder):
     FQINV_BASE = AGPR(9, "fqinv_base")
     BOP = [AGPR(i, f"B{i}") for i in (0, 1, 2, 3, 4, 5)]      # fq12_mul operand copy (final exponentiation only)
 
-    def __init__(self, do_miller=True, do_fexp=True, track=False):
+    PAIR_SLOT0 = 56          # scratch slots of pair j: PAIR_SLOT0 + 7 j + {PX, PY, QX, QY, RX, RY, RZ}
+
+    def __init__(self, do_miller=True, do_fexp=True, track=False, multi=False):
         super().__init__(do_miller, do_fexp, track)
+        self.multi = multi
         self.labels = {n: f"L1_{n}_%=" for n in L1V3_NAMES}
         for op in ("add", "sub", "rsub"):
             for i in range(N_HOME):
@@ -514,7 +517,9 @@ class KernelBuilder3(KP.KernelBuilder):
         e.emit(f"v_mov_b32_e32 v{V_FLAG}, 0", vw=[V_FLAG])
         p = Prog3(e, self.labels)
         p.set_temps(self.miller_temps())
-        if self.do_miller:
+        if self.do_miller and self.multi:
+            self.miller_main_multi(e, p)
+        elif self.do_miller:
             self.miller_main(e, p)
         else:
             # f_in (MyFq12, SoA): components 0..5 are the c0 parts of w^0..w^5, 6..11 the c1 parts.
@@ -608,6 +613,185 @@ class KernelBuilder3(KP.KernelBuilder):
         if self.track:
             self.call2(e, "L2_descale")
         p.reset_tags()
+
+    # ---------------------------------------------------------------------------------------------
+    # multi-pairing: shared f, k pairs per lane (multi_miller_loop_native, miller_loop_native.rs:192-282).
+    # Pair state (P, Q converted; R projective) lives in scratch and is swapped through the resident slots.
+    S_JP = 97                  # pair counter
+    S_PHASE = 91               # scratch: loop bookkeeping
+
+    def pair_select(self, e):
+        """S_GBASE <- byte offset of pair S_JP's scratch block."""
+        e.salu(f"s_mul_i32 s{S_TMP0}, s{self.S_JP}, 7")
+        e.salu(f"s_add_u32 s{S_TMP0}, s{S_TMP0}, {self.PAIR_SLOT0}")
+        e.salu(f"s_mul_i32 s{S_GBASE}, s{S_TMP0}, s{S_GSTRIDE}")
+
+    def pair_in(self, e, p, with_q):
+        """Resident slots <- scratch block of the selected pair: all loads issued back to back, one wait."""
+        dests = [self.PX, self.PY] + ([self.QX, self.QY] if with_q else []) + list(self.R)
+        srcs = [0, 1] + ([2, 3] if with_q else []) + [4, 5, 6]
+        land = [A0, B0] + [HOME0 + SLOT_DW * i for i in range(5)]
+        p.reset_tags()
+        p.wait()
+        for n, k in enumerate(srcs):
+            e.salu(f"s_mul_i32 s{S_TMP0}, s{S_GSTRIDE}, {k}")
+            e.salu(f"s_add_u32 s{S_TMP0}, s{S_TMP0}, s{S_GBASE}")
+            e.salu(f"s_add_u32 s62, s64, s{S_TMP0}")
+            e.salu("s_addc_u32 s63, s65, 0")
+            for c in range(N_CHUNK):
+                r = land[n] + 4 * c
+                e.emit(f"global_load_dwordx4 v[{r}:{r + 3}], v{V_GOFF}, {S_GADDR} offset:{16 * c}", kind="vmem", vw=range(r, r + 4))
+        e.raw("s_waitcnt vmcnt(0)")
+        for n, d in enumerate(dests):
+            r0 = land[n]
+            if d.kind == "agpr":
+                for i in range(SLOT_DW):
+                    e.emit(f"v_accvgpr_write_b32 a{SLOT_DW * d.idx + i}, v{r0 + i}")
+            elif d.kind == "lds":
+                for c in range(N_CHUNK):
+                    base, off = p._lds_addr(d, c)
+                    e.emit(f"ds_write_b128 v{base}, v[{r0 + 4 * c}:{r0 + 4 * c + 3}] offset:{off}", kind="lds")
+            elif d.kind == "home":
+                h0 = HOME0 + SLOT_DW * d.idx
+                if h0 != r0:
+                    for i in range(SLOT_DW):
+                        e.emit(f"v_mov_b32_e32 v{h0 + i}, v{r0 + i}", vw=[h0 + i])
+            p.slot_e[p.key(d)] = E_STORE_MAX
+        p.reset_tags()
+
+    def pair_out(self, e, p):
+        """scratch block of the selected pair <- R (the only state a step changes)."""
+        p.reset_tags()
+        for k, src in zip((4, 5, 6), self.R):
+            p.A(src).to(GlobDyn(k))
+        p.reset_tags()
+
+    def pair_loop(self, e, name, body):
+        """for S_JP in 0..k-1: body()"""
+        L = self.lab
+        e.salu(f"s_mov_b32 s{self.S_JP}, 0")
+        e.label(L(f"L_pl_{name}"))
+        self.pair_select(e)
+        body()
+        e.salu(f"s_add_u32 s{self.S_JP}, s{self.S_JP}, 1")
+        e.salu(f"s_cmp_lt_u32 s{self.S_JP}, s{S_K}")
+        e.salu(f"s_cbranch_scc1 {L(f'L_pl_{name}')}")
+
+    def miller_main_multi(self, e, p):
+        L = self.lab
+        # ---- init: convert P_j, Q_j into scratch, R_j = (Q_j, 1)
+        e.salu(f"s_mul_i32 s{S_NSTRIDE}, s{S_N}, s{S_K}")
+        e.salu(f"s_lshl_b32 s{S_NSTRIDE}, s{S_NSTRIDE}, 3")          # bytes between limb planes of the PAIR batches
+        e.emit(f"v_lshrrev_b32_e32 v{V_IDX8}, 3, v{V_IDX8}", vw=[V_IDX8])   # clamped group index
+        e.emit(f"v_mul_lo_u32 v{V_IDX8}, v{V_IDX8}, s{S_K}", vw=[V_IDX8])
+        e.emit(f"v_lshlrev_b32_e32 v{V_IDX8}, 3, v{V_IDX8}", vw=[V_IDX8])   # byte offset of the group's first pair
+
+        def init_pair():
+            # element offset of pair j = (group*k + j) * 8
+            e.salu(f"s_lshl_b32 s{S_TMP1}, s{self.S_JP}, 3")
+            e.emit(f"v_add_u32_e32 v{V_IDX8}, s{S_TMP1}, v{V_IDX8}", vw=[V_IDX8])
+            self.io_walk_begin(e, S_G1)
+            self.io_load_fq2_into_A(e, p, c1_present=False)
+            p.to(GlobDyn(0))
+            self.io_load_fq2_into_A(e, p, c1_present=False)
+            p.to(GlobDyn(1))
+            self.io_walk_begin(e, S_G2)
+            self.io_load_fq2_into_A(e, p)
+            p.to(GlobDyn(2))
+            p.store(A0, GlobDyn(4))
+            self.io_load_fq2_into_A(e, p)
+            p.to(GlobDyn(3))
+            p.store(A0, GlobDyn(5))
+            self.one_into_A(e)
+            p.set_A_fresh()
+            p.to(GlobDyn(6))
+            p.wait()
+            e.salu(f"s_lshl_b32 s{S_TMP1}, s{self.S_JP}, 3")
+            e.emit(f"v_subrev_u32_e32 v{V_IDX8}, s{S_TMP1}, v{V_IDX8}", vw=[V_IDX8])
+            p.reset_tags()
+
+        self.pair_loop(e, "init", init_pair)
+        if self.track:
+            self.one_into_A(e)
+            p.set_A_fresh()
+            p.to(self.SCALE)
+            p.reset_tags()
+
+        # ---- top digit: f = product of the tangent lines at Q_j
+        def first_step():
+            self.pair_in(e, p, with_q=False)
+            e.salu(f"s_cmp_eq_u32 s{self.S_JP}, 0")
+            e.salu(f"s_cbranch_scc0 {L('L_mf_rest')}")
+            self.call2(e, "L2_dblfirst")
+            e.salu(f"s_branch {L('L_mf_done')}")
+            e.label(L("L_mf_rest"))
+            self.call2(e, "L2_dblmul")
+            e.label(L("L_mf_done"))
+            self.pair_out(e, p)
+
+        self.pair_loop(e, "first", first_step)
+        e.salu(f"s_mov_b32 s{S_I}, 63")
+        e.label(L("L_mloop"))
+        e.salu(f"s_cmp_eq_u32 s{S_I}, 63")
+        e.salu(f"s_cbranch_scc1 {L('L_mskip')}")
+        self.call2(e, "L2_sqr")
+        if self.track:
+            self.call2(e, "L2_sqscale")
+
+        def dbl_pair():
+            self.pair_in(e, p, with_q=False)
+            self.call2(e, "L2_dblmul")
+            self.pair_out(e, p)
+
+        self.pair_loop(e, "dbl", dbl_pair)
+        e.label(L("L_mskip"))
+        e.salu(f"s_bitcmp1_b64 {S_NAF_NZ}, s{S_I}")
+        e.salu(f"s_cbranch_scc0 {L('L_mnoadd')}")
+
+        def add_pair():
+            self.pair_in(e, p, with_q=True)
+            p.mov(self.SX, self.QX)
+            p.A(self.QY)
+            p.wait()
+            e.salu(f"s_bitcmp1_b64 {S_NAF_NEG}, s{S_I}")
+            e.salu(f"s_cbranch_scc0 {L('L_mpos')}")
+            e.salu(f"s_call_b64 {S_RET1}, {self.labels['neg']}")
+            e.label(L("L_mpos"))
+            p.tagA = None
+            p.to(self.SY)
+            self.call2(e, "L2_addmul")
+            self.pair_out(e, p)
+
+        self.pair_loop(e, "add", add_pair)
+        e.label(L("L_mnoadd"))
+        e.salu(f"s_sub_u32 s{S_I}, s{S_I}, 1")
+        e.salu(f"s_cbranch_scc0 {L('L_mloop')}")
+        xi = (9, 1)
+        c = f2pow(xi, (P_INT - 1) // 6)
+        c2 = f2mul(c, c)
+        c3 = f2mul(c2, c)
+        C2, C3 = Const(c2[0], c2[1], "c2"), Const(c3[0], c3[1], "c3")
+
+        def end_pair():
+            self.pair_in(e, p, with_q=True)
+            p.A(self.QX).conj().mul(C2).to(self.SX)
+            p.A(self.QY).conj().mul(C3).to(self.SY)
+            self.call2(e, "L2_addmul")
+            p.reset_tags()
+            p.A(self.SX).conj().mul(C2).to(self.SX)
+            p.A(self.SY).conj().neg().mul(C3).to(self.SY)
+            self.call2(e, "L2_addmul_last")
+            p.reset_tags()
+
+        self.pair_loop(e, "end", end_pair)
+        if self.track:
+            self.call2(e, "L2_descale")
+        p.reset_tags()
+        # output indexing is per group again
+        e.salu(f"s_lshl_b32 s{S_NSTRIDE}, s{S_N}, 3")
+        e.salu(f"s_sub_u32 s{S_TMP1}, s{S_N}, 1")
+        e.emit(f"v_min_u32_e32 v{V_IDX8}, s{S_TMP1}, v{V_IDX}", vw=[V_IDX8])
+        e.emit(f"v_lshlrev_b32_e32 v{V_IDX8}, 3, v{V_IDX8}", vw=[V_IDX8])
 
     def store_out(self, e, p):
         p.reset_tags()
