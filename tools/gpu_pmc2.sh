@@ -1,0 +1,24 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_v3
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+BENCH="python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o trace -- $BENCH > $OUT/trace.log 2>&1; echo "trace rc=$?"
+i=0
+for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH" "SQ_IFETCH SQ_IFETCH_LEVEL SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+  i=$((i+1))
+  timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT -o pmc_$i -- $BENCH > $OUT/pmc_$i.log 2>&1; echo "pmc $i rc=$?"; tail -2 $OUT/pmc_$i.log | cut -c1-200
+done
+cd $GRAFT_REPO_ROOT
+python3 - <<'PY'
+import csv, glob, os, collections
+for f in sorted(glob.glob("gpurun_out/prof_v3/pmc_*counter_collection.csv")):
+    agg=collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if "k3_pairing" in r.get("Kernel_Name",""):
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k,v in agg.items(): print(os.path.basename(f), k, sum(v)/len(v))
+PY
+head -3 $OUT/trace_kernel_stats.csv | cut -c1-200

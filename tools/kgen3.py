@@ -176,6 +176,28 @@ class L1v3:
         self.fips_direct([(a0, b0), (na1, b1)], a0)
         self.pool.free(*na1)
 
+    def r_mul3(self):
+        """A <- A*B + H0*H1 + H2*H3 (Fq2 products, H_k = home block k), ONE reduction per output component:
+        two fused six-product column passes.  H0 and H2 are destroyed (their c1 halves get negated)."""
+        blocks = [(A0, B0), (HOME0, HOME0 + SLOT_DW), (HOME0 + 2 * SLOT_DW, HOME0 + 3 * SLOT_DW)]
+        xs = [(self.blk(x, 0), self.blk(x, 1)) for x, _ in blocks]
+        ys = [(self.blk(y, 0), self.blk(y, 1)) for _, y in blocks]
+        t = [self.pool.alloc() for _ in range(NL)]
+        prods = []
+        for (x0, x1), (y0, y1) in zip(xs, ys):
+            prods += [(x0, y1), (x1, y0)]
+        self.fips_direct(prods, t)                                   # c1
+        for (x0, x1) in xs:
+            for r in x1:
+                self.e.emit(f"v_sub_u32_e32 v{r}, 0, v{r}", vw=[r])
+        prods = []
+        for (x0, x1), (y0, y1) in zip(xs, ys):
+            prods += [(x0, y0), (x1, y1)]
+        self.fips_direct(prods, self.blk(A0, 0))                     # c0, in place over A.c0
+        for i in range(NL):
+            self.e.emit(f"v_mov_b32_e32 v{A0 + NL + i}, v{t[i]}", vw=[A0 + NL + i])
+        self.pool.free(*t)
+
     def r_sqr(self):
         """(a0 + a1 u)^2 = (a0+a1)(a0-a1) + 2 a0 a1 u ; both passes write in place."""
         a0, a1 = self.blk(A0, 0), self.blk(A0, 1)
@@ -347,7 +369,7 @@ class L1v3:
         self.pool.free(*d)
 
 
-L1V3_NAMES = ["mul", "sqr", "mulfq", "add", "sub", "rsub", "dbl", "neg", "negc1", "mulxi", "norm", "fqmul", "fqsqr", "cvtin", "cvtout"]
+L1V3_NAMES = ["mul", "mul3", "sqr", "mulfq", "add", "sub", "rsub", "dbl", "neg", "negc1", "mulxi", "norm", "fqmul", "fqsqr", "cvtin", "cvtout"]
 
 if __name__ == "__main__":
     for n in L1V3_NAMES:

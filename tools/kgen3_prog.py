@@ -136,6 +136,90 @@ class Prog3(KP.Prog):
             self.load(B0, y)
             self.tagB = y
 
+    # ---- operand blocks H0..H3 of the three-term multiply (home registers 0..3 used as raw blocks)
+    def reserve_blocks(self):
+        self._saved_tmp = self.free_tmp
+        self.free_tmp = [t for t in self.free_tmp if not (t.kind == "home" and t.idx < 4)]
+        assert len(self._saved_tmp) - len(self.free_tmp) == 4, "home blocks 0..3 must be free"
+        self.tagH = [None] * 4
+        self.eH = [None] * 4
+
+    def release_blocks(self):
+        held = [t for t in self._saved_tmp if t.kind == "home" and t.idx < 4]
+        self.free_tmp = held + self.free_tmp
+
+    def ldH(self, k, slot):
+        """home block k <- slot (straight ds_read for LDS slots)."""
+        if self.tagH[k] is slot:
+            return self
+        blk = HOME0 + SLOT_DW * k
+        self.load(blk, slot)
+        self.tagH[k] = slot
+        self.eH[k] = self.e_of(slot)
+        return self
+
+    def mul3(self, y):
+        """A <- A*y + H0*H1 + H2*H3"""
+        self._B(y)
+        eA = self.eA if self.eA is not None else E_STORE_MAX
+        worst = max(eA + self.e_of(y), self.eH[0] + self.eH[1], self.eH[2] + self.eH[3])
+        self._need(math.log2(6 * NL) + worst <= COL_LIMIT, f"mul3 {worst}")
+        self._raw_call("mul3")
+        self.eA = E_NORM
+        self.tagH[0] = self.tagH[2] = None          # destroyed
+        return self
+
+    def mul_by_034(self, F, L0, L3, L4):
+        """f *= L0 + L3 w^3 + L4 w^4 with one reduction per output coefficient (xi folded into the line)."""
+        self.reserve_blocks()
+        L3x, L4x = self.tmp(), self.tmp()
+        self.A(L3).mulxi().to(L3x)
+        self.A(L4).mulxi().to(L4x)
+        c = [self.tmp() for _ in range(5)]
+        # c0 = a0 L0 + a3 xiL3 + a2 xiL4 ; c1 = a1 L0 + a4 xiL3 + a3 xiL4 ; c2 = a2 L0 + a5 xiL3 + a4 xiL4
+        for k, (i0, i3, i4) in enumerate(((0, 3, 2), (1, 4, 3), (2, 5, 4))):
+            self.ldH(1, L3x).ldH(3, L4x).ldH(0, F[i3]).ldH(2, F[i4])
+            self.A(F[i0]).mul3(L0).to(c[k])
+        # c3 = a3 L0 + a0 L3 + a5 xiL4
+        self.ldH(1, L3).ldH(3, L4x).ldH(0, F[0]).ldH(2, F[5])
+        self.A(F[3]).mul3(L0).to(c[3])
+        # c4 = a4 L0 + a1 L3 + a0 L4 ; c5 = a5 L0 + a2 L3 + a1 L4
+        self.ldH(1, L3).ldH(3, L4).ldH(0, F[1]).ldH(2, F[0])
+        self.A(F[4]).mul3(L0).to(c[4])
+        self.ldH(0, F[2]).ldH(2, F[1])
+        self.A(F[5]).mul3(L0).to(F[5])
+        for k in range(5):
+            self.mov(F[k], c[k])
+        self.rel(L3x, L4x, *c)
+        self.release_blocks()
+
+    def mul_by_235(self, F, L2, L3, L5):
+        """f *= L2 w^2 + L3 w^3 + L5 w^5, same scheme."""
+        self.reserve_blocks()
+        L2x, L3x, L5x = self.tmp(), self.tmp(), self.tmp()
+        self.A(L2).mulxi().to(L2x)
+        self.A(L3).mulxi().to(L3x)
+        self.A(L5).mulxi().to(L5x)
+        c = [self.tmp() for _ in range(5)]
+        # c0 = xi (a4 b2 + a3 b3 + a1 b5) ; c1 = xi (a5 b2 + a4 b3 + a2 b5)
+        for k, (i2, i3, i5) in enumerate(((4, 3, 1), (5, 4, 2))):
+            self.ldH(1, L3x).ldH(3, L5x).ldH(0, F[i3]).ldH(2, F[i5])
+            self.A(F[i2]).mul3(L2x).to(c[k])
+        # c2 = a0 b2 + xi (a5 b3 + a3 b5)
+        self.ldH(1, L3x).ldH(3, L5x).ldH(0, F[5]).ldH(2, F[3])
+        self.A(F[0]).mul3(L2).to(c[2])
+        # c3 = a1 b2 + a0 b3 + xi a4 b5 ; c4 = a2 b2 + a1 b3 + xi a5 b5
+        for k, (i2, i3, i5) in ((3, (1, 0, 4)), (4, (2, 1, 5))):
+            self.ldH(1, L3).ldH(3, L5x).ldH(0, F[i3]).ldH(2, F[i5])
+            self.A(F[i2]).mul3(L2).to(c[k])
+        # c5 = a3 b2 + a2 b3 + a0 b5
+        self.ldH(1, L3).ldH(3, L5).ldH(0, F[2]).ldH(2, F[0])
+        self.A(F[3]).mul3(L2).to(F[5])
+        for k in range(5):
+            self.mov(F[k], c[k])
+        self.rel(L2x, L3x, L5x, *c)
+        self.release_blocks()
+
     def set_A_fresh(self, e=E_NORM):
         """A was filled by hand-written code with a value whose limbs are < 2^e."""
         self.tagA = None
@@ -278,12 +362,16 @@ class KernelBuilder3(KP.KernelBuilder):
             # during f^2 the line (AGPR 6..8) and the addition point (AGPR 4, 5) are dead
             self.l2_routine("L2_sqr", lambda p: p.fq12_sqr(self.F), self.miller_temps(extra=(4, 5, 6, 7, 8)))
             self.l2_routine("L2_dblmul", lambda p: (p.dbl_step(self.R, (self.PX, self.PY), self.LINE, scale=sc),
-                                                    p.mul_by_034(self.F, *self.LINE)), self.miller_temps())
+                                                    p.mul_by_034(self.F, *self.LINE)), self.miller_temps(extra=(4, 5)))
             self.l2_routine("L2_dblfirst", lambda p: self._dbl_first(p), self.miller_temps())
-            self.l2_routine("L2_addmul", lambda p: (p.add_step(self.R, (self.SX, self.SY), (self.PX, self.PY), self.LINE, scale=sc, update=True),
-                                                    p.mul_by_235(self.F, *self.LINE)), self.miller_temps())
-            self.l2_routine("L2_addmul_last", lambda p: (p.add_step(self.R, (self.SX, self.SY), (self.PX, self.PY), self.LINE, scale=sc, update=False),
-                                                         p.mul_by_235(self.F, *self.LINE)), self.miller_temps())
+            def addmul(p, update):
+                p.add_step(self.R, (self.SX, self.SY), (self.PX, self.PY), self.LINE, scale=sc, update=update)
+                glob = [t for t in p.free_tmp if t.kind == "glob"]
+                p.free_tmp = [t for t in p.free_tmp if t.kind != "glob"] + [self.SX, self.SY] + glob    # S is dead now
+                p.mul_by_235(self.F, *self.LINE)
+
+            self.l2_routine("L2_addmul", lambda p: addmul(p, True), self.miller_temps())
+            self.l2_routine("L2_addmul_last", lambda p: addmul(p, False), self.miller_temps())
             if self.track:
                 self.l2_routine("L2_fqinv", self._fq_inv, self.miller_temps())
                 self.l2_routine("L2_descale", self._descale, self.miller_temps())
@@ -297,9 +385,9 @@ class KernelBuilder3(KP.KernelBuilder):
                 self.l2_routine(f"L2_frob{k}", lambda p, k=k: self._frobenius(p, k), self.fexp_temps())
             self.l2_routine("L2_inv", self._fq12_inv, self.fexp_temps())
             self.l2_routine("L2_stG", lambda p: [p.A(self.F[i]).to(GlobDyn(i)) for i in range(6)], self.fexp_temps())
-            self.l2_routine("L2_ldG", lambda p: [p.A(GlobDyn(i)).to(self.F[i]) for i in range(6)], self.fexp_temps())
-            self.l2_routine("L2_ldGc", lambda p: [(p.A(GlobDyn(i)).neg().to(self.F[i]) if i % 2 else p.A(GlobDyn(i)).to(self.F[i])) for i in range(6)],
-                            self.fexp_temps())
+            self.l2_routine("L2_ldG", lambda p: self.batch_load_globdyn(p.e, p, range(6), self.F), self.fexp_temps())
+            self.l2_routine("L2_ldGc", lambda p: (self.batch_load_globdyn(p.e, p, range(6), self.F),
+                                                  [p.A(self.F[i]).neg().to(self.F[i]) for i in (1, 3, 5)]), self.fexp_temps())
             self.l2_routine("L2_conjF", lambda p: [p.A(self.F[i]).neg().to(self.F[i]) for i in (1, 3, 5)], self.fexp_temps())
             self._powx_routine()
         self.main_body(main)
@@ -308,21 +396,53 @@ class KernelBuilder3(KP.KernelBuilder):
             out.extend(e.finalize())
         return out
 
+    def batch_load_globdyn(self, e, p, ks, dests):
+        """dests[i] <- scratch slot (S_GBASE + ks[i]): all global loads issued back to back into landing registers
+        (blocks A, B and the home registers -- every temporary is dead at a routine boundary), ONE wait, then the
+        stores.  A dependent load->wait->store round trip per slot costs ~2 us each."""
+        land = [A0, B0] + [HOME0 + SLOT_DW * i for i in range(N_HOME)]
+        assert len(ks) <= len(land)
+        p.reset_tags()
+        p.wait()
+        for n, k in enumerate(ks):
+            e.salu(f"s_mul_i32 s{S_TMP0}, s{S_GSTRIDE}, {k}")
+            e.salu(f"s_add_u32 s{S_TMP0}, s{S_TMP0}, s{S_GBASE}")
+            e.salu(f"s_add_u32 s62, s64, s{S_TMP0}")
+            e.salu("s_addc_u32 s63, s65, 0")
+            for c in range(N_CHUNK):
+                r = land[n] + 4 * c
+                e.emit(f"global_load_dwordx4 v[{r}:{r + 3}], v{V_GOFF}, {S_GADDR} offset:{16 * c}", kind="vmem", vw=range(r, r + 4))
+        e.raw("s_waitcnt vmcnt(0)")
+        for n, d in enumerate(dests):
+            r0 = land[n]
+            if d.kind == "agpr":
+                for i in range(SLOT_DW):
+                    e.emit(f"v_accvgpr_write_b32 a{SLOT_DW * d.idx + i}, v{r0 + i}")
+            elif d.kind == "lds":
+                for c in range(N_CHUNK):
+                    base, off = p._lds_addr(d, c)
+                    e.emit(f"ds_write_b128 v{base}, v[{r0 + 4 * c}:{r0 + 4 * c + 3}] offset:{off}", kind="lds")
+            elif d.kind == "home":
+                h0 = HOME0 + SLOT_DW * d.idx
+                if h0 != r0:
+                    for i in range(SLOT_DW):
+                        e.emit(f"v_mov_b32_e32 v{h0 + i}, v{r0 + i}", vw=[h0 + i])
+            else:
+                raise ValueError(d.kind)
+            p.slot_e[p.key(d)] = E_STORE_MAX
+        p.reset_tags()
+
     def _mulG_routines(self):
         e, p = self.new_prog(self.fexp_temps())
         e.label(self.lab("L2_mulGc"))
-        for i in range(6):
-            if i % 2:
-                p.A(GlobDyn(i)).neg().to(self.BOP[i])
-            else:
-                p.A(GlobDyn(i)).to(self.BOP[i])
+        self.batch_load_globdyn(e, p, range(6), self.BOP)
+        for i in (1, 3, 5):
+            p.A(self.BOP[i]).neg().to(self.BOP[i])
         p.wait()
         e.salu(f"s_branch {self.lab('L2_mul_body')}")
         e.label(self.lab("L2_mulG"))
         p.reset_tags()
-        for i in range(6):
-            p.A(GlobDyn(i)).to(self.BOP[i])
-        p.wait()
+        self.batch_load_globdyn(e, p, range(6), self.BOP)
         e.label(self.lab("L2_mul_body"))
         p.reset_tags()
         p.fq12_mul(self.F, self.BOP)
@@ -602,13 +722,17 @@ class KernelBuilder3(KP.KernelBuilder):
         c2 = f2mul(c, c)
         c3 = f2mul(c2, c)
         C2, C3 = Const(c2[0], c2[1], "c2"), Const(c3[0], c3[1], "c3")
+        # Q1 -> S ; -Q2 (derived from Q1) -> the Q slots, which are dead from here on.  (The sparse multiplication
+        # inside L2_addmul uses the S slots as temporaries, so -Q2 must exist before the first call.)
         p.reset_tags()
         p.A(self.QX).conj().mul(C2).to(self.SX)
         p.A(self.QY).conj().mul(C3).to(self.SY)
+        p.A(self.SX).conj().mul(C2).to(self.QX)
+        p.A(self.SY).conj().neg().mul(C3).to(self.QY)
         self.call2(e, "L2_addmul")
         p.reset_tags()
-        p.A(self.SX).conj().mul(C2).to(self.SX)
-        p.A(self.SY).conj().neg().mul(C3).to(self.SY)
+        p.mov(self.SX, self.QX)
+        p.mov(self.SY, self.QY)
         self.call2(e, "L2_addmul_last")
         if self.track:
             self.call2(e, "L2_descale")
@@ -630,34 +754,7 @@ class KernelBuilder3(KP.KernelBuilder):
         """Resident slots <- scratch block of the selected pair: all loads issued back to back, one wait."""
         dests = [self.PX, self.PY] + ([self.QX, self.QY] if with_q else []) + list(self.R)
         srcs = [0, 1] + ([2, 3] if with_q else []) + [4, 5, 6]
-        land = [A0, B0] + [HOME0 + SLOT_DW * i for i in range(5)]
-        p.reset_tags()
-        p.wait()
-        for n, k in enumerate(srcs):
-            e.salu(f"s_mul_i32 s{S_TMP0}, s{S_GSTRIDE}, {k}")
-            e.salu(f"s_add_u32 s{S_TMP0}, s{S_TMP0}, s{S_GBASE}")
-            e.salu(f"s_add_u32 s62, s64, s{S_TMP0}")
-            e.salu("s_addc_u32 s63, s65, 0")
-            for c in range(N_CHUNK):
-                r = land[n] + 4 * c
-                e.emit(f"global_load_dwordx4 v[{r}:{r + 3}], v{V_GOFF}, {S_GADDR} offset:{16 * c}", kind="vmem", vw=range(r, r + 4))
-        e.raw("s_waitcnt vmcnt(0)")
-        for n, d in enumerate(dests):
-            r0 = land[n]
-            if d.kind == "agpr":
-                for i in range(SLOT_DW):
-                    e.emit(f"v_accvgpr_write_b32 a{SLOT_DW * d.idx + i}, v{r0 + i}")
-            elif d.kind == "lds":
-                for c in range(N_CHUNK):
-                    base, off = p._lds_addr(d, c)
-                    e.emit(f"ds_write_b128 v{base}, v[{r0 + 4 * c}:{r0 + 4 * c + 3}] offset:{off}", kind="lds")
-            elif d.kind == "home":
-                h0 = HOME0 + SLOT_DW * d.idx
-                if h0 != r0:
-                    for i in range(SLOT_DW):
-                        e.emit(f"v_mov_b32_e32 v{h0 + i}, v{r0 + i}", vw=[h0 + i])
-            p.slot_e[p.key(d)] = E_STORE_MAX
-        p.reset_tags()
+        self.batch_load_globdyn(e, p, srcs, dests)
 
     def pair_out(self, e, p):
         """scratch block of the selected pair <- R (the only state a step changes)."""
@@ -776,10 +873,12 @@ class KernelBuilder3(KP.KernelBuilder):
             self.pair_in(e, p, with_q=True)
             p.A(self.QX).conj().mul(C2).to(self.SX)
             p.A(self.QY).conj().mul(C3).to(self.SY)
+            p.A(self.SX).conj().mul(C2).to(self.QX)
+            p.A(self.SY).conj().neg().mul(C3).to(self.QY)
             self.call2(e, "L2_addmul")
             p.reset_tags()
-            p.A(self.SX).conj().mul(C2).to(self.SX)
-            p.A(self.SY).conj().neg().mul(C3).to(self.SY)
+            p.mov(self.SX, self.QX)
+            p.mov(self.SY, self.QY)
             self.call2(e, "L2_addmul_last")
             p.reset_tags()
 
