@@ -23,23 +23,74 @@ from kgen_prog import (AGPR, GLOB, HOME, LDS, Const, GlobDyn, Slot, S_FIN, S_G1,
                        S_ITEM, S_J, S_K, S_N, S_NAF_NEG, S_NAF_NZ, S_NITEMS, S_NSTRIDE, S_OUT, S_SAVE_EXEC, S_SCRATCH, S_STATUS, S_TMP0, S_TMP1,
                        S_XNAF_NEG, S_XNAF_NZ, f2mul, f2pow, naf_masks, x_naf)
 
-E_NORM = float(LB)          # limb exponent of a normalised value
-E_STORE_MAX = 28.01         # stored values keep at most one addition of slack
-E_MULXI_MAX = 27.6          # 10 * 2^e must stay below 2^31
-E_LIMIT = 30.9              # int32 limbs
-COL_LIMIT = 62.5            # signed 64-bit column sums (margin 0.5 bit)
-N_CHUNK = SLOT_DW // 4      # 16-byte chunks per slot
+# ---- static bound tracking: every value carries an interval [lo, hi] (in units of 2^27) that contains all of
+# its limbs 0..NL-2 (both Fq2 components); the top limb is small by construction (values stay below ~2^262).
+R_NORM = (0.0, 1.0)          # Montgomery-reduction outputs / normalised values / constants
+STORE_MAG = 3.05             # stored values may keep limbs up to 3 units (e.g. 3t - 2z of normalised t, z)
+LIMB_MAG = 15.9              # int32 limbs: |limb| < 2^31 = 16 units
+COL_LIMIT = 62.5             # log2 bound of a signed 64-bit column sum (0.5 bit of margin)
+N_CHUNK = SLOT_DW // 4       # 16-byte chunks per slot
+E_NORM = 27.0
+E_STORE_MAX = 27.0 + math.log2(STORE_MAG)
 
 
-def lsum(a, b):
-    return math.log2(2.0 ** a + 2.0 ** b)
+def mag(r):
+    return max(abs(r[0]), abs(r[1]))
+
+
+def lg(r):
+    """log2 of the largest limb magnitude of a value with range r."""
+    return 27.0 + math.log2(max(mag(r), 1e-9))
+
+
+def r_add(a, b):
+    return (a[0] + b[0], a[1] + b[1])
+
+
+def r_sub(a, b):
+    return (a[0] - b[1], a[1] - b[0])
+
+
+def r_neg(a):
+    return (-a[1], -a[0])
+
+
+def r_hull(a, b):
+    return (min(a[0], b[0]), max(a[1], b[1]))
+
+
+def r_mulxi(a):
+    l, h = a
+    c0 = (9 * l - h, 9 * h - l)
+    c1 = (10 * min(l, 0) if False else min(10 * l, 10 * h), max(10 * l, 10 * h))
+    return r_hull(c0, c1)
 
 
 class Prog3(KP.Prog):
     def __init__(self, e, l1_labels):
         super().__init__(e, l1_labels)
-        self.eA = None
-        self.slot_e = {}
+        self.rA = None
+        self.slot_r = {}
+
+    UNKNOWN = (-STORE_MAG, STORE_MAG)      # contract for values stored by other routines
+
+    # compatibility shims (exponent view of the interval)
+    @property
+    def eA(self):
+        return None if self.rA is None else lg(self.rA)
+
+    @eA.setter
+    def eA(self, e):
+        self.rA = None if e is None else ((0.0, 2.0 ** (e - 27.0)) if e <= 27.0 else (-(2.0 ** (e - 27.0)), 2.0 ** (e - 27.0)))
+
+    @property
+    def slot_e(self):
+        outer = self
+
+        class _View(dict):
+            def __setitem__(s2, k, e):
+                outer.slot_r[k] = (0.0, 1.0) if e <= 27.0 else (-(2.0 ** (e - 27.0)), 2.0 ** (e - 27.0))
+        return _View()
 
     # ---------------------------------------------------------------- bounds
     @staticmethod
@@ -50,10 +101,13 @@ class Prog3(KP.Prog):
             return ("const", slot.name)
         return (slot.kind, slot.idx)
 
-    def e_of(self, slot):
+    def r_of(self, slot):
         if slot.kind == "const":
-            return E_NORM
-        return self.slot_e.get(self.key(slot), E_STORE_MAX)     # contract at routine boundaries
+            return R_NORM
+        return self.slot_r.get(self.key(slot), self.UNKNOWN)
+
+    def e_of(self, slot):
+        return lg(self.r_of(slot))
 
     def reset_tags(self):
         super().reset_tags()
@@ -128,7 +182,7 @@ class Prog3(KP.Prog):
         if self.tagA is not x:
             self.load(A0, x)
             self.tagA = x
-            self.eA = self.e_of(x)
+            self.rA = self.r_of(x)
         return self
 
     def _B(self, y):
@@ -155,17 +209,17 @@ class Prog3(KP.Prog):
         blk = HOME0 + SLOT_DW * k
         self.load(blk, slot)
         self.tagH[k] = slot
-        self.eH[k] = self.e_of(slot)
+        self.eH[k] = self.r_of(slot)
         return self
 
     def mul3(self, y):
         """A <- A*y + H0*H1 + H2*H3"""
         self._B(y)
-        eA = self.eA if self.eA is not None else E_STORE_MAX
-        worst = max(eA + self.e_of(y), self.eH[0] + self.eH[1], self.eH[2] + self.eH[3])
-        self._need(math.log2(6 * NL) + worst <= COL_LIMIT, f"mul3 {worst}")
+        rA = self.rA if self.rA is not None else self.UNKNOWN
+        worst = mag(rA) * mag(self.r_of(y)) + mag(self.eH[0]) * mag(self.eH[1]) + mag(self.eH[2]) * mag(self.eH[3])
+        self._need(math.log2(2 * NL) + 54.0 + math.log2(worst) <= COL_LIMIT, f"mul3 {worst}")
         self._raw_call("mul3")
-        self.eA = E_NORM
+        self.rA = R_NORM
         self.tagH[0] = self.tagH[2] = None          # destroyed
         return self
 
@@ -221,83 +275,103 @@ class Prog3(KP.Prog):
         self.release_blocks()
 
     def set_A_fresh(self, e=E_NORM):
-        """A was filled by hand-written code with a value whose limbs are < 2^e."""
+        """A was filled by hand-written code with a normalised value."""
         self.tagA = None
-        self.eA = e
+        self.rA = R_NORM
+
+    INLINE_SMALL = bool(int(os.environ.get("KGEN3_INLINE_SMALL", "0")))
 
     def _raw_call(self, name):
         self.wait()
-        self.e.salu(f"s_call_b64 {S_RET1}, {self.l1[name]}")
+        base = name.split("_h")[0]
+        if self.INLINE_SMALL and base in ("add", "sub", "rsub", "dbl", "neg", "negc1"):
+            g = L1v3(self.e)
+            if "_h" in name:
+                g.home_variant(base, int(name.split("_h")[1]))
+            else:
+                getattr(g, "r_" + name)()
+        else:
+            self.e.salu(f"s_call_b64 {S_RET1}, {self.l1[name]}")
         self.tagA = None
         self._count(name)
 
     def norm(self):
         self._raw_call("norm")
-        self.eA = E_NORM
+        self.rA = R_NORM
         return self
 
     def _need(self, ok, what):
         if not ok:
             raise AssertionError("bound violated: " + what)
 
-    def call(self, name, eB=None, direct=None):
-        eA = self.eA if self.eA is not None else E_STORE_MAX
+    def call(self, name, rB=None, direct=None):
+        rA = self.rA if self.rA is not None else self.UNKNOWN
+        if isinstance(rB, float):
+            rB = (-(2.0 ** (rB - 27.0)), 2.0 ** (rB - 27.0))
+
+        def col(n_terms, x, y):
+            return math.log2(n_terms) + 54.0 + math.log2(max(mag(x), 1e-9)) + math.log2(max(mag(y), 1e-9))
+
         if name == "mul":
-            if math.log2(2 * NL) + eA + eB > COL_LIMIT:
+            if col(2 * NL, rA, rB) > COL_LIMIT:
                 self.norm()
-                eA = E_NORM
-            self._need(math.log2(2 * NL) + eA + eB <= COL_LIMIT, f"mul {eA} {eB}")
-            out = E_NORM
-        elif name == "mulfq" or name == "fqmul":
-            if math.log2(NL) + eA + eB > COL_LIMIT:
+                rA = R_NORM
+            self._need(col(2 * NL, rA, rB) <= COL_LIMIT, f"mul {rA} {rB}")
+            out = R_NORM
+        elif name in ("mulfq", "fqmul"):
+            if col(NL, rA, rB) > COL_LIMIT:
                 self.norm()
-                eA = E_NORM
-            self._need(math.log2(NL) + eA + eB <= COL_LIMIT, f"{name} {eA} {eB}")
-            out = E_NORM
+                rA = R_NORM
+            self._need(col(NL, rA, rB) <= COL_LIMIT, f"{name} {rA} {rB}")
+            out = R_NORM
         elif name in ("sqr", "fqsqr"):
-            if math.log2(NL) + 2 * (eA + 1) > COL_LIMIT or eA + 1 > E_LIMIT:
+            t, u, d = r_add(rA, rA), r_sub(rA, rA), (2 * rA[0], 2 * rA[1])
+            if max(col(NL, t, u), col(NL, rA, d)) > COL_LIMIT or mag(t) > LIMB_MAG:
                 self.norm()
-                eA = E_NORM
-            out = E_NORM
+                rA = R_NORM
+            out = R_NORM
         elif name in ("add", "sub", "rsub"):
-            if lsum(eA, eB) > E_LIMIT:
+            f = {"add": r_add, "sub": r_sub, "rsub": lambda x, y: r_sub(y, x)}[name]
+            if mag(f(rA, rB)) > LIMB_MAG:
                 self.norm()
-                eA = E_NORM
-            out = lsum(eA, eB)
-            self._need(out <= E_LIMIT, f"{name} {eA} {eB}")
+                rA = R_NORM
+            out = f(rA, rB)
+            self._need(mag(out) <= LIMB_MAG, f"{name} {rA} {rB}")
         elif name == "dbl":
-            if eA + 1 > E_LIMIT:
+            if 2 * mag(rA) > LIMB_MAG:
                 self.norm()
-                eA = E_NORM
-            out = eA + 1
-        elif name in ("neg", "negc1"):
-            out = eA
+                rA = R_NORM
+            out = (2 * rA[0], 2 * rA[1])
+        elif name == "neg":
+            out = r_neg(rA)
+        elif name == "negc1":
+            out = r_hull(rA, r_neg(rA))
         elif name == "mulxi":
-            if eA > E_MULXI_MAX:
+            if mag(r_mulxi(rA)) > LIMB_MAG:
                 self.norm()
-                eA = E_NORM
-            out = eA + math.log2(10)
+                rA = R_NORM
+            out = r_mulxi(rA)
         elif name == "norm":
-            out = E_NORM
+            out = R_NORM
         else:
             raise ValueError(name)
         self._raw_call(direct or name)
-        self.eA = out
+        self.rA = out
         return self
 
     def _bin(self, name, y):
         if y.kind == "home" and name in ("add", "sub", "rsub"):
-            return self.call(name, self.e_of(y), direct=f"{name}_h{y.idx}")
+            return self.call(name, self.r_of(y), direct=f"{name}_h{y.idx}")
         self._B(y)
-        return self.call(name, self.e_of(y))
+        return self.call(name, self.r_of(y))
 
     def to(self, dst):
-        eA = self.eA if self.eA is not None else E_STORE_MAX
-        if eA > E_STORE_MAX:
+        rA = self.rA if self.rA is not None else self.UNKNOWN
+        if mag(rA) > STORE_MAG:
             self.norm()
         self.wait()
         self.store(A0, dst)
-        self.slot_e[self.key(dst)] = self.eA if self.eA is not None else E_STORE_MAX
+        self.slot_r[self.key(dst)] = self.rA if self.rA is not None else self.UNKNOWN
         self.tagA = dst
         if self.tagB is dst:
             self.tagB = None
@@ -429,7 +503,7 @@ class KernelBuilder3(KP.KernelBuilder):
                         e.emit(f"v_mov_b32_e32 v{h0 + i}, v{r0 + i}", vw=[h0 + i])
             else:
                 raise ValueError(d.kind)
-            p.slot_e[p.key(d)] = E_STORE_MAX
+            p.slot_r[p.key(d)] = p.UNKNOWN
         p.reset_tags()
 
     def _mulG_routines(self):
@@ -549,7 +623,7 @@ class KernelBuilder3(KP.KernelBuilder):
         p.set_A_fresh()
         for k in (1, 2, 5):
             p.store(A0, self.F[k])
-            p.slot_e[p.key(self.F[k])] = E_NORM
+            p.slot_r[p.key(self.F[k])] = R_NORM
 
     def _fq_inv(self, p):
         """A.c0 <- A.c0^(p-2) (Fermat; fixed exponent).  Input/outputs normalised."""
@@ -582,7 +656,7 @@ class KernelBuilder3(KP.KernelBuilder):
         e = p.e
         n0, tmp = p.tmp(), p.tmp()
         p.A(src)
-        if p.eA > E_NORM:
+        if mag(p.rA) > 2.0:
             p.norm()
         p._raw_call("fqsqr")
         p.set_A_fresh()
@@ -591,10 +665,10 @@ class KernelBuilder3(KP.KernelBuilder):
         p.wait()
         for i in range(NL):
             e.emit(f"v_mov_b32_e32 v{A0 + i}, v{A0 + NL + i}", vw=[A0 + i])
-        eS = p.eA
+        rS = p.rA
         p.tagA = None
-        p.eA = eS
-        if p.eA > E_NORM + 0.5:
+        p.rA = rS
+        if mag(p.rA) > 2.0:
             p.norm()
         p._raw_call("fqsqr")
         p.set_A_fresh()
@@ -680,11 +754,11 @@ class KernelBuilder3(KP.KernelBuilder):
         self.io_load_fq2_into_A(e, p)                            # Q.x
         p.to(self.QX)
         p.store(A0, self.R[0])
-        p.slot_e[p.key(self.R[0])] = E_NORM
+        p.slot_r[p.key(self.R[0])] = R_NORM
         self.io_load_fq2_into_A(e, p)                            # Q.y
         p.to(self.QY)
         p.store(A0, self.R[1])
-        p.slot_e[p.key(self.R[1])] = E_NORM
+        p.slot_r[p.key(self.R[1])] = R_NORM
         self.one_into_A(e)
         p.set_A_fresh()
         p.to(self.R[2])
