@@ -164,14 +164,14 @@ def main():
         rec = {
             "metric": "BN254 pairings/sec (whole node)", "value": value, "unit": "pairings/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (254-bit Montgomery, integer VALU)",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i32x10 (254-bit Montgomery, signed radix-2^27 limbs, integer VALU)",
             "data": "synthetic: on-device [s]G1, [t]G2 subgroup points, SplitMix64 scalars, seed 0xB2540001",
             "config": {"workload": f"2^{args.log2_batch} independent pairings per GPU per step "
                                    f"(BASELINE.json configs[1]; pairing() = final_exp_native(miller_loop_native))",
                        "pairings_per_gpu": n, "layout": "SoA limb-major u64 Montgomery, inputs resident in HBM"},
             "roofline": {"bound": "valu-int32-mul", "achieved": achieved / 1e12, "peak": PEAK_MUL32_PER_S / 1e12, "unit": "T mul32/s",
                          "frac": achieved / PEAK_MUL32_PER_S, "traffic": None,
-                         "kernel": "k_pairing<true,true>", "kernel_ms_avg": kern_avg_ms, "kernel_ms_min": kern_ms[0],
+                         "kernel": "k3_pairing", "kernel_ms_avg": kern_avg_ms, "kernel_ms_min": kern_ms[0],
                          "work_per_unit": f"{W_MUL32_PER_PAIRING} mul32 = {W_FQMUL_PER_PAIRING} fqmul x 136 per pairing (SURVEY.md 8d)",
                          "frac_of_nominal_quarter_rate_peak": achieved / NOMINAL_PEAK_MUL32_PER_S,
                          "hbm_note": "algorithmic HBM bytes are 576 B/pairing (<0.01% of 8 TB/s): not the bound"},

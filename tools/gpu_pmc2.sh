@@ -1,6 +1,6 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"
-OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_v3
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_v3b
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
@@ -14,7 +14,7 @@ done
 cd $GRAFT_REPO_ROOT
 python3 - <<'PY'
 import csv, glob, os, collections
-for f in sorted(glob.glob("gpurun_out/prof_v3/pmc_*counter_collection.csv")):
+for f in sorted(glob.glob("gpurun_out/prof_v3b/pmc_*counter_collection.csv")):
     agg=collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if "k3_pairing" in r.get("Kernel_Name",""):
