@@ -279,7 +279,7 @@ class Prog3(KP.Prog):
         self.tagA = None
         self.rA = R_NORM
 
-    INLINE_SMALL = bool(int(os.environ.get("KGEN3_INLINE_SMALL", "0")))
+    INLINE_SMALL = bool(int(os.environ.get("KGEN3_INLINE_SMALL", "1")))
 
     def _raw_call(self, name):
         self.wait()
@@ -465,8 +465,22 @@ class KernelBuilder3(KP.KernelBuilder):
             self.l2_routine("L2_conjF", lambda p: [p.A(self.F[i]).neg().to(self.F[i]) for i in (1, 3, 5)], self.fexp_temps())
             self._powx_routine()
         self.main_body(main)
+        # Layout: s_call_b64 / s_branch reach +-128 KB.  The leaf routines (called from everywhere) and the main
+        # control code sit in the middle, the L2 routines are split around them by size.
+        secs = [(e, len(e.finalize())) for e in self.sections]
+        total = sum(n for _, n in secs)
+        first, second, acc = [], [], 0
+        for e, n in secs:
+            if acc + n <= total // 2:
+                first.append(e)
+                acc += n
+            else:
+                second.append(e)
+        main.salu(f"s_branch {self.lab('L_exit')}")       # main is no longer the last section
+        tail = Emitter()
+        tail.label(self.lab("L_exit"))
         out = []
-        for e in [self._pro, l1e] + self.sections + [main]:
+        for e in [self._pro] + first + [main, l1e] + second + [tail]:
             out.extend(e.finalize())
         return out
 
