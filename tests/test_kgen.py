@@ -233,7 +233,14 @@ def test_l1_v3_routines():
         assert sum(m2.v[i] << (32 * i) for i in range(8)) == ext
 
 
-def _run_kernel3(kb, g1=None, g2=None, fin=None, k=1):
+def _first_diff(a, b):
+    for i, (x, y) in enumerate(zip(a, b)):
+        if x != y:
+            return f"call {i}: executed {a[max(0, i - 3):i + 3]} certified {b[max(0, i - 3):i + 3]}"
+    return f"lengths {len(a)} vs {len(b)}"
+
+
+def _run_kernel3(kb, g1=None, g2=None, fin=None, k=1, check_seq=True):
     lines = _concretize(kb.build()) + ["s_endpgm"]
     m = S.Machine()
 
@@ -249,7 +256,14 @@ def _run_kernel3(kb, g1=None, g2=None, fin=None, k=1):
                       ("s14", 256 * 80), ("s[16:17]", STAT), ("s18", 0), ("s19", 1)):
         m.sset(name, val)
     m.v[255] = 0
+    m.call_log = []
     S.run(lines, m)
+    if check_seq:
+        # the statically certified call sequence (value bounds, tools/kgen3_prog.py: certify_values) is the one executed
+        rep = kb.certify_values(k_pairs=k)
+        log = [re.sub(r"_\d+$", "", x) for x in m.call_log]
+        assert log == rep["sequence"], _first_diff(log, rep["sequence"])
+        assert rep["max_stored"] <= K3P.V_CAP
     out = []
     for c in range(12):
         v = 0

@@ -11,6 +11,7 @@ multiplications, G2 steps, Miller loop, final exponentiation) on the v3 register
     canonical output).
 """
 import math
+import re
 import os
 import sys
 
@@ -21,10 +22,27 @@ from kgen3 import (A0, B0, HOME0, L1V3_NAMES, L1v3, LB, MASK, N0P, N_AGPR_SLOTS,
                    S_RET3, SLOT_DW, V_FLAG, V_GOFF, V_IDX, V_IDX8, V_LDS, V_TID, mont3, to_limbs)
 from kgen_prog import (AGPR, GLOB, HOME, LDS, Const, GlobDyn, Slot, S_FIN, S_G1, S_G2, S_GADDR, S_GBASE, S_GRID, S_GSTRIDE, S_I, S_IOADDR,  # noqa: E402
                        S_ITEM, S_J, S_K, S_N, S_NAF_NEG, S_NAF_NZ, S_NITEMS, S_NSTRIDE, S_OUT, S_SAVE_EXEC, S_SCRATCH, S_STATUS, S_TMP0, S_TMP1,
-                       S_XNAF_NEG, S_XNAF_NZ, f2mul, f2pow, naf_masks, x_naf)
+                       S_XNAF_NEG, S_XNAF_NZ, S_XNAF_RED, f2mul, f2pow, naf_masks, x_naf)
 
 # ---- static bound tracking: every value carries an interval [lo, hi] (in units of 2^27) that contains all of
 # its limbs 0..NL-2 (both Fq2 components); the top limb is small by construction (values stay below ~2^262).
+RED_RUN = 4                  # cyclotomic squarings in a row before the x-power loop reduces the representative
+
+
+def x_red_mask(digits):
+    """Bit j set: digit j of the x-power loop (walked from the top, as L3_powx does) is zero and closes a run of
+    RED_RUN squarings without a multiplication -> L2_redF is called there."""
+    mask, run = 0, 0
+    for j in range(len(digits) - 1, -1, -1):
+        run += 1
+        if digits[j] != 0:
+            run = 0
+        elif run == RED_RUN:
+            mask |= 1 << j
+            run = 0
+    return mask
+
+
 R_NORM = (0.0, 1.0)          # Montgomery-reduction outputs / normalised values / constants
 STORE_MAG = 3.05             # stored values may keep limbs up to 3 units (e.g. 3t - 2z of normalised t, z)
 LIMB_MAG = 15.9              # int32 limbs: |limb| < 2^31 = 16 units
@@ -32,6 +50,14 @@ COL_LIMIT = 62.5             # log2 bound of a signed 64-bit column sum (0.5 bit
 N_CHUNK = SLOT_DW // 4       # 16-byte chunks per slot
 E_NORM = 27.0
 E_STORE_MAX = 27.0 + math.log2(STORE_MAG)
+
+
+# Value bounds (in units of p): a Montgomery reduction maps a sum of products of values a_i b_i to
+# sum(a_i b_i) / R' + (< p), and R'/p = 2^16.4, so reductions contract; additions and x(9+u) grow values.
+# Every stored value must stay below V_STORE p, which keeps the top limb (weight 2^243) below 2^17.
+K_RP = float((1 << (NL * LB)) // P_INT)
+V_STORE = 64.0          # assumed bound (in p) of a value another routine left in a slot
+V_CAP = 65536.0         # nothing larger is ever stored: the top limb (weight 2^243) then stays below 2^27 = one unit
 
 
 def mag(r):
@@ -71,8 +97,24 @@ class Prog3(KP.Prog):
         super().__init__(e, l1_labels)
         self.rA = None
         self.slot_r = {}
+        self.vA = V_STORE
+        self.slot_v = {}
+        self.max_v = 0.0
+        self.entry_v = {}           # certification: bounds of the values other routines left in the slots
+        self.default_v = V_STORE
+        self.read_keys = {}         # slot keys whose entry bound was used -> the bound
 
     UNKNOWN = (-STORE_MAG, STORE_MAG)      # contract for values stored by other routines
+
+    def v_of(self, slot):
+        if slot.kind == "const":
+            return 1.0
+        k = self.key(slot)
+        if k in self.slot_v:
+            return self.slot_v[k]
+        v = self.entry_v.get(k, self.default_v)
+        self.read_keys[k] = v
+        return v
 
     # compatibility shims (exponent view of the interval)
     @property
@@ -93,6 +135,12 @@ class Prog3(KP.Prog):
         return _View()
 
     # ---------------------------------------------------------------- bounds
+    def r_norm(self):
+        """Limb interval of a normalised value (a reduction or norm output): limbs 0..NL-2 lie in [0, 2^27); the
+        top limb (weight 2^243) is signed and carries the representative: |top| <= vA p / 2^243 = vA / K_RP units."""
+        t = self.vA / K_RP
+        return (-t, max(1.0, t))
+
     @staticmethod
     def key(slot):
         if slot.kind == "globdyn":
@@ -183,6 +231,7 @@ class Prog3(KP.Prog):
             self.load(A0, x)
             self.tagA = x
             self.rA = self.r_of(x)
+            self.vA = self.v_of(x)
         return self
 
     def _B(self, y):
@@ -197,6 +246,7 @@ class Prog3(KP.Prog):
         assert len(self._saved_tmp) - len(self.free_tmp) == 4, "home blocks 0..3 must be free"
         self.tagH = [None] * 4
         self.eH = [None] * 4
+        self.vH = [V_STORE] * 4
 
     def release_blocks(self):
         held = [t for t in self._saved_tmp if t.kind == "home" and t.idx < 4]
@@ -210,6 +260,7 @@ class Prog3(KP.Prog):
         self.load(blk, slot)
         self.tagH[k] = slot
         self.eH[k] = self.r_of(slot)
+        self.vH[k] = self.v_of(slot)
         return self
 
     def mul3(self, y):
@@ -218,8 +269,9 @@ class Prog3(KP.Prog):
         rA = self.rA if self.rA is not None else self.UNKNOWN
         worst = mag(rA) * mag(self.r_of(y)) + mag(self.eH[0]) * mag(self.eH[1]) + mag(self.eH[2]) * mag(self.eH[3])
         self._need(math.log2(2 * NL) + 54.0 + math.log2(worst) <= COL_LIMIT, f"mul3 {worst}")
+        self.vA = 2 * (self.vA * self.v_of(y) + self.vH[0] * self.vH[1] + self.vH[2] * self.vH[3]) / K_RP + 1
         self._raw_call("mul3")
-        self.rA = R_NORM
+        self.rA = self.r_norm()
         self.tagH[0] = self.tagH[2] = None          # destroyed
         return self
 
@@ -275,9 +327,10 @@ class Prog3(KP.Prog):
         self.release_blocks()
 
     def set_A_fresh(self, e=E_NORM):
-        """A was filled by hand-written code with a normalised value."""
+        """A was filled by hand-written code with a normalised, reduced value."""
         self.tagA = None
         self.rA = R_NORM
+        self.vA = 2.0
 
     INLINE_SMALL = bool(int(os.environ.get("KGEN3_INLINE_SMALL", "1")))
 
@@ -297,14 +350,19 @@ class Prog3(KP.Prog):
 
     def norm(self):
         self._raw_call("norm")
-        self.rA = R_NORM
+        self.rA = self.r_norm()
         return self
 
     def _need(self, ok, what):
         if not ok:
             raise AssertionError("bound violated: " + what)
 
-    def call(self, name, rB=None, direct=None):
+    def call(self, name, rB=None, direct=None, vB=1.0):
+        vA = self.vA
+        v_out = {"mul": 2 * vA * vB / K_RP + 1, "mulfq": vA * vB / K_RP + 1, "fqmul": vA * vB / K_RP + 1, "sqr": 4 * vA * vA / K_RP + 1,
+                   "fqsqr": vA * vA / K_RP + 1, "add": vA + vB, "sub": vA + vB, "rsub": vA + vB, "dbl": 2 * vA, "neg": vA, "negc1": vA,
+                   "mulxi": 10 * vA, "norm": vA}[name]
+        reduced = (-v_out / K_RP, max(1.0, v_out / K_RP))       # limb interval of a reduction output (see r_norm)
         rA = self.rA if self.rA is not None else self.UNKNOWN
         if isinstance(rB, float):
             rB = (-(2.0 ** (rB - 27.0)), 2.0 ** (rB - 27.0))
@@ -315,32 +373,32 @@ class Prog3(KP.Prog):
         if name == "mul":
             if col(2 * NL, rA, rB) > COL_LIMIT:
                 self.norm()
-                rA = R_NORM
+                rA = self.rA
             self._need(col(2 * NL, rA, rB) <= COL_LIMIT, f"mul {rA} {rB}")
-            out = R_NORM
+            out = reduced
         elif name in ("mulfq", "fqmul"):
             if col(NL, rA, rB) > COL_LIMIT:
                 self.norm()
-                rA = R_NORM
+                rA = self.rA
             self._need(col(NL, rA, rB) <= COL_LIMIT, f"{name} {rA} {rB}")
-            out = R_NORM
+            out = reduced
         elif name in ("sqr", "fqsqr"):
             t, u, d = r_add(rA, rA), r_sub(rA, rA), (2 * rA[0], 2 * rA[1])
             if max(col(NL, t, u), col(NL, rA, d)) > COL_LIMIT or mag(t) > LIMB_MAG:
                 self.norm()
-                rA = R_NORM
-            out = R_NORM
+                rA = self.rA
+            out = reduced
         elif name in ("add", "sub", "rsub"):
             f = {"add": r_add, "sub": r_sub, "rsub": lambda x, y: r_sub(y, x)}[name]
             if mag(f(rA, rB)) > LIMB_MAG:
                 self.norm()
-                rA = R_NORM
+                rA = self.rA
             out = f(rA, rB)
             self._need(mag(out) <= LIMB_MAG, f"{name} {rA} {rB}")
         elif name == "dbl":
             if 2 * mag(rA) > LIMB_MAG:
                 self.norm()
-                rA = R_NORM
+                rA = self.rA
             out = (2 * rA[0], 2 * rA[1])
         elif name == "neg":
             out = r_neg(rA)
@@ -349,21 +407,22 @@ class Prog3(KP.Prog):
         elif name == "mulxi":
             if mag(r_mulxi(rA)) > LIMB_MAG:
                 self.norm()
-                rA = R_NORM
+                rA = self.rA
             out = r_mulxi(rA)
         elif name == "norm":
-            out = R_NORM
+            out = reduced
         else:
             raise ValueError(name)
         self._raw_call(direct or name)
+        self.vA = v_out
         self.rA = out
         return self
 
     def _bin(self, name, y):
         if y.kind == "home" and name in ("add", "sub", "rsub"):
-            return self.call(name, self.r_of(y), direct=f"{name}_h{y.idx}")
+            return self.call(name, self.r_of(y), direct=f"{name}_h{y.idx}", vB=self.v_of(y))
         self._B(y)
-        return self.call(name, self.r_of(y))
+        return self.call(name, self.r_of(y), vB=self.v_of(y))
 
     def to(self, dst):
         rA = self.rA if self.rA is not None else self.UNKNOWN
@@ -372,6 +431,9 @@ class Prog3(KP.Prog):
         self.wait()
         self.store(A0, dst)
         self.slot_r[self.key(dst)] = self.rA if self.rA is not None else self.UNKNOWN
+        self._need(self.vA <= V_CAP, f"value bound {self.vA} p at store")
+        self.slot_v[self.key(dst)] = self.vA
+        self.max_v = max(self.max_v, self.vA)
         self.tagA = dst
         if self.tagB is dst:
             self.tagB = None
@@ -399,10 +461,22 @@ class KernelBuilder3(KP.KernelBuilder):
                 self.labels[f"{op}_h{i}"] = f"L1_{op}_h{i}_%="
 
     def new_prog(self, temps):
+        if not hasattr(self, "l2_bodies"):
+            self.l2_bodies, self.l2_exit, self.l2_maxv = {}, {}, {}
         e = Emitter()
         p = Prog3(e, self.labels)
         p.set_temps(temps)
         return e, p
+
+    def l2_routine(self, name, body, temps):
+        """Also records the value bounds (units of p) the routine leaves in every non-temporary slot, given that all
+        its inputs were below V_STORE p: the basis of the inductive certification in certify_values()."""
+        p = super().l2_routine(name, body, temps)
+        tk = {Prog3.key(t) for t in temps}
+        self.l2_bodies[name] = (body, temps)
+        self.l2_exit[name] = {k: v for k, v in p.slot_v.items() if k not in tk}
+        self.l2_maxv[name] = p.max_v
+        return p
 
     def miller_temps(self, extra=()):
         """Fast temporaries of the Miller-loop routines: homes 0..6, AGPR 10 (11 when no scale is tracked),
@@ -454,6 +528,7 @@ class KernelBuilder3(KP.KernelBuilder):
             if not (self.do_miller and self.track):
                 self.l2_routine("L2_fqinv", self._fq_inv, self.fexp_temps())
             self.l2_routine("L2_cyc", lambda p: p.fq12_cyc_sqr(self.F), self.fexp_temps())
+            self.l2_routine("L2_redF", self._reduce_f, self.fexp_temps())
             self._mulG_routines()
             for k in (1, 2, 3):
                 self.l2_routine(f"L2_frob{k}", lambda p, k=k: self._frobenius(p, k), self.fexp_temps())
@@ -483,6 +558,151 @@ class KernelBuilder3(KP.KernelBuilder):
         for e in [self._pro] + first + [main, l1e] + second + [tail]:
             out.extend(e.finalize())
         return out
+
+    # ------------------------------------------------------------------ value-bound certification
+    # Limb bounds are closed per routine (every store enforces STORE_MAG, every multiplication its column sums).
+    # VALUE bounds cross routine boundaries: each routine is generated assuming its inputs are below V_STORE p and
+    # the tracker only needs "value <= K_RP * limb interval" (the top limb).  certify_values() replays the real
+    # call sequences (data independent: NAF digits only) with the routines' own transfer functions and checks
+    # that every routine still generates IDENTICAL code and passes all its checks under the true entry bounds.
+    @staticmethod
+    def _grid(v):
+        """Round a bound up to a coarse grid (sound, and makes the memo hit)."""
+        if v <= 1.0:
+            return 1.0
+        s_ = 2.0 ** (math.floor(math.log2(v)) - 3)
+        return math.ceil(v / s_) * s_
+
+    @staticmethod
+    def _norm_text(lines):
+        return [re.sub(r"_\d+_\d+_%=", "_%=", l_) for l_ in lines]      # per-instance loop label suffixes
+
+    def _eval(self, name, state, body=None, temps=None):
+        """Abstract run of L2 routine `name` from `state` (slot key -> bound): returns (exit bounds, max stored)."""
+        if body is None:
+            body, temps = self.l2_bodies[name]
+        memo = self._memo.setdefault(name, [])
+        for reads, ex, mv in memo:
+            if all(self._grid(state.get(k, 2.0)) == v for k, v in reads.items()):
+                return ex, mv
+        e, p = self.new_prog(temps)
+        p.entry_v = {k: self._grid(v) for k, v in state.items()}
+        p.default_v = 2.0                       # never-written slots hold converted inputs
+        body(p)
+        ref = self._ref_text.get(name)
+        if ref is not None:
+            assert self._norm_text(e.finalize()) == ref, f"{name}: code depends on the value bounds"
+        tk = {Prog3.key(t) for t in temps}
+        ex = {k: v for k, v in p.slot_v.items() if k not in tk}
+        memo.append((dict(p.read_keys), ex, p.max_v))
+        return ex, p.max_v
+
+    def certify_values(self, k_pairs=1):
+        """Replays the kernel's L2 call sequence on value bounds.  Returns a report dict; raises on any violation."""
+        self._memo, self._ref_text = {}, {}
+        for name, (body, temps) in self.l2_bodies.items():       # the shipped code of each routine body
+            e, p = self.new_prog(temps)
+            body(p)
+            self._ref_text[name] = self._norm_text(e.finalize())
+        st, worst, calls = {}, 0.0, 0
+        fk = [Prog3.key(s_) for s_ in self.F]
+
+        seq = []                          # labels in call order: cross-checked against the simulator's call log
+
+        def run(name, label=None, **kw):
+            nonlocal worst, calls
+            ex, mv = self._eval(name, st, **kw)
+            st.update(ex)
+            worst = max(worst, mv)
+            calls += 1
+            seq.append(label or name)
+            if name in ("L2_descale", "L2_inv"):
+                seq.append("L2_fqinv")           # nested: the Fq inversion (fixed exponent, outputs below 2 p)
+
+        report = {}
+        if self.do_miller:
+            # converted inputs (< 2 p): P, Q, R = (Q, 1), scale = 1; S = +-Q on the non-zero digits
+            run("L2_dblfirst")
+            for _ in range(k_pairs - 1):
+                run("L2_dblmul")
+            for i in range(63, -1, -1):
+                if i != 63:
+                    run("L2_sqr")
+                    if self.track:
+                        run("L2_sqscale")
+                    for _ in range(k_pairs):
+                        run("L2_dblmul")
+                if SIX_U_PLUS_2_NAF[i] != 0:
+                    for _ in range(k_pairs):
+                        st[Prog3.key(self.SX)] = st[Prog3.key(self.SY)] = 2.0
+                        run("L2_addmul")
+            for _ in range(k_pairs):                                    # per pair: + Q1, then - Q2
+                for s_ in (self.SX, self.SY, self.QX, self.QY):         # Frobenius images: reduction outputs
+                    st[Prog3.key(s_)] = 2.0
+                run("L2_addmul")
+                run("L2_addmul_last")
+            if self.track:
+                run("L2_descale")
+            report["miller_f_out"] = max(st[k] for k in fk)
+        if self.do_fexp:
+            G = {}
+
+            def mul_body(p):
+                p.fq12_mul(self.F, self.BOP)
+
+            naf = x_naf()[:-1]
+            red = x_red_mask(naf)
+            for op in self.fexp_trace:
+                if op[0] == "st":
+                    G[op[1]] = [st.get(k, 2.0) for k in fk]
+                    seq.append("L2_stG")
+                elif op[0] == "ld":
+                    for k, v in zip(fk, G[op[1]]):
+                        st[k] = v
+                    seq.append("L2_ldGc" if op[2] else "L2_ldG")
+                elif op[0] == "mul":
+                    for b, v in zip(self.BOP, G[op[1]]):
+                        st[Prog3.key(b)] = v
+                    run("L2_mul_body", label="L2_mulGc" if op[2] else "L2_mulG", body=mul_body, temps=self.fexp_temps())
+                elif op[0] == "powx":
+                    j = op[1]
+                    run("L2_redF")
+                    G[j] = [st[k] for k in fk]
+                    seq.append("L2_stG")
+                    for d in range(len(naf) - 1, -1, -1):
+                        run("L2_cyc")
+                        if naf[d] != 0:
+                            for b, v in zip(self.BOP, G[j]):
+                                st[Prog3.key(b)] = v
+                            run("L2_mul_body", label="L2_mulGc" if naf[d] < 0 else "L2_mulG", body=mul_body, temps=self.fexp_temps())
+                        elif red >> d & 1:
+                            run("L2_redF")
+                else:
+                    run(op[1])
+            report["fexp_f_out"] = max(st[k] for k in fk)
+        report["max_stored"] = worst
+        report["calls"] = calls
+        report["sequence"] = seq
+        assert worst <= V_CAP
+        return report
+
+    def _reduce_f(self, p):
+        """F <- F * 1 (a Montgomery multiplication by the constant one): same residues, representatives back in
+        [0, ~1.01 p).  Every cyclotomic squaring roughly doubles the representative (3t - 2z), so the x-power loop
+        calls this after RED_RUN squarings in a row without a multiplication (see x_red_mask)."""
+        one = Const(1, 0, "one")
+        for k in range(6):
+            p.A(self.F[k]).mulfq(one).to(self.F[k])
+
+    def _powx_entry(self, e):
+        # reduce the base once (and keep the reduced copy): every multiplication by it then contracts the accumulator
+        e.salu(f"s_call_b64 {S_RET2}, {self.lab('L2_redF')}")
+        e.salu(f"s_call_b64 {S_RET2}, {self.lab('L2_stG')}")
+
+    def _powx_zero_digit(self, e):
+        e.salu(f"s_bitcmp1_b64 {S_XNAF_RED}, s{S_J}")
+        e.salu(f"s_cbranch_scc0 {self.lab('L3_powx_next')}")
+        e.salu(f"s_call_b64 {S_RET2}, {self.lab('L2_redF')}")
 
     def batch_load_globdyn(self, e, p, ks, dests):
         """dests[i] <- scratch slot (S_GBASE + ks[i]): all global loads issued back to back into landing registers
@@ -573,6 +793,9 @@ class KernelBuilder3(KP.KernelBuilder):
         xn = x_naf()
         nz, neg = naf_masks(xn[:-1])
         self.x_top = len(xn) - 1
+        red = x_red_mask(xn[:-1])
+        e.salu(f"s_mov_b32 s48, 0x{red & 0xFFFFFFFF:x}")
+        e.salu(f"s_mov_b32 s49, 0x{red >> 32:x}")
         e.salu(f"s_mov_b32 s72, 0x{nz & 0xFFFFFFFF:x}")
         e.salu(f"s_mov_b32 s73, 0x{nz >> 32:x}")
         e.salu(f"s_mov_b32 s74, 0x{neg & 0xFFFFFFFF:x}")

@@ -23,6 +23,7 @@ S_NAF_NZ = "s[68:69]"     # 6u+2 NAF: non-zero mask, negative mask (digits 0..63
 S_NAF_NEG = "s[70:71]"
 S_XNAF_NZ = "s[72:73]"    # BN_X NAF masks
 S_XNAF_NEG = "s[74:75]"
+S_XNAF_RED = "s[48:49]"   # v3 only: digits after which the accumulator's representative is reduced (L2_redF)
 S_J = 76                  # pow_x digit index
 S_GBASE = 77              # global Fq12 register operand of fq12_mul (slot number * stride, low 32 bits)
 S_ITEM = 78
@@ -871,22 +872,32 @@ class KernelBuilder:
         (final_exp_native.rs:56-84); division by a unitary element = multiplication by its conjugate."""
         e = Emitter()
         e.label(self.lab("L3_powx"))
+        self._powx_entry(e)
         e.salu(f"s_mov_b32 s{S_J}, {self.x_top - 1}")
         e.label(self.lab("L3_powx_loop"))
         e.salu(f"s_call_b64 {S_RET2}, {self.lab('L2_cyc')}")
         e.salu(f"s_bitcmp1_b64 {S_XNAF_NZ}, s{S_J}")
-        e.salu(f"s_cbranch_scc0 {self.lab('L3_powx_next')}")
+        e.salu(f"s_cbranch_scc0 {self.lab('L3_powx_zero')}")
         e.salu(f"s_bitcmp1_b64 {S_XNAF_NEG}, s{S_J}")
         e.salu(f"s_cbranch_scc1 {self.lab('L3_powx_neg')}")
         e.salu(f"s_call_b64 {S_RET2}, {self.lab('L2_mulG')}")
         e.salu(f"s_branch {self.lab('L3_powx_next')}")
         e.label(self.lab("L3_powx_neg"))
         e.salu(f"s_call_b64 {S_RET2}, {self.lab('L2_mulGc')}")
+        e.salu(f"s_branch {self.lab('L3_powx_next')}")
+        e.label(self.lab("L3_powx_zero"))
+        self._powx_zero_digit(e)
         e.label(self.lab("L3_powx_next"))
         e.salu(f"s_sub_u32 s{S_J}, s{S_J}, 1")
         e.salu(f"s_cbranch_scc0 {self.lab('L3_powx_loop')}")
         e.salu(f"s_setpc_b64 {S_RET3}")
         self.sections.append(e)
+
+    def _powx_entry(self, e):
+        """Hook at the entry of the x-power routine (F = base, S_GBASE selects the base's scratch register)."""
+
+    def _powx_zero_digit(self, e):
+        """Hook for a zero digit of the x-power loop (the v3 builder reduces the accumulator here)."""
 
     # ---------------------------------------------------------------------------------------------
     def gsel(self, e, j):
@@ -1012,24 +1023,31 @@ class KernelBuilder:
     def fexp_main(self, e, p):
         """final_exp_native on F (LDS), F-centric schedule (tests/sched_model.py: final_exp_gpu)."""
         G0, GM, G2, G3, G4, G5, G6, G7 = range(8)
+        tr = self.fexp_trace = []         # the straight-line call sequence, replayed by the v3 bound certification
 
         def st(j):
+            tr.append(("st", j))
             self.gsel(e, j)
             self.call2(e, "L2_stG")
 
         def ld(j, conj=False):
+            tr.append(("ld", j, conj))
             self.gsel(e, j)
             self.call2(e, "L2_ldGc" if conj else "L2_ldG")
 
         def mul(j, conj=False):
+            tr.append(("mul", j, conj))
             self.gsel(e, j)
             self.call2(e, "L2_mulGc" if conj else "L2_mulG")
 
         def powx(j):
+            tr.append(("powx", j))
             self.gsel(e, j)
             e.salu(f"s_call_b64 {S_RET3}, {self.lab('L3_powx')}")
 
-        c2 = lambda n: self.call2(e, n)  # noqa: E731
+        def c2(n):
+            tr.append(("call", n))
+            self.call2(e, n)
         # easy part (:195-206)
         st(G0); c2("L2_inv"); mul(G0, conj=True); st(G0); c2("L2_frob2"); mul(G0)
         # hard part (:130-169)

@@ -39,6 +39,8 @@ class Machine:
         self.count_valu = 0
         self.count_nop = 0
         self.max_acc = 0      # largest |column accumulator| seen (v3 kernels)
+        self.call_log = None  # list: labels of the L2 routines called, in order (bound certification cross-check)
+        self.max_stored = 0   # largest |signed dword| written to LDS (v3: limb magnitudes of stored values)
 
     # ---------------------------------------------------------------- scalar register helpers
     def sget(self, name):
@@ -351,6 +353,8 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None):
                 pc = labels[a[0]]
             elif op == "s_call_b64":
                 m.sset(a[0], pc)          # "return address" = next instruction index
+                if m.call_log is not None and a[1].startswith("L2_"):
+                    m.call_log.append(a[1].replace("_%=", ""))
                 pc = labels[a[1]]
             elif op == "s_setpc_b64":
                 pc = m.sget(a[0])
@@ -393,6 +397,8 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None):
                             raise SimError("store of uninitialised register: " + text)
                         if m.exec:
                             m.lds[base + off + 4 * k] = v[lo + k]
+                            sv = v[lo + k] - (1 << 32) if v[lo + k] >> 31 else v[lo + k]
+                            m.max_stored = max(m.max_stored, abs(sv))
             elif op.startswith("global_load_dword") or op.startswith("global_store_dword"):
                 n = {"": 1, "x2": 2, "x4": 4}[op.split("dword")[1]]
                 off = 0
