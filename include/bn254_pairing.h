@@ -57,6 +57,9 @@ const char* bn254_strerror(int status);
 int bn254_last_status(int device, void* stream);
 /* Bytes of device scratch a call over n lanes will use (informational). */
 size_t bn254_scratch_bytes(size_t n, size_t k);
+/* Scratch and the status word are kept per (device, stream), so calls on different streams are independent;
+ * this frees what the library holds for `stream` (call it before destroying a stream you used). */
+int bn254_release_stream(int device, void* stream);
 
 /* ---- the hot path -------------------------------------------------------------------- */
 
@@ -84,6 +87,22 @@ int bn254_multi_pairing_batch_dev(const uint64_t* g1, const uint64_t* g2, uint64
                                   int do_final_exp, int device, void* stream);
 int bn254_multi_pairing_batch(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_groups, size_t k,
                               int do_final_exp, int device, void* stream);
+
+/* The check the reference's tests apply to a product of pairings (final_exp_native.rs:245-263,
+ * `final_exp_native(multi_miller_loop_native(pairs)) == MyFq12::one`), i.e. the Groth16 verifier shape:
+ * verdict[g] = 1 iff group g's product of k pairings is exactly one, else 0.  One byte per group leaves the
+ * device instead of 384. */
+int bn254_multi_pairing_check_batch_dev(const uint64_t* g1, const uint64_t* g2, uint8_t* verdict, size_t n_groups, size_t k,
+                                        int device, void* stream);
+int bn254_multi_pairing_check_batch(const uint64_t* g1, const uint64_t* g2, uint8_t* verdict, size_t n_groups, size_t k,
+                                    int device, void* stream);
+
+/* ---- one process, several GPUs: host pointers, contiguous slices of the batch per device
+ * 0..n_devices-1, no exchange step; every device runs the same kernels on a private stream.  Independent
+ * pairings (src/pairing.rs:20-22) or k-pair groups (src/miller_loop_native.rs:324-326, groups stay whole). */
+int bn254_pairing_sharded(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n, int n_devices);
+int bn254_multi_pairing_sharded(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_groups, size_t k,
+                                int do_final_exp, int n_devices);
 
 /* ---- batched public helpers of the reference ------------------------------------------ */
 

@@ -128,4 +128,28 @@ inline std::vector<MyFq12> pairing_batch(const std::vector<G1Affine>& ps, const 
     return r;
 }
 
+// One process, several GPUs: contiguous slices per device (bn254_pairing_sharded).
+inline std::vector<MyFq12> pairing_sharded(const std::vector<G1Affine>& ps, const std::vector<G2Affine>& qs, int n_devices) {
+    const size_t n = ps.size();
+    if (qs.size() != n) throw Panic(BN254_ERR_INVALID_ARG);
+    std::vector<uint64_t> g1(8 * n), g2(16 * n), out(48 * n);
+    for (size_t i = 0; i < n; i++) { detail::pack_g1(ps[i], g1.data(), n, i); detail::pack_g2(qs[i], g2.data(), n, i); }
+    check(bn254_pairing_sharded(g1.data(), g2.data(), out.data(), n, n_devices));
+    std::vector<MyFq12> r(n);
+    for (size_t i = 0; i < n; i++) r[i] = detail::unpack_fq12(out.data(), n, i);
+    return r;
+}
+
+// final_exp_native(multi_miller_loop_native(group)) == MyFq12::one for every group of k pairs
+// (the product check of final_exp_native.rs:245-263; a Groth16 verifier's shape): one verdict per group.
+inline std::vector<uint8_t> multi_pairing_check_batch(const std::vector<G1Affine>& ps, const std::vector<G2Affine>& qs, size_t k, int device = 0) {
+    const size_t np = ps.size();
+    if (qs.size() != np || k == 0 || np % k != 0) throw Panic(BN254_ERR_INVALID_ARG);
+    std::vector<uint64_t> g1(8 * np), g2(16 * np);
+    for (size_t i = 0; i < np; i++) { detail::pack_g1(ps[i], g1.data(), np, i); detail::pack_g2(qs[i], g2.data(), np, i); }
+    std::vector<uint8_t> verdict(np / k);
+    check(bn254_multi_pairing_check_batch(g1.data(), g2.data(), verdict.data(), np / k, k, device, nullptr));
+    return verdict;
+}
+
 }  // namespace bn254

@@ -70,6 +70,11 @@ _PROTOS = {
     "bn254_final_exp_batch": (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "bn254_multi_pairing_batch_dev": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "bn254_multi_pairing_batch": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_multi_pairing_check_batch_dev": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_multi_pairing_check_batch": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_pairing_sharded": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_int]),
+    "bn254_multi_pairing_sharded": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int]),
+    "bn254_release_stream": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p]),
     "bn254_fq12_mul_batch_dev": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "bn254_fq12_mul_batch": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "bn254_frobenius_map_batch_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
@@ -205,6 +210,34 @@ def multi_pairing_batch(g1, g2, n_groups, k, do_final_exp=True, device=0):
     return out
 
 
+def multi_pairing_check_batch(g1, g2, n_groups, k, device=0):
+    """verdict[g] = (final_exp_native(multi_miller_loop_native(group g)) == MyFq12::one), the product check of
+    final_exp_native.rs:245-263 / a Groth16 verifier: uint8 array of n_groups entries."""
+    lib = load_library()
+    g1, g2 = _np_in(g1, G1_WORDS, n_groups * k), _np_in(g2, G2_WORDS, n_groups * k)
+    out = np.empty(n_groups, dtype=np.uint8)
+    _check(lib.bn254_multi_pairing_check_batch(_ptr(g1), _ptr(g2), _ptr(out), n_groups, k, device, None), "multi-pairing check")
+    return out
+
+
+def pairing_sharded(g1, g2, n, n_devices):
+    """pairing_batch over devices 0..n_devices-1 of this process (contiguous slices, no exchange step)."""
+    lib = load_library()
+    g1, g2 = _np_in(g1, G1_WORDS, n), _np_in(g2, G2_WORDS, n)
+    out = np.empty(FQ12_WORDS * n, dtype=np.uint64)
+    _check(lib.bn254_pairing_sharded(_ptr(g1), _ptr(g2), _ptr(out), n, n_devices), "pairing (sharded)")
+    return out
+
+
+def multi_pairing_sharded(g1, g2, n_groups, k, n_devices, do_final_exp=True):
+    lib = load_library()
+    g1, g2 = _np_in(g1, G1_WORDS, n_groups * k), _np_in(g2, G2_WORDS, n_groups * k)
+    out = np.empty(FQ12_WORDS * n_groups, dtype=np.uint64)
+    _check(lib.bn254_multi_pairing_sharded(_ptr(g1), _ptr(g2), _ptr(out), n_groups, k, 1 if do_final_exp else 0, n_devices),
+           "multi_miller_loop_native (sharded)")
+    return out
+
+
 def fq12_mul_batch(a, b, n, device=0):
     lib = load_library()
     a, b = _np_in(a, FQ12_WORDS, n), _np_in(b, FQ12_WORDS, n)
@@ -256,6 +289,15 @@ def final_exp_batch_dev(f, out, n, device=0, stream=None):
 def multi_pairing_batch_dev(g1, g2, out, n_groups, k, do_final_exp=True, device=0, stream=None):
     _check(load_library().bn254_multi_pairing_batch_dev(_dev(g1), _dev(g2), _dev(out), n_groups, k, 1 if do_final_exp else 0, device,
                                                         _stream(stream)), "multi_miller_loop_native")
+
+
+def multi_pairing_check_batch_dev(g1, g2, verdict, n_groups, k, device=0, stream=None):
+    _check(load_library().bn254_multi_pairing_check_batch_dev(_dev(g1), _dev(g2), _dev(verdict), n_groups, k, device, _stream(stream)),
+           "multi-pairing check")
+
+
+def release_stream(device=0, stream=None):
+    _check(load_library().bn254_release_stream(device, _stream(stream)), "release_stream")
 
 
 def generate_pairs_dev(seed, g1_out, g2_out, n, device=0, stream=None):

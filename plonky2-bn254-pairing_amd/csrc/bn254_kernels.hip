@@ -9,7 +9,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <map>
 #include <mutex>
+#include <thread>
 #include <vector>
 #include "bn254_dev.h"
 #include "pairing_asm_gen.h"
@@ -358,22 +360,48 @@ k_generate(uint64_t seed, uint64_t* g1_out, uint64_t* g2_out, size_t n, uint4* s
     }
 }
 
+// verdict[i] = 1 iff Fq12 element i equals MyFq12::one (coeffs[0] = R mod p in ark's Montgomery limbs, the rest 0):
+// the check pattern of final_exp_native.rs:245-263 (a Groth16-style product of pairings == 1), one byte per group.
+__global__ void __launch_bounds__(256) k_is_one(const uint64_t* __restrict__ f, uint8_t* __restrict__ verdict, size_t n) {
+    const uint64_t one[4] = {0xd35d438dc58f0d9dull, 0x0a78eb28f5c70b3dull, 0x666ea36f7879462cull, 0x0e0a77c19a07df2full};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint64_t diff = 0;
+        for (int c = 0; c < 12; c++)
+            for (int l = 0; l < 4; l++) diff |= f[((size_t)c * 4 + l) * n + i] ^ (c == 0 ? one[l] : 0ull);
+        verdict[i] = diff == 0 ? 1 : 0;
+    }
+}
+
 // ------------------------------------------------------------------ host side
-struct DeviceCtx {
-    bool init = false;
-    int n_cu = 0;
+// Scratch and the status word are per (device, stream): calls on different streams of one device are independent
+// ("library is re-entrant, one HIP stream per call").
+struct StreamCtx {
     uint4* scratch = nullptr;
     size_t scratch_bytes = 0;
     int* status = nullptr;
     int8_t* naf = nullptr;     // device copy of NAF digits for pow
     size_t naf_cap = 0;
+    uint64_t* tmp = nullptr;   // Fq12 staging of the == 1 verdict path
+    size_t tmp_bytes = 0;
+};
+struct DeviceCtx {
+    bool init = false;
+    int n_cu = 0;
+    std::map<hipStream_t, StreamCtx> streams;
 };
 std::mutex g_mu;
 DeviceCtx g_ctx[64];
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { return BN254_ERR_HIP; } } while (0)
 
-int ctx_get(int device, size_t k, DeviceCtx** out, uint32_t* grid_out, size_t n_items) {
+struct LaunchCtx {
+    StreamCtx* s;
+    int n_cu;
+    uint4* scratch;
+    int* status;
+};
+
+int ctx_get(int device, void* stream, size_t k, LaunchCtx* out, uint32_t* grid_out, size_t n_items) {
     int cnt = 0;
     if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) return BN254_ERR_NO_DEVICE;
     if (device < 0 || device >= cnt || device >= 64) return BN254_ERR_INVALID_ARG;
@@ -384,22 +412,17 @@ int ctx_get(int device, size_t k, DeviceCtx** out, uint32_t* grid_out, size_t n_
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, device));
         c.n_cu = prop.multiProcessorCount;
-        HIPCHK(hipMalloc(&c.status, sizeof(int)));
-        HIPCHK(hipMemset(c.status, 0, sizeof(int)));
-        HIPCHK(hipFuncSetAttribute((const void*)k_pairing<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k_pairing<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k_pairing<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k_fq12_op, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k_generate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k2_pairing, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k2_miller, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k2_fexp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k3_pairing, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k3_miller, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k3_fexp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k3_mpairing, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k3_mmiller, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+        const void* kernels[] = {(const void*)k_pairing<true, true>, (const void*)k_pairing<true, false>, (const void*)k_pairing<false, true>,
+                                 (const void*)k_fq12_op, (const void*)k_generate, (const void*)k2_pairing, (const void*)k2_miller,
+                                 (const void*)k2_fexp, (const void*)k3_pairing, (const void*)k3_miller, (const void*)k3_fexp,
+                                 (const void*)k3_mpairing, (const void*)k3_mmiller};
+        for (const void* f : kernels) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
         c.init = true;
+    }
+    StreamCtx& sc = c.streams[(hipStream_t)stream];
+    if (!sc.status) {
+        HIPCHK(hipMalloc(&sc.status, sizeof(int)));
+        HIPCHK(hipMemsetAsync(sc.status, 0, sizeof(int), (hipStream_t)stream));
     }
     uint32_t grid = (uint32_t)(n_items < (size_t)c.n_cu ? n_items : (size_t)c.n_cu);
     if (grid == 0) grid = 1;
@@ -407,12 +430,15 @@ int ctx_get(int device, size_t k, DeviceCtx** out, uint32_t* grid_out, size_t n_
     size_t need = slots * 64 * (size_t)c.n_cu * BLOCK;   // sized for a full grid so the buffer is stable
     size_t need3 = (size_t)(V3_GSLOTS + 7 * (k > 1 ? k : 0)) * V3_SLOT_BYTES * (size_t)c.n_cu * BLOCK;
     if (need3 > need) need = need3;
-    if (need > c.scratch_bytes) {
-        if (c.scratch) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(c.scratch)); c.scratch = nullptr; c.scratch_bytes = 0; }
-        if (hipMalloc(&c.scratch, need) != hipSuccess) return BN254_ERR_ALLOC;
-        c.scratch_bytes = need;
+    if (need > sc.scratch_bytes) {
+        if (sc.scratch) { HIPCHK(hipStreamSynchronize((hipStream_t)stream)); HIPCHK(hipFree(sc.scratch)); sc.scratch = nullptr; sc.scratch_bytes = 0; }
+        if (hipMalloc(&sc.scratch, need) != hipSuccess) return BN254_ERR_ALLOC;
+        sc.scratch_bytes = need;
     }
-    *out = &c;
+    out->s = &sc;
+    out->n_cu = c.n_cu;
+    out->scratch = sc.scratch;
+    out->status = sc.status;
     *grid_out = grid;
     return BN254_OK;
 }
@@ -421,9 +447,9 @@ template <bool M, bool F>
 int launch_pairing(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in, uint64_t* out, size_t n_groups, size_t k, int device, void* stream) {
     if (n_groups == 0) return BN254_OK;
     if (!out || (M && (!g1 || !g2)) || (!M && !f_in) || k == 0 || k > 64) return BN254_ERR_INVALID_ARG;
-    DeviceCtx* c; uint32_t grid;
+    LaunchCtx lc; LaunchCtx* c = &lc; uint32_t grid;
     size_t n_items = (n_groups + BLOCK - 1) / BLOCK;
-    int rc = ctx_get(device, k, &c, &grid, n_items);
+    int rc = ctx_get(device, stream, k, &lc, &grid, n_items);
     if (rc) return rc;
     static const bool use_v1 = (getenv("BN254_FORCE_V1") != nullptr);
     static const bool use_v2 = (getenv("BN254_FORCE_V2") != nullptr);
@@ -471,21 +497,21 @@ int launch_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_
               int device, void* stream) {
     if (n == 0) return BN254_OK;
     if (!a || !out || (op == OP_MUL && !b)) return BN254_ERR_INVALID_ARG;
-    DeviceCtx* c; uint32_t grid;
+    LaunchCtx lc; LaunchCtx* c = &lc; uint32_t grid;
     size_t n_items = (n + BLOCK - 1) / BLOCK;
-    int rc = ctx_get(device, 1, &c, &grid, n_items);
+    int rc = ctx_get(device, stream, 1, &lc, &grid, n_items);
     if (rc) return rc;
     const int8_t* naf_dev = nullptr;
     if (op == OP_POW) {
-        std::lock_guard<std::mutex> lk(g_mu);
-        if ((size_t)naf_len > c->naf_cap) {
-            if (c->naf) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(c->naf)); }
-            HIPCHK(hipMalloc(&c->naf, (size_t)naf_len + 64));
-            c->naf_cap = (size_t)naf_len + 64;
+        StreamCtx* sc = c->s;
+        if ((size_t)naf_len > sc->naf_cap) {
+            if (sc->naf) { HIPCHK(hipStreamSynchronize((hipStream_t)stream)); HIPCHK(hipFree(sc->naf)); sc->naf = nullptr; }
+            HIPCHK(hipMalloc(&sc->naf, (size_t)naf_len + 64));
+            sc->naf_cap = (size_t)naf_len + 64;
         }
-        HIPCHK(hipMemcpyAsync(c->naf, naf_host, (size_t)naf_len, hipMemcpyHostToDevice, (hipStream_t)stream));
+        HIPCHK(hipMemcpyAsync(sc->naf, naf_host, (size_t)naf_len, hipMemcpyHostToDevice, (hipStream_t)stream));
         HIPCHK(hipStreamSynchronize((hipStream_t)stream));   // naf_host may be a caller temporary
-        naf_dev = c->naf;
+        naf_dev = sc->naf;
     }
     hipLaunchKernelGGL(k_fq12_op, dim3(grid), dim3(BLOCK), LDS_BYTES, (hipStream_t)stream,
                        op, a, b, out, n, power, naf_dev, naf_len, c->scratch, (uint32_t)(c->n_cu * BLOCK), c->status);
@@ -564,11 +590,17 @@ int bn254_last_status(int device, void* stream) {
     if (device < 0 || device >= cnt || device >= 64) return BN254_ERR_INVALID_ARG;
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-    DeviceCtx& c = g_ctx[device];
-    if (!c.init) return BN254_OK;
+    int* status = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        DeviceCtx& c = g_ctx[device];
+        auto it = c.streams.find((hipStream_t)stream);
+        if (!c.init || it == c.streams.end()) return BN254_OK;
+        status = it->second.status;
+    }
     int h = 0;
-    HIPCHK(hipMemcpy(&h, c.status, sizeof(int), hipMemcpyDeviceToHost));
-    if (h) { HIPCHK(hipMemset(c.status, 0, sizeof(int))); return BN254_ERR_ZERO_DIVISOR; }
+    HIPCHK(hipMemcpy(&h, status, sizeof(int), hipMemcpyDeviceToHost));
+    if (h) { HIPCHK(hipMemset(status, 0, sizeof(int))); return BN254_ERR_ZERO_DIVISOR; }
     return BN254_OK;
 }
 
@@ -648,9 +680,9 @@ int bn254_myfq12_to_ark_index(int j) {
 int bn254_generate_pairs_dev(uint64_t seed, uint64_t* g1_out, uint64_t* g2_out, size_t n, int device, void* stream) {
     if (n == 0) return BN254_OK;
     if (!g1_out || !g2_out) return BN254_ERR_INVALID_ARG;
-    DeviceCtx* c; uint32_t grid;
+    LaunchCtx lc; LaunchCtx* c = &lc; uint32_t grid;
     size_t n_items = (n + BLOCK - 1) / BLOCK;
-    int rc = ctx_get(device, 1, &c, &grid, n_items);
+    int rc = ctx_get(device, stream, 1, &lc, &grid, n_items);
     if (rc) return rc;
     hipLaunchKernelGGL(k_generate, dim3(grid), dim3(BLOCK), LDS_BYTES, (hipStream_t)stream, seed, g1_out, g2_out, n, c->scratch,
                        (uint32_t)(c->n_cu * BLOCK));
@@ -658,7 +690,61 @@ int bn254_generate_pairs_dev(uint64_t seed, uint64_t* g1_out, uint64_t* g2_out, 
     return BN254_OK;
 }
 
+int bn254_multi_pairing_check_batch_dev(const uint64_t* g1, const uint64_t* g2, uint8_t* verdict, size_t n_groups, size_t k, int device,
+                                        void* stream) {
+    if (n_groups == 0) return BN254_OK;
+    if (!g1 || !g2 || !verdict || k == 0 || k > 64) return BN254_ERR_INVALID_ARG;
+    LaunchCtx lc; uint32_t grid;
+    int rc = ctx_get(device, stream, k, &lc, &grid, (n_groups + BLOCK - 1) / BLOCK);
+    if (rc) return rc;
+    StreamCtx* sc = lc.s;
+    size_t need = 384 * n_groups;
+    if (need > sc->tmp_bytes) {
+        if (sc->tmp) { HIPCHK(hipStreamSynchronize((hipStream_t)stream)); HIPCHK(hipFree(sc->tmp)); sc->tmp = nullptr; sc->tmp_bytes = 0; }
+        if (hipMalloc(&sc->tmp, need) != hipSuccess) return BN254_ERR_ALLOC;
+        sc->tmp_bytes = need;
+    }
+    if ((rc = launch_pairing<true, true>(g1, g2, nullptr, sc->tmp, n_groups, k, device, stream))) return rc;
+    size_t blocks = (n_groups + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_is_one, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, sc->tmp, verdict, n_groups);
+    HIPCHK(hipGetLastError());
+    return BN254_OK;
+}
+
+int bn254_release_stream(int device, void* stream) {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) return BN254_ERR_NO_DEVICE;
+    if (device < 0 || device >= cnt || device >= 64) return BN254_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    std::lock_guard<std::mutex> lk(g_mu);
+    DeviceCtx& c = g_ctx[device];
+    auto it = c.streams.find((hipStream_t)stream);
+    if (it == c.streams.end()) return BN254_OK;
+    StreamCtx& sc = it->second;
+    if (sc.scratch) (void)hipFree(sc.scratch);
+    if (sc.status) (void)hipFree(sc.status);
+    if (sc.naf) (void)hipFree(sc.naf);
+    if (sc.tmp) (void)hipFree(sc.tmp);
+    c.streams.erase(it);
+    return BN254_OK;
+}
+
 // ---- host-pointer variants: stage through the device, synchronise, report the status word
+int bn254_multi_pairing_check_batch(const uint64_t* g1, const uint64_t* g2, uint8_t* verdict, size_t n_groups, size_t k, int device, void* stream) {
+    if (n_groups == 0) return BN254_OK;
+    if (!g1 || !g2 || !verdict || k == 0) return BN254_ERR_INVALID_ARG;
+    if (bn254_device_count() <= 0) return BN254_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return BN254_ERR_INVALID_ARG;
+    Staged s; uint64_t *d1, *d2, *d3; int rc; size_t np = n_groups * k;
+    if ((rc = s.up(g1, 8 * np, &d1, (hipStream_t)stream)) || (rc = s.up(g2, 16 * np, &d2, (hipStream_t)stream)) ||
+        (rc = s.up(nullptr, (n_groups + 7) / 8, &d3, (hipStream_t)stream))) return rc;
+    if ((rc = bn254_multi_pairing_check_batch_dev(d1, d2, (uint8_t*)d3, n_groups, k, device, stream))) return rc;
+    if (hipMemcpyAsync(verdict, d3, n_groups, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return BN254_ERR_HIP;
+    return bn254_last_status(device, stream);
+}
+
 int bn254_pairing_batch(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n, int device, void* stream) {
     if (n == 0) return BN254_OK;
     if (!g1 || !g2 || !out) return BN254_ERR_INVALID_ARG;
@@ -729,6 +815,59 @@ int bn254_pow_batch(const uint64_t* a, const uint64_t* exp, size_t exp_limbs, ui
     if ((rc = s.up(a, 48 * n, &d1, (hipStream_t)stream)) || (rc = s.up(nullptr, 48 * n, &d3, (hipStream_t)stream))) return rc;
     if ((rc = bn254_pow_batch_dev(d1, exp, exp_limbs, d3, n, device, stream))) return rc;
     return finish_host(out, d3, 48 * n, device, stream);
+}
+
+
+// ---- single-process multi-GPU: contiguous slices of the batch per device, no exchange step.  One host
+// thread per device stages its slice of every limb plane (2-D copies out of / into the caller's SoA arrays), runs the
+// same kernels on a private stream and writes its slice of the result.  Units are pairings (k = 1) or k-pair groups.
+static int run_shard(int dev, const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_units, size_t k, int do_final_exp, size_t u0,
+                     size_t cnt) {
+    if (cnt == 0) return BN254_OK;
+    if (hipSetDevice(dev) != hipSuccess) return BN254_ERR_INVALID_ARG;
+    hipStream_t st;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return BN254_ERR_HIP;
+    int rc = BN254_OK;
+    {
+        Staged s; uint64_t *d1, *d2, *d3;
+        size_t np = cnt * k, np_all = n_units * k;
+        if ((rc = s.up(nullptr, 8 * np, &d1, st)) || (rc = s.up(nullptr, 16 * np, &d2, st)) || (rc = s.up(nullptr, 48 * cnt, &d3, st))) goto done;
+        if (hipMemcpy2DAsync(d1, np * 8, g1 + u0 * k, np_all * 8, np * 8, 8, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpy2DAsync(d2, np * 8, g2 + u0 * k, np_all * 8, np * 8, 16, hipMemcpyHostToDevice, st) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
+        rc = (k == 1 && do_final_exp) ? bn254_pairing_batch_dev(d1, d2, d3, cnt, dev, st)
+                                      : bn254_multi_pairing_batch_dev(d1, d2, d3, cnt, k, do_final_exp, dev, st);
+        if (rc) goto done;
+        if (hipMemcpy2DAsync(out + u0, n_units * 8, d3, cnt * 8, cnt * 8, 48, hipMemcpyDeviceToHost, st) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
+        rc = bn254_last_status(dev, st);
+    done:
+        (void)hipStreamSynchronize(st);
+    }
+    (void)bn254_release_stream(dev, st);
+    (void)hipStreamDestroy(st);
+    return rc;
+}
+
+int bn254_multi_pairing_sharded(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_groups, size_t k, int do_final_exp, int n_devices) {
+    if (n_groups == 0) return BN254_OK;
+    if (!g1 || !g2 || !out || k == 0 || k > 64 || n_devices <= 0) return BN254_ERR_INVALID_ARG;
+    int cnt = bn254_device_count();
+    if (cnt <= 0) return BN254_ERR_NO_DEVICE;
+    if (n_devices > cnt) return BN254_ERR_INVALID_ARG;
+    std::vector<int> rcs((size_t)n_devices, BN254_OK);
+    std::vector<std::thread> th;
+    size_t per = (n_groups + (size_t)n_devices - 1) / (size_t)n_devices;
+    for (int d = 0; d < n_devices; d++) {
+        size_t u0 = per * (size_t)d;
+        size_t c = u0 >= n_groups ? 0 : (n_groups - u0 < per ? n_groups - u0 : per);
+        th.emplace_back([=, &rcs] { rcs[(size_t)d] = run_shard(d, g1, g2, out, n_groups, k, do_final_exp, u0, c); });
+    }
+    for (auto& t : th) t.join();
+    for (int rc : rcs) if (rc) return rc;
+    return BN254_OK;
+}
+
+int bn254_pairing_sharded(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n, int n_devices) {
+    return bn254_multi_pairing_sharded(g1, g2, out, n, 1, 1, n_devices);
 }
 
 }  // extern "C"

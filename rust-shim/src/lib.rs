@@ -15,6 +15,9 @@ extern "C" {
     fn bn254_final_exp_batch(f: *const u64, out: *mut u64, n: usize, device: c_int, stream: *mut c_void) -> c_int;
     fn bn254_multi_pairing_batch(g1: *const u64, g2: *const u64, out: *mut u64, n_groups: usize, k: usize, do_final_exp: c_int,
                                  device: c_int, stream: *mut c_void) -> c_int;
+    fn bn254_multi_pairing_check_batch(g1: *const u64, g2: *const u64, verdict: *mut u8, n_groups: usize, k: usize, device: c_int,
+                                       stream: *mut c_void) -> c_int;
+    fn bn254_pairing_sharded(g1: *const u64, g2: *const u64, out: *mut u64, n: usize, n_devices: c_int) -> c_int;
     fn bn254_frobenius_map_batch(a: *const u64, power: usize, out: *mut u64, n: usize, device: c_int, stream: *mut c_void) -> c_int;
     fn bn254_pow_batch(a: *const u64, exp: *const u64, exp_limbs: usize, out: *mut u64, n: usize, device: c_int, stream: *mut c_void) -> c_int;
     fn bn254_get_naf(exp: *const u64, exp_limbs: usize, naf: *mut i8) -> c_long;
@@ -101,5 +104,20 @@ pub fn pairing_batch(ps: &[G1Affine], qs: &[G2Affine]) -> Vec<MyFq12> {
     let (g1, g2) = (pack_g1(ps), pack_g2(qs)); let mut out = vec![0u64; 48 * n];
     ok(unsafe { bn254_pairing_batch(g1.as_ptr(), g2.as_ptr(), out.as_mut_ptr(), n, 0, core::ptr::null_mut()) });
     (0..n).map(|i| { let mut c = [0u64; 48]; for w in 0..48 { c[w] = out[w * n + i]; } unpack_fq12(&c) }).collect()
+}
+/// New: the same batch spread over the first `n_devices` GPUs of this process (contiguous slices, no exchange).
+pub fn pairing_sharded(ps: &[G1Affine], qs: &[G2Affine], n_devices: i32) -> Vec<MyFq12> {
+    assert_eq!(ps.len(), qs.len()); let n = ps.len();
+    let (g1, g2) = (pack_g1(ps), pack_g2(qs)); let mut out = vec![0u64; 48 * n];
+    ok(unsafe { bn254_pairing_sharded(g1.as_ptr(), g2.as_ptr(), out.as_mut_ptr(), n, n_devices) });
+    (0..n).map(|i| { let mut c = [0u64; 48]; for w in 0..48 { c[w] = out[w * n + i]; } unpack_fq12(&c) }).collect()
+}
+/// New: `final_exp_native(multi_miller_loop_native(group)) == MyFq12::one` for every group of k pairs
+/// (the check of final_exp_native.rs:245-263), one verdict per group instead of 384 bytes.
+pub fn multi_pairing_check_batch(ps: &[G1Affine], qs: &[G2Affine], k: usize) -> Vec<bool> {
+    assert!(k > 0 && ps.len() == qs.len() && ps.len() % k == 0); let n_groups = ps.len() / k;
+    let (g1, g2) = (pack_g1(ps), pack_g2(qs)); let mut v = vec![0u8; n_groups];
+    ok(unsafe { bn254_multi_pairing_check_batch(g1.as_ptr(), g2.as_ptr(), v.as_mut_ptr(), n_groups, k, 0, core::ptr::null_mut()) });
+    v.into_iter().map(|b| b != 0).collect()
 }
 #[allow(dead_code)] fn _ark_index(j: i32) -> i32 { unsafe { bn254_myfq12_to_ark_index(j) } }

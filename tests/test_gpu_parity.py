@@ -158,3 +158,90 @@ def test_large_batch_properties():
     got = out[:48 * n].cpu().numpy().view(np.uint64).reshape(48, n)[:, pos].reshape(-1).copy()
     want = H.oracle_pairing(pk.layout.to_aos(g1h, 8), pk.layout.to_aos(g2h, 16), 64, threads=16)
     assert np.array_equal(pk.layout.to_aos(got, 48), want)
+
+
+def test_multi_pairing_check_verdicts(vec):
+    """On-device `== MyFq12::one` verdict (final_exp_native.rs:245-263): product-one groups interleaved with groups that
+    are not; the byte verdict equals the comparison done on the full Fq12 outputs."""
+    pk = H.pkg()
+    t3 = vec["t3"]
+    P3 = [tuple(int(x, 16) for x in p) for p in t3["g1"]]
+    Q3 = [((int(q[0], 16), int(q[1], 16)), (int(q[2], 16), int(q[3], 16))) for q in t3["g2"]]
+    P, Q = _golden_points(vec)
+    n_groups = 259
+    ps, qs, want = [], [], []
+    for g in range(n_groups):
+        if g % 3 == 1:                                   # a group whose product is not one
+            i, j = g % len(P), (g + 1) % len(P)
+            ps += [P[i], P[j]]
+            qs += [Q[i], Q[j]]
+            want.append(0)
+        else:
+            ps += P3
+            qs += Q3
+            want.append(1)
+    g1, g2 = H.to_soa(H.g1_aos(ps), 8), H.to_soa(H.g2_aos(qs), 16)
+    verdict = pk.multi_pairing_check_batch(g1, g2, n_groups, 2)
+    assert verdict.dtype == np.uint8 and verdict.tolist() == want
+    full = H.fq12_from_aos(H.to_aos(pk.multi_pairing_batch(g1, g2, n_groups, 2, do_final_exp=True), 48), n_groups)
+    assert [int(o == [1] + [0] * 11) for o in full] == want
+    # k = 1: e(P, Q) is never one for subgroup points
+    v1 = pk.multi_pairing_check_batch(H.to_soa(H.g1_aos(P), 8), H.to_soa(H.g2_aos(Q), 16), len(P), 1)
+    assert not v1.any()
+
+
+def test_sharded_entry_point_single_process(vec):
+    """bn254_pairing_sharded / bn254_multi_pairing_sharded (one process, several devices): slices are staged with 2-D
+    copies out of the caller's SoA planes; with every visible device the result equals the single-device call."""
+    pk = H.pkg()
+    n = 300
+    P, Q = H.subgroup_points(n, seed=77)
+    g1, g2 = H.to_soa(H.g1_aos(P), 8), H.to_soa(H.g2_aos(Q), 16)
+    want = pk.pairing_batch(g1, g2, n)
+    n_dev = pk.device_count()
+    for d in sorted({1, n_dev}):
+        assert np.array_equal(pk.pairing_sharded(g1, g2, n, d), want)
+    k, n_groups = 3, 100
+    assert np.array_equal(pk.multi_pairing_sharded(g1, g2, n_groups, k, n_dev), pk.multi_pairing_batch(g1, g2, n_groups, k))
+    with pytest.raises(pk.Bn254Error) as ei:
+        pk.pairing_sharded(g1, g2, n, n_dev + 1)
+    assert ei.value.status == pk.ERR_INVALID_ARG
+
+
+def test_streams_are_independent():
+    """Two streams of one device run concurrently on private scratch and status words."""
+    import torch
+    pk = H.pkg()
+    n = 1 << 14
+    dev = torch.device("cuda:0")
+    bufs = []
+    for seed in (11, 12):
+        g1 = torch.zeros(8 * n, dtype=torch.int64, device=dev)
+        g2 = torch.zeros(16 * n, dtype=torch.int64, device=dev)
+        pk.generate_pairs_dev(seed, g1, g2, n, 0, torch.cuda.current_stream(dev))
+        bufs.append((g1, g2, torch.zeros(48 * n, dtype=torch.int64, device=dev), torch.zeros(48 * n, dtype=torch.int64, device=dev)))
+    torch.cuda.synchronize()
+    for g1, g2, ref, _ in bufs:                           # reference: one after the other on the current stream
+        pk.pairing_batch_dev(g1, g2, ref, n, 0, torch.cuda.current_stream(dev))
+    pk.last_status(0, torch.cuda.current_stream(dev))
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    for rep in range(3):
+        for (g1, g2, _, out), st in zip(bufs, streams):
+            pk.pairing_batch_dev(g1, g2, out, n, 0, st)
+    for st in streams:
+        pk.last_status(0, st)
+    for _, _, ref, out in bufs:
+        assert torch.equal(ref, out)
+    for st in streams:
+        pk.release_stream(0, st)
+
+
+def test_empty_and_single_element_batches(vec):
+    pk = H.pkg()
+    assert pk.pairing_batch(np.zeros(0, np.uint64), np.zeros(0, np.uint64), 0).size == 0
+    assert pk.multi_pairing_check_batch(np.zeros(0, np.uint64), np.zeros(0, np.uint64), 0, 4).size == 0
+    P, Q = _golden_points(vec)
+    g1, g2 = H.to_soa(H.g1_aos(P[:1]), 8), H.to_soa(H.g2_aos(Q[:1]), 16)
+    assert H.fq12_from_aos(pk.pairing_batch(g1, g2, 1), 1)[0] == HX(vec["pairing"][0])
+    with pytest.raises(pk.Bn254Error):
+        pk.pairing_batch(g1, g2, 2)                       # buffer length does not match n
