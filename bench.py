@@ -34,6 +34,20 @@ W_FQMUL_PER_PAIRING = 16_810
 PEAK_MUL32_PER_S = 554e9 * 64
 NOMINAL_PEAK_MUL32_PER_S = 9.83e12
 LOG2_BATCH = 16
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_final_pmc.json")     # rocprofv3 --pmc passes of this same command (tools/gpu_profile.sh)
+
+
+def pmc_traffic(log2_batch):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary (FETCH_SIZE/WRITE_SIZE, corrected as the
+    MI355X guide prescribes); None when the summary is missing or was taken at another batch size."""
+    try:
+        with open(PMC_SUMMARY) as f:
+            notes = json.load(f)["_notes"]
+        if log2_batch != LOG2_BATCH:
+            return None, None
+        return notes["hbm_bytes_per_launch_corrected"], notes.get("valu_insts_per_wave")
+    except Exception:
+        return None, None
 
 
 def parse():
@@ -161,6 +175,7 @@ def main():
         value = total / elapsed
         per_gpu_rate = n / (kern_avg_ms * 1e-3)
         achieved = per_gpu_rate * W_MUL32_PER_PAIRING
+        traffic, insts_per_wave = pmc_traffic(args.log2_batch)
         rec = {
             "metric": "BN254 pairings/sec (whole node)", "value": value, "unit": "pairings/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -170,10 +185,18 @@ def main():
                                    f"(BASELINE.json configs[1]; pairing() = final_exp_native(miller_loop_native))",
                        "pairings_per_gpu": n, "layout": "SoA limb-major u64 Montgomery, inputs resident in HBM"},
             "roofline": {"bound": "valu-int32-mul", "achieved": achieved / 1e12, "peak": PEAK_MUL32_PER_S / 1e12, "unit": "T mul32/s",
-                         "frac": achieved / PEAK_MUL32_PER_S, "traffic": None,
+                         "frac": achieved / PEAK_MUL32_PER_S, "traffic": traffic,
+                         "traffic_note": "HBM bytes per launch, PMC FETCH_SIZE x2 + WRITE_SIZE (profiles/r01_final_pmc.json, separate --pmc passes "
+                                         "of this command); algorithmic bytes per launch = 576 B x pairings; the excess is the final "
+                                         "exponentiation's scratch registers (~2 % of 8 TB/s)",
+                         "algorithmic_bytes_per_launch": 576 * n,
                          "kernel": "k3_pairing", "kernel_ms_avg": kern_avg_ms, "kernel_ms_min": kern_ms[0],
                          "work_per_unit": f"{W_MUL32_PER_PAIRING} mul32 = {W_FQMUL_PER_PAIRING} fqmul x 136 per pairing (SURVEY.md 8d)",
                          "frac_of_nominal_quarter_rate_peak": achieved / NOMINAL_PEAK_MUL32_PER_S,
+                         "valu_issue": None if not insts_per_wave else {
+                             "wave_instr_per_s": insts_per_wave * (n / 64) / (kern_avg_ms * 1e-3), "peak_wave_instr_per_s": 1024 * 2.4e9 / 4,
+                             "frac": insts_per_wave * (n / 64) / (kern_avg_ms * 1e-3) / (1024 * 2.4e9 / 4),
+                             "note": "all VALU instructions the kernel issues (SQ_INSTS_VALU per wave) against 1024 SIMDs x 2.4 GHz / 4 cycles"},
                          "hbm_note": "algorithmic HBM bytes are 576 B/pairing (<0.01% of 8 TB/s): not the bound"},
         }
         if args.extra and world == 1:

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""summarize_prof.py <rocprofv3 output dir> <tag> -- per-launch PMC averages of the dominant kernel -> JSON summary.
+
+Writes <dir>/<tag>_pmc.json and <dir>/<tag>_kernel_stats.csv (copy both to profiles/).  HBM bytes follow
+/opt/skills/guides/MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE count kilobytes (x1024); on gfx950 FETCH_SIZE
+under-reports wide coalesced reads by 2x, so the read side is doubled."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+KERNEL = os.environ.get("PROF_KERNEL", "k3_pairing")
+LOG2_BATCH = 16
+
+
+def main():
+    out, tag = sys.argv[1], sys.argv[2]
+    agg = collections.defaultdict(list)
+    for f in sorted(glob.glob(os.path.join(out, "pmc_*counter_collection.csv"))):
+        for r in csv.DictReader(open(f)):
+            if KERNEL in r.get("Kernel_Name", ""):
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    s = {k: sum(v) / len(v) for k, v in agg.items()}
+    notes = {"kernel": f"{KERNEL}, n=2^{LOG2_BATCH}, per-launch averages (rocprofv3 --pmc, separate passes; bench.py --steps 3 --warmup 1)"}
+    stats = glob.glob(os.path.join(out, "trace_kernel_stats.csv"))
+    if stats:
+        rows = list(csv.DictReader(open(stats[0])))
+        for r in rows:
+            if KERNEL in r["Name"]:
+                notes["kernel_ms_avg_rocprof"] = float(r["AverageNs"]) / 1e6
+                notes["kernel_calls"] = int(r["Calls"])
+        with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w") as g:
+            g.write(open(stats[0]).read())
+    if "FETCH_SIZE" in s and "WRITE_SIZE" in s:
+        notes["FETCH_SIZE/WRITE_SIZE unit"] = "KB; gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md) -> doubled"
+        notes["hbm_bytes_per_launch_corrected"] = (2 * s["FETCH_SIZE"] + s["WRITE_SIZE"]) * 1024
+        notes["algorithmic_bytes_per_launch"] = 576 << LOG2_BATCH
+    if "SQ_WAVE_CYCLES" in s and "SQ_ACTIVE_INST_VALU" in s:
+        notes["valu_busy_fraction_of_wave_cycles"] = s["SQ_ACTIVE_INST_VALU"] / s["SQ_WAVE_CYCLES"]
+        notes["cycles_per_valu_instruction_active"] = 4 * s["SQ_ACTIVE_INST_VALU"] / s["SQ_INSTS_VALU"]      # counters tick every 4 cycles
+        notes["valu_insts_per_wave"] = s["SQ_INSTS_VALU"] / s["SQ_WAVES"]
+    if "SQ_WAIT_ANY" in s and "SQ_WAVE_CYCLES" in s:
+        notes["wait_fraction"] = s["SQ_WAIT_ANY"] / s["SQ_WAVE_CYCLES"]
+    if "SQ_ACTIVE_INST_LDS" in s and "SQ_WAVE_CYCLES" in s:
+        notes["lds_fraction"] = s["SQ_ACTIVE_INST_LDS"] / s["SQ_WAVE_CYCLES"]
+    s["_notes"] = notes
+    with open(os.path.join(out, f"{tag}_pmc.json"), "w") as g:
+        json.dump(s, g, indent=1)
+    print(json.dumps(notes, indent=1))
+
+
+if __name__ == "__main__":
+    main()
