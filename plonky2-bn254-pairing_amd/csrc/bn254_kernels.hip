@@ -231,7 +231,7 @@ BN254_ASM_KERNEL(k3_miller, BN254_ASM3_MILLER)
 BN254_ASM_KERNEL(k3_fexp, BN254_ASM3_FEXP)
 BN254_ASM_KERNEL(k3_mpairing, BN254_ASM3_MPAIRING)   // k pairs per lane, shared f (multi_miller_loop_native) + final exp
 BN254_ASM_KERNEL(k3_mmiller, BN254_ASM3_MMILLER)     // k pairs per lane, exact multi_miller_loop_native value
-constexpr int V3_GSLOTS = 56;         // eight Fq12 registers + eight overflow temporaries (+ 7 per pair in the multi kernels)
+constexpr int V3_GSLOTS = 80;         // twelve Fq12 registers + eight overflow temporaries (+ 7 per pair in the multi kernels)
 constexpr int V3_SLOT_BYTES = 80;
 
 enum { OP_MUL = 0, OP_FROB = 1, OP_POW = 2, OP_INV = 3, OP_SQR = 4, OP_CYC_SQR = 5 };

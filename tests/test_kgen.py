@@ -208,7 +208,7 @@ def test_l1_v3_routines():
         want = {"mul": ((a0 * b0 - a1 * b1) * RPI, (a0 * b1 + a1 * b0) * RPI), "sqr": ((a0 * a0 - a1 * a1) * RPI, 2 * a0 * a1 * RPI),
                 "mulfq": (a0 * b0 * RPI, a1 * b0 * RPI), "fqmul": (a0 * b0 * RPI, None), "fqsqr": (a0 * a0 * RPI, None),
                 "add": (a0 + b0, a1 + b1), "sub": (a0 - b0, a1 - b1), "rsub": (b0 - a0, b1 - a1), "dbl": (2 * a0, 2 * a1),
-                "neg": (-a0, -a1), "negc1": (a0, -a1), "norm": (a0, a1)}
+                "neg": (-a0, -a1), "negc1": (a0, -a1), "norm": (a0, a1), "redn": (a0, a1)}
         if sl == 0:
             want["mulxi"] = (9 * a0 - a1, a0 + 9 * a1)
         for name, (w0, w1) in want.items():
@@ -217,8 +217,19 @@ def test_l1_v3_routines():
             assert (val(m, 0) - w0) % P == 0, name
             if w1 is not None:
                 assert (val(m, 1) - w1) % P == 0, name
-            if name == "norm":
+            if name in ("norm", "redn"):
                 assert all(0 <= m.v[K3.NL * j + i] < (1 << K3.LB) for j in range(2) for i in range(K3.NL - 1))
+            if name == "redn":
+                assert all(-P // 64 < val(m, j) < P + P // 64 for j in range(2))
+    # redn on large representatives (x + t p, |t| up to the certified cap) with unnormalised limbs
+    for t in range(40):
+        xs = [rnd() + rng.randrange(-60000, 60000) * P for _ in range(2)]
+        m = _m3(xs, rng, [0, 1, 3][t % 3])
+        before = [val(m, j) for j in range(2)]
+        S.run_block(B["redn"], m)
+        for j in range(2):
+            assert (val(m, j) - xs[j]) % P == 0 and -P // 64 < val(m, j) < P + P // 64, (t, j, before[j] // P, val(m, j) // P)
+            assert all(0 <= m.v[K3.NL * j + i] < (1 << K3.LB) for i in range(K3.NL - 1))
     # boundary conversions: ark 4 x u64 Montgomery (R = 2^256) <-> internal; cvtout is canonical
     for t in range(20):
         x = rnd()

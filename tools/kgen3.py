@@ -29,6 +29,8 @@ from kgen import Emitter, Pool, P_INT  # noqa: E402
 NL = 10
 LB = 27
 MASK = (1 << LB) - 1
+REDN_SHIFT = 41                                         # q = (top limb * REDN_C) >> 41 ~ top limb * 2^243 / p
+REDN_C = (1 << (REDN_SHIFT + 243)) // P_INT             # < 2^31: fits a signed multiply-high
 RP = 1 << (NL * LB)                       # R' = 2^270
 N0P = (-pow(P_INT, -1, 1 << LB)) % (1 << LB)
 P_L = [(P_INT >> (LB * i)) & MASK for i in range(NL)]
@@ -294,6 +296,31 @@ class L1v3:
         self.norm_limbs(self.blk(A0, 0))
         self.norm_limbs(self.blk(A0, 1))
 
+    def redn_limbs(self, a):
+        """Normalise AND reduce the representative: a <- a - q p with q = floor(top limb * 2^243 / p) (the top limb, weight
+        2^243, carries the representative; the lower limbs change the quotient by < 0.01).  Result: limbs 0..NL-2 in
+        [0, 2^27), value in (-0.01 p, 1.01 p).  One signed 64-bit carry chain: 4 instructions per limb."""
+        q, t = self.pool.alloc(), self.pool.alloc()
+        acc = self.pool.alloc_pair()
+        P = f"v[{acc}:{acc + 1}]"
+        self.e.emit(f"v_mov_b32_e32 v{t}, 0x{REDN_C:x}", vw=[t])
+        self.e.emit(f"v_mul_hi_i32 v{q}, v{a[NL - 1]}, v{t}", vw=[q])
+        self.e.emit(f"v_ashrrev_i32_e32 v{q}, {REDN_SHIFT - 32}, v{q}", vw=[q])
+        self.e.emit(f"v_sub_u32_e32 v{q}, 0, v{q}", vw=[q])                       # -q
+        for i in range(NL):
+            self.e.emit(f"v_mad_i64_i32 {P}, vcc, v{q}, {self.p[i]}, {P if i else 0}", w=["vcc"], vw=[acc, acc + 1])
+            self.e.emit(f"v_mad_i64_i32 {P}, vcc, v{a[i]}, 1, {P}", w=["vcc"], vw=[acc, acc + 1])
+            if i < NL - 1:
+                self.e.emit(f"v_and_b32_e32 v{a[i]}, 0x{MASK:x}, v{acc}", vw=[a[i]])
+                self.e.emit(f"v_ashrrev_i64 {P}, {LB}, {P}", vw=[acc, acc + 1])
+            else:
+                self.e.emit(f"v_mov_b32_e32 v{a[i]}, v{acc}", vw=[a[i]])
+        self.pool.free(q, t, acc, acc + 1)
+
+    def r_redn(self):
+        self.redn_limbs(self.blk(A0, 0))
+        self.redn_limbs(self.blk(A0, 1))
+
     # ------------------------------------------------------------------ boundary conversions
     def r_cvtin(self):
         """A.c0 <- internal form of the packed external value in v[0:7] (8 x u32, canonical, Montgomery R = 2^256).
@@ -369,7 +396,7 @@ class L1v3:
         self.pool.free(*d)
 
 
-L1V3_NAMES = ["mul", "mul3", "sqr", "mulfq", "add", "sub", "rsub", "dbl", "neg", "negc1", "mulxi", "norm", "fqmul", "fqsqr", "cvtin", "cvtout"]
+L1V3_NAMES = ["mul", "mul3", "sqr", "mulfq", "add", "sub", "rsub", "dbl", "neg", "negc1", "mulxi", "norm", "redn", "fqmul", "fqsqr", "cvtin", "cvtout"]
 
 if __name__ == "__main__":
     for n in L1V3_NAMES:

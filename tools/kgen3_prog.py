@@ -26,6 +26,25 @@ from kgen_prog import (AGPR, GLOB, HOME, LDS, Const, GlobDyn, Slot, S_FIN, S_G1,
 
 # ---- static bound tracking: every value carries an interval [lo, hi] (in units of 2^27) that contains all of
 # its limbs 0..NL-2 (both Fq2 components); the top limb is small by construction (values stay below ~2^262).
+# ---- x-power schedule of the final exponentiation (F <- F^BN_X for cyclotomic F, three times per pairing).
+# pow_native (final_exp_native.rs:56-84) walks the NAF of BN_X: 62 squarings + 23 multiplications.  The value F^x does
+# not depend on the chain, so the kernels use a signed fixed-set recoding instead: digits in {0, +-1, +-5, +-9, +-13}
+# (found by exhaustive search over digit sets, tools/exp/xchain.py): 59 squarings + 12 multiplications in the loop and
+# b^4, b^5, b^9, b^13 from 2 squarings + 3 multiplications: 61 S + 15 M instead of 62 S + 23 M (a squaring costs a
+# third of a multiplication).  Negative digits multiply by the conjugate (= inverse of a unitary element).
+X_POWERS = (1, 5, 9, 13)
+X_DIGITS = (-13, -1, 0, 0, 0, 0, 0, 0, 0, 5, 0, 0, 0, 0, 0, 0, 9, 0, 0, 0, 0, -13, 0, 0, 0, 0, -13, 0, 0, 0, 0, 9, 0, 0, 0, 0, -5, 0, 0, 0, -13,
+            0, 0, 0, 0, 13, 0, 0, 0, 0, 0, 5, 0, 0, -13, 0, 0, 0, 0, 9)            # least significant first
+assert sum(d << i for i, d in enumerate(X_DIGITS)) == 4965661367192848881 and X_DIGITS[-1] in X_POWERS
+assert all(d == 0 or abs(d) in X_POWERS for d in X_DIGITS)
+G_POW = {5: 8, 9: 9, 13: 10}     # scratch Fq12 registers of b^5, b^9, b^13 (b itself: the caller's register)
+G_B4 = 11                        # b^4 (only while the powers are built)
+N_GREG = 12                      # Fq12 scratch registers G0..G11 = slots 0..71
+GLOB_TMP0 = 6 * N_GREG           # eight overflow temporaries: slots 72..79
+S_PB = 47                        # byte offset of the base's scratch register during the x-power routine
+S_XIDX0, S_XIDX1 = "s[50:51]", "s[52:53]"      # which power a non-zero digit selects (index into X_POWERS)
+
+RED_POWERS = True            # reduce the representatives of b^5, b^9, b^13 before they are stored
 RED_RUN = 4                  # cyclotomic squarings in a row before the x-power loop reduces the representative
 
 
@@ -353,6 +372,10 @@ class Prog3(KP.Prog):
         self.rA = self.r_norm()
         return self
 
+    def redn(self):
+        """Normalise and bring the representative back to (-0.01 p, 1.01 p) (L1 redn: quotient from the top limb)."""
+        return self.call("redn")
+
     def _need(self, ok, what):
         if not ok:
             raise AssertionError("bound violated: " + what)
@@ -361,7 +384,7 @@ class Prog3(KP.Prog):
         vA = self.vA
         v_out = {"mul": 2 * vA * vB / K_RP + 1, "mulfq": vA * vB / K_RP + 1, "fqmul": vA * vB / K_RP + 1, "sqr": 4 * vA * vA / K_RP + 1,
                    "fqsqr": vA * vA / K_RP + 1, "add": vA + vB, "sub": vA + vB, "rsub": vA + vB, "dbl": 2 * vA, "neg": vA, "negc1": vA,
-                   "mulxi": 10 * vA, "norm": vA}[name]
+                   "mulxi": 10 * vA, "norm": vA, "redn": 1.01}[name]
         reduced = (-v_out / K_RP, max(1.0, v_out / K_RP))       # limb interval of a reduction output (see r_norm)
         rA = self.rA if self.rA is not None else self.UNKNOWN
         if isinstance(rB, float):
@@ -411,6 +434,10 @@ class Prog3(KP.Prog):
             out = r_mulxi(rA)
         elif name == "norm":
             out = reduced
+        elif name == "redn":
+            # the quotient estimate reads the top limb: it must hold the representative (|top| < 2^31) and nothing else
+            self._need(vA <= V_CAP and mag(rA) <= LIMB_MAG, f"redn {vA} {rA}")
+            out = reduced
         else:
             raise ValueError(name)
         self._raw_call(direct or name)
@@ -450,7 +477,7 @@ class KernelBuilder3(KP.KernelBuilder):
     FQINV_BASE = AGPR(9, "fqinv_base")
     BOP = [AGPR(i, f"B{i}") for i in (0, 1, 2, 3, 4, 5)]      # fq12_mul operand copy (final exponentiation only)
 
-    PAIR_SLOT0 = 56          # scratch slots of pair j: PAIR_SLOT0 + 7 j + {PX, PY, QX, QY, RX, RY, RZ}
+    PAIR_SLOT0 = GLOB_TMP0 + 8          # scratch slots of pair j: PAIR_SLOT0 + 7 j + {PX, PY, QX, QY, RX, RY, RZ}
 
     def __init__(self, do_miller=True, do_fexp=True, track=False, multi=False):
         super().__init__(do_miller, do_fexp, track)
@@ -482,11 +509,11 @@ class KernelBuilder3(KP.KernelBuilder):
         """Fast temporaries of the Miller-loop routines: homes 0..6, AGPR 10 (11 when no scale is tracked),
         plus routine-specific dead slots; global scratch slots only as overflow."""
         return ([HOME(i) for i in range(7)] + [AGPR(10)] + ([] if self.track else [AGPR(11)]) + [AGPR(i) for i in extra]
-                + [GLOB(48 + i) for i in range(8)])
+                + [GLOB(GLOB_TMP0 + i) for i in range(8)])
 
     def fexp_temps(self):
         # LDS 6,7 ; homes ; AGPR 6..11 (0..5 hold the multiplication operand)
-        return [HOME(i) for i in range(8)] + [LDS(6), LDS(7)] + [AGPR(i) for i in (6, 7, 8, 10, 11)] + [GLOB(48 + i) for i in range(8)]
+        return [HOME(i) for i in range(8)] + [LDS(6), LDS(7)] + [AGPR(i) for i in (6, 7, 8, 10, 11)] + [GLOB(GLOB_TMP0 + i) for i in range(8)]
 
     # ---------------------------------------------------------------------------------------------
     def build(self):
@@ -650,8 +677,6 @@ class KernelBuilder3(KP.KernelBuilder):
             def mul_body(p):
                 p.fq12_mul(self.F, self.BOP)
 
-            naf = x_naf()[:-1]
-            red = x_red_mask(naf)
             for op in self.fexp_trace:
                 if op[0] == "st":
                     G[op[1]] = [st.get(k, 2.0) for k in fk]
@@ -666,15 +691,34 @@ class KernelBuilder3(KP.KernelBuilder):
                     run("L2_mul_body", label="L2_mulGc" if op[2] else "L2_mulG", body=mul_body, temps=self.fexp_temps())
                 elif op[0] == "powx":
                     j = op[1]
-                    run("L2_redF")
-                    G[j] = [st[k] for k in fk]
-                    seq.append("L2_stG")
-                    for d in range(len(naf) - 1, -1, -1):
+
+                    def mul_by(reg, conj=False):
+                        for b_, v in zip(self.BOP, G[reg]):
+                            st[Prog3.key(b_)] = v
+                        run("L2_mul_body", label="L2_mulGc" if conj else "L2_mulG", body=mul_body, temps=self.fexp_temps())
+
+                    def store(reg):
+                        G[reg] = [st[k] for k in fk]
+                        seq.append("L2_stG")
+
+                    run("L2_redF"); store(j)
+                    run("L2_cyc"); run("L2_cyc"); store(G_B4)
+                    for reg, src in ((G_POW[5], j), (G_POW[9], G_B4), (G_POW[13], G_B4)):
+                        mul_by(src)
+                        if RED_POWERS:
+                            run("L2_redF")
+                        store(reg)
+                    top = X_DIGITS[-1]
+                    if top != 13:
+                        for k, v in zip(fk, G[j if top == 1 else G_POW[top]]):
+                            st[k] = v
+                        seq.append("L2_ldG")
+                    xd = X_DIGITS[:-1]
+                    red = x_red_mask(xd)
+                    for d in range(len(xd) - 1, -1, -1):
                         run("L2_cyc")
-                        if naf[d] != 0:
-                            for b, v in zip(self.BOP, G[j]):
-                                st[Prog3.key(b)] = v
-                            run("L2_mul_body", label="L2_mulGc" if naf[d] < 0 else "L2_mulG", body=mul_body, temps=self.fexp_temps())
+                        if xd[d] != 0:
+                            mul_by(j if abs(xd[d]) == 1 else G_POW[abs(xd[d])], conj=xd[d] < 0)
                         elif red >> d & 1:
                             run("L2_redF")
                 else:
@@ -687,22 +731,75 @@ class KernelBuilder3(KP.KernelBuilder):
         return report
 
     def _reduce_f(self, p):
-        """F <- F * 1 (a Montgomery multiplication by the constant one): same residues, representatives back in
-        [0, ~1.01 p).  Every cyclotomic squaring roughly doubles the representative (3t - 2z), so the x-power loop
-        calls this after RED_RUN squarings in a row without a multiplication (see x_red_mask)."""
-        one = Const(1, 0, "one")
+        """F <- the same residues with representatives back in (-0.01 p, 1.01 p) (L1 redn).  Every cyclotomic squaring
+        roughly doubles the representative (3t - 2z), so the x-power loop calls this after RED_RUN squarings in a row
+        without a multiplication (see x_red_mask), and on the base and its stored powers."""
         for k in range(6):
-            p.A(self.F[k]).mulfq(one).to(self.F[k])
+            p.A(self.F[k]).redn().to(self.F[k])
 
-    def _powx_entry(self, e):
-        # reduce the base once (and keep the reduced copy): every multiplication by it then contracts the accumulator
-        e.salu(f"s_call_b64 {S_RET2}, {self.lab('L2_redF')}")
-        e.salu(f"s_call_b64 {S_RET2}, {self.lab('L2_stG')}")
+    def _powx_routine(self):
+        """F <- F^BN_X for cyclotomic F (base b = F on entry, S_GBASE = its scratch register): the X_DIGITS schedule.
+        Same value as pow_native(a, [BN_X]) (final_exp_native.rs:56-84) for unitary a."""
+        e = Emitter()
+        L = self.lab
 
-    def _powx_zero_digit(self, e):
+        def c2(name):
+            e.salu(f"s_call_b64 {S_RET2}, {L(name)}")
+
+        def greg(j):
+            e.salu(f"s_mul_i32 s{S_GBASE}, s{S_GSTRIDE}, {6 * j}")
+
+        e.label(L("L3_powx"))
+        e.salu(f"s_mov_b32 s{S_PB}, s{S_GBASE}")
+        # reduced copies of the base and its powers: every multiplication by one of them contracts the accumulator
+        c2("L2_redF"); c2("L2_stG")                                   # G[base] = b
+        c2("L2_cyc"); c2("L2_cyc"); greg(G_B4); c2("L2_stG")          # b^4
+        e.salu(f"s_mov_b32 s{S_GBASE}, s{S_PB}")
+        red = (lambda: c2("L2_redF")) if RED_POWERS else (lambda: None)
+        c2("L2_mulG"); red(); greg(G_POW[5]); c2("L2_stG")            # b^5 = b^4 b
+        greg(G_B4); c2("L2_mulG"); red(); greg(G_POW[9]); c2("L2_stG")             # b^9 = b^5 b^4
+        greg(G_B4); c2("L2_mulG"); red(); greg(G_POW[13]); c2("L2_stG")            # b^13 = b^9 b^4
+        top = X_DIGITS[-1]
+        if top == 1:
+            e.salu(f"s_mov_b32 s{S_GBASE}, s{S_PB}")
+        else:
+            greg(G_POW[top])
+        if top != 13:
+            c2("L2_ldG")
+        e.salu(f"s_mov_b32 s{S_J}, {self.x_top - 1}")
+        e.label(L("L3_powx_loop"))
+        c2("L2_cyc")
+        e.salu(f"s_bitcmp1_b64 {S_XNAF_NZ}, s{S_J}")
+        e.salu(f"s_cbranch_scc0 {L('L3_powx_zero')}")
+        # select the power: S_GBASE <- register of b^(X_POWERS[idx])
+        e.salu(f"s_mov_b32 s{S_GBASE}, s{S_PB}")
+        for bit, mask in ((0, S_XIDX0), (1, S_XIDX1)):
+            e.salu(f"s_bitcmp1_b64 {mask}, s{S_J}")
+            e.salu(f"s_cselect_b32 s{S_TMP0}, {1 << bit}, 0")
+            e.salu(f"s_{'mov' if bit == 0 else 'or'}_b32 s{S_TMP1}, s{S_TMP0}" + (f", s{S_TMP1}" if bit else ""))
+        e.salu(f"s_cmp_eq_u32 s{S_TMP1}, 0")
+        e.salu(f"s_cbranch_scc1 {L('L3_powx_sel')}")
+        # registers of b^5, b^9, b^13 are consecutive: G_POW[5] + (idx - 1)
+        e.salu(f"s_add_u32 s{S_TMP1}, s{S_TMP1}, {G_POW[5] - 1}")
+        e.salu(f"s_mul_i32 s{S_TMP1}, s{S_TMP1}, 6")
+        e.salu(f"s_mul_i32 s{S_GBASE}, s{S_GSTRIDE}, s{S_TMP1}")
+        e.label(L("L3_powx_sel"))
+        e.salu(f"s_bitcmp1_b64 {S_XNAF_NEG}, s{S_J}")
+        e.salu(f"s_cbranch_scc1 {L('L3_powx_neg')}")
+        c2("L2_mulG")
+        e.salu(f"s_branch {L('L3_powx_next')}")
+        e.label(L("L3_powx_neg"))
+        c2("L2_mulGc")
+        e.salu(f"s_branch {L('L3_powx_next')}")
+        e.label(L("L3_powx_zero"))
         e.salu(f"s_bitcmp1_b64 {S_XNAF_RED}, s{S_J}")
-        e.salu(f"s_cbranch_scc0 {self.lab('L3_powx_next')}")
-        e.salu(f"s_call_b64 {S_RET2}, {self.lab('L2_redF')}")
+        e.salu(f"s_cbranch_scc0 {L('L3_powx_next')}")
+        c2("L2_redF")
+        e.label(L("L3_powx_next"))
+        e.salu(f"s_sub_u32 s{S_J}, s{S_J}, 1")
+        e.salu(f"s_cbranch_scc0 {L('L3_powx_loop')}")
+        e.salu(f"s_setpc_b64 {S_RET3}")
+        self.sections.append(e)
 
     def batch_load_globdyn(self, e, p, ks, dests):
         """dests[i] <- scratch slot (S_GBASE + ks[i]): all global loads issued back to back into landing registers
@@ -790,16 +887,15 @@ class KernelBuilder3(KP.KernelBuilder):
         e.salu(f"s_mov_b32 s69, 0x{nz >> 32:x}")
         e.salu(f"s_mov_b32 s70, 0x{neg & 0xFFFFFFFF:x}")
         e.salu(f"s_mov_b32 s71, 0x{neg >> 32:x}")
-        xn = x_naf()
-        nz, neg = naf_masks(xn[:-1])
-        self.x_top = len(xn) - 1
-        red = x_red_mask(xn[:-1])
-        e.salu(f"s_mov_b32 s48, 0x{red & 0xFFFFFFFF:x}")
-        e.salu(f"s_mov_b32 s49, 0x{red >> 32:x}")
-        e.salu(f"s_mov_b32 s72, 0x{nz & 0xFFFFFFFF:x}")
-        e.salu(f"s_mov_b32 s73, 0x{nz >> 32:x}")
-        e.salu(f"s_mov_b32 s74, 0x{neg & 0xFFFFFFFF:x}")
-        e.salu(f"s_mov_b32 s75, 0x{neg >> 32:x}")
+        xd = list(X_DIGITS[:-1])                       # the top digit is the initial value of the accumulator
+        nz, neg = naf_masks([(d > 0) - (d < 0) for d in xd])
+        self.x_top = len(xd)
+        idx = [X_POWERS.index(abs(d)) if d else 0 for d in xd]
+        red = x_red_mask(xd)
+        for reg, val in ((72, nz), (74, neg), (48, red), (50, sum((i & 1) << j for j, i in enumerate(idx))),
+                         (52, sum((i >> 1) << j for j, i in enumerate(idx)))):
+            e.salu(f"s_mov_b32 s{reg}, 0x{val & 0xFFFFFFFF:x}")
+            e.salu(f"s_mov_b32 s{reg + 1}, 0x{val >> 32:x}")
         e.salu(f"s_lshl_b32 s{S_NSTRIDE}, s{S_N}, 3")
         e.salu(f"s_add_u32 s{S_NITEMS}, s{S_N}, 255")
         e.salu(f"s_lshr_b32 s{S_NITEMS}, s{S_NITEMS}, 8")

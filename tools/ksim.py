@@ -39,6 +39,7 @@ class Machine:
         self.count_valu = 0
         self.count_nop = 0
         self.max_acc = 0      # largest |column accumulator| seen (v3 kernels)
+        self.profile = None   # dict: (region label, opcode) -> dynamic count, when set to {} before run()
         self.call_log = None  # list: labels of the L2 routines called, in order (bound certification cross-check)
         self.max_stored = 0   # largest |signed dword| written to LDS (v3: limb magnitudes of stored values)
 
@@ -146,10 +147,23 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None):
     pc = labels[entry] if entry else 0
     v = m.v
     steps = 0
+    region = None
+    if m.profile is not None:          # region of an instruction = nearest preceding L1_/L2_/L3_/L_main label
+        region, cur = [], "prologue"
+        by_pc = {}
+        for name, at in labels.items():
+            if name.startswith(("L1_", "L2_", "L3_", "L_main", "LM_")):
+                by_pc.setdefault(at, name)
+        for i in range(len(prog)):
+            cur = by_pc.get(i, cur)
+            region.append(cur)
     while True:
         if pc >= len(prog):
             raise SimError("fell off the end of the program")
         op, a, text = prog[pc]
+        if region is not None:
+            k_ = (region[pc], op)
+            m.profile[k_] = m.profile.get(k_, 0) + 1
         pc += 1
         steps += 1
         if steps > max_steps:
@@ -238,6 +252,12 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None):
                 m.count_valu += 1
             elif op == "v_mov_b32_e32":
                 m.vset(a[0], m.vsrc(a[1]))
+                m.count_valu += 1
+            elif op == "v_mul_hi_i32":
+                x, y = m.vsrc(a[1]), m.vsrc(a[2])
+                x = x - (1 << 32) if x >> 31 else x
+                y = y - (1 << 32) if y >> 31 else y
+                m.vset(a[0], ((x * y) >> 32) & M32)
                 m.count_valu += 1
             elif op == "v_mul_lo_u32":
                 m.vset(a[0], m.vsrc(a[1]) * m.vsrc(a[2]))
@@ -331,6 +351,12 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None):
                 r = m.vsrc(a[1], False) & m.vsrc(a[2], False)
                 m.sset(a[0], r)
                 m.scc = 1 if r else 0
+            elif op == "s_or_b32":
+                r = m.vsrc(a[1], False) | m.vsrc(a[2], False)
+                m.sset(a[0], r)
+                m.scc = 1 if r else 0
+            elif op == "s_cselect_b32":
+                m.sset(a[0], m.vsrc(a[1], False) if m.scc else m.vsrc(a[2], False))
             elif op == "s_cmp_eq_u32":
                 m.scc = 1 if m.vsrc(a[0], False) == m.vsrc(a[1], False) else 0
             elif op == "s_cmp_lg_u32":
