@@ -25,7 +25,6 @@ def main():
     init = [f"v_mov_b32 v{i}, 0x{(0x1234567 * (i + 3)) & 0x7ffffff:x}" for i in range(120)]
     init += [f"v_accvgpr_write_b32 a{i}, v{i}" for i in range(64)]
     init += [f"s_mov_b32 s{36 + i}, 0x{(0x2345671 * (i + 1)) & 0x7ffffff:x}" for i in range(10)] + ["s_mov_b32 s46, 0x5e4c2b9"]
-    init += ["v_mov_b32 v119, 0"]                    # LDS address for ds_* experiments
     names = list(variants)
     for vi, name in enumerate(names):
         body = " \\\n".join(f'"{esc(l)}\\n"' for l in variants[name])
@@ -35,6 +34,7 @@ def main():
     extern __shared__ uint32_t lds_pad[];
     if (iters < 0) lds_pad[threadIdx.x] = 1;
     asm volatile({" ".join('"' + l + chr(92) + 'n"' for l in init)} ::: {clob});
+    asm volatile("v_lshlrev_b32 v119, 4, %0\\n v_lshlrev_b32 v118, 2, %0\\n v_lshlrev_b32 v117, 3, %0" :: "v"(threadIdx.x) : "v117", "v118", "v119");
     uint64_t t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) asm volatile({" ".join(["BODY%d" % vi] * rep)} ::: {clob});
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -65,7 +65,7 @@ int main() {
     for vi, name in enumerate(names):
         n = len([l for l in variants[name] if l.strip() and not l.strip().endswith(":")])
         out.append(f'    {{ double a = timeit(k{vi}a, dbuf, iters), b = timeit(k{vi}b, dbuf, iters); double c = (b - a) / 2.0;\n'
-                   f'      printf("%-44s %5d instr  %9.1f cycles  %6.3f cycles/instr\\n", "{name}", {n}, c, c / {max(n, 1)}.0); }}\n')
+                   f'      printf("%-44s %5d instr  %9.1f cycles  %6.3f cycles/instr\\n", "{name}", {n}, c, c / {max(n, 1)}.0); fflush(stdout); }}\n')
     out.append("    CK(hipFree(dbuf));\n    return 0;\n}\n")
     open(sys.argv[2], "w").write("".join(out))
 
