@@ -643,3 +643,84 @@ if __name__ == "__main__":
         getattr(g2, name)()
         lines = e2.finalize()
         print(name, "instrs", len(lines), "nops", sum(1 for l in lines if l.startswith("s_nop")), "max tmp", max(g2.pool.used) if g2.pool.used else None)
+
+
+# ------------------------------------------------------------------------------------------ code alignment post-pass
+# Measured on gfx950 (tools/exp/l1_bench.py, DESIGN.md "issue model"): a lone wave issues one VALU instruction per 4 cycles, but an
+# 8-byte instruction that is only 4-byte aligned costs ~1 extra cycle on average (it straddles a 32-byte fetch window every
+# fourth time, +4 cycles).  align_code() keeps every 8-byte instruction 8-byte aligned: a 4-byte VOP1/VOP2 instruction in front
+# of it is re-encoded as VOP3 (_e64, 8 bytes, same operation and speed) or, where that is impossible, an s_nop is inserted;
+# labels are 8-byte aligned with s_nop padding.
+_INLINE_INT = re.compile(r"^-?\d+$|^0x[0-9a-fA-F]+$")
+_VOP3_ONLY = ("v_mad_", "v_mul_lo_u32", "v_mul_hi_u32", "v_mul_hi_i32", "v_ashrrev_i64", "v_lshlrev_b64", "v_lshrrev_b64", "v_lshl_add_", "v_lshl_or_",
+              "v_and_or_", "v_add3_", "v_alignbit_", "v_bfe_", "v_accvgpr_", "v_fma_", "v_perm_", "v_pk_", "v_mbcnt_", "v_readlane_", "v_writelane_",
+              "v_add_lshl_", "v_xad_", "v_or3_", "v_dot", "v_mfma", "v_cvt_pk")
+_MEM = ("ds_", "global_", "flat_", "buffer_", "scratch_", "s_load_", "s_store_", "s_buffer_", "s_memtime", "s_memrealtime", "s_dcache")
+_NO_E64 = ("v_addc_co_u32", "v_subb_co_u32", "v_subbrev_co_u32", "v_add_co_u32", "v_sub_co_u32", "v_subrev_co_u32", "v_cndmask_b32", "v_cmp", "v_nop",
+           "v_readfirstlane", "v_movrel", "v_swap", "v_fmac", "v_mac", "v_madmk", "v_madak", "v_fmamk", "v_fmaak")
+
+
+def _operands(text):
+    rest = text.split(None, 1)[1] if " " in text.strip() else ""
+    return [t.strip() for t in re.split(r",(?![^\[]*\])", rest) if t.strip()]
+
+
+def _has_literal(text):
+    for t in _operands(text):
+        t0 = t.split()[0]
+        if _INLINE_INT.match(t0):
+            v = int(t0, 0)
+            if not -16 <= v <= 64:
+                return True
+    return False
+
+
+def insn_size(text):
+    """Encoded size in bytes (4 or 8) of one gfx950 instruction as the generators write it."""
+    op = text.split()[0]
+    if op.startswith(_MEM) or op.endswith("_e64") or op.startswith(_VOP3_ONLY):
+        return 8
+    if op.startswith("s_") or op.startswith("v_"):
+        if op in ("s_waitcnt", "s_nop", "s_endpgm", "s_branch", "s_barrier", "s_sleep") or op.startswith(("s_cbranch", "s_call_b64", "s_setpc", "s_getpc")):
+            return 4
+        return 8 if _has_literal(text) else 4
+    raise ValueError("unknown instruction class: " + text)
+
+
+def _to_e64(text):
+    """VOP3 re-encoding of a 4-byte VOP1/VOP2 instruction, or None when there is none with the same syntax."""
+    op = text.split()[0]
+    if not op.startswith("v_") or op.startswith(_NO_E64) or _has_literal(text):
+        return None
+    base = op[:-4] if op.endswith("_e32") else op
+    if op.endswith("_e64"):
+        return None
+    return base + "_e64" + text[len(op):]
+
+
+def align_code(lines):
+    out, off, last = [], 0, None            # last: index in `out` of the previous instruction if it may be re-encoded
+    for ln in lines:
+        t = ln.strip()
+        if not t or t.startswith((";", "//", ".")):
+            out.append(ln)
+            continue
+        if t.endswith(":"):
+            if off % 8:
+                out.append("s_nop 0")
+                off += 4
+            out.append(ln)
+            last = None
+            continue
+        size = insn_size(t)
+        if size == 8 and off % 8:
+            conv = _to_e64(out[last]) if last is not None else None
+            if conv is not None:
+                out[last] = conv
+            else:
+                out.append("s_nop 0")
+            off += 4
+        out.append(ln)
+        off += size
+        last = len(out) - 1 if size == 4 else None
+    return out

@@ -119,24 +119,50 @@ class L1v3:
         self.pool.free(acc, acc + 1, *m)
         self.pool.free(*res)
 
-    def fips_direct(self, prods, out):
-        """Same, writing result limbs straight into `out` (out must not overlap any input)."""
+    def fips_direct(self, prods, out, fillers=(), gap=8):
+        """Same, writing result limbs straight into `out` (out must not overlap any input).
+
+        fillers: independent fast-class instructions [(text, vw, earliest column, latest column)] that are dropped into the
+        multiply runs (one after every `gap` consecutive slow-class instructions).  A lone wave issues back-to-back
+        v_mad_i64_i32 at 5 cycles each but at 4 when a fast-class instruction breaks the run (issue model), so
+        work that has to be done anyway (negations, copies) is free there.  A filler is emitted no earlier than column
+        `earliest` and before column `latest` starts; leftovers follow the pass."""
         acc = self.pool.alloc_pair()
         P = f"v[{acc}:{acc + 1}]"
         m = [self.pool.alloc() for _ in range(NL)]
         first = True
+        todo = list(fillers)
+        run = 0
+        col = 0
+
+        def fill(force_before=None):
+            nonlocal run
+            for j, (text, vw, lo, hi) in enumerate(todo):
+                if (force_before is None and lo <= col) or (force_before is not None and hi <= force_before):
+                    self.e.emit(text, vw=vw)
+                    del todo[j]
+                    run = 0
+                    return True
+            return False
+
+        def slow(text, **kw):
+            nonlocal run
+            self.e.emit(text, **kw)
+            run += 1
+            if run >= gap:
+                fill()
 
         def mad(x, y):
             nonlocal first
             X = f"v{x}" if isinstance(x, int) else x
             Y = f"v{y}" if isinstance(y, int) else y
-            if first:
-                self.e.emit(f"v_mad_i64_i32 {P}, vcc, {X}, {Y}, 0", w=["vcc"], vw=[acc, acc + 1])
-                first = False
-            else:
-                self.e.emit(f"v_mad_i64_i32 {P}, vcc, {X}, {Y}, {P}", w=["vcc"], vw=[acc, acc + 1])
+            slow(f"v_mad_i64_i32 {P}, vcc, {X}, {Y}, {0 if first else P}", w=["vcc"], vw=[acc, acc + 1])
+            first = False
 
         for k in range(2 * NL - 1):
+            col = k
+            while fill(force_before=k):
+                pass
             lo_i, hi_i = max(0, k - (NL - 1)), min(NL - 1, k)
             for (a, b) in prods:
                 for i in range(lo_i, hi_i + 1):
@@ -144,16 +170,20 @@ class L1v3:
             if k < NL:
                 for i in range(k):
                     mad(m[i], self.p[k - i])
-                self.e.emit(f"v_mul_lo_u32 v{m[k]}, v{acc}, {self.n0}", vw=[m[k]])
+                slow(f"v_mul_lo_u32 v{m[k]}, v{acc}, {self.n0}", vw=[m[k]])
                 self.e.emit(f"v_and_b32_e32 v{m[k]}, 0x{MASK:x}, v{m[k]}", vw=[m[k]])
+                run = 0
                 mad(m[k], self.p[0])
-                self.e.emit(f"v_ashrrev_i64 {P}, {LB}, {P}", vw=[acc, acc + 1])
+                slow(f"v_ashrrev_i64 {P}, {LB}, {P}", vw=[acc, acc + 1])
             else:
                 for i in range(k - (NL - 1), NL):
                     mad(m[i], self.p[k - i])
                 self.e.emit(f"v_and_b32_e32 v{out[k - NL]}, 0x{MASK:x}, v{acc}", vw=[out[k - NL]])
-                self.e.emit(f"v_ashrrev_i64 {P}, {LB}, {P}", vw=[acc, acc + 1])
+                run = 0
+                slow(f"v_ashrrev_i64 {P}, {LB}, {P}", vw=[acc, acc + 1])
         self.e.emit(f"v_mov_b32_e32 v{out[NL - 1]}, v{acc}", vw=[out[NL - 1]])
+        for (text, vw, lo, hi) in todo:
+            self.e.emit(text, vw=vw)
         self.pool.free(acc, acc + 1, *m)
 
     # ------------------------------------------------------------------ blocks
@@ -172,6 +202,7 @@ class L1v3:
         (pass 1: a0 b1 + a1 b0), then c0 over a0 (pass 2: a0 b0 + (-a1) b1 with -a1 kept in temporaries)."""
         a0, a1, b0, b1 = self.blk(A0, 0), self.blk(A0, 1), self.blk(B0, 0), self.blk(B0, 1)
         na1 = [self.pool.alloc() for _ in range(NL)]
+        # (measured: spreading these negations into pass 1's multiply runs as fillers is 1-3 % SLOWER than doing them up front)
         for i in range(NL):
             self.e.emit(f"v_sub_u32_e32 v{na1[i]}, 0, v{a1[i]}", vw=[na1[i]])
         self.fips_direct([(a1, b0), (a0, b1)], a1)
@@ -188,16 +219,15 @@ class L1v3:
         prods = []
         for (x0, x1), (y0, y1) in zip(xs, ys):
             prods += [(x0, y1), (x1, y0)]
-        self.fips_direct(prods, t)                                   # c1
-        for (x0, x1) in xs:
-            for r in x1:
-                self.e.emit(f"v_sub_u32_e32 v{r}, 0, v{r}", vw=[r])
+        # x1[i] is dead in pass 1 after column i + NL - 1: its negation (for pass 2) rides in the upper columns
+        neg = [(f"v_sub_u32_e32 v{x1[i]}, 0, v{x1[i]}", [x1[i]], NL + i, 99) for i in range(NL) for (x0, x1) in xs]
+        self.fips_direct(prods, t, fillers=neg, gap=6)                # c1
         prods = []
         for (x0, x1), (y0, y1) in zip(xs, ys):
             prods += [(x0, y0), (x1, y1)]
-        self.fips_direct(prods, self.blk(A0, 0))                     # c0, in place over A.c0
-        for i in range(NL):
-            self.e.emit(f"v_mov_b32_e32 v{A0 + NL + i}, v{t[i]}", vw=[A0 + NL + i])
+        # c1 (in t) moves into A.c1 as soon as pass 2 has read A.c1[i] for the last time (column i + NL - 1)
+        mov = [(f"v_mov_b32_e32 v{A0 + NL + i}, v{t[i]}", [A0 + NL + i], NL + i, 99) for i in range(NL)]
+        self.fips_direct(prods, self.blk(A0, 0), fillers=mov)        # c0, in place over A.c0
         self.pool.free(*t)
 
     def r_sqr(self):
@@ -226,11 +256,7 @@ class L1v3:
 
     def r_fqsqr(self):
         a0 = self.blk(A0, 0)
-        t = [self.pool.alloc() for _ in range(NL)]
-        for i in range(NL):
-            self.e.emit(f"v_mov_b32_e32 v{t[i]}, v{a0[i]}", vw=[t[i]])
-        self.fips_direct([(a0, t)], a0)
-        self.pool.free(*t)
+        self.fips_direct([(a0, a0)], a0)            # result limb j lands after column j + NL, when a0[j] is dead
 
     def r_add(self):
         for h in range(2):

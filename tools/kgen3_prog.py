@@ -17,7 +17,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import kgen_prog as KP  # noqa: E402
-from kgen import Emitter, P_INT, SIX_U_PLUS_2_NAF  # noqa: E402
+from kgen import Emitter, P_INT, SIX_U_PLUS_2_NAF, align_code  # noqa: E402
 from kgen3 import (A0, B0, HOME0, L1V3_NAMES, L1v3, LB, MASK, N0P, N_AGPR_SLOTS, N_HOME, N_LDS_SLOTS, NL, P_L, S_N0, S_P, S_RET1, S_RET2,  # noqa: E402
                    S_RET3, SLOT_DW, V_FLAG, V_GOFF, V_IDX, V_IDX8, V_LDS, V_TID, mont3, to_limbs)
 from kgen_prog import (AGPR, GLOB, HOME, LDS, Const, GlobDyn, Slot, S_FIN, S_G1, S_G2, S_GADDR, S_GBASE, S_GRID, S_GSTRIDE, S_I, S_IOADDR,  # noqa: E402
@@ -44,6 +44,7 @@ GLOB_TMP0 = 6 * N_GREG           # eight overflow temporaries: slots 72..79
 S_PB = 47                        # byte offset of the base's scratch register during the x-power routine
 S_XIDX0, S_XIDX1 = "s[50:51]", "s[52:53]"      # which power a non-zero digit selects (index into X_POWERS)
 
+ALIGN_CODE = bool(int(os.environ.get("KGEN3_ALIGN", "1")))     # keep 8-byte instructions 8-byte aligned (kgen.align_code)
 RED_POWERS = True            # reduce the representatives of b^5, b^9, b^13 before they are stored
 RED_RUN = 4                  # cyclotomic squarings in a row before the x-power loop reduces the representative
 
@@ -584,7 +585,7 @@ class KernelBuilder3(KP.KernelBuilder):
         out = []
         for e in [self._pro] + first + [main, l1e] + second + [tail]:
             out.extend(e.finalize())
-        return out
+        return [".p2align 3"] + align_code(out) if ALIGN_CODE else out
 
     # ------------------------------------------------------------------ value-bound certification
     # Limb bounds are closed per routine (every store enforces STORE_MAG, every multiplication its column sums).

@@ -142,7 +142,11 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None):
         if ln.endswith(":"):
             labels[ln[:-1]] = len(prog)
             continue
+        if ln.startswith("."):
+            continue                                  # assembler directives (.p2align)
         op, _, rest = ln.partition(" ")
+        if op.endswith("_e64"):
+            op = op[:-4] + "_e32"                     # VOP3 re-encodings of VOP1/VOP2 instructions (kgen.align_code)
         prog.append((op, _split_args(rest.strip()), ln))
     pc = labels[entry] if entry else 0
     v = m.v
