@@ -353,11 +353,14 @@ class Prog3(KP.Prog):
         self.vA = 2.0
 
     INLINE_SMALL = bool(int(os.environ.get("KGEN3_INLINE_SMALL", "1")))
+    # a call/return pair costs a lone wave ~70 cycles (two taken branches, each refilling the instruction buffer): routines of
+    # up to ~50 instructions are inlined (norm: 6.6 k calls per pairing, mulxi: 2.4 k)
+    INLINE_SET = ("add", "sub", "rsub", "dbl", "neg", "negc1") + tuple(os.environ.get("KGEN3_INLINE_MORE", "norm,mulxi").split(","))
 
     def _raw_call(self, name):
         self.wait()
         base = name.split("_h")[0]
-        if self.INLINE_SMALL and base in ("add", "sub", "rsub", "dbl", "neg", "negc1"):
+        if self.INLINE_SMALL and base in self.INLINE_SET:
             g = L1v3(self.e)
             if "_h" in name:
                 g.home_variant(base, int(name.split("_h")[1]))
