@@ -1,9 +1,13 @@
 #!/bin/bash
-# One GPU-box round: parity tests, smoke, bench, rocprof kernel trace.  Outputs under gpurun_out/.
-cd "$GRAFT_REPO_ROOT"
-mkdir -p gpurun_out
-export TMPDIR=/tmp
-timeout 1200 python -m pytest tests -x -q -m gpu > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
-timeout 600 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/smoke.log
-timeout 900 python bench.py --steps 5 --warmup 1 --extra > gpurun_out/bench.log 2>&1; echo "bench rc=$?" >> gpurun_out/bench.log
-tail -3 gpurun_out/pytest_gpu.log; tail -2 gpurun_out/smoke.log; tail -2 gpurun_out/bench.log
+# Full GPU round (run through gpurun): parity tests, smoke, bench with the extra configs, rocprofv3 profile.
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
+TAG=${1:-r01_final}
+timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+timeout 300 python -c "import __graft_entry__ as g; g.build(); g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 900 python bench.py --steps 10 --warmup 2 --extra > gpurun_out/bench_$TAG.log 2>&1; grep '^{"metric' gpurun_out/bench_$TAG.log > gpurun_out/bench_$TAG.json; python - <<PY
+import json
+r=json.load(open("gpurun_out/bench_$TAG.json"))
+print("pairings/s", r["value"], "ms/step", r["ms_per_step"], "roofline", r["roofline"]["frac"], "cpu", r.get("cpu_baseline",{}).get("value"), "verified", r.get("verified_vs_oracle"))
+print(json.dumps(r.get("extra"), indent=1))
+PY
+bash tools/gpu_profile.sh $TAG 2>&1 | tail -14
