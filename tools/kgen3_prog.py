@@ -120,11 +120,16 @@ class Prog3(KP.Prog):
         self.vA = V_STORE
         self.slot_v = {}
         self.max_v = 0.0
+        self.norm_keys = frozenset()
         self.entry_v = {}           # certification: bounds of the values other routines left in the slots
         self.default_v = V_STORE
         self.read_keys = {}         # slot keys whose entry bound was used -> the bound
 
     UNKNOWN = (-STORE_MAG, STORE_MAG)      # contract for values stored by other routines
+    # slots in `norm_keys` hold NORMALISED values on every routine boundary (the Fq12 accumulator and the operand
+    # copies of the final exponentiation): limbs 0..NL-2 in [0, 2^27), top limb within the value cap.  Their
+    # consumers start from a 3x tighter interval, which removes most normalisations inside the routines.
+    STORED_NORM = (-1.0, 1.0)              # (negations / conjugates of normalised values included)
 
     def v_of(self, slot):
         if slot.kind == "const":
@@ -172,7 +177,8 @@ class Prog3(KP.Prog):
     def r_of(self, slot):
         if slot.kind == "const":
             return R_NORM
-        return self.slot_r.get(self.key(slot), self.UNKNOWN)
+        k = self.key(slot)
+        return self.slot_r.get(k, self.STORED_NORM if k in self.norm_keys else self.UNKNOWN)
 
     def e_of(self, slot):
         return lg(self.r_of(slot))
@@ -457,7 +463,10 @@ class Prog3(KP.Prog):
 
     def to(self, dst):
         rA = self.rA if self.rA is not None else self.UNKNOWN
-        if mag(rA) > STORE_MAG:
+        if self.key(dst) in self.norm_keys:
+            if rA[0] < self.STORED_NORM[0] or rA[1] > self.STORED_NORM[1]:
+                self.norm()
+        elif mag(rA) > STORE_MAG:
             self.norm()
         self.wait()
         self.store(A0, dst)
@@ -491,13 +500,27 @@ class KernelBuilder3(KP.KernelBuilder):
             for i in range(N_HOME):
                 self.labels[f"{op}_h{i}"] = f"L1_{op}_h{i}_%="
 
-    def new_prog(self, temps):
+    _phase = "miller"
+
+    def new_prog(self, temps, phase=None):
         if not hasattr(self, "l2_bodies"):
-            self.l2_bodies, self.l2_exit, self.l2_maxv = {}, {}, {}
+            self.l2_bodies, self.l2_exit, self.l2_maxv, self.l2_phase = {}, {}, {}, {}
         e = Emitter()
         p = Prog3(e, self.labels)
         p.set_temps(temps)
+        p.norm_keys = self.norm_keys(phase or self._phase)
         return e, p
+
+    NORM_CONTRACT = bool(int(os.environ.get("KGEN3_NORM_CONTRACT", "1")))
+
+    def norm_keys(self, phase):
+        """Slots that hold normalised values on every routine boundary of `phase` (Prog3.norm_keys)."""
+        if not self.NORM_CONTRACT:
+            return frozenset()
+        keys = [Prog3.key(s_) for s_ in self.F]
+        if phase == "fexp":
+            keys += [Prog3.key(s_) for s_ in self.BOP] + [("globdyn", i) for i in range(6)]
+        return frozenset(keys)
 
     def l2_routine(self, name, body, temps):
         """Also records the value bounds (units of p) the routine leaves in every non-temporary slot, given that all
@@ -505,6 +528,7 @@ class KernelBuilder3(KP.KernelBuilder):
         p = super().l2_routine(name, body, temps)
         tk = {Prog3.key(t) for t in temps}
         self.l2_bodies[name] = (body, temps)
+        self.l2_phase[name] = self._phase
         self.l2_exit[name] = {k: v for k, v in p.slot_v.items() if k not in tk}
         self.l2_maxv[name] = p.max_v
         return p
@@ -536,6 +560,7 @@ class KernelBuilder3(KP.KernelBuilder):
                 g.home_variant(op, i)
                 l1e.salu(f"s_setpc_b64 {S_RET1}")
         self.sections = []
+        self._phase = "miller"
         if self.do_miller:
             sc = self.SCALE if self.track else None
             # during f^2 the line (AGPR 6..8) and the addition point (AGPR 4, 5) are dead
@@ -555,6 +580,7 @@ class KernelBuilder3(KP.KernelBuilder):
                 self.l2_routine("L2_fqinv", self._fq_inv, self.miller_temps())
                 self.l2_routine("L2_descale", self._descale, self.miller_temps())
                 self.l2_routine("L2_sqscale", lambda p: p.A(self.SCALE).sqr().to(self.SCALE), self.miller_temps())
+        self._phase = "fexp"
         if self.do_fexp:
             if not (self.do_miller and self.track):
                 self.l2_routine("L2_fqinv", self._fq_inv, self.fexp_temps())
@@ -570,6 +596,7 @@ class KernelBuilder3(KP.KernelBuilder):
                                                   [p.A(self.F[i]).neg().to(self.F[i]) for i in (1, 3, 5)]), self.fexp_temps())
             self.l2_routine("L2_conjF", lambda p: [p.A(self.F[i]).neg().to(self.F[i]) for i in (1, 3, 5)], self.fexp_temps())
             self._powx_routine()
+        self._phase = "miller"              # the main program only touches F
         self.main_body(main)
         # Layout: s_call_b64 / s_branch reach +-128 KB.  The leaf routines (called from everywhere) and the main
         # control code sit in the middle, the L2 routines are split around them by size.
@@ -616,7 +643,7 @@ class KernelBuilder3(KP.KernelBuilder):
         for reads, ex, mv in memo:
             if all(self._grid(state.get(k, 2.0)) == v for k, v in reads.items()):
                 return ex, mv
-        e, p = self.new_prog(temps)
+        e, p = self.new_prog(temps, phase=self.l2_phase.get(name, "fexp"))
         p.entry_v = {k: self._grid(v) for k, v in state.items()}
         p.default_v = 2.0                       # never-written slots hold converted inputs
         body(p)
@@ -632,7 +659,7 @@ class KernelBuilder3(KP.KernelBuilder):
         """Replays the kernel's L2 call sequence on value bounds.  Returns a report dict; raises on any violation."""
         self._memo, self._ref_text = {}, {}
         for name, (body, temps) in self.l2_bodies.items():       # the shipped code of each routine body
-            e, p = self.new_prog(temps)
+            e, p = self.new_prog(temps, phase=self.l2_phase[name])
             body(p)
             self._ref_text[name] = self._norm_text(e.finalize())
         st, worst, calls = {}, 0.0, 0
@@ -838,7 +865,7 @@ class KernelBuilder3(KP.KernelBuilder):
                         e.emit(f"v_mov_b32_e32 v{h0 + i}, v{r0 + i}", vw=[h0 + i])
             else:
                 raise ValueError(d.kind)
-            p.slot_r[p.key(d)] = p.UNKNOWN
+            p.slot_r.pop(p.key(d), None)
         p.reset_tags()
 
     def _mulG_routines(self):
@@ -1048,6 +1075,7 @@ class KernelBuilder3(KP.KernelBuilder):
         e.emit(f"v_mov_b32_e32 v{V_FLAG}, 0", vw=[V_FLAG])
         p = Prog3(e, self.labels)
         p.set_temps(self.miller_temps())
+        p.norm_keys = self.norm_keys("miller")
         if self.do_miller and self.multi:
             self.miller_main_multi(e, p)
         elif self.do_miller:
