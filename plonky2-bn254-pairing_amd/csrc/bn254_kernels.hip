@@ -565,6 +565,10 @@ long get_naf_host(const uint64_t* exp_in, size_t n, int8_t* naf) {
 // ------------------------------------------------------------------ extern "C"
 extern "C" {
 
+constexpr size_t PIPE_CHUNK = 2 * 65536;      // lanes per chunk of the host-pointer pipeline (two full grids)
+static int run_pipeline(const int* devices, int n_dev, const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_units, size_t k,
+                        int do_final_exp);
+
 int bn254_device_count(void) {
     int cnt = 0;
     if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
@@ -750,6 +754,10 @@ int bn254_pairing_batch(const uint64_t* g1, const uint64_t* g2, uint64_t* out, s
     if (!g1 || !g2 || !out) return BN254_ERR_INVALID_ARG;
     if (bn254_device_count() <= 0) return BN254_ERR_NO_DEVICE;
     if (hipSetDevice(device) != hipSuccess) return BN254_ERR_INVALID_ARG;
+    if (n > PIPE_CHUNK) {                 // large batch: chunked, copies overlapped with compute (private streams)
+        if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return BN254_ERR_HIP;
+        return run_pipeline(&device, 1, g1, g2, out, n, 1, 1);
+    }
     Staged s; uint64_t *d1, *d2, *d3; int rc;
     if ((rc = s.up(g1, 8 * n, &d1, (hipStream_t)stream)) || (rc = s.up(g2, 16 * n, &d2, (hipStream_t)stream)) || (rc = s.up(nullptr, 48 * n, &d3, (hipStream_t)stream))) return rc;
     if ((rc = bn254_pairing_batch_dev(d1, d2, d3, n, device, stream))) return rc;
@@ -781,6 +789,10 @@ int bn254_multi_pairing_batch(const uint64_t* g1, const uint64_t* g2, uint64_t* 
     if (!g1 || !g2 || !out || k == 0) return BN254_ERR_INVALID_ARG;
     if (bn254_device_count() <= 0) return BN254_ERR_NO_DEVICE;
     if (hipSetDevice(device) != hipSuccess) return BN254_ERR_INVALID_ARG;
+    if (n_groups > PIPE_CHUNK && k <= 64) {
+        if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return BN254_ERR_HIP;
+        return run_pipeline(&device, 1, g1, g2, out, n_groups, k, do_final_exp);
+    }
     Staged s; uint64_t *d1, *d2, *d3; int rc; size_t np = n_groups * k;
     if ((rc = s.up(g1, 8 * np, &d1, (hipStream_t)stream)) || (rc = s.up(g2, 16 * np, &d2, (hipStream_t)stream)) || (rc = s.up(nullptr, 48 * n_groups, &d3, (hipStream_t)stream))) return rc;
     if ((rc = bn254_multi_pairing_batch_dev(d1, d2, d3, n_groups, k, do_final_exp, device, stream))) return rc;
@@ -818,27 +830,34 @@ int bn254_pow_batch(const uint64_t* a, const uint64_t* exp, size_t exp_limbs, ui
 }
 
 
-// ---- single-process multi-GPU: contiguous slices of the batch per device, no exchange step.  One host
-// thread per device stages its slice of every limb plane (2-D copies out of / into the caller's SoA arrays), runs the
-// same kernels on a private stream and writes its slice of the result.  Units are pairings (k = 1) or k-pair groups.
-static int run_shard(int dev, const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_units, size_t k, int do_final_exp, size_t u0,
-                     size_t cnt) {
-    if (cnt == 0) return BN254_OK;
+// ---- host-pointer pipeline, one or several GPUs of this process: contiguous slices of the batch per device,
+// no exchange step.  A slice is cut into chunks of PIPE_CHUNK lanes (two full grids); a worker thread owns one private
+// stream and device buffers for one chunk and walks every second chunk of its device: it stages its chunk of every limb
+// plane (2-D copies straight out of / into the caller's SoA arrays), launches the kernel and copies the result back.  Two
+// workers per device alternate, so one worker's copies run under the other's kernel (the kernels fill the chip and
+// serialise).  Units are pairings (k = 1) or k-pair groups.
+
+static int run_chunks(int dev, const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_units, size_t k, int do_final_exp, size_t u0,
+                      size_t cnt, size_t chunk, size_t first, size_t step) {
+    if (cnt == 0 || first * chunk >= cnt) return BN254_OK;
     if (hipSetDevice(dev) != hipSuccess) return BN254_ERR_INVALID_ARG;
     hipStream_t st;
     if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return BN254_ERR_HIP;
     int rc = BN254_OK;
     {
         Staged s; uint64_t *d1, *d2, *d3;
-        size_t np = cnt * k, np_all = n_units * k;
-        if ((rc = s.up(nullptr, 8 * np, &d1, st)) || (rc = s.up(nullptr, 16 * np, &d2, st)) || (rc = s.up(nullptr, 48 * cnt, &d3, st))) goto done;
-        if (hipMemcpy2DAsync(d1, np * 8, g1 + u0 * k, np_all * 8, np * 8, 8, hipMemcpyHostToDevice, st) != hipSuccess ||
-            hipMemcpy2DAsync(d2, np * 8, g2 + u0 * k, np_all * 8, np * 8, 16, hipMemcpyHostToDevice, st) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
-        rc = (k == 1 && do_final_exp) ? bn254_pairing_batch_dev(d1, d2, d3, cnt, dev, st)
-                                      : bn254_multi_pairing_batch_dev(d1, d2, d3, cnt, k, do_final_exp, dev, st);
-        if (rc) goto done;
-        if (hipMemcpy2DAsync(out + u0, n_units * 8, d3, cnt * 8, cnt * 8, 48, hipMemcpyDeviceToHost, st) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
-        rc = bn254_last_status(dev, st);
+        size_t cap = cnt < chunk ? cnt : chunk, np_all = n_units * k;
+        if ((rc = s.up(nullptr, 8 * cap * k, &d1, st)) || (rc = s.up(nullptr, 16 * cap * k, &d2, st)) || (rc = s.up(nullptr, 48 * cap, &d3, st))) goto done;
+        for (size_t c0 = first * chunk; c0 < cnt; c0 += step * chunk) {
+            size_t m = cnt - c0 < chunk ? cnt - c0 : chunk, np = m * k, base = u0 + c0;
+            if (hipMemcpy2DAsync(d1, np * 8, g1 + base * k, np_all * 8, np * 8, 8, hipMemcpyHostToDevice, st) != hipSuccess ||
+                hipMemcpy2DAsync(d2, np * 8, g2 + base * k, np_all * 8, np * 8, 16, hipMemcpyHostToDevice, st) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
+            rc = (k == 1 && do_final_exp) ? bn254_pairing_batch_dev(d1, d2, d3, m, dev, st)
+                                          : bn254_multi_pairing_batch_dev(d1, d2, d3, m, k, do_final_exp, dev, st);
+            if (rc) goto done;
+            if (hipMemcpy2DAsync(out + base, n_units * 8, d3, m * 8, m * 8, 48, hipMemcpyDeviceToHost, st) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
+            if ((rc = bn254_last_status(dev, st))) goto done;        // also: the buffers are free for the next chunk
+        }
     done:
         (void)hipStreamSynchronize(st);
     }
@@ -847,23 +866,39 @@ static int run_shard(int dev, const uint64_t* g1, const uint64_t* g2, uint64_t* 
     return rc;
 }
 
+// devices[0..n_dev): the batch is split into n_dev contiguous slices
+static int run_pipeline(const int* devices, int n_dev, const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_units, size_t k,
+                        int do_final_exp) {
+    size_t chunk = PIPE_CHUNK;                        // lanes = units (one unit per lane whatever k is)
+    size_t per = (n_units + (size_t)n_dev - 1) / (size_t)n_dev;
+    std::vector<int> rcs;
+    std::vector<std::thread> th;
+    rcs.reserve((size_t)n_dev * 2);
+    for (int d = 0; d < n_dev; d++) {
+        size_t u0 = per * (size_t)d;
+        size_t c = u0 >= n_units ? 0 : (n_units - u0 < per ? n_units - u0 : per);
+        size_t workers = c > chunk ? 2 : 1;
+        for (size_t w = 0; w < workers; w++) {
+            rcs.push_back(BN254_OK);
+            int* slot = &rcs.back();
+            int dev = devices[d];
+            th.emplace_back([=] { *slot = run_chunks(dev, g1, g2, out, n_units, k, do_final_exp, u0, c, chunk, w, workers); });
+        }
+    }
+    for (auto& t : th) t.join();
+    for (int rc : rcs) if (rc) return rc;
+    return BN254_OK;
+}
+
 int bn254_multi_pairing_sharded(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_groups, size_t k, int do_final_exp, int n_devices) {
     if (n_groups == 0) return BN254_OK;
     if (!g1 || !g2 || !out || k == 0 || k > 64 || n_devices <= 0) return BN254_ERR_INVALID_ARG;
     int cnt = bn254_device_count();
     if (cnt <= 0) return BN254_ERR_NO_DEVICE;
     if (n_devices > cnt) return BN254_ERR_INVALID_ARG;
-    std::vector<int> rcs((size_t)n_devices, BN254_OK);
-    std::vector<std::thread> th;
-    size_t per = (n_groups + (size_t)n_devices - 1) / (size_t)n_devices;
-    for (int d = 0; d < n_devices; d++) {
-        size_t u0 = per * (size_t)d;
-        size_t c = u0 >= n_groups ? 0 : (n_groups - u0 < per ? n_groups - u0 : per);
-        th.emplace_back([=, &rcs] { rcs[(size_t)d] = run_shard(d, g1, g2, out, n_groups, k, do_final_exp, u0, c); });
-    }
-    for (auto& t : th) t.join();
-    for (int rc : rcs) if (rc) return rc;
-    return BN254_OK;
+    std::vector<int> devs((size_t)n_devices);
+    for (int d = 0; d < n_devices; d++) devs[(size_t)d] = d;
+    return run_pipeline(devs.data(), n_devices, g1, g2, out, n_groups, k, do_final_exp);
 }
 
 int bn254_pairing_sharded(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n, int n_devices) {

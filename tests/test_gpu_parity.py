@@ -245,3 +245,31 @@ def test_empty_and_single_element_batches(vec):
     assert H.fq12_from_aos(pk.pairing_batch(g1, g2, 1), 1)[0] == HX(vec["pairing"][0])
     with pytest.raises(pk.Bn254Error):
         pk.pairing_batch(g1, g2, 2)                       # buffer length does not match n
+
+
+def test_host_pipeline_matches_device_path():
+    """Host-pointer calls above 2^17 lanes run chunked on private streams (copies under compute): same limbs as the
+    single-launch device path, ragged tail included; also for k-pair groups."""
+    import torch
+    pk = H.pkg()
+    n = (1 << 17) * 2 + 300
+    dev = torch.device("cuda:0")
+    g1 = torch.zeros(8 * n, dtype=torch.int64, device=dev)
+    g2 = torch.zeros(16 * n, dtype=torch.int64, device=dev)
+    out = torch.zeros(48 * n, dtype=torch.int64, device=dev)
+    st = torch.cuda.current_stream(dev)
+    pk.generate_pairs_dev(0xB2540003, g1, g2, n, 0, st)
+    pk.pairing_batch_dev(g1, g2, out, n, 0, st)
+    pk.last_status(0, st)
+    h1, h2 = g1.cpu().numpy().view(np.uint64).copy(), g2.cpu().numpy().view(np.uint64).copy()
+    assert np.array_equal(pk.pairing_batch(h1, h2, n), out.cpu().numpy().view(np.uint64))
+    k = 2
+    groups = n // k
+    og = torch.zeros(48 * groups, dtype=torch.int64, device=dev)
+    # the first groups*k pairs of every plane, re-packed to batch length groups*k
+    sel = lambda t, planes: t.view(planes, n)[:, :groups * k].contiguous().view(-1)
+    g1k, g2k = sel(g1, 8), sel(g2, 16)
+    pk.multi_pairing_batch_dev(g1k, g2k, og, groups, k, True, 0, st)
+    pk.last_status(0, st)
+    got = pk.multi_pairing_batch(g1k.cpu().numpy().view(np.uint64).copy(), g2k.cpu().numpy().view(np.uint64).copy(), groups, k)
+    assert np.array_equal(got, og.cpu().numpy().view(np.uint64))
