@@ -273,3 +273,40 @@ def test_host_pipeline_matches_device_path():
     pk.last_status(0, st)
     got = pk.multi_pairing_batch(g1k.cpu().numpy().view(np.uint64).copy(), g2k.cpu().numpy().view(np.uint64).copy(), groups, k)
     assert np.array_equal(got, og.cpu().numpy().view(np.uint64))
+
+
+def test_full_size_product_check():
+    """Size-independent property at BASELINE configs[1] size: e(P_i, Q_i) e(P_i, -Q_i) = 1 for all 2^16 generated pairs
+    (T3 pattern, final_exp_native.rs:245-263), through the shared-f multi-pairing kernel and the on-device verdict."""
+    import torch
+    pk = H.pkg()
+    n = 1 << 16
+    dev = torch.device("cuda:0")
+    g1 = torch.zeros(8 * n, dtype=torch.int64, device=dev)
+    g2 = torch.zeros(16 * n, dtype=torch.int64, device=dev)
+    st = torch.cuda.current_stream(dev)
+    pk.generate_pairs_dev(0xB2540004, g1, g2, n, 0, st)
+    pk.last_status(0, st)
+    h1 = g1.cpu().numpy().view(np.uint64).reshape(8, n)
+    h2 = g2.cpu().numpy().view(np.uint64).reshape(16, n)
+    # -Q: y -> p - y on both components (Montgomery limbs negate like canonical ones); y != 0 on these curves
+    P_LIMBS = [0x3c208c16d87cfd47, 0x97816a916871ca8d, 0xb85045b68181585d, 0x30644e72e131a029]
+    neg = h2.copy()
+    for comp in (2, 3):
+        borrow = np.zeros(n, dtype=np.uint64)
+        for l in range(4):
+            y = h2[comp * 4 + l]
+            pl = np.uint64(P_LIMBS[l])
+            d = pl - y - borrow
+            borrow = ((y + borrow > pl) | ((borrow == 1) & (y == np.uint64(0xFFFFFFFFFFFFFFFF)))).astype(np.uint64)
+            neg[comp * 4 + l] = d
+    # groups of k = 2: (P_i, Q_i), (P_i, -Q_i); pair j of group i is element 2 i + j
+    g1k = np.repeat(h1, 2, axis=1)
+    g2k = np.empty((16, 2 * n), dtype=np.uint64)
+    g2k[:, 0::2], g2k[:, 1::2] = h2, neg
+    verdict = pk.multi_pairing_check_batch(g1k.reshape(-1), g2k.reshape(-1), n, 2)
+    assert verdict.shape == (n,) and bool(verdict.all())
+    # and flipping one pair of one group breaks exactly that group
+    g2k[:, 2 * 777 + 1] = h2[:, 778]
+    v2 = pk.multi_pairing_check_batch(g1k.reshape(-1), g2k.reshape(-1), n, 2)
+    assert int(v2.sum()) == n - 1 and v2[777] == 0
