@@ -88,10 +88,11 @@ def test_oracle_parity_ragged_batch():
 
 
 def test_multi_pairing_batch_vs_oracle():
-    """Groth16 shape (k = 4) and k = 3 over a ragged batch of groups; shared-f Miller value and final value."""
+    """Groth16 shape (k = 4), k = 3, and long groups (k = 9, and the maximum k = 64) over ragged batches of groups;
+    shared-f Miller value and final value."""
     pk = H.pkg()
     base_P, base_Q = H.subgroup_points(8)
-    for k, n_groups in ((4, 70), (3, 5)):
+    for k, n_groups in ((4, 70), (3, 5), (9, 3), (64, 2)):
         n = n_groups * k
         P = [base_P[(i * 5 + 1) % 8] for i in range(n)]
         Q = [base_Q[(i * 3 + i // 8) % 8] for i in range(n)]
