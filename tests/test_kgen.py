@@ -221,6 +221,26 @@ def test_l1_v3_routines():
                 assert all(0 <= m.v[K3.NL * j + i] < (1 << K3.LB) for j in range(2) for i in range(K3.NL - 1))
             if name == "redn":
                 assert all(-P // 64 < val(m, j) < P + P // 64 for j in range(2))
+    # sqr4 (fused Fq4 squaring of the cyclotomic squaring): normalised operands, also with negated limbs (conjugates)
+    f2m = lambda x, y: ((x[0] * y[0] - x[1] * y[1]) % P, (x[0] * y[1] + x[1] * y[0]) % P)
+    for t in range(24):
+        a, b = (rnd(), rnd()), (rnd(), rnd())
+        m = _m3([a[0], a[1], b[0], b[1]], rng, 0)
+        if t % 3 == 1:                       # -a, -b as limb-wise negations
+            for r in range(4 * K3.NL):
+                m.v[r] = (-m.v[r]) & 0xFFFFFFFF
+            a, b = ((-a[0]) % P, (-a[1]) % P), ((-b[0]) % P, (-b[1]) % P)
+        for r in range(K3.HOME0, K3.HOME0 + 3 * K3.SLOT_DW):
+            m.v[r] = rng.getrandbits(32)     # scratch blocks hold garbage
+        S.run_block(B["sqr4"], m)
+        b2 = f2m(b, b)
+        xib2 = ((9 * b2[0] - b2[1]) % P, (9 * b2[1] + b2[0]) % P)
+        a2 = f2m(a, a)
+        ab = f2m(a, b)
+        for j, w in enumerate(((a2[0] + xib2[0]) * RPI, (a2[1] + xib2[1]) * RPI, 2 * ab[0] * RPI, 2 * ab[1] * RPI)):
+            assert (val(m, j) - w) % P == 0, ("sqr4", t, j)
+        assert all(0 <= m.v[K3.NL * j + i] < (1 << K3.LB) for j in range(2) for i in range(K3.NL - 1))
+        assert all(0 <= m.v[K3.NL * j + i] < (2 << K3.LB) for j in (2, 3) for i in range(K3.NL - 1))
     # redn on large representatives (x + t p, |t| up to the certified cap) with unnormalised limbs
     for t in range(40):
         xs = [rnd() + rng.randrange(-60000, 60000) * P for _ in range(2)]

@@ -724,3 +724,25 @@ def align_code(lines):
         off += size
         last = len(out) - 1 if size == 4 else None
     return out
+
+
+def max_branch_distance(lines):
+    """Largest |target - (pc + 4)| in bytes over all s_call_b64 / s_branch / s_cbranch_* with a label target."""
+    off, lab, ins = 0, {}, []
+    for l in lines:
+        t = l.strip()
+        if not t or t.startswith((";", "//", ".")):
+            continue
+        if t.endswith(":"):
+            lab[t[:-1]] = off
+            continue
+        ins.append((off, t))
+        off += insn_size(t)
+    worst = 0
+    for o, t in ins:
+        op = t.split()[0]
+        if op in ("s_call_b64", "s_branch") or op.startswith("s_cbranch"):
+            tgt = t.split(",")[-1].strip() if op == "s_call_b64" else t.split()[-1]
+            if tgt in lab:
+                worst = max(worst, abs(lab[tgt] - (o + 4)))
+    return worst

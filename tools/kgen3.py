@@ -244,6 +244,51 @@ class L1v3:
         self.pool.free(*t)
         self.pool.free(*u)
 
+    def r_sqr4(self):
+        """Fq4 squaring for the Granger-Scott cyclotomic squaring, fused: (a + b y)^2 with y^2 = xi, a in block A, b in block B
+        (both NORMALISED: |limb| <= 2^27):  A <- a^2 + xi b^2 (normalised),  B <- 2 a b (limbs below 2^28).
+        t = a b ; S = xi b + a ; P = (a + b) S ; r0 = P - t - xi t.  Scratch: home blocks 0..2 (the caller reserves them),
+        the pool for the column passes.  Worst column: 20 products of |a + b| <= 2 units by |S| <= 11 units plus the reduction:
+        450 * 2^54 < 2^63."""
+        a0, a1, b0, b1 = self.blk(A0, 0), self.blk(A0, 1), self.blk(B0, 0), self.blk(B0, 1)
+        t0, t1 = self.blk(HOME0, 0), self.blk(HOME0, 1)
+        u0, u1 = self.blk(HOME0 + SLOT_DW, 0), self.blk(HOME0 + SLOT_DW, 1)
+        s0, s1 = self.blk(HOME0 + 2 * SLOT_DW, 0), self.blk(HOME0 + 2 * SLOT_DW, 1)
+        n = [self.pool.alloc() for _ in range(NL)]
+        for i in range(NL):
+            self.e.emit(f"v_sub_u32_e32 v{n[i]}, 0, v{a1[i]}", vw=[n[i]])
+        self.fips_direct([(a1, b0), (a0, b1)], t1)                     # t = a b (a, b stay intact)
+        self.fips_direct([(a0, b0), (n, b1)], t0)
+        for i in range(NL):
+            self.e.emit(f"v_add_u32_e32 v{u0[i]}, v{a0[i]}, v{b0[i]}", vw=[u0[i]])                  # u = a + b
+            self.e.emit(f"v_add_u32_e32 v{u1[i]}, v{a1[i]}, v{b1[i]}", vw=[u1[i]])
+            self.e.emit(f"v_sub_u32_e32 v{n[i]}, 0, v{u1[i]}", vw=[n[i]])                           # -u1 for the second pass
+            self.e.emit(f"v_lshl_add_u32 v{s0[i]}, v{b0[i]}, 3, v{b0[i]}", vw=[s0[i]])              # S = xi b + a
+            self.e.emit(f"v_sub_u32_e32 v{s0[i]}, v{s0[i]}, v{b1[i]}", vw=[s0[i]])
+            self.e.emit(f"v_add_u32_e32 v{s0[i]}, v{s0[i]}, v{a0[i]}", vw=[s0[i]])
+            self.e.emit(f"v_lshl_add_u32 v{s1[i]}, v{b1[i]}, 3, v{b1[i]}", vw=[s1[i]])
+            self.e.emit(f"v_add_u32_e32 v{s1[i]}, v{s1[i]}, v{b0[i]}", vw=[s1[i]])
+            self.e.emit(f"v_add_u32_e32 v{s1[i]}, v{s1[i]}, v{a1[i]}", vw=[s1[i]])
+        self.fips_direct([(u1, s0), (u0, s1)], u1)                     # P = u S, in place over u
+        self.fips_direct([(u0, s0), (n, s1)], u0)
+        self.pool.free(*n)
+        w = self.pool.alloc()
+        for i in range(NL):
+            # r0 = P - t - xi t = (P0 - 10 t0 + t1, P1 - 10 t1 - t0)
+            self.e.emit(f"v_lshl_add_u32 v{w}, v{t0[i]}, 3, v{t0[i]}", vw=[w])
+            self.e.emit(f"v_add_u32_e32 v{w}, v{w}, v{t0[i]}", vw=[w])
+            self.e.emit(f"v_add_u32_e32 v{a0[i]}, v{u0[i]}, v{t1[i]}", vw=[a0[i]])
+            self.e.emit(f"v_sub_u32_e32 v{a0[i]}, v{a0[i]}, v{w}", vw=[a0[i]])
+            self.e.emit(f"v_lshl_add_u32 v{w}, v{t1[i]}, 3, v{t1[i]}", vw=[w])
+            self.e.emit(f"v_add_u32_e32 v{w}, v{w}, v{t1[i]}", vw=[w])
+            self.e.emit(f"v_sub_u32_e32 v{a1[i]}, v{u1[i]}, v{t0[i]}", vw=[a1[i]])
+            self.e.emit(f"v_sub_u32_e32 v{a1[i]}, v{a1[i]}, v{w}", vw=[a1[i]])
+            self.e.emit(f"v_lshlrev_b32_e32 v{b0[i]}, 1, v{t0[i]}", vw=[b0[i]])                     # r1 = 2 t
+            self.e.emit(f"v_lshlrev_b32_e32 v{b1[i]}, 1, v{t1[i]}", vw=[b1[i]])
+        self.pool.free(w)
+        self.norm_limbs(a0)
+        self.norm_limbs(a1)
+
     def r_mulfq(self):
         """A <- (A.c0 * B.c0, A.c1 * B.c0), in place"""
         a0, a1, k = self.blk(A0, 0), self.blk(A0, 1), self.blk(B0, 0)
@@ -422,7 +467,7 @@ class L1v3:
         self.pool.free(*d)
 
 
-L1V3_NAMES = ["mul", "mul3", "sqr", "mulfq", "add", "sub", "rsub", "dbl", "neg", "negc1", "mulxi", "norm", "redn", "fqmul", "fqsqr", "cvtin", "cvtout"]
+L1V3_NAMES = ["mul", "mul3", "sqr", "sqr4", "mulfq", "add", "sub", "rsub", "dbl", "neg", "negc1", "mulxi", "norm", "redn", "fqmul", "fqsqr", "cvtin", "cvtout"]
 
 if __name__ == "__main__":
     for n in L1V3_NAMES:

@@ -17,7 +17,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import kgen_prog as KP  # noqa: E402
-from kgen import Emitter, P_INT, SIX_U_PLUS_2_NAF, align_code  # noqa: E402
+from kgen import Emitter, P_INT, SIX_U_PLUS_2_NAF, align_code, max_branch_distance  # noqa: E402
 from kgen3 import (A0, B0, HOME0, L1V3_NAMES, L1v3, LB, MASK, N0P, N_AGPR_SLOTS, N_HOME, N_LDS_SLOTS, NL, P_L, S_N0, S_P, S_RET1, S_RET2,  # noqa: E402
                    S_RET3, SLOT_DW, V_FLAG, V_GOFF, V_IDX, V_IDX8, V_LDS, V_TID, mont3, to_limbs)
 from kgen_prog import (AGPR, GLOB, HOME, LDS, Const, GlobDyn, Slot, S_FIN, S_G1, S_G2, S_GADDR, S_GBASE, S_GRID, S_GSTRIDE, S_I, S_IOADDR,  # noqa: E402
@@ -229,7 +229,6 @@ class Prog3(KP.Prog):
         self._count("ld_" + slot.kind)
 
     def store(self, blk, slot):
-        assert blk == A0
         if slot.kind == "lds":
             for c in range(N_CHUNK):
                 base, off = self._lds_addr(slot, c)
@@ -273,10 +272,12 @@ class Prog3(KP.Prog):
         self.tagH = [None] * 4
         self.eH = [None] * 4
         self.vH = [V_STORE] * 4
+        self._blocks_reserved = True
 
     def release_blocks(self):
         held = [t for t in self._saved_tmp if t.kind == "home" and t.idx < 4]
         self.free_tmp = held + self.free_tmp
+        self._blocks_reserved = False
 
     def ldH(self, k, slot):
         """home block k <- slot (straight ds_read for LDS slots)."""
@@ -300,6 +301,39 @@ class Prog3(KP.Prog):
         self.rA = self.r_norm()
         self.tagH[0] = self.tagH[2] = None          # destroyed
         return self
+
+    USE_SQR4 = bool(int(os.environ.get("KGEN3_SQR4", "1")))
+
+    def fq4_sqr(self, a, b, r0, r1):
+        """(a + b y)^2, y^2 = xi: r0 = a^2 + xi b^2, r1 = 2 a b -- one fused L1 routine (sqr4) when the home blocks are
+        reserved and both operands are normalised; the generic two-multiplication form otherwise."""
+        ra, rb = self.r_of(a), self.r_of(b)
+        if not (self.USE_SQR4 and getattr(self, "_blocks_reserved", False) and mag(ra) <= 1.0 and mag(rb) <= 1.0):
+            return super().fq4_sqr(a, b, r0, r1)
+        self.A(a)
+        self._B(b)
+        va, vb = self.vA, self.v_of(b)
+        v_t = 2 * va * vb / K_RP + 1
+        v_p = 2 * (va + vb) * (va + 10 * vb) / K_RP + 1
+        self._raw_call("sqr4")
+        self.tagH = [None] * 4                      # home blocks 0..2 are scratch of the routine
+        self.vA = v_p + 11 * v_t
+        self.rA = self.r_norm()
+        self.to(r0)
+        self.wait()
+        self.store(B0, r1)                          # block B holds r1 = 2 t
+        k1 = self.key(r1)
+        self.slot_v[k1] = 2 * v_t
+        self.max_v = max(self.max_v, 2 * v_t)
+        self._need(2 * v_t <= V_CAP, "sqr4 r1 value")
+        self.slot_r[k1] = (-2 * v_t / K_RP, max(2.0, 2 * v_t / K_RP))
+        self._need(k1 not in self.norm_keys, "sqr4: r1 is not normalised")
+        self.tagB = r1
+
+    def fq12_cyc_sqr(self, F):
+        self.reserve_blocks()
+        super().fq12_cyc_sqr(F)
+        self.release_blocks()
 
     def mul_by_034(self, F, L0, L3, L4):
         """f *= L0 + L3 w^3 + L4 w^4 with one reduction per output coefficient (xi folded into the line)."""
@@ -509,6 +543,8 @@ class KernelBuilder3(KP.KernelBuilder):
         p = Prog3(e, self.labels)
         p.set_temps(temps)
         p.norm_keys = self.norm_keys(phase or self._phase)
+        if self._cold:
+            p.INLINE_SET = Prog3.INLINE_SET[:6]          # routines that run once per pairing call norm / mulxi (code size)
         return e, p
 
     NORM_CONTRACT = bool(int(os.environ.get("KGEN3_NORM_CONTRACT", "1")))
@@ -522,10 +558,15 @@ class KernelBuilder3(KP.KernelBuilder):
             keys += [Prog3.key(s_) for s_ in self.BOP] + [("globdyn", i) for i in range(6)]
         return frozenset(keys)
 
+    COLD = ("L2_inv", "L2_frob1", "L2_frob2", "L2_frob3", "L2_dblfirst", "L2_addmul_last", "L2_descale", "L2_fqinv")
+    _cold = False
+
     def l2_routine(self, name, body, temps):
         """Also records the value bounds (units of p) the routine leaves in every non-temporary slot, given that all
         its inputs were below V_STORE p: the basis of the inductive certification in certify_values()."""
+        self._cold = name in self.COLD
         p = super().l2_routine(name, body, temps)
+        self._cold = False
         tk = {Prog3.key(t) for t in temps}
         self.l2_bodies[name] = (body, temps)
         self.l2_phase[name] = self._phase
@@ -541,7 +582,8 @@ class KernelBuilder3(KP.KernelBuilder):
 
     def fexp_temps(self):
         # LDS 6,7 ; homes ; AGPR 6..11 (0..5 hold the multiplication operand)
-        return [HOME(i) for i in range(8)] + [LDS(6), LDS(7)] + [AGPR(i) for i in (6, 7, 8, 10, 11)] + [GLOB(GLOB_TMP0 + i) for i in range(8)]
+        # fastest first: home registers, then AGPR slots (80 cycles either way), then LDS (a slot store costs 130-270 cycles)
+        return [HOME(i) for i in range(8)] + [AGPR(i) for i in (6, 7, 8, 10, 11)] + [LDS(6), LDS(7)] + [GLOB(GLOB_TMP0 + i) for i in range(8)]
 
     # ---------------------------------------------------------------------------------------------
     def build(self):
@@ -560,6 +602,7 @@ class KernelBuilder3(KP.KernelBuilder):
                 g.home_variant(op, i)
                 l1e.salu(f"s_setpc_b64 {S_RET1}")
         self.sections = []
+        self.control_sections = []
         self._phase = "miller"
         if self.do_miller:
             sc = self.SCALE if self.track else None
@@ -613,9 +656,12 @@ class KernelBuilder3(KP.KernelBuilder):
         tail = Emitter()
         tail.label(self.lab("L_exit"))
         out = []
-        for e in [self._pro] + first + [main, l1e] + second + [tail]:
+        for e in [self._pro] + first + [main] + self.control_sections + [l1e] + second + [tail]:
             out.extend(e.finalize())
-        return [".p2align 3"] + align_code(out) if ALIGN_CODE else out
+        out = [".p2align 3"] + align_code(out) if ALIGN_CODE else out
+        worst = max_branch_distance(out)
+        assert worst < 131072 - 512, f"branch of {worst} bytes: s_call_b64 / s_branch reach +-128 KB (re-balance the layout)"
+        return out
 
     # ------------------------------------------------------------------ value-bound certification
     # Limb bounds are closed per routine (every store enforces STORE_MAG, every multiplication its column sums).
@@ -643,7 +689,9 @@ class KernelBuilder3(KP.KernelBuilder):
         for reads, ex, mv in memo:
             if all(self._grid(state.get(k, 2.0)) == v for k, v in reads.items()):
                 return ex, mv
+        self._cold = name in self.COLD
         e, p = self.new_prog(temps, phase=self.l2_phase.get(name, "fexp"))
+        self._cold = False
         p.entry_v = {k: self._grid(v) for k, v in state.items()}
         p.default_v = 2.0                       # never-written slots hold converted inputs
         body(p)
@@ -659,7 +707,9 @@ class KernelBuilder3(KP.KernelBuilder):
         """Replays the kernel's L2 call sequence on value bounds.  Returns a report dict; raises on any violation."""
         self._memo, self._ref_text = {}, {}
         for name, (body, temps) in self.l2_bodies.items():       # the shipped code of each routine body
+            self._cold = name in self.COLD
             e, p = self.new_prog(temps, phase=self.l2_phase[name])
+            self._cold = False
             body(p)
             self._ref_text[name] = self._norm_text(e.finalize())
         st, worst, calls = {}, 0.0, 0
@@ -830,7 +880,7 @@ class KernelBuilder3(KP.KernelBuilder):
         e.salu(f"s_sub_u32 s{S_J}, s{S_J}, 1")
         e.salu(f"s_cbranch_scc0 {L('L3_powx_loop')}")
         e.salu(f"s_setpc_b64 {S_RET3}")
-        self.sections.append(e)
+        self.control_sections.append(e)           # control code: placed next to the main program (it calls L2 routines of both halves)
 
     def batch_load_globdyn(self, e, p, ks, dests):
         """dests[i] <- scratch slot (S_GBASE + ks[i]): all global loads issued back to back into landing registers
