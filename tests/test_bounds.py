@@ -31,7 +31,7 @@ def test_value_bounds_of_shipped_kernels(name, kw):
         if kw["do_miller"]:
             assert rep["miller_f_out"] < 2.0            # the Miller loop hands over a freshly reduced f
         if kw["do_fexp"]:
-            assert rep["fexp_f_out"] < 256.0
+            assert rep["fexp_f_out"] < 4096.0          # cvtout (one more Montgomery multiplication) canonicalises any representative
 
 
 def test_reduction_schedule_of_the_x_power_loop():

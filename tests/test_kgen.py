@@ -241,6 +241,38 @@ def test_l1_v3_routines():
             assert (val(m, j) - w) % P == 0, ("sqr4", t, j)
         assert all(0 <= m.v[K3.NL * j + i] < (1 << K3.LB) for j in range(2) for i in range(K3.NL - 1))
         assert all(0 <= m.v[K3.NL * j + i] < (2 << K3.LB) for j in (2, 3) for i in range(K3.NL - 1))
+    # mul6 (fused Fq6 multiplication): operands in home blocks 0..5, limbs up to 2 units (sums of two normalised values)
+    xi = lambda x: ((9 * x[0] - x[1]) % P, (9 * x[1] + x[0]) % P)
+    f2a = lambda x, y: ((x[0] + y[0]) % P, (x[1] + y[1]) % P)
+    for t in range(10):
+        a = [(rnd(), rnd()) for _ in range(3)]
+        b = [(rnd(), rnd()) for _ in range(3)]
+        m = _m3([], rng, 0)
+        for r in range(K3.HOME0 + 6 * K3.SLOT_DW, K3.HOME0 + 8 * K3.SLOT_DW):
+            m.v[r] = rng.getrandbits(32)
+        for r in range(0, 2 * K3.SLOT_DW):
+            m.v[r] = rng.getrandbits(32)
+        for k, el in enumerate(a + b):
+            for h in range(2):
+                if t % 2:                     # a sum of two normalised values, limb by limb
+                    part = rng.randrange(P)
+                    limbs = [x + y for x, y in zip(K3.to_limbs(part), K3.to_limbs((el[h] - part) % P))]
+                else:
+                    limbs = K3.to_limbs(el[h])
+                for i, w in enumerate(limbs):
+                    m.v[K3.HOME0 + K3.SLOT_DW * k + K3.NL * h + i] = w & 0xFFFFFFFF
+        S.run_block(B["mul6"], m)
+        v = [f2m(a[i], b[i]) for i in range(3)]
+        cross = lambda i, j: f2m(f2a(a[i], a[j]), f2a(b[i], b[j]))
+        sub = lambda x, y: ((x[0] - y[0]) % P, (x[1] - y[1]) % P)
+        want = [f2a(v[0], xi(sub(sub(cross(1, 2), v[1]), v[2]))), f2a(sub(sub(cross(0, 1), v[0]), v[1]), xi(v[2])),
+                f2a(sub(sub(cross(0, 2), v[0]), v[2]), v[1])]
+        where = [K3.HOME0 + K3.SLOT_DW, K3.A0, K3.HOME0]            # c0 -> home 1, c1 -> A, c2 -> home 0
+        for c in range(3):
+            for h in range(2):
+                regs = [m.v[where[c] + K3.NL * h + i] for i in range(K3.NL)]
+                assert (_sval(regs) - want[c][h] * RPI) % P == 0, ("mul6", t, c, h)
+                assert all(0 <= r < (1 << K3.LB) for r in regs[:-1])
     # redn on large representatives (x + t p, |t| up to the certified cap) with unnormalised limbs
     for t in range(40):
         xs = [rnd() + rng.randrange(-60000, 60000) * P for _ in range(2)]

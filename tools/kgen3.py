@@ -289,6 +289,84 @@ class L1v3:
         self.norm_limbs(a0)
         self.norm_limbs(a1)
 
+    # ------------------------------------------------------------------ fused Fq6 multiplication
+    def _fq2_mul(self, x, y, o):
+        """o <- x * y (Fq2; x, y, o = (c0 limbs, c1 limbs)); o may be x itself (in place, as r_mul) or a disjoint block."""
+        (x0, x1), (y0, y1), (o0, o1) = x, y, o
+        n = [self.pool.alloc() for _ in range(NL)]
+        for i in range(NL):
+            self.e.emit(f"v_sub_u32_e32 v{n[i]}, 0, v{x1[i]}", vw=[n[i]])
+        self.fips_direct([(x1, y0), (x0, y1)], o1)
+        self.fips_direct([(x0, y0), (n, y1)], o0)
+        self.pool.free(*n)
+
+    def _lw(self, op, d, a, b):
+        for h in range(2):
+            self.limbwise(op, d[h], a[h], b[h])
+
+    def _add_xi(self, d, x):
+        """d += xi * x  (xi = 9 + u): d0 += 9 x0 - x1 ; d1 += 9 x1 + x0"""
+        t = self.pool.alloc()
+        for i in range(NL):
+            self.e.emit(f"v_lshl_add_u32 v{t}, v{x[0][i]}, 3, v{x[0][i]}", vw=[t])
+            self.e.emit(f"v_sub_u32_e32 v{t}, v{t}, v{x[1][i]}", vw=[t])
+            self.e.emit(f"v_add_u32_e32 v{d[0][i]}, v{d[0][i]}, v{t}", vw=[d[0][i]])
+            self.e.emit(f"v_lshl_add_u32 v{t}, v{x[1][i]}, 3, v{x[1][i]}", vw=[t])
+            self.e.emit(f"v_add_u32_e32 v{t}, v{t}, v{x[0][i]}", vw=[t])
+            self.e.emit(f"v_add_u32_e32 v{d[1][i]}, v{d[1][i]}, v{t}", vw=[d[1][i]])
+        self.pool.free(t)
+
+    def _mulxi_inplace(self, x):
+        t = self.pool.alloc()
+        for i in range(NL):
+            self.e.emit(f"v_lshl_add_u32 v{t}, v{x[0][i]}, 3, v{x[0][i]}", vw=[t])
+            self.e.emit(f"v_sub_u32_e32 v{t}, v{t}, v{x[1][i]}", vw=[t])
+            self.e.emit(f"v_lshl_add_u32 v{x[1][i]}, v{x[1][i]}, 3, v{x[1][i]}", vw=[x[1][i]])
+            self.e.emit(f"v_add_u32_e32 v{x[1][i]}, v{x[1][i]}, v{x[0][i]}", vw=[x[1][i]])
+            self.e.emit(f"v_mov_b32_e32 v{x[0][i]}, v{t}", vw=[x[0][i]])
+        self.pool.free(t)
+
+    def r_mul6(self):
+        """Fq6 multiplication (Fq2[v]/(v^3 - xi), Karatsuba: six Fq2 multiplications), fused: a = (a0, a1, a2) in home blocks
+        0..2, b in home blocks 3..5, limbs of magnitude <= 2 units (sums of two normalised values are fine).  Results, all
+        NORMALISED:  c0 -> home block 1,  c1 -> block A,  c2 -> home block 0.  Scratch: home blocks 6, 7, blocks A, B, the pool.
+        Every input block is destroyed.  Worst column: 20 products of 4 x 4 units plus the reduction: 330 * 2^54 < 2^63."""
+        H = lambda k: (self.blk(HOME0 + SLOT_DW * k, 0), self.blk(HOME0 + SLOT_DW * k, 1))
+        a, b = [H(0), H(1), H(2)], [H(3), H(4), H(5)]
+        v0, v1 = H(6), H(7)
+        A, B = (self.blk(A0, 0), self.blk(A0, 1)), (self.blk(B0, 0), self.blk(B0, 1))
+        self._fq2_mul(a[0], b[0], v0)
+        self._fq2_mul(a[1], b[1], v1)
+        # c1 = (a0 + a1)(b0 + b1) - v0 - v1 + xi v2
+        self._lw("v_add_u32_e32", A, a[0], a[1])
+        self._lw("v_add_u32_e32", B, b[0], b[1])
+        self._fq2_mul(A, B, A)
+        self._lw("v_sub_u32_e32", A, A, v0)
+        self._lw("v_sub_u32_e32", A, A, v1)
+        v2 = B
+        self._fq2_mul(a[2], b[2], v2)
+        self._add_xi(A, v2)
+        # c2 = (a0 + a2)(b0 + b2) - v0 - v2 + v1   (in place over a0 / b0: both are dead afterwards)
+        self._lw("v_add_u32_e32", a[0], a[0], a[2])
+        self._lw("v_add_u32_e32", b[0], b[0], b[2])
+        self._fq2_mul(a[0], b[0], a[0])
+        self._lw("v_sub_u32_e32", a[0], a[0], v0)
+        self._lw("v_sub_u32_e32", a[0], a[0], v2)
+        self._lw("v_add_u32_e32", a[0], a[0], v1)
+        # c0 = v0 + xi ((a1 + a2)(b1 + b2) - v1 - v2)   (in place over a1 / b1)
+        self._lw("v_add_u32_e32", a[1], a[1], a[2])
+        self._lw("v_add_u32_e32", b[1], b[1], b[2])
+        self._fq2_mul(a[1], b[1], a[1])
+        self._lw("v_sub_u32_e32", a[1], a[1], v1)
+        self._lw("v_sub_u32_e32", a[1], a[1], v2)
+        for h in range(2):
+            self.norm_limbs(a[1][h])                     # 3 units: x xi would overflow int32 otherwise
+        self._mulxi_inplace(a[1])
+        self._lw("v_add_u32_e32", a[1], a[1], v0)
+        for blk in (a[1], A, a[0]):
+            for h in range(2):
+                self.norm_limbs(blk[h])
+
     def r_mulfq(self):
         """A <- (A.c0 * B.c0, A.c1 * B.c0), in place"""
         a0, a1, k = self.blk(A0, 0), self.blk(A0, 1), self.blk(B0, 0)
@@ -467,7 +545,7 @@ class L1v3:
         self.pool.free(*d)
 
 
-L1V3_NAMES = ["mul", "mul3", "sqr", "sqr4", "mulfq", "add", "sub", "rsub", "dbl", "neg", "negc1", "mulxi", "norm", "redn", "fqmul", "fqsqr", "cvtin", "cvtout"]
+L1V3_NAMES = ["mul", "mul3", "mul6", "sqr", "sqr4", "mulfq", "add", "sub", "rsub", "dbl", "neg", "negc1", "mulxi", "norm", "redn", "fqmul", "fqsqr", "cvtin", "cvtout"]
 
 if __name__ == "__main__":
     for n in L1V3_NAMES:

@@ -44,6 +44,7 @@ GLOB_TMP0 = 6 * N_GREG           # eight overflow temporaries: slots 72..79
 S_PB = 47                        # byte offset of the base's scratch register during the x-power routine
 S_XIDX0, S_XIDX1 = "s[50:51]", "s[52:53]"      # which power a non-zero digit selects (index into X_POWERS)
 
+USE_MUL6 = bool(int(os.environ.get("KGEN3_MUL6", "1")))          # fused Fq6 multiplication (L1 mul6) in fq12_mul / fq12_sqr
 ALIGN_CODE = bool(int(os.environ.get("KGEN3_ALIGN", "1")))     # keep 8-byte instructions 8-byte aligned (kgen.align_code)
 RED_POWERS = True            # reduce the representatives of b^5, b^9, b^13 before they are stored
 RED_RUN = 4                  # cyclotomic squarings in a row before the x-power loop reduces the representative
@@ -302,6 +303,106 @@ class Prog3(KP.Prog):
         self.tagH[0] = self.tagH[2] = None          # destroyed
         return self
 
+    homes_free = False
+
+    def _mul6_regs(self, a, b, a_plus=None, b_plus=None):
+        """Fused Fq6 multiplication (L1 mul6) of (a + a_plus) by (b + b_plus), coefficient-wise sums formed while the operands
+        are loaded into the home blocks.  Returns the three result 'slots' [c0, c1, c2]: c0 = HOME(1), c1 = block A (None),
+        c2 = HOME(0), all normalised, with their bounds recorded; every home block is clobbered."""
+        va = max(self.v_of(s_) for s_ in a) + (max(self.v_of(s_) for s_ in a_plus if s_ is not None) if a_plus else 0.0)
+        vb = max(self.v_of(s_) for s_ in b) + (max(self.v_of(s_) for s_ in b_plus if s_ is not None) if b_plus else 0.0)
+        for base, slots, plus in ((0, a, a_plus), (3, b, b_plus)):
+            for k, s_ in enumerate(slots):
+                blk = HOME0 + SLOT_DW * (base + k)
+                s2 = plus[k] if plus else None
+                m_ = mag(self.r_of(s_)) + (mag(self.r_of(s2)) if s2 is not None else 0.0)
+                if m_ > 2.0:                                  # mul6 takes limbs of up to two units
+                    self.A(s_)
+                    if s2 is not None:
+                        self.add(s2)
+                    self.norm()
+                    self.wait()
+                    for i in range(SLOT_DW):
+                        self.e.emit(f"v_mov_b32_e32 v{blk + i}, v{A0 + i}", vw=[blk + i])
+                else:
+                    self.load(blk, s_)
+                    if s2 is not None:
+                        self.load(A0, s2)
+                        self.tagA = None
+                        self.wait()
+                        for i in range(SLOT_DW):
+                            self.e.emit(f"v_add_u32_e32 v{blk + i}, v{blk + i}, v{A0 + i}", vw=[blk + i])
+        self._raw_call("mul6")
+        self.tagB = None
+        v_prod = 2 * va * vb / K_RP + 1
+        v_sum = 8 * va * vb / K_RP + 1
+        res = [HOME(1, "mul6.c0"), None, HOME(0, "mul6.c2")]
+        for slot, v in ((res[0], 10 * (v_sum + 2 * v_prod) + v_prod), (res[2], v_sum + 3 * v_prod)):
+            self._need(v <= V_CAP, f"mul6 result value {v}")
+            self.slot_r[self.key(slot)] = (-v / K_RP, max(1.0, v / K_RP))
+            self.slot_v[self.key(slot)] = v
+            self.max_v = max(self.max_v, v)
+        self.vA = v_sum + 12 * v_prod
+        self._need(self.vA <= V_CAP, f"mul6 result value {self.vA}")
+        self.rA = (-self.vA / K_RP, max(1.0, self.vA / K_RP))
+        self.tagA = None
+        return res
+
+    def fq6_mul(self, a, b, out, a_plus=None, b_plus=None):
+        """(a0, a1, a2)(b0, b1, b2) in Fq2[v]/(v^3 - xi): ONE fused L1 routine (mul6: operands in the home blocks, results
+        normalised) when the routine keeps no temporary in the home registers; six calls plus glue otherwise."""
+        if not self.homes_free:
+            assert a_plus is None and b_plus is None
+            return super().fq6_mul(a, b, out)
+        res = self._mul6_regs(a, b, a_plus, b_plus)
+        self.to(out[1])                                       # c1 sits in block A
+        self.A(res[0]).to(out[0])
+        self.A(res[2]).to(out[2])
+
+    def fq12_mul(self, F, Bs, conj_b=False):
+        """F <- F * B on the fused Fq6 multiplication: the sums of the third product are formed while its operands are
+        loaded and its results are combined straight from the registers (B is not modified)."""
+        if not self.homes_free:
+            return super().fq12_mul(F, Bs, conj_b)
+        if conj_b:
+            for k in (1, 3, 5):
+                self.A(Bs[k]).neg().to(Bs[k])
+        A_0, A_1 = [F[0], F[2], F[4]], [F[1], F[3], F[5]]
+        B_0, B_1 = [Bs[0], Bs[2], Bs[4]], [Bs[1], Bs[3], Bs[5]]
+        T0 = [self.tmp() for _ in range(3)]
+        T1 = [self.tmp() for _ in range(3)]
+        self.fq6_mul(A_0, B_0, T0)
+        self.fq6_mul(A_1, B_1, T1)
+        M = self._mul6_regs(A_0, B_0, A_1, B_1)               # (A0 + A1)(B0 + B1)
+        self.sub(T0[1]).sub(T1[1]).to(F[3])                   # c1 is in block A
+        self.A(M[0]).sub(T0[0]).sub(T1[0]).to(F[1])
+        self.A(M[2]).sub(T0[2]).sub(T1[2]).to(F[5])
+        self.A(T1[2]).mulxi().add(T0[0]).to(F[0])
+        self.A(T0[1]).add(T1[0]).to(F[2])
+        self.A(T0[2]).add(T1[1]).to(F[4])
+        self.rel(*T0)
+        self.rel(*T1)
+
+    def fq12_sqr(self, F):
+        """F <- F^2 (complex squaring over Fq6: t = A0 A1, u = (A0 + A1)(A0 + v A1)) on the fused Fq6 multiplication."""
+        if not self.homes_free:
+            return super().fq12_sqr(F)
+        A_0, A_1 = [F[0], F[2], F[4]], [F[1], F[3], F[5]]
+        T = [self.tmp() for _ in range(3)]
+        S0 = self.tmp()
+        self.fq6_mul(A_0, A_1, T)
+        self.A(F[5]).mulxi().add(F[0]).to(S0)                 # first coefficient of A0 + v A1
+        U = self._mul6_regs(A_0, [S0, F[2], F[4]], A_1, [None, F[1], F[3]])
+        self.sub(T[1]).sub(T[0]).to(F[2])                     # u1 - t1 - t0   (u1 is in block A)
+        X = S0
+        self.A(T[2]).mulxi().to(X)
+        self.A(U[0]).sub(T[0]).sub(X).to(F[0])
+        self.A(U[2]).sub(T[2]).sub(T[1]).to(F[4])
+        self.A(T[0]).dbl().to(F[1])
+        self.A(T[1]).dbl().to(F[3])
+        self.A(T[2]).dbl().to(F[5])
+        self.rel(S0, *T)
+
     USE_SQR4 = bool(int(os.environ.get("KGEN3_SQR4", "1")))
 
     def fq4_sqr(self, a, b, r0, r1):
@@ -514,9 +615,21 @@ class Prog3(KP.Prog):
         return self
 
 
+class _PhaseList(list):
+    """The builder's section list: remembers in which phase (Miller loop / final exponentiation) a section was added."""
+
+    def __init__(self, kb):
+        super().__init__()
+        self.kb = kb
+
+    def append(self, e):
+        self.kb.section_phase[id(e)] = self.kb._phase
+        super().append(e)
+
+
 class KernelBuilder3(KP.KernelBuilder):
     F = [LDS(i, f"F{i}") for i in range(6)]
-    R = [LDS(6, "RX"), LDS(7, "RY"), HOME(7, "RZ")]
+    R = [LDS(6, "RX"), LDS(7, "RY"), AGPR(9, "RZ")]          # RZ shares AGPR 9 with the Fq-inversion base (R is dead by then)
     SCALE = AGPR(11, "scale")
     QX, QY, PX, PY = AGPR(0, "QX"), AGPR(1, "QY"), AGPR(2, "PX"), AGPR(3, "PY")
     SX, SY = AGPR(4, "SX"), AGPR(5, "SY")
@@ -543,6 +656,7 @@ class KernelBuilder3(KP.KernelBuilder):
         p = Prog3(e, self.labels)
         p.set_temps(temps)
         p.norm_keys = self.norm_keys(phase or self._phase)
+        p.homes_free = USE_MUL6 and not any(t.kind == "home" for t in temps)
         if self._cold:
             p.INLINE_SET = Prog3.INLINE_SET[:6]          # routines that run once per pairing call norm / mulxi (code size)
         return e, p
@@ -574,40 +688,44 @@ class KernelBuilder3(KP.KernelBuilder):
         self.l2_maxv[name] = p.max_v
         return p
 
-    def miller_temps(self, extra=()):
+    def miller_temps(self, extra=(), no_homes=False):
         """Fast temporaries of the Miller-loop routines: homes 0..6, AGPR 10 (11 when no scale is tracked),
         plus routine-specific dead slots; global scratch slots only as overflow."""
-        return ([HOME(i) for i in range(7)] + [AGPR(10)] + ([] if self.track else [AGPR(11)]) + [AGPR(i) for i in extra]
+        if no_homes:                     # routines built on the fused Fq6 multiplication (all eight home blocks are its workspace)
+            return [AGPR(10)] + ([] if self.track else [AGPR(11)]) + [AGPR(i) for i in extra] + [GLOB(GLOB_TMP0 + i) for i in range(8)]
+        return ([HOME(i) for i in range(8)] + [AGPR(10)] + ([] if self.track else [AGPR(11)]) + [AGPR(i) for i in extra]
                 + [GLOB(GLOB_TMP0 + i) for i in range(8)])
 
-    def fexp_temps(self):
+    def fexp_temps(self, no_homes=False):
         # LDS 6,7 ; homes ; AGPR 6..11 (0..5 hold the multiplication operand)
         # fastest first: home registers, then AGPR slots (80 cycles either way), then LDS (a slot store costs 130-270 cycles)
-        return [HOME(i) for i in range(8)] + [AGPR(i) for i in (6, 7, 8, 10, 11)] + [LDS(6), LDS(7)] + [GLOB(GLOB_TMP0 + i) for i in range(8)]
+        return ([] if no_homes else [HOME(i) for i in range(8)]) + [AGPR(i) for i in (6, 7, 8, 10, 11)] + [LDS(6), LDS(7)] + [GLOB(GLOB_TMP0 + i) for i in range(8)]
 
     # ---------------------------------------------------------------------------------------------
     def build(self):
         main = Emitter()
         self.prologue(main)
-        l1e = Emitter()
+        l1 = {}                                  # one section per leaf routine: their order is chosen below
         for n in L1V3_NAMES:
-            g = L1v3(l1e)
-            l1e.label(self.labels[n])
-            getattr(g, "r_" + n)()
-            l1e.salu(f"s_setpc_b64 {S_RET1}")
+            l1[n] = Emitter()
+            l1[n].label(self.labels[n])
+            getattr(L1v3(l1[n]), "r_" + n)()
+            l1[n].salu(f"s_setpc_b64 {S_RET1}")
         for op in ("add", "sub", "rsub"):
             for i in range(N_HOME):
-                g = L1v3(l1e)
-                l1e.label(self.labels[f"{op}_h{i}"])
-                g.home_variant(op, i)
-                l1e.salu(f"s_setpc_b64 {S_RET1}")
-        self.sections = []
+                n = f"{op}_h{i}"
+                l1[n] = Emitter()
+                l1[n].label(self.labels[n])
+                L1v3(l1[n]).home_variant(op, i)
+                l1[n].salu(f"s_setpc_b64 {S_RET1}")
+        self.sections = _PhaseList(self)
+        self.section_phase = {}
         self.control_sections = []
         self._phase = "miller"
         if self.do_miller:
             sc = self.SCALE if self.track else None
             # during f^2 the line (AGPR 6..8) and the addition point (AGPR 4, 5) are dead
-            self.l2_routine("L2_sqr", lambda p: p.fq12_sqr(self.F), self.miller_temps(extra=(4, 5, 6, 7, 8)))
+            self.l2_routine("L2_sqr", lambda p: p.fq12_sqr(self.F), self.miller_temps(extra=(4, 5, 6, 7, 8), no_homes=USE_MUL6))
             self.l2_routine("L2_dblmul", lambda p: (p.dbl_step(self.R, (self.PX, self.PY), self.LINE, scale=sc),
                                                     p.mul_by_034(self.F, *self.LINE)), self.miller_temps(extra=(4, 5)))
             self.l2_routine("L2_dblfirst", lambda p: self._dbl_first(p), self.miller_temps())
@@ -643,20 +761,35 @@ class KernelBuilder3(KP.KernelBuilder):
         self.main_body(main)
         # Layout: s_call_b64 / s_branch reach +-128 KB.  The leaf routines (called from everywhere) and the main
         # control code sit in the middle, the L2 routines are split around them by size.
-        secs = [(e, len(e.finalize())) for e in self.sections]
-        total = sum(n for _, n in secs)
-        first, second, acc = [], [], 0
-        for e, n in secs:
-            if acc + n <= total // 2:
-                first.append(e)
-                acc += n
-            else:
-                second.append(e)
-        main.salu(f"s_branch {self.lab('L_exit')}")       # main is no longer the last section
+        # Miller-loop routines in front of the block, final-exponentiation routines behind it, the small ones (called from
+        # the main program) nearest to the middle, the big cold ones (Fq12 inversion) at the far ends
+        size = {id(e): len(e.finalize()) for e in self.sections}
+        first = sorted([e for e in self.sections if self.section_phase[id(e)] == "miller"], key=lambda e: -size[id(e)])
+        second = sorted([e for e in self.sections if self.section_phase[id(e)] == "fexp"], key=lambda e: size[id(e)])
+        tot = lambda lst: sum(size[id(e)] for e in lst)
+        while second and tot(second) - tot(first) > 2 * size[id(second[-1])]:      # one-phase kernels: balance the two sides
+            first.insert(0, second.pop())
+        while first and tot(first) - tot(second) > 2 * size[id(first[0])]:
+            second.append(first.pop(0))
+        main.salu(f"s_branch {self.lab('L_exit_hop')}")   # main is not the last section; the end is out of reach in one hop
+        hop = Emitter()
+        hop.label(self.lab("L_exit_hop"))
+        hop.salu(f"s_branch {self.lab('L_exit')}")
         tail = Emitter()
         tail.label(self.lab("L_exit"))
+        # leaf routines nobody calls are dropped; the others are ordered by where their callers sit: routines called only
+        # from the sections in front of the block come first, those called only from behind last
+        def calls(secs_, lbl):
+            return sum(1 for e_ in secs_ for it in e_.ins if it["text"].startswith("s_call_b64") and it["text"].endswith(lbl))
+        front, back = first + [main] + self.control_sections, second
+        order = []
+        for n, e_ in l1.items():
+            nf, nb = calls(front, self.labels[n]), calls(back, self.labels[n])
+            if nf + nb:
+                order.append((nb / (nf + nb), -len(e_.ins) if nb <= nf else len(e_.ins), n))
+        order.sort()
         out = []
-        for e in [self._pro] + first + [main] + self.control_sections + [l1e] + second + [tail]:
+        for e in [self._pro] + first + [main] + self.control_sections + [l1[n] for _, _, n in order] + [hop] + second + [tail]:
             out.extend(e.finalize())
         out = [".p2align 3"] + align_code(out) if ALIGN_CODE else out
         worst = max_branch_distance(out)
@@ -769,14 +902,14 @@ class KernelBuilder3(KP.KernelBuilder):
                 elif op[0] == "mul":
                     for b, v in zip(self.BOP, G[op[1]]):
                         st[Prog3.key(b)] = v
-                    run("L2_mul_body", label="L2_mulGc" if op[2] else "L2_mulG", body=mul_body, temps=self.fexp_temps())
+                    run("L2_mul_body", label="L2_mulGc" if op[2] else "L2_mulG", body=mul_body, temps=self.fexp_temps(no_homes=USE_MUL6))
                 elif op[0] == "powx":
                     j = op[1]
 
                     def mul_by(reg, conj=False):
                         for b_, v in zip(self.BOP, G[reg]):
                             st[Prog3.key(b_)] = v
-                        run("L2_mul_body", label="L2_mulGc" if conj else "L2_mulG", body=mul_body, temps=self.fexp_temps())
+                        run("L2_mul_body", label="L2_mulGc" if conj else "L2_mulG", body=mul_body, temps=self.fexp_temps(no_homes=USE_MUL6))
 
                     def store(reg):
                         G[reg] = [st[k] for k in fk]
@@ -919,7 +1052,7 @@ class KernelBuilder3(KP.KernelBuilder):
         p.reset_tags()
 
     def _mulG_routines(self):
-        e, p = self.new_prog(self.fexp_temps())
+        e, p = self.new_prog(self.fexp_temps(no_homes=USE_MUL6))
         e.label(self.lab("L2_mulGc"))
         self.batch_load_globdyn(e, p, range(6), self.BOP)
         for i in (1, 3, 5):
