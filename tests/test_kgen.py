@@ -221,6 +221,8 @@ def test_l1_v3_routines():
                 assert all(0 <= m.v[K3.NL * j + i] < (1 << K3.LB) for j in range(2) for i in range(K3.NL - 1))
             if name == "redn":
                 assert all(-P // 64 < val(m, j) < P + P // 64 for j in range(2))
+    xi = lambda x: ((9 * x[0] - x[1]) % P, (9 * x[1] + x[0]) % P)
+    f2a = lambda x, y: ((x[0] + y[0]) % P, (x[1] + y[1]) % P)
     # sqr4 (fused Fq4 squaring of the cyclotomic squaring): normalised operands, also with negated limbs (conjugates)
     f2m = lambda x, y: ((x[0] * y[0] - x[1] * y[1]) % P, (x[0] * y[1] + x[1] * y[0]) % P)
     for t in range(24):
@@ -241,6 +243,28 @@ def test_l1_v3_routines():
             assert (val(m, j) - w) % P == 0, ("sqr4", t, j)
         assert all(0 <= m.v[K3.NL * j + i] < (1 << K3.LB) for j in range(2) for i in range(K3.NL - 1))
         assert all(0 <= m.v[K3.NL * j + i] < (2 << K3.LB) for j in (2, 3) for i in range(K3.NL - 1))
+    # sqr4c / sqr4cx: the same with the Granger-Scott recombination fused (zc, zd in home blocks 3, 4)
+    for t in range(12):
+        a, b, zc, zd = [(rnd(), rnd()) for _ in range(4)]
+        for name in ("sqr4c", "sqr4cx"):
+            m = _m3([a[0], a[1], b[0], b[1]], rng, 0)
+            for r in range(K3.HOME0, K3.HOME0 + 3 * K3.SLOT_DW):
+                m.v[r] = rng.getrandbits(32)
+            for k, el in ((3, zc), (4, zd)):
+                for h in range(2):
+                    for i, w in enumerate(K3.to_limbs(el[h])):
+                        m.v[K3.HOME0 + K3.SLOT_DW * k + K3.NL * h + i] = w
+            S.run_block(B[name], m)
+            b2 = f2m(b, b)
+            a2 = f2m(a, a)
+            r0 = f2a(a2, xi(b2))
+            tt = f2m(a, b)
+            if name == "sqr4cx":
+                tt = xi(tt)
+            want = [3 * r0[0] * RPI - 2 * zc[0], 3 * r0[1] * RPI - 2 * zc[1], 6 * tt[0] * RPI + 2 * zd[0], 6 * tt[1] * RPI + 2 * zd[1]]
+            for j in range(4):
+                assert (val(m, j) - want[j]) % P == 0, (name, t, j)
+            assert all(0 <= m.v[K3.NL * j + i] < (1 << K3.LB) for j in range(4) for i in range(K3.NL - 1))
     # mul6 (fused Fq6 multiplication): operands in home blocks 0..5, limbs up to 2 units (sums of two normalised values)
     xi = lambda x: ((9 * x[0] - x[1]) % P, (9 * x[1] + x[0]) % P)
     f2a = lambda x, y: ((x[0] + y[0]) % P, (x[1] + y[1]) % P)

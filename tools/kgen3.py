@@ -244,7 +244,7 @@ class L1v3:
         self.pool.free(*t)
         self.pool.free(*u)
 
-    def r_sqr4(self):
+    def r_sqr4(self, combine=None):
         """Fq4 squaring for the Granger-Scott cyclotomic squaring, fused: (a + b y)^2 with y^2 = xi, a in block A, b in block B
         (both NORMALISED: |limb| <= 2^27):  A <- a^2 + xi b^2 (normalised),  B <- 2 a b (limbs below 2^28).
         t = a b ; S = xi b + a ; P = (a + b) S ; r0 = P - t - xi t.  Scratch: home blocks 0..2 (the caller reserves them),
@@ -283,11 +283,45 @@ class L1v3:
             self.e.emit(f"v_add_u32_e32 v{w}, v{w}, v{t1[i]}", vw=[w])
             self.e.emit(f"v_sub_u32_e32 v{a1[i]}, v{u1[i]}, v{t0[i]}", vw=[a1[i]])
             self.e.emit(f"v_sub_u32_e32 v{a1[i]}, v{a1[i]}, v{w}", vw=[a1[i]])
-            self.e.emit(f"v_lshlrev_b32_e32 v{b0[i]}, 1, v{t0[i]}", vw=[b0[i]])                     # r1 = 2 t
-            self.e.emit(f"v_lshlrev_b32_e32 v{b1[i]}, 1, v{t1[i]}", vw=[b1[i]])
-        self.pool.free(w)
+            if combine is None:
+                self.e.emit(f"v_lshlrev_b32_e32 v{b0[i]}, 1, v{t0[i]}", vw=[b0[i]])                 # r1 = 2 t
+                self.e.emit(f"v_lshlrev_b32_e32 v{b1[i]}, 1, v{t1[i]}", vw=[b1[i]])
         self.norm_limbs(a0)
         self.norm_limbs(a1)
+        if combine is not None:
+            # Granger-Scott recombination with zc (home block 3) and zd (home block 4), both normalised:
+            #   A <- 3 r0 - 2 zc ;  B <- 3 r1 + 2 zd = 6 t + 2 zd   (combine == "xi": B <- 3 xi r1 + 2 zd = 6 xi t + 2 zd)
+            zc = (self.blk(HOME0 + 3 * SLOT_DW, 0), self.blk(HOME0 + 3 * SLOT_DW, 1))
+            zd = (self.blk(HOME0 + 4 * SLOT_DW, 0), self.blk(HOME0 + 4 * SLOT_DW, 1))
+            for h, ah in enumerate((a0, a1)):
+                for i in range(NL):
+                    self.e.emit(f"v_lshl_add_u32 v{w}, v{ah[i]}, 1, v{ah[i]}", vw=[w])
+                    self.e.emit(f"v_sub_u32_e32 v{w}, v{w}, v{zc[h][i]}", vw=[w])
+                    self.e.emit(f"v_sub_u32_e32 v{ah[i]}, v{w}, v{zc[h][i]}", vw=[ah[i]])
+            src = (t0, t1)
+            if combine == "xi":
+                for i in range(NL):                                       # B <- xi t, then normalise (10 units)
+                    self.e.emit(f"v_lshl_add_u32 v{b0[i]}, v{t0[i]}, 3, v{t0[i]}", vw=[b0[i]])
+                    self.e.emit(f"v_sub_u32_e32 v{b0[i]}, v{b0[i]}, v{t1[i]}", vw=[b0[i]])
+                    self.e.emit(f"v_lshl_add_u32 v{b1[i]}, v{t1[i]}, 3, v{t1[i]}", vw=[b1[i]])
+                    self.e.emit(f"v_add_u32_e32 v{b1[i]}, v{b1[i]}, v{t0[i]}", vw=[b1[i]])
+                self.norm_limbs(b0)
+                self.norm_limbs(b1)
+                src = (b0, b1)
+            for h, bh in enumerate((b0, b1)):
+                for i in range(NL):
+                    self.e.emit(f"v_lshl_add_u32 v{w}, v{src[h][i]}, 1, v{src[h][i]}", vw=[w])      # 3 x
+                    self.e.emit(f"v_add_u32_e32 v{w}, v{w}, v{zd[h][i]}", vw=[w])
+                    self.e.emit(f"v_lshlrev_b32_e32 v{bh[i]}, 1, v{w}", vw=[bh[i]])                  # 2 (3 x + zd) = 6 x + 2 zd
+            for blk in (a0, a1, b0, b1):
+                self.norm_limbs(blk)
+        self.pool.free(w)
+
+    def r_sqr4c(self):
+        self.r_sqr4(combine="plain")
+
+    def r_sqr4cx(self):
+        self.r_sqr4(combine="xi")
 
     # ------------------------------------------------------------------ fused Fq6 multiplication
     def _fq2_mul(self, x, y, o):
@@ -545,7 +579,7 @@ class L1v3:
         self.pool.free(*d)
 
 
-L1V3_NAMES = ["mul", "mul3", "mul6", "sqr", "sqr4", "mulfq", "add", "sub", "rsub", "dbl", "neg", "negc1", "mulxi", "norm", "redn", "fqmul", "fqsqr", "cvtin", "cvtout"]
+L1V3_NAMES = ["mul", "mul3", "mul6", "sqr", "sqr4", "sqr4c", "sqr4cx", "mulfq", "add", "sub", "rsub", "dbl", "neg", "negc1", "mulxi", "norm", "redn", "fqmul", "fqsqr", "cvtin", "cvtout"]
 
 if __name__ == "__main__":
     for n in L1V3_NAMES:

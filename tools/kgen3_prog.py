@@ -266,17 +266,18 @@ class Prog3(KP.Prog):
             self.tagB = y
 
     # ---- operand blocks H0..H3 of the three-term multiply (home registers 0..3 used as raw blocks)
-    def reserve_blocks(self):
+    def reserve_blocks(self, count=4):
         self._saved_tmp = self.free_tmp
-        self.free_tmp = [t for t in self.free_tmp if not (t.kind == "home" and t.idx < 4)]
-        assert len(self._saved_tmp) - len(self.free_tmp) == 4, "home blocks 0..3 must be free"
+        self._n_reserved = count
+        self.free_tmp = [t for t in self.free_tmp if not (t.kind == "home" and t.idx < count)]
+        assert len(self._saved_tmp) - len(self.free_tmp) == count, f"home blocks 0..{count - 1} must be free"
         self.tagH = [None] * 4
         self.eH = [None] * 4
         self.vH = [V_STORE] * 4
         self._blocks_reserved = True
 
     def release_blocks(self):
-        held = [t for t in self._saved_tmp if t.kind == "home" and t.idx < 4]
+        held = [t for t in self._saved_tmp if t.kind == "home" and t.idx < self._n_reserved]
         self.free_tmp = held + self.free_tmp
         self._blocks_reserved = False
 
@@ -431,9 +432,48 @@ class Prog3(KP.Prog):
         self._need(k1 not in self.norm_keys, "sqr4: r1 is not normalised")
         self.tagB = r1
 
+    def _sqr4c(self, a, b, zc, zd, out_a, out_b, xi=False):
+        """out_a <- 3 (a^2 + xi b^2) - 2 zc ; out_b <- 3 (2 a b) + 2 zd  (xi: 3 xi (2 a b) + 2 zd): one Fq4 squaring of the
+        Granger-Scott cyclotomic squaring with its recombination, in ONE L1 routine.  All four operands normalised."""
+        for s_ in (a, b, zc, zd):
+            self._need(mag(self.r_of(s_)) <= 1.0, f"sqr4c operand {s_} is not normalised")
+        self.load(HOME0 + 3 * SLOT_DW, zc)
+        self.load(HOME0 + 4 * SLOT_DW, zd)
+        self.A(a)
+        self._B(b)
+        va, vb, vc, vd = self.vA, self.v_of(b), self.v_of(zc), self.v_of(zd)
+        v_t = 2 * va * vb / K_RP + 1
+        v_p = 2 * (va + vb) * (va + 10 * vb) / K_RP + 1
+        self._raw_call("sqr4cx" if xi else "sqr4c")
+        self.tagH = [None] * 4
+        self.vA = 3 * (v_p + 11 * v_t) + 2 * vc
+        self.rA = self.r_norm()
+        self.to(out_a)
+        v_b = (60 if xi else 6) * v_t + 2 * vd
+        self._need(v_b <= V_CAP, "sqr4c value")
+        self.wait()
+        self.store(B0, out_b)
+        k1 = self.key(out_b)
+        self.slot_v[k1] = v_b
+        self.max_v = max(self.max_v, v_b)
+        self.slot_r[k1] = (-v_b / K_RP, max(1.0, v_b / K_RP))
+        self.tagB = out_b
+
     def fq12_cyc_sqr(self, F):
-        self.reserve_blocks()
-        super().fq12_cyc_sqr(F)
+        """Granger-Scott squaring (F in the cyclotomic subgroup), in place: three fused Fq4 squarings with recombination."""
+        if not (self.USE_SQR4 and all(mag(self.r_of(s_)) <= 1.0 for s_ in F)):
+            self.reserve_blocks()
+            super().fq12_cyc_sqr(F)
+            self.release_blocks()
+            return
+        self.reserve_blocks(5)
+        t2, t5 = self.tmp(), self.tmp()
+        self._sqr4c(F[1], F[4], F[2], F[5], t2, t5)            # F2' = 3 t2 - 2 F2 ; F5' = 3 t3 + 2 F5  (kept aside: F2, F5 are read below)
+        self._sqr4c(F[0], F[3], F[0], F[3], F[0], F[3])        # F0' = 3 t0 - 2 F0 ; F3' = 3 t1 + 2 F3
+        self._sqr4c(F[2], F[5], F[4], F[1], F[4], F[1], xi=True)   # F4' = 3 t4 - 2 F4 ; F1' = 3 xi t5 + 2 F1
+        self.mov(F[2], t2)
+        self.mov(F[5], t5)
+        self.rel(t2, t5)
         self.release_blocks()
 
     def mul_by_034(self, F, L0, L3, L4):
@@ -767,9 +807,9 @@ class KernelBuilder3(KP.KernelBuilder):
         first = sorted([e for e in self.sections if self.section_phase[id(e)] == "miller"], key=lambda e: -size[id(e)])
         second = sorted([e for e in self.sections if self.section_phase[id(e)] == "fexp"], key=lambda e: size[id(e)])
         tot = lambda lst: sum(size[id(e)] for e in lst)
-        while second and tot(second) - tot(first) > 2 * size[id(second[-1])]:      # one-phase kernels: balance the two sides
+        while second and tot(second) - tot(first) > size[id(second[-1])]:      # one-phase kernels: balance the two sides
             first.insert(0, second.pop())
-        while first and tot(first) - tot(second) > 2 * size[id(first[0])]:
+        while first and tot(first) - tot(second) > size[id(first[0])]:
             second.append(first.pop(0))
         main.salu(f"s_branch {self.lab('L_exit_hop')}")   # main is not the last section; the end is out of reach in one hop
         hop = Emitter()
