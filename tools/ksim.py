@@ -39,6 +39,7 @@ class Machine:
         self.count_valu = 0
         self.count_nop = 0
         self.max_acc = 0      # largest |column accumulator| seen (v3 kernels)
+        self.l2_stack, self.l2_incl = [], {}     # profile mode: instructions inclusive of callees, per outermost L2 routine
         self.profile = None   # dict: (region label, opcode) -> dynamic count, when set to {} before run()
         self.call_log = None  # list: labels of the L2 routines called, in order (bound certification cross-check)
         self.max_stored = 0   # largest |signed dword| written to LDS (v3: limb magnitudes of stored values)
@@ -168,6 +169,12 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None):
         if region is not None:
             k_ = (region[pc], op)
             m.profile[k_] = m.profile.get(k_, 0) + 1
+            if op == "s_call_b64" and a[1].startswith("L2_"):
+                m.l2_stack.append(a[1])
+            elif op == "s_setpc_b64" and a[0] == "s[56:57]" and m.l2_stack:
+                m.l2_stack.pop()
+            top = m.l2_stack[0] if m.l2_stack else "(main)"
+            m.l2_incl[top] = m.l2_incl.get(top, 0) + 1
         pc += 1
         steps += 1
         if steps > max_steps:
