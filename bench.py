@@ -126,13 +126,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback by design)")
+    if os.environ.get("BENCH_SHARE_GPU"):          # test hook: several ranks on one GPU (RCCL refuses that: use gloo)
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     n = 1 << args.log2_batch
     g1 = torch.zeros(8 * n, dtype=torch.int64, device=dev)
@@ -164,7 +170,7 @@ def main():
     elapsed = time.perf_counter() - t0
     pkg.last_status(local_rank, stream)
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms = sorted(a.elapsed_time(b) for a, b in evs)
