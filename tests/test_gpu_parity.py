@@ -264,6 +264,13 @@ def test_host_pipeline_matches_device_path():
     pk.last_status(0, st)
     h1, h2 = g1.cpu().numpy().view(np.uint64).copy(), g2.cpu().numpy().view(np.uint64).copy()
     assert np.array_equal(pk.pairing_batch(h1, h2, n), out.cpu().numpy().view(np.uint64))
+    # lanes of the second and third work items of a wave (persistent grid loop) against the oracle
+    pos = np.array([65536, 65537 + 255, 99999, 131071, 131072, 200000, 262143, 262144, n - 1])
+    g1s = h1.reshape(8, n)[:, pos].reshape(-1).copy()
+    g2s = h2.reshape(16, n)[:, pos].reshape(-1).copy()
+    want = H.oracle_pairing(pk.layout.to_aos(g1s, 8), pk.layout.to_aos(g2s, 16), len(pos), threads=9)
+    got = out.cpu().numpy().view(np.uint64).reshape(48, n)[:, pos].reshape(-1).copy()
+    assert np.array_equal(pk.layout.to_aos(got, 48), want)
     k = 2
     groups = n // k
     og = torch.zeros(48 * groups, dtype=torch.int64, device=dev)
