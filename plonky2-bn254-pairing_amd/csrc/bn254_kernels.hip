@@ -231,6 +231,7 @@ BN254_ASM_KERNEL(k3_miller, BN254_ASM3_MILLER)
 BN254_ASM_KERNEL(k3_fexp, BN254_ASM3_FEXP)
 BN254_ASM_KERNEL(k3_mpairing, BN254_ASM3_MPAIRING)   // k pairs per lane, shared f (multi_miller_loop_native) + final exp
 BN254_ASM_KERNEL(k3_mmiller, BN254_ASM3_MMILLER)     // k pairs per lane, exact multi_miller_loop_native value
+BN254_ASM_KERNEL(k3_op, BN254_ASM3_OP)               // batched helpers: MyFq12 Mul / frobenius_map_native / pow_native (k = op | power << 8 | naf_len << 16)
 constexpr int V3_GSLOTS = 80;         // twelve Fq12 registers + eight overflow temporaries (+ 7 per pair in the multi kernels)
 constexpr int V3_SLOT_BYTES = 80;
 
@@ -415,7 +416,7 @@ int ctx_get(int device, void* stream, size_t k, LaunchCtx* out, uint32_t* grid_o
         const void* kernels[] = {(const void*)k_pairing<true, true>, (const void*)k_pairing<true, false>, (const void*)k_pairing<false, true>,
                                  (const void*)k_fq12_op, (const void*)k_generate, (const void*)k2_pairing, (const void*)k2_miller,
                                  (const void*)k2_fexp, (const void*)k3_pairing, (const void*)k3_miller, (const void*)k3_fexp,
-                                 (const void*)k3_mpairing, (const void*)k3_mmiller};
+                                 (const void*)k3_mpairing, (const void*)k3_mmiller, (const void*)k3_op};
         for (const void* f : kernels) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
         c.init = true;
     }
@@ -502,9 +503,11 @@ int launch_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_
     int rc = ctx_get(device, stream, 1, &lc, &grid, n_items);
     if (rc) return rc;
     const int8_t* naf_dev = nullptr;
+    static const bool use_v1 = (getenv("BN254_FORCE_V1") != nullptr) || (getenv("BN254_FORCE_V2") != nullptr);
     if (op == OP_POW) {
+        while (naf_len > 0 && naf_host[naf_len - 1] == 0) naf_len--;        // the top digit of a NAF is +1
         StreamCtx* sc = c->s;
-        if ((size_t)naf_len > sc->naf_cap) {
+        if ((size_t)naf_len + 64 > sc->naf_cap) {
             if (sc->naf) { HIPCHK(hipStreamSynchronize((hipStream_t)stream)); HIPCHK(hipFree(sc->naf)); sc->naf = nullptr; }
             HIPCHK(hipMalloc(&sc->naf, (size_t)naf_len + 64));
             sc->naf_cap = (size_t)naf_len + 64;
@@ -512,6 +515,16 @@ int launch_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_
         HIPCHK(hipMemcpyAsync(sc->naf, naf_host, (size_t)naf_len, hipMemcpyHostToDevice, (hipStream_t)stream));
         HIPCHK(hipStreamSynchronize((hipStream_t)stream));   // naf_host may be a caller temporary
         naf_dev = sc->naf;
+    }
+    // v3 assembly (signed radix-2^27 limbs): Mul, frobenius_map_native, pow_native.  k = op | power << 8 | naf_len << 16
+    if (!use_v1 && (op == OP_MUL || op == OP_FROB || (op == OP_POW && naf_len >= 1 && naf_len < 65536)) && n < (1ull << 29)) {
+        uint32_t kk = op == OP_MUL ? 0u : op == OP_FROB ? (1u | ((uint32_t)(power % 12) << 8)) : (2u | ((uint32_t)naf_len << 16));
+        if (op == OP_POW) for (int t = 0; t < naf_len; t++) if (naf_host[t] < 0) { kk |= 1u << 8; break; }   // 1/a is needed
+        uint32_t stride = grid * BLOCK * V3_SLOT_BYTES;
+        hipLaunchKernelGGL(k3_op, dim3(grid), dim3(BLOCK), LDS_BYTES, (hipStream_t)stream, b, (const uint64_t*)naf_dev, a, out,
+                           (uint32_t)n, kk, c->scratch, stride, c->status);
+        HIPCHK(hipGetLastError());
+        return BN254_OK;
     }
     hipLaunchKernelGGL(k_fq12_op, dim3(grid), dim3(BLOCK), LDS_BYTES, (hipStream_t)stream,
                        op, a, b, out, n, power, naf_dev, naf_len, c->scratch, (uint32_t)(c->n_cu * BLOCK), c->status);

@@ -318,3 +318,26 @@ def test_full_size_product_check():
     g2k[:, 2 * 777 + 1] = h2[:, 778]
     v2 = pk.multi_pairing_check_batch(g1k.reshape(-1), g2k.reshape(-1), n, 2)
     assert int(v2.sum()) == n - 1 and v2[777] == 0
+
+
+def test_helpers_vs_oracle_multi_limb_exponent():
+    """pow_native with a three-limb exponent (NAF with -1 digits and a carry across limbs), frobenius_map_native for
+    every power 0..11 and MyFq12 Mul on a ragged batch of arbitrary (non-unitary) elements, against the oracle."""
+    pk = H.pkg()
+    n = 300
+    xs = H.rand_fq12(n, seed=11)
+    a = H.fq12_aos(xs)
+    a_soa = H.to_soa(a, 48)
+    exp = [0xFFFFFFFFFFFFFFF7, 0x0123456789ABCDEF, 0x00000000DEADBEEF]
+    rc, want = H.oracle_pow_native(a, exp, n)
+    assert rc == 0 and np.array_equal(H.to_aos(pk.pow_batch(a_soa, exp, n), 48), want)
+    for power in range(12):
+        assert np.array_equal(H.to_aos(pk.frobenius_map_batch(a_soa, power, n), 48), H.oracle_frobenius(a, power, n)), power
+    b = H.fq12_aos(xs[7:] + xs[:7])
+    assert np.array_equal(H.to_aos(pk.fq12_mul_batch(a_soa, H.to_soa(b, 48), n), 48), H.oracle_fq12_mul(a, b, n))
+    # pow_native(0, e): the reference divides (and panics) only on a -1 digit
+    z = np.zeros(48 * 2, dtype=np.uint64)
+    assert not pk.pow_batch(z, [5], 2).any()                  # NAF(5) = 101
+    with pytest.raises(pk.Bn254Error) as ei:
+        pk.pow_batch(z, [7], 2)                               # NAF(7) = 100(-1)
+    assert ei.value.status == pk.ERR_ZERO_DIVISOR

@@ -401,3 +401,30 @@ def test_v3_multi_pairing_kernel(vec):
     g1, g2 = soa([HX(vec["g1"][i]) for i in idx]), soa([HX(vec["g2"][i]) for i in idx])
     out, m = _run_kernel3(K3P.KernelBuilder3(do_miller=True, do_fexp=False, track=True, multi=True), g1, g2, k=k)
     assert out == HX(g["miller"])
+
+
+def test_v3_helper_kernel(vec):
+    """k3_op: MyFq12 Mul, frobenius_map_native and pow_native on the v3 representation (general, non-unitary elements)."""
+    xs = [HX(x) for x in vec["fq12_in"]]
+    fq12_words = lambda x: [w for c in x for w in R.limbs4(R.to_mont(c))]
+    kb = K3P.KernelBuilder3(helper=True)
+    a, b = xs[1], xs[2]
+    # Mul: a * b (golden fq12_mul[i] = fq12_in[i] * fq12_in[i + 1])
+    out, m = _run_kernel3(kb, g1=fq12_words(b), fin=fq12_words(a), k=kb.OP_MUL, check_seq=False)
+    assert out == HX(vec["fq12_mul"][1]) and STAT not in m.gmem
+    # frobenius_map_native, powers 1, 2, 3, 6, 11
+    for power in (1, 2, 3, 6, 11):
+        out, m = _run_kernel3(kb, fin=fq12_words(a), k=kb.OP_FROB | power << 8, check_seq=False)
+        assert out == HX(vec["frobenius"][str(power)][1]), f"frobenius power {power}"
+    # pow_native(a, [BN_X]) with the reference's NAF (get_naf), -1 digits divide
+    naf = R.get_naf([R.BN_X])
+    while naf[-1] == 0:
+        naf.pop()
+    assert naf[-1] == 1
+    packed = bytes((d & 0xFF) for d in naf) + b"\0" * 8
+    words = [int.from_bytes(packed[8 * i: 8 * i + 8], "little") for i in range(len(packed) // 8)]
+    out, m = _run_kernel3(kb, g2=words, fin=fq12_words(a), k=kb.OP_POW | 1 << 8 | len(naf) << 16, check_seq=False)
+    assert out == HX(vec["pow_x"][1]) and STAT not in m.gmem
+    # an exponent without -1 digits never divides: a = 0 is not an error (0^5 = 0)
+    out, m = _run_kernel3(kb, g2=[0x0000000000010001], fin=[0] * 48, k=kb.OP_POW | 3 << 16, check_seq=False)
+    assert out == [0] * 12 and STAT not in m.gmem

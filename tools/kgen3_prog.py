@@ -679,9 +679,14 @@ class KernelBuilder3(KP.KernelBuilder):
 
     PAIR_SLOT0 = GLOB_TMP0 + 8          # scratch slots of pair j: PAIR_SLOT0 + 7 j + {PX, PY, QX, QY, RX, RY, RZ}
 
-    def __init__(self, do_miller=True, do_fexp=True, track=False, multi=False):
+    def __init__(self, do_miller=True, do_fexp=True, track=False, multi=False, helper=False):
+        """helper: the batched public helpers of the reference on Fq12 batches -- MyFq12 `Mul`, frobenius_map_native
+        (final_exp_native.rs:17-54), pow_native (:56-84) -- selected at run time by the kernel's `k` argument."""
+        if helper:
+            do_miller, do_fexp, track, multi = False, True, False, False
         super().__init__(do_miller, do_fexp, track)
         self.multi = multi
+        self.helper = helper
         self.labels = {n: f"L1_{n}_%=" for n in L1V3_NAMES}
         for op in ("add", "sub", "rsub"):
             for i in range(N_HOME):
@@ -797,6 +802,10 @@ class KernelBuilder3(KP.KernelBuilder):
                                                   [p.A(self.F[i]).neg().to(self.F[i]) for i in (1, 3, 5)]), self.fexp_temps())
             self.l2_routine("L2_conjF", lambda p: [p.A(self.F[i]).neg().to(self.F[i]) for i in (1, 3, 5)], self.fexp_temps())
             self._powx_routine()
+            if self.helper:
+                for k in range(4, 12):
+                    self.l2_routine(f"L2_frob{k}", lambda p, k=k: self._frobenius(p, k), self.fexp_temps())
+                self.l2_routine("L2_sqrF", lambda p: p.fq12_sqr(self.F), self.fexp_temps(no_homes=USE_MUL6))
         self._phase = "miller"              # the main program only touches F
         self.main_body(main)
         # Layout: s_call_b64 / s_branch reach +-128 KB.  The leaf routines (called from everywhere) and the main
@@ -983,6 +992,60 @@ class KernelBuilder3(KP.KernelBuilder):
         report["sequence"] = seq
         assert worst <= V_CAP
         return report
+
+    def certify_helper(self):
+        """Value bounds of the helper kernel: its loops are data dependent (NAF of the caller's exponent), so the bounds
+        must hold for ANY order of squarings and multiplications: iterate the routines' transfer functions from the
+        converted inputs to a fixed point and check it (and every intermediate store) against the cap."""
+        self._memo, self._ref_text = {}, {}
+        fk = [Prog3.key(s_) for s_ in self.F]
+        st, worst = {}, 0.0
+
+        def run(name, **kw):
+            nonlocal worst
+            ex, mv = self._eval(name, st, **kw)
+            st.update(ex)
+            worst = max(worst, mv)
+
+        def mul_body(p):
+            p.fq12_mul(self.F, self.BOP)
+
+        def mul_by(g):
+            for b_, v in zip(self.BOP, g):
+                st[Prog3.key(b_)] = v
+            run("L2_mul_body", body=mul_body, temps=self.fexp_temps(no_homes=USE_MUL6))
+
+        g0 = [2.0] * 6                                    # a (converted input)
+        run("L2_inv")
+        run("L2_redF")
+        g1 = [st[k] for k in fk]                          # 1 / a, reduced
+        for k in range(1, 12):
+            for k_ in fk:
+                st[k_] = 2.0
+            run(f"L2_frob{k}")
+        for k_ in fk:
+            st[k_] = 2.0
+        mul_by(g0)                                        # Mul: one multiplication of converted inputs
+        hi = 2.0
+        for _ in range(8):                                # pow loop: (square, reduce, [multiply by a or 1/a, reduce]) in any order
+            for k_ in fk:
+                st[k_] = hi
+            run("L2_sqrF")
+            run("L2_redF")
+            after = max(st[k] for k in fk)
+            for g in (g0, g1):
+                for k_ in fk:
+                    st[k_] = max(hi, after)
+                mul_by(g)
+                run("L2_redF")
+                after = max(after, max(st[k] for k in fk))
+            if after <= hi:
+                break
+            hi = after
+        else:
+            raise AssertionError("helper kernel: value bounds do not reach a fixed point")
+        assert worst <= V_CAP
+        return {"fixed_point": hi, "max_stored": worst}
 
     def _reduce_f(self, p):
         """F <- the same residues with representatives back in (-0.01 p, 1.01 p) (L1 redn).  Every cyclotomic squaring
@@ -1304,32 +1367,105 @@ class KernelBuilder3(KP.KernelBuilder):
         elif self.do_miller:
             self.miller_main(e, p)
         else:
-            # f_in (MyFq12, SoA): components 0..5 are the c0 parts of w^0..w^5, 6..11 the c1 parts.
-            # two passes over the batch: c1 parts first into AGPR staging, then c0 parts
-            self.io_walk_begin(e, S_FIN)
-            for k in range(6):
-                self.io_load_fq(e, A0)
-                e.raw("s_waitcnt vmcnt(0)")
-                self.cvt_call(e, "cvtin")
-                for i in range(NL):
-                    e.emit(f"v_accvgpr_write_b32 a{NL * k + i}, v{A0 + i}")       # c0 of coefficient k
-            for k in range(6):
-                self.io_load_fq(e, A0)
-                e.raw("s_waitcnt vmcnt(0)")
-                self.cvt_call(e, "cvtin")
-                for i in range(NL):
-                    e.emit(f"v_mov_b32_e32 v{A0 + NL + i}, v{A0 + i}", vw=[A0 + NL + i])
-                for i in range(NL):
-                    e.emit(f"v_accvgpr_read_b32 v{A0 + i}, a{NL * k + i}", vw=[A0 + i])
-                p.set_A_fresh()
-                p.to(self.F[k])
-            p.reset_tags()
-        if self.do_fexp:
+            self.load_fq12_into_F(e, p, S_FIN)
+        if self.helper:
+            self.helper_main(e, p)
+        elif self.do_fexp:
             self.fexp_main(e, p)
         self.store_out(e, p)
         e.salu(f"s_add_u32 s{S_ITEM}, s{S_ITEM}, s{S_GRID}")
         e.salu(f"s_branch {L('L_item')}")
         e.label(L("L_done"))
+
+    def load_fq12_into_F(self, e, p, ptr):
+        """F <- the lane's MyFq12 of the SoA batch at `ptr` (components 0..5 are the c0 parts of w^0..w^5, 6..11 the c1
+        parts): two passes over the planes, c0 parts first into AGPR staging (the operand slots, free at that point)."""
+        self.io_walk_begin(e, ptr)
+        for k in range(6):
+            self.io_load_fq(e, A0)
+            e.raw("s_waitcnt vmcnt(0)")
+            self.cvt_call(e, "cvtin")
+            for i in range(NL):
+                e.emit(f"v_accvgpr_write_b32 a{NL * k + i}, v{A0 + i}")       # c0 of coefficient k
+        for k in range(6):
+            self.io_load_fq(e, A0)
+            e.raw("s_waitcnt vmcnt(0)")
+            self.cvt_call(e, "cvtin")
+            for i in range(NL):
+                e.emit(f"v_mov_b32_e32 v{A0 + NL + i}, v{A0 + i}", vw=[A0 + NL + i])
+            for i in range(NL):
+                e.emit(f"v_accvgpr_read_b32 v{A0 + i}, a{NL * k + i}", vw=[A0 + i])
+            p.set_A_fresh()
+            p.to(self.F[k])
+        p.reset_tags()
+
+    # ---------------------------------------------------------------------------------------------
+    # batched helpers: k argument = op | power << 8 | naf_len << 16
+    OP_MUL, OP_FROB, OP_POW = 0, 1, 2
+
+    def helper_main(self, e, p):
+        L = self.lab
+
+        def gsel(j):
+            e.salu(f"s_mul_i32 s{S_GBASE}, s{S_GSTRIDE}, {6 * j}")
+
+        def c2(name):
+            self.call2(e, name)
+
+        e.salu(f"s_and_b32 s{S_TMP0}, s{S_K}, 0xff")
+        e.salu(f"s_cmp_eq_u32 s{S_TMP0}, {self.OP_FROB}")
+        e.salu(f"s_cbranch_scc1 {L('L_h_frob')}")
+        e.salu(f"s_cmp_eq_u32 s{S_TMP0}, {self.OP_POW}")
+        e.salu(f"s_cbranch_scc1 {L('L_h_pow')}")
+        # ---- MyFq12 Mul: F holds a; b comes from the g1 pointer
+        gsel(0); c2("L2_stG")
+        self.load_fq12_into_F(e, p, S_G1)
+        gsel(0); c2("L2_mulG")
+        e.salu(f"s_branch {L('L_h_done')}")
+        # ---- frobenius_map_native(a, power), power = 0..11
+        e.label(L("L_h_frob"))
+        e.salu(f"s_lshr_b32 s{S_TMP0}, s{S_K}, 8")
+        e.salu(f"s_and_b32 s{S_TMP0}, s{S_TMP0}, 0xf")
+        for k in range(1, 12):
+            e.salu(f"s_cmp_eq_u32 s{S_TMP0}, {k}")
+            e.salu(f"s_cbranch_scc0 {L(f'L_h_nf{k}')}")
+            c2(f"L2_frob{k}")
+            e.salu(f"s_branch {L('L_h_done')}")
+            e.label(L(f"L_h_nf{k}"))
+        e.salu(f"s_branch {L('L_h_done')}")                      # power 0: identity
+        # ---- pow_native(a, exp): NAF digits (int8, least significant first) at the g2 pointer, top digit = +1
+        e.label(L("L_h_pow"))
+        gsel(0); c2("L2_stG")                                     # G0 = a
+        e.salu(f"s_bitcmp1_b32 s{S_K}, 8")                        # bit 8: the NAF has a -1 digit (only then is 1/a formed: the
+        e.salu(f"s_cbranch_scc0 {L('L_h_noinv')}")                 # reference divides -- and panics on a = 0 -- only on such a digit)
+        c2("L2_inv"); c2("L2_redF")
+        gsel(1); c2("L2_stG")                                     # G1 = 1/a   (`res / a` on a -1 digit, final_exp_native.rs:72-75)
+        gsel(0); c2("L2_ldG")                                     # res = a (the top digit)
+        e.label(L("L_h_noinv"))
+        e.salu(f"s_lshr_b32 s{S_J}, s{S_K}, 16")
+        e.salu(f"s_sub_u32 s{S_J}, s{S_J}, 2")
+        e.salu(f"s_cbranch_scc1 {L('L_h_done')}")                 # a single digit: a^1
+        e.label(L("L_h_ploop"))
+        c2("L2_sqrF"); c2("L2_redF")            # the loop length is the caller's: representatives are reduced every step
+        e.salu(f"s_and_b32 s{S_TMP0}, s{S_J}, 0xfffffffc")
+        e.salu(f"s_load_dword s{S_TMP1}, {S_G2}, s{S_TMP0}")
+        e.salu(f"s_and_b32 s{S_TMP0}, s{S_J}, 3")
+        e.salu(f"s_lshl_b32 s{S_TMP0}, s{S_TMP0}, 3")
+        e.raw("s_waitcnt lgkmcnt(0)")
+        e.salu(f"s_lshr_b32 s{S_TMP1}, s{S_TMP1}, s{S_TMP0}")
+        e.salu(f"s_sext_i32_i8 s{S_TMP1}, s{S_TMP1}")
+        e.salu(f"s_cmp_eq_i32 s{S_TMP1}, 0")
+        e.salu(f"s_cbranch_scc1 {L('L_h_pnext')}")
+        e.salu(f"s_cmp_gt_i32 s{S_TMP1}, 0")
+        e.salu(f"s_cselect_b32 s{S_TMP1}, 0, 1")                   # register 0 (a) for +1, 1 (1/a) for -1
+        e.salu(f"s_mul_i32 s{S_TMP1}, s{S_TMP1}, 6")
+        e.salu(f"s_mul_i32 s{S_GBASE}, s{S_GSTRIDE}, s{S_TMP1}")
+        c2("L2_mulG"); c2("L2_redF")
+        e.label(L("L_h_pnext"))
+        e.salu(f"s_sub_u32 s{S_J}, s{S_J}, 1")
+        e.salu(f"s_cbranch_scc0 {L('L_h_ploop')}")
+        e.label(L("L_h_done"))
+        p.reset_tags()
 
     def miller_main(self, e, p):
         L = self.lab

@@ -368,6 +368,19 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None):
                 m.scc = 1 if r else 0
             elif op == "s_cselect_b32":
                 m.sset(a[0], m.vsrc(a[1], False) if m.scc else m.vsrc(a[2], False))
+            elif op == "s_load_dword":
+                addr = m.sget(a[1]) + m.vsrc(a[2], False)
+                if addr % 4 or addr not in m.gmem:
+                    raise SimError(f"s_load_dword from unmapped / unaligned address {addr:#x}")
+                m.sset(a[0], m.gmem[addr])
+            elif op == "s_sext_i32_i8":
+                x = m.vsrc(a[1], False) & 0xFF
+                m.sset(a[0], (x - 256 if x & 0x80 else x) & M32)
+            elif op in ("s_cmp_eq_i32", "s_cmp_gt_i32"):
+                x, y = m.vsrc(a[0], False), m.vsrc(a[1], False)
+                x = x - (1 << 32) if x >> 31 else x
+                y = y - (1 << 32) if y >> 31 else y
+                m.scc = 1 if (x == y if op == "s_cmp_eq_i32" else x > y) else 0
             elif op == "s_cmp_eq_u32":
                 m.scc = 1 if m.vsrc(a[0], False) == m.vsrc(a[1], False) else 0
             elif op == "s_cmp_lg_u32":
