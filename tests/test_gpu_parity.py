@@ -136,7 +136,7 @@ def test_final_exp_zero_is_an_error():
 def test_large_batch_properties():
     """BASELINE configs[1] size (2^16): on-device inputs, spot-check vs oracle + bilinearity-free invariants:
     every output is in the order-r subgroup's image under x -> x^r == 1 is too slow on CPU for all, so check
-    (a) 64 random positions against the oracle, (b) determinism of two runs, (c) no lane wrote outside its slot."""
+    (a) 2048 random positions against the oracle, (b) determinism of two runs, (c) no lane wrote outside its slot."""
     import torch
     pk = H.pkg()
     n = 1 << 16
@@ -153,11 +153,11 @@ def test_large_batch_properties():
     assert torch.equal(out[:48 * n], out2)
     assert bool((out[48 * n:] == -1).all())
     rng = np.random.default_rng(5)
-    pos = np.sort(rng.choice(n, size=64, replace=False))
+    pos = np.sort(rng.choice(n, size=2048, replace=False))
     g1h = g1.cpu().numpy().view(np.uint64).reshape(8, n)[:, pos].reshape(-1).copy()
     g2h = g2.cpu().numpy().view(np.uint64).reshape(16, n)[:, pos].reshape(-1).copy()
     got = out[:48 * n].cpu().numpy().view(np.uint64).reshape(48, n)[:, pos].reshape(-1).copy()
-    want = H.oracle_pairing(pk.layout.to_aos(g1h, 8), pk.layout.to_aos(g2h, 16), 64, threads=16)
+    want = H.oracle_pairing(pk.layout.to_aos(g1h, 8), pk.layout.to_aos(g2h, 16), len(pos), threads=min(64, len(__import__("os").sched_getaffinity(0))))
     assert np.array_equal(pk.layout.to_aos(got, 48), want)
 
 
