@@ -534,9 +534,10 @@ class Prog3(KP.Prog):
         self.vA = 2.0
 
     INLINE_SMALL = bool(int(os.environ.get("KGEN3_INLINE_SMALL", "1")))
-    # a call/return pair costs a lone wave ~70 cycles (two taken branches, each refilling the instruction buffer): routines of
-    # up to ~50 instructions are inlined (norm: 6.6 k calls per pairing, mulxi: 2.4 k)
-    INLINE_SET = ("add", "sub", "rsub", "dbl", "neg", "negc1") + tuple(os.environ.get("KGEN3_INLINE_MORE", "norm,mulxi").split(","))
+    # a call/return pair costs a lone wave ~70 cycles (two taken branches, each refilling the instruction buffer): the
+    # 20-instruction routines are inlined.  norm (54) and mulxi (50) were worth inlining (+0.6 %) while every Fq2 operation
+    # was its own call; with the fused leaf routines it makes no measurable difference, so they are called (smaller code).
+    INLINE_SET = ("add", "sub", "rsub", "dbl", "neg", "negc1") + tuple([x for x in os.environ.get("KGEN3_INLINE_MORE", "").split(",") if x])
 
     def _raw_call(self, name):
         self.wait()
