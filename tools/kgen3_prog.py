@@ -535,9 +535,9 @@ class Prog3(KP.Prog):
 
     INLINE_SMALL = bool(int(os.environ.get("KGEN3_INLINE_SMALL", "1")))
     # a call/return pair costs a lone wave ~70 cycles (two taken branches, each refilling the instruction buffer): the
-    # 20-instruction routines are inlined.  norm (54) and mulxi (50) were worth inlining (+0.6 %) while every Fq2 operation
-    # was its own call; with the fused leaf routines it makes no measurable difference, so they are called (smaller code).
-    INLINE_SET = ("add", "sub", "rsub", "dbl", "neg", "negc1") + tuple([x for x in os.environ.get("KGEN3_INLINE_MORE", "").split(",") if x])
+    # 20-instruction routines are inlined; so are norm (54) and mulxi (50): +0.6 % while every Fq2 operation was its own
+    # call, +0.4 % (same box, A/B) with the fused leaf routines, for 6 % more code.
+    INLINE_SET = ("add", "sub", "rsub", "dbl", "neg", "negc1") + tuple([x for x in os.environ.get("KGEN3_INLINE_MORE", "norm,mulxi").split(",") if x])
 
     def _raw_call(self, name):
         self.wait()
