@@ -464,12 +464,13 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None):
                 if op.startswith("global_load"):
                     dst, voff, sbase = toks[0], toks[1], toks[2]
                     addr = m.sget(sbase) + m.vsrc(voff) + off
-                    lo = int(re.match(r"v\[?(\d+)", dst).group(1))
+                    mm = re.match(r"([va])\[?(\d+)", dst)               # gfx90a+: loads can target AGPRs directly
+                    lo, bank = int(mm.group(2)), (v if mm.group(1) == "v" else m.a)
                     for k in range(n):
                         x = m.gmem.get(addr + 4 * k)
                         if x is None:
                             raise SimError(f"global read of unwritten address {hex(addr + 4 * k)}: {text}")
-                        v[lo + k] = x
+                        bank[lo + k] = x
                 else:
                     voff, src, sbase = toks[0], toks[1], toks[2]
                     addr = m.sget(sbase) + m.vsrc(voff) + off
