@@ -203,6 +203,10 @@ def main():
                              "wave_instr_per_s": insts_per_wave * (n / 64) / (kern_avg_ms * 1e-3), "peak_wave_instr_per_s": 1024 * 2.4e9 / 4,
                              "frac": insts_per_wave * (n / 64) / (kern_avg_ms * 1e-3) / (1024 * 2.4e9 / 4),
                              "note": "all VALU instructions the kernel issues (SQ_INSTS_VALU per wave) against 1024 SIMDs x 2.4 GHz / 4 cycles"},
+                         "hbm": {"bound": "hbm", "achieved": 576 * n / (kern_avg_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                 "frac": 576 * n / (kern_avg_ms * 1e-3) / 8e12, "traffic": traffic,
+                                 "note": "the schema's HBM view of the same kernel: algorithmic bytes (576 B/pairing) over the launch time "
+                                         "against 8 TB/s -- three orders of magnitude from the bound (SURVEY.md 8d: integer-VALU bound)"},
                          "hbm_note": "algorithmic HBM bytes are 576 B/pairing (<0.01% of 8 TB/s): not the bound"},
         }
         if args.extra and world == 1:
