@@ -482,20 +482,20 @@ class Prog3(KP.Prog):
         L3x, L4x = self.tmp(), self.tmp()
         self.A(L3).mulxi().to(L3x)
         self.A(L4).mulxi().to(L4x)
-        c = [self.tmp() for _ in range(5)]
+        c = [self.tmp() for _ in range(3)]
         # c0 = a0 L0 + a3 xiL3 + a2 xiL4 ; c1 = a1 L0 + a4 xiL3 + a3 xiL4 ; c2 = a2 L0 + a5 xiL3 + a4 xiL4
         for k, (i0, i3, i4) in enumerate(((0, 3, 2), (1, 4, 3), (2, 5, 4))):
             self.ldH(1, L3x).ldH(3, L4x).ldH(0, F[i3]).ldH(2, F[i4])
             self.A(F[i0]).mul3(L0).to(c[k])
-        # c3 = a3 L0 + a0 L3 + a5 xiL4
+        # c3 = a3 L0 + a0 L3 + a5 xiL4   (a3 is not read again: the result goes straight to its place)
         self.ldH(1, L3).ldH(3, L4x).ldH(0, F[0]).ldH(2, F[5])
-        self.A(F[3]).mul3(L0).to(c[3])
+        self.A(F[3]).mul3(L0).to(F[3])
         # c4 = a4 L0 + a1 L3 + a0 L4 ; c5 = a5 L0 + a2 L3 + a1 L4
         self.ldH(1, L3).ldH(3, L4).ldH(0, F[1]).ldH(2, F[0])
-        self.A(F[4]).mul3(L0).to(c[4])
+        self.A(F[4]).mul3(L0).to(F[4])
         self.ldH(0, F[2]).ldH(2, F[1])
         self.A(F[5]).mul3(L0).to(F[5])
-        for k in range(5):
+        for k in range(3):
             self.mov(F[k], c[k])
         self.rel(L3x, L4x, *c)
         self.release_blocks()
@@ -507,7 +507,7 @@ class Prog3(KP.Prog):
         self.A(L2).mulxi().to(L2x)
         self.A(L3).mulxi().to(L3x)
         self.A(L5).mulxi().to(L5x)
-        c = [self.tmp() for _ in range(5)]
+        c = [self.tmp() for _ in range(4)]
         # c0 = xi (a4 b2 + a3 b3 + a1 b5) ; c1 = xi (a5 b2 + a4 b3 + a2 b5)
         for k, (i2, i3, i5) in enumerate(((4, 3, 1), (5, 4, 2))):
             self.ldH(1, L3x).ldH(3, L5x).ldH(0, F[i3]).ldH(2, F[i5])
@@ -518,11 +518,11 @@ class Prog3(KP.Prog):
         # c3 = a1 b2 + a0 b3 + xi a4 b5 ; c4 = a2 b2 + a1 b3 + xi a5 b5
         for k, (i2, i3, i5) in ((3, (1, 0, 4)), (4, (2, 1, 5))):
             self.ldH(1, L3).ldH(3, L5x).ldH(0, F[i3]).ldH(2, F[i5])
-            self.A(F[i2]).mul3(L2).to(c[k])
+            self.A(F[i2]).mul3(L2).to(c[k] if k == 3 else F[4])           # a4 is not read after c3
         # c5 = a3 b2 + a2 b3 + a0 b5
         self.ldH(1, L3).ldH(3, L5).ldH(0, F[2]).ldH(2, F[0])
         self.A(F[3]).mul3(L2).to(F[5])
-        for k in range(5):
+        for k in range(4):
             self.mov(F[k], c[k])
         self.rel(L2x, L3x, L5x, *c)
         self.release_blocks()

@@ -436,7 +436,7 @@ class Prog:
                 self.A(scale).mul(C).to(scale)
         self.A(C).mul(THREE_B).to(E)
         self.A(E).dbl().add(E).to(Fv)
-        self.A(Y).mul(Z).dbl().to(H)
+        self.A(Y).add(Z).sqr().sub(Bq).sub(C).to(H)            # H = 2 Y Z = (Y + Z)^2 - Y^2 - Z^2: a squaring instead of a multiplication
         # line
         self.A(C).dbl().dbl().dbl().add(C).to(T)            # 9 C
         self.A(Bq).mulxi().sub(T).to(L0)
