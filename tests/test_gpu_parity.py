@@ -341,3 +341,21 @@ def test_helpers_vs_oracle_multi_limb_exponent():
     with pytest.raises(pk.Bn254Error) as ei:
         pk.pow_batch(z, [7], 2)                               # NAF(7) = 100(-1)
     assert ei.value.status == pk.ERR_ZERO_DIVISOR
+
+
+def test_host_pipeline_chunk_edges():
+    """Chunk boundaries of the host-pointer pipeline: one lane more than a chunk (a 1-lane tail chunk for the second worker)
+    and exactly one chunk (single-launch path), against the device path."""
+    import torch
+    pk = H.pkg()
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev)
+    for n in ((1 << 17) + 1, 1 << 17):
+        g1 = torch.zeros(8 * n, dtype=torch.int64, device=dev)
+        g2 = torch.zeros(16 * n, dtype=torch.int64, device=dev)
+        out = torch.zeros(48 * n, dtype=torch.int64, device=dev)
+        pk.generate_pairs_dev(0xB2540005 + n, g1, g2, n, 0, st)
+        pk.pairing_batch_dev(g1, g2, out, n, 0, st)
+        pk.last_status(0, st)
+        got = pk.pairing_batch(g1.cpu().numpy().view(np.uint64).copy(), g2.cpu().numpy().view(np.uint64).copy(), n)
+        assert np.array_equal(got, out.cpu().numpy().view(np.uint64)), n
