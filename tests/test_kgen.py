@@ -297,6 +297,23 @@ def test_l1_v3_routines():
                 regs = [m.v[where[c] + K3.NL * h + i] for i in range(K3.NL)]
                 assert (_sval(regs) - want[c][h] * RPI) % P == 0, ("mul6", t, c, h)
                 assert all(0 <= r < (1 << K3.LB) for r in regs[:-1])
+    # extreme operands: every limb at the largest magnitude the routines accept (the simulator traps any signed 64-bit
+    # overflow of a column accumulator and any int32 overflow shows up as a wrong residue)
+    top = (1 << K3.LB) - 1
+    for name, mag_, homes in (("mul6", 2, range(6)), ("sqr4c", 1, (3, 4)), ("sqr4cx", 1, (3, 4)), ("mul", 3, ()), ("mul3", 2.4, range(4))):       # mul3: the tracker bounds the SUM of the three operand-magnitude products by 18
+        for pattern in (lambda i: 1, lambda i: -1, lambda i: 1 if i % 2 else -1, lambda i: 1 if (i // 2) % 2 else -1):
+            m = _m3([], rng, 0)
+            for r in range(0, K3.HOME0 + 8 * K3.SLOT_DW):
+                m.v[r] = rng.getrandbits(32) if r >= 2 * K3.SLOT_DW else None
+            blocks = [K3.A0, K3.B0] + [K3.HOME0 + K3.SLOT_DW * k for k in homes]
+            for blk in blocks:
+                for i in range(K3.SLOT_DW):
+                    m.v[blk + i] = int(pattern(i) * mag_ * top) & 0xFFFFFFFF
+            for r in range(K3.A0, K3.A0 + 2 * K3.SLOT_DW):
+                if m.v[r] is None:
+                    m.v[r] = 0
+            S.run_block(B[name], m)
+            assert m.max_acc < (1 << 63)
     # redn on large representatives (x + t p, |t| up to the certified cap) with unnormalised limbs
     for t in range(40):
         xs = [rnd() + rng.randrange(-60000, 60000) * P for _ in range(2)]
