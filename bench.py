@@ -2,24 +2,38 @@
 """bench.py -- BN254 pairings/sec on MI355X (BASELINE.json metric), one JSON line on rank 0.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU)
 
 A step = one pass of the hot path (`pairing()` = final_exp_native(miller_loop_native(Q, P)),
-src/pairing.rs:20-22) over one batch of synthetic subgroup points that is already resident in
-HBM.  Workload at N = 1: BASELINE.json configs[1], 2^16 independent pairings.  For N > 1 every
-rank owns its own 2^16 batch (independent units, no data-path collective): weak scaling.
+/root/reference/src/pairing.rs:20-22) over one batch of synthetic subgroup points that is already
+resident in HBM when the timed region starts.
+
+  N = 1   BASELINE.json configs[2]: 2^20 independent pairings on one MI355X (the largest single-GPU
+          configuration).  configs[1] (2^16) and configs[3] (Groth16 shape, 2^18 groups x 4 pairs) are
+          timed too and reported under "extra" (not the headline `value`).
+  N > 1   BASELINE.json configs[4]: 2^21 pairings per GPU (2^24 on 8 GPUs), one process per GPU.  Rank 0
+          generates the whole batch on its device and SCATTERS the contiguous slices over RCCL
+          (plonky2-bn254-pairing_amd/sharded.py: grouped isend/irecv on device tensors); the K timed steps are
+          the per-rank compute on the resident shard (`value` = all ranks' pairings / max-over-ranks time,
+          weak scaling); afterwards the Fq12 outputs are GATHERED to rank 0.  Scatter and gather times are
+          reported separately ("exchange"), together with the world size RCCL actually saw ("rccl_ranks").
+
+With `--gpus N` and no WORLD_SIZE in the environment this script starts the N ranks itself (a child
+`python -m torch.distributed.run`, started BEFORE this process imports torch or touches the GPU) and exits
+with the child's code; under the driver's own torch.distributed.run launch it reads RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* from the environment.
 
 The JSON line also carries
   roofline     -- integer-VALU bound (2,286,160 mul32 of algorithmic work per pairing)
                   against the calibrated v_mad_u64_u32 issue peak of gfx950 (tools/valu_calib.hip,
                   profiles/valu_calib_r01.txt); kernel time from HIP events on the launch stream
   cpu_baseline -- the C oracle (a port of the reference's schedule) timed on the host cores on a
-                  bounded sample, rank 0, N = 1 only.
+                  bounded sample (single thread and all cores), rank 0, N = 1 only.
+The process exits non-zero (and prints no headline line) when the GPU results do not match the oracle.
 """
 import argparse
-import importlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -28,66 +42,149 @@ sys.path.insert(0, ROOT)
 
 W_MUL32_PER_PAIRING = 2_286_160          # 16,810 fqmul x 136 mul32
 W_FQMUL_PER_PAIRING = 16_810
+W_MUL32_PER_GROTH16_GROUP = 4_572_184    # 33,619 fqmul x 136 mul32 (k = 4, shared final exp)
 # Calibrated peak (tools/valu_calib.hip on MI355X, profiles/valu_calib_r01.txt): v_mad_u64_u32 issues at
 # ~554 G wave-instructions/s chip-wide at 8 waves/SIMD = 35.5 T mul32/s.  (SURVEY's nominal quarter-rate
 # assumption was 9.83 T mul32/s; the measured rate is 3.6x that.)
 PEAK_MUL32_PER_S = 554e9 * 64
 NOMINAL_PEAK_MUL32_PER_S = 9.83e12
-LOG2_BATCH = 16
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_final_pmc.json")     # rocprofv3 --pmc passes of this same command (tools/gpu_profile.sh)
+LOG2_SINGLE = 20                         # configs[2]
+LOG2_PER_GPU_MULTI = 21                  # configs[4]: 2^24 over 8 GPUs
+PMC_SUMMARY = os.environ.get("BENCH_PMC_SUMMARY", os.path.join(ROOT, "profiles", "r02_pmc.json"))
 
 
-def pmc_traffic(log2_batch):
-    """HBM bytes per launch of the dominant kernel from the committed PMC summary (FETCH_SIZE/WRITE_SIZE, corrected as the
-    MI355X guide prescribes); None when the summary is missing or was taken at another batch size."""
-    try:
-        with open(PMC_SUMMARY) as f:
-            notes = json.load(f)["_notes"]
-        if log2_batch != LOG2_BATCH:
-            return None, None
-        return notes["hbm_bytes_per_launch_corrected"], notes.get("valu_insts_per_wave")
-    except Exception:
-        return None, None
-
-
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--log2-batch", type=int, default=LOG2_BATCH, help="pairings per GPU per step = 2^k (default: configs[1])")
+    ap.add_argument("--log2-batch", type=int, default=None,
+                    help="pairings per GPU per step = 2^k (default: 20 at N = 1 = configs[2], 21 at N > 1 = configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--extra", action="store_true", help="also time configs[2] (2^20 pairings) and configs[3] (Groth16: 2^18 groups x 4 pairs); "
-                                                        "reported under \"extra\" in the same JSON line")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    return ap.parse_args()
+    ap.add_argument("--no-extra", action="store_true", help="skip configs[1] and configs[3] (reported under \"extra\" at N = 1)")
+    ap.add_argument("--cpu-seconds", type=float, default=16.0, help="wall-clock budget of the cpu_baseline legs (single thread + all cores)")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+def launch_ranks(args, argv):
+    """--gpus N without a torch.distributed environment: start N fresh rank processes.  Nothing in this process has
+    imported torch or initialised HIP (a process that has must not exec / fork GPU work on this pool)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+# ------------------------------------------------------------------------------------------------ cpu baseline
+def host_cpu_info():
+    info = {"nproc": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None, "cgroup_cpu_max": None}
+    for p in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(p) as f:
+                info["cgroup_cpu_max"] = f.read().strip()
+            break
+        except OSError:
+            pass
+    return info
+
+
+def usable_cores(info):
+    cores = info["affinity"] or info["nproc"] or 1
+    q = info["cgroup_cpu_max"]
+    if q:
+        parts = q.split()
+        try:
+            if len(parts) == 2 and parts[0] != "max":
+                cores = max(1, min(cores, int(int(parts[0]) / int(parts[1]))))
+            elif len(parts) == 1 and int(parts[0]) > 0:
+                cores = max(1, min(cores, int(parts[0]) // 100000))
+        except ValueError:
+            pass
+    return cores
 
 
 def cpu_baseline(pkg, g1_soa, g2_soa, n_avail, seconds):
-    """Oracle (port of the reference schedule) on the host cores, bounded sample of the same inputs."""
-    import numpy as np
+    """Oracle (port of the reference schedule) on the host cores, bounded sample of the same inputs: one thread, then all
+    usable cores with >= 64 pairings per thread per call (thread start-up is noise at that size)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import helpers as H
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    chunk = 16 * cores
+    info = host_cpu_info()
+    cores = usable_cores(info)
     g1a = pkg.layout.to_aos(g1_soa, 8)
     g2a = pkg.layout.to_aos(g2_soa, 16)
     H.oracle_pairing(g1a[:8], g2a[:16], 1)          # one-time constant tables outside the timed region
-    done, t0 = 0, time.time()
-    while done + chunk <= n_avail and (time.time() - t0) < seconds:
-        H.oracle_pairing(g1a[8 * done: 8 * (done + chunk)], g2a[16 * done: 16 * (done + chunk)], chunk, threads=cores)
+    # single thread
+    done1, t0, budget1 = 0, time.time(), seconds * 0.35
+    while done1 + 32 <= n_avail and (time.time() - t0) < budget1:
+        H.oracle_pairing(g1a[8 * done1: 8 * (done1 + 32)], g2a[16 * done1: 16 * (done1 + 32)], 32, threads=1)
+        done1 += 32
+    dt1 = time.time() - t0
+    single = done1 / dt1
+    # all cores
+    chunk = min(n_avail, 64 * cores)
+    done, t0, budget = 0, time.time(), seconds * 0.65
+    while (time.time() - t0) < budget:
+        lo = done % max(1, n_avail - chunk + 1)
+        H.oracle_pairing(g1a[8 * lo: 8 * (lo + chunk)], g2a[16 * lo: 16 * (lo + chunk)], chunk, threads=cores)
         done += chunk
     dt = time.time() - t0
     return {"value": done / dt, "unit": "pairings/s", "cores": cores, "kind": "port",
-            "sample": f"first {done} pairings of the same batch, C oracle (reference schedule: affine G2 steps with an inversion "
-                      f"per step, NAF pow with divisions), {cores} pthreads, {dt:.1f} s"}
+            "single_thread": {"value": single, "unit": "pairings/s", "cores": 1, "sample": f"{done1} pairings, {dt1:.1f} s"},
+            "all_cores": {"value": done / dt, "unit": "pairings/s", "cores": cores, "per_thread": done / dt / cores,
+                          "sample": f"{done} pairings in calls of {chunk} ({chunk // cores} per thread), {dt:.1f} s"},
+            "host": info,
+            "sample": f"pairings of the same batch through the C oracle (reference schedule: affine G2 steps with an inversion per "
+                      f"step, NAF pow with divisions; constants cached): {done1} on one thread in {dt1:.1f} s, {done} on {cores} pthreads in {dt:.1f} s"}
 
 
-def extra_configs(pkg, torch, dev, local_rank, stream):
-    """BASELINE.json configs[2] and configs[3] on one GPU (not the headline `value`)."""
+def pmc_summary():
+    """Counter-derived fields come from the committed rocprofv3 --pmc summary of this same command (collected in separate
+    passes as the MI355X guide prescribes), NOT from this run: they are labelled as such."""
+    try:
+        with open(PMC_SUMMARY) as f:
+            return json.load(f).get("_notes", {})
+    except Exception:
+        return {}
+
+
+# ------------------------------------------------------------------------------------------------ one rank
+def load_engine():
+    """The HIP engine, or -- for the CPU launcher test only -- an injected stand-in (BENCH_TEST_ENGINE=module:attr under tests/)."""
+    hook = os.environ.get("BENCH_TEST_ENGINE")
+    if hook:
+        import importlib
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        mod, attr = hook.split(":")
+        return getattr(importlib.import_module(mod), attr)(), True
+    import __graft_entry__
+    return __graft_entry__.build(), False
+
+
+def spot_check(pkg, torch, g1, g2, out, n, positions, threads):
+    """GPU results at `positions` equal the oracle's on the same inputs (bit-exact)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers as H
+    pos = torch.as_tensor(positions, device=g1.device)
+    g1h = g1.view(8, n)[:, pos].cpu().numpy().view(np.uint64).reshape(-1).copy()
+    g2h = g2.view(16, n)[:, pos].cpu().numpy().view(np.uint64).reshape(-1).copy()
+    got = out.view(48, n)[:, pos].cpu().numpy().view(np.uint64).reshape(-1).copy()
+    want = H.oracle_pairing(pkg.layout.to_aos(g1h, 8), pkg.layout.to_aos(g2h, 16), len(positions), threads=threads)
+    return bool(np.array_equal(pkg.layout.to_aos(got, 48), want))
+
+
+def extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n):
+    """BASELINE.json configs[1] and configs[3] on one GPU (not the headline `value`); inputs: the resident 2^20 batch."""
     out = {}
 
-    def timed(fn, reps=2):
+    def timed(fn, reps):
         fn()
         torch.cuda.synchronize(dev)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -98,134 +195,211 @@ def extra_configs(pkg, torch, dev, local_rank, stream):
         torch.cuda.synchronize(dev)
         return a.elapsed_time(b) / reps
 
-    n = 1 << 20
-    g1 = torch.zeros(8 * n, dtype=torch.int64, device=dev)
-    g2 = torch.zeros(16 * n, dtype=torch.int64, device=dev)
-    o = torch.zeros(48 * n, dtype=torch.int64, device=dev)
-    pkg.generate_pairs_dev(0xB2540002, g1, g2, n, device=local_rank, stream=stream)
-    ms = timed(lambda: pkg.pairing_batch_dev(g1, g2, o, n, device=local_rank, stream=stream))
-    out["2^20 independent pairings"] = {"ms": ms, "pairings_per_s": n / (ms * 1e-3)}
+    m = 1 << 16
+    sel = lambda t, planes: t.view(planes, n)[:, :m].contiguous().view(-1)
+    s1, s2 = sel(g1, 8), sel(g2, 16)
+    o = torch.zeros(48 * m, dtype=torch.int64, device=dev)
+    ms = timed(lambda: pkg.pairing_batch_dev(s1, s2, o, m, device=local_rank, stream=stream), 10)
+    out["configs[1]: 2^16 independent pairings"] = {"ms": ms, "pairings_per_s": m / (ms * 1e-3),
+                                                    "roofline_frac": m / (ms * 1e-3) * W_MUL32_PER_PAIRING / PEAK_MUL32_PER_S}
     groups, k = 1 << 18, 4
+    assert groups * k <= n
     o2 = torch.zeros(48 * groups, dtype=torch.int64, device=dev)
-    ms = timed(lambda: pkg.multi_pairing_batch_dev(g1, g2, o2, groups, k, True, device=local_rank, stream=stream))
-    out["Groth16 shape: 2^18 groups x 4 pairs, shared final exp"] = {"ms": ms, "groups_per_s": groups / (ms * 1e-3),
-                                                                      "pairs_per_s": groups * k / (ms * 1e-3)}
+    ms = timed(lambda: pkg.multi_pairing_batch_dev(g1, g2, o2, groups, k, True, device=local_rank, stream=stream), 2)
+    out["configs[3]: Groth16 shape, 2^18 groups x 4 pairs, shared final exp"] = {
+        "ms": ms, "groups_per_s": groups / (ms * 1e-3), "pairs_per_s": groups * k / (ms * 1e-3),
+        "roofline_frac": groups / (ms * 1e-3) * W_MUL32_PER_GROTH16_GROUP / PEAK_MUL32_PER_S}
     pkg.last_status(local_rank, stream)
     return out
 
 
-def main():
-    args = parse()
+def run_rank(args):
     import numpy as np
     import torch
-    import __graft_entry__
-    pkg = __graft_entry__.build()
+    pkg, test_engine = load_engine()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback by design)")
-    if os.environ.get("BENCH_SHARE_GPU"):          # test hook: several ranks on one GPU (RCCL refuses that: use gloo)
-        local_rank = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    on_gpu = not test_engine
+    if on_gpu:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (no CPU fallback by design)")
+        if os.environ.get("BENCH_SHARE_GPU"):      # test hook: several ranks on one GPU (RCCL refuses that: use gloo)
+            local_rank = local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        stream = torch.cuda.current_stream(dev)
+        sync = lambda: torch.cuda.synchronize(dev)
+    else:
+        dev, stream, sync = torch.device("cpu"), None, (lambda: None)
+    dist = None
     if world > 1:
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        if backend == "nccl":
+        import torch.distributed as dist
+        if backend == "nccl" and on_gpu:
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=backend)
+    sharded = __import__("importlib").import_module("plonky2-bn254-pairing_amd.sharded") if world > 1 else None
 
-    n = 1 << args.log2_batch
+    log2 = args.log2_batch if args.log2_batch is not None else (LOG2_SINGLE if world == 1 else LOG2_PER_GPU_MULTI)
+    n = 1 << log2                                   # pairings per GPU per step
+    n_total = n * world
+    exchange = None
     g1 = torch.zeros(8 * n, dtype=torch.int64, device=dev)
     g2 = torch.zeros(16 * n, dtype=torch.int64, device=dev)
     out = torch.zeros(48 * n, dtype=torch.int64, device=dev)
-    stream = torch.cuda.current_stream(dev)
-    pkg.generate_pairs_dev(0xB2540001 + 7919 * rank, g1, g2, n, device=local_rank, stream=stream)
-    pkg.last_status(local_rank, stream)
+    full = None
+    if world == 1:
+        pkg.generate_pairs_dev(0xB2540001, g1, g2, n, device=local_rank, stream=stream)
+        pkg.last_status(local_rank, stream)
+    else:
+        # configs[4]: the whole batch exists on rank 0 only; slices travel over RCCL (device tensors, grouped isend/irecv)
+        if rank == 0:
+            f1 = torch.zeros(8 * n_total, dtype=torch.int64, device=dev)
+            f2 = torch.zeros(16 * n_total, dtype=torch.int64, device=dev)
+            pkg.generate_pairs_dev(0xB2540001, f1, f2, n_total, device=local_rank, stream=stream)
+            pkg.last_status(local_rank, stream)
+            full = (f1, f2)
+        sync()
+        dist.barrier()
+        t0 = time.perf_counter()
+        sharded.scatter_inputs(full[0] if full else None, full[1] if full else None, n_total, g1, g2, dist)
+        sync()
+        dist.barrier()
+        exchange = {"scatter_ms": (time.perf_counter() - t0) * 1e3}
 
     def step():
         pkg.pairing_batch_dev(g1, g2, out, n, device=local_rank, stream=stream)
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize(dev)
+    sync()
     if dist:
         dist.barrier()
-    torch.cuda.synchronize(dev)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    sync()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)] if on_gpu else []
     t0 = time.perf_counter()
-    for a, b in evs:
-        a.record(stream)
-        step()
-        b.record(stream)
-    torch.cuda.synchronize(dev)
+    if on_gpu:
+        for a, b in evs:
+            a.record(stream)
+            step()
+            b.record(stream)
+    else:
+        for _ in range(args.steps):
+            step()
+    sync()
     if dist:
         dist.barrier()
-    torch.cuda.synchronize(dev)
+    sync()
     elapsed = time.perf_counter() - t0
     pkg.last_status(local_rank, stream)
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if (backend == "nccl" and on_gpu) else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kern_ms = sorted(a.elapsed_time(b) for a, b in evs)
+    kern_ms = sorted(a.elapsed_time(b) for a, b in evs) if on_gpu else [elapsed / args.steps * 1e3]
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
 
+    gathered = None
+    if world > 1:
+        sync()
+        dist.barrier()
+        t0 = time.perf_counter()
+        gathered = sharded.gather_outputs(out, n_total, dist, device=dev)
+        sync()
+        dist.barrier()
+        exchange["gather_ms"] = (time.perf_counter() - t0) * 1e3
+        exchange["bytes_scattered"] = 192 * (n_total - n)
+        exchange["bytes_gathered"] = 384 * (n_total - n)
+        exchange["note"] = ("rank 0 -> peers: G1/G2 slices, peers -> rank 0: Fq12 outputs; torch.distributed batch_isend_irecv on device "
+                            "tensors (backend nccl = RCCL over xGMI); wall-clock incl. the staging copies, outside the timed steps")
+
+    rc = 0
     if rank == 0:
-        total = n * world * args.steps
+        total = n_total * args.steps
         value = total / elapsed
         per_gpu_rate = n / (kern_avg_ms * 1e-3)
         achieved = per_gpu_rate * W_MUL32_PER_PAIRING
-        traffic, insts_per_wave = pmc_traffic(args.log2_batch)
+        notes = pmc_summary()
+        same_cfg = notes.get("log2_batch") == log2
+        traffic = notes.get("hbm_bytes_per_launch_corrected") if same_cfg else None
+        insts_per_wave = notes.get("valu_insts_per_wave")
+        cfg_name = "configs[2]" if (world == 1 and log2 == 20) else ("configs[4]" if (world > 1 and log2 == 21) else "custom size")
         rec = {
             "metric": "BN254 pairings/sec (whole node)", "value": value, "unit": "pairings/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i32x10 (254-bit Montgomery, signed radix-2^27 limbs, integer VALU)",
-            "data": "synthetic: on-device [s]G1, [t]G2 subgroup points, SplitMix64 scalars, seed 0xB2540001",
-            "config": {"workload": f"2^{args.log2_batch} independent pairings per GPU per step "
-                                   f"(BASELINE.json configs[1]; pairing() = final_exp_native(miller_loop_native))",
-                       "pairings_per_gpu": n, "layout": "SoA limb-major u64 Montgomery, inputs resident in HBM"},
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "i32 limbs (254-bit Montgomery field, signed reduced-radix limbs, 32x32->64 integer multiply-add on the VALU)",
+            "data": "synthetic: on-device [s]G1, [t]G2 subgroup points, SplitMix64 scalars, seed 0xB2540001" + (" [TEST ENGINE, not a measurement]" if test_engine else ""),
+            "config": {"workload": f"2^{log2} independent pairings per GPU per step, {world} GPU(s): BASELINE.json {cfg_name}; "
+                                   f"pairing() = final_exp_native(miller_loop_native)",
+                       "pairings_per_gpu": n, "pairings_total": n_total, "layout": "SoA limb-major u64 Montgomery, inputs resident in HBM",
+                       "sharding": None if world == 1 else "contiguous slices per rank, scattered from / gathered to rank 0 over RCCL outside the timed steps; no data-path collective"},
             "roofline": {"bound": "valu-int32-mul", "achieved": achieved / 1e12, "peak": PEAK_MUL32_PER_S / 1e12, "unit": "T mul32/s",
                          "frac": achieved / PEAK_MUL32_PER_S, "traffic": traffic,
-                         "traffic_note": "HBM bytes per launch, PMC FETCH_SIZE x2 + WRITE_SIZE (profiles/r01_final_pmc.json, separate --pmc passes "
-                                         "of this command); algorithmic bytes per launch = 576 B x pairings; the excess is the final "
-                                         "exponentiation's scratch registers (~2 % of 8 TB/s)",
+                         "traffic_note": f"HBM bytes per launch from the committed PMC summary {os.path.relpath(PMC_SUMMARY, ROOT)} (separate --pmc passes of this "
+                                         "command; raw and corrected counters there), not measured in this run; algorithmic bytes per launch = 576 B x pairings",
                          "algorithmic_bytes_per_launch": 576 * n,
-                         "kernel": "k3_pairing", "kernel_ms_avg": kern_avg_ms, "kernel_ms_min": kern_ms[0],
+                         "kernel": "k_pairing", "kernel_ms_avg": kern_avg_ms, "kernel_ms_min": kern_ms[0],
                          "work_per_unit": f"{W_MUL32_PER_PAIRING} mul32 = {W_FQMUL_PER_PAIRING} fqmul x 136 per pairing (SURVEY.md 8d)",
                          "frac_of_nominal_quarter_rate_peak": achieved / NOMINAL_PEAK_MUL32_PER_S,
                          "valu_issue": None if not insts_per_wave else {
+                             "source": "SQ_INSTS_VALU per wave from the committed PMC summary x this run's kernel time",
                              "wave_instr_per_s": insts_per_wave * (n / 64) / (kern_avg_ms * 1e-3), "peak_wave_instr_per_s": 1024 * 2.4e9 / 4,
                              "frac": insts_per_wave * (n / 64) / (kern_avg_ms * 1e-3) / (1024 * 2.4e9 / 4),
-                             "note": "all VALU instructions the kernel issues (SQ_INSTS_VALU per wave) against 1024 SIMDs x 2.4 GHz / 4 cycles"},
+                             "note": "all VALU instructions the kernel issues against 1024 SIMDs x 2.4 GHz / 4 cycles"},
                          "hbm": {"bound": "hbm", "achieved": 576 * n / (kern_avg_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                                  "frac": 576 * n / (kern_avg_ms * 1e-3) / 8e12, "traffic": traffic,
                                  "note": "the schema's HBM view of the same kernel: algorithmic bytes (576 B/pairing) over the launch time "
-                                         "against 8 TB/s -- three orders of magnitude from the bound (SURVEY.md 8d: integer-VALU bound)"},
-                         "hbm_note": "algorithmic HBM bytes are 576 B/pairing (<0.01% of 8 TB/s): not the bound"},
+                                         "against 8 TB/s -- three orders of magnitude from the bound (SURVEY.md 8d: integer-VALU bound)"}},
         }
-        if args.extra and world == 1:
-            rec["extra"] = extra_configs(pkg, torch, dev, local_rank, stream)
-        if world == 1 and not args.no_cpu_baseline:
-            m = min(n, 1 << 14)
-            g1h = g1.cpu().numpy().view(np.uint64).reshape(8, n)[:, :m].reshape(-1).copy()
-            g2h = g2.cpu().numpy().view(np.uint64).reshape(16, n)[:, :m].reshape(-1).copy()
+        if world > 1:
+            rec["rccl_ranks"] = dist.get_world_size()
+            rec["dist_backend"] = backend
+            rec["exchange"] = exchange
+            step_ms = elapsed / args.steps * 1e3
+            rec["value_incl_exchange"] = n_total / ((step_ms + exchange["scatter_ms"] + exchange["gather_ms"]) * 1e-3)
+        # correctness gate: oracle spot checks on every run (first / last lanes, a work-item boundary, other ranks' slices)
+        if on_gpu:
+            threads = min(32, usable_cores(host_cpu_info()))
+            pos = sorted({0, 1, 255, 256, n // 2 + 77, n - 257, n - 1, 65535 % n, 65536 % n})
+            ok = spot_check(pkg, torch, g1, g2, out, n, pos, threads)
+            if world > 1:
+                gp = sorted({n, n + 1, n_total // 2 + 5, n_total - 1})
+                ok = ok and spot_check(pkg, torch, full[0], full[1], gathered, n_total, gp, threads)
+                ok = ok and bool(torch.equal(gathered.view(48, n_total)[:, :n], out.view(48, n)))
+            rec["verified_vs_oracle"] = ok
+            if not ok:
+                print("bench.py: GPU results differ from the oracle -- no measurement reported", file=sys.stderr)
+                rc = 3
+        if rc == 0 and on_gpu and world == 1 and not args.no_extra and log2 == LOG2_SINGLE:
+            rec["extra"] = extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n)
+        if rc == 0 and on_gpu and world == 1 and not args.no_cpu_baseline:
+            m = min(n, 1 << 15)
+            g1h = g1.view(8, n)[:, :m].cpu().numpy().view(np.uint64).reshape(-1).copy()
+            g2h = g2.view(16, n)[:, :m].cpu().numpy().view(np.uint64).reshape(-1).copy()
             rec["cpu_baseline"] = cpu_baseline(pkg, g1h, g2h, m, args.cpu_seconds)
-            # sanity: the first few GPU results equal the oracle's on the same inputs
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            import helpers as H
-            k = 8
-            want = H.oracle_pairing(pkg.layout.to_aos(g1h, 8)[:8 * k], pkg.layout.to_aos(g2h, 16)[:16 * k], k)
-            got = pkg.layout.to_aos(out.cpu().numpy().view(np.uint64).reshape(48, n)[:, :k].reshape(-1).copy(), 48)
-            rec["verified_vs_oracle"] = bool(np.array_equal(got, want))
-        print(json.dumps(rec), flush=True)
+        if rc == 0:
+            print(json.dumps(rec), flush=True)
     if dist:
+        if rc:
+            dist.destroy_process_group()
+            sys.exit(rc)
+        dist.barrier()
         dist.destroy_process_group()
+    return rc
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, argv))
+    sys.exit(run_rank(args))
 
 
 if __name__ == "__main__":

@@ -1,14 +1,17 @@
-"""Multi-GPU sharding of independent pairings: one process per GPU, contiguous
-slices of the SoA batch per rank, NO data-path collective -- the units are independent.  The only
-optional exchanges are the north star's scatter of inputs from rank 0 and gather of Fq12 outputs to
-rank 0 (torch.distributed: backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+"""Multi-GPU sharding of independent pairings: one process per GPU, contiguous slices of the
+SoA batch per rank, NO data-path collective -- the units (`pairing(p, q)`, /root/reference/src/pairing.rs:20-22)
+are independent.  The only exchanges are the north star's scatter of the G1/G2 inputs from rank 0 and the gather
+of the Fq12 outputs to rank 0, as grouped point-to-point operations (`torch.distributed.batch_isend_irecv`:
+one grouped RCCL launch per direction under backend "nccl", the same code over CPU tensors under "gloo").
 
-`compute(g1_soa, g2_soa, n_local)` is the per-rank hot path: the HIP engine in production
-(default), anything with the same signature in tests.
+All buffers are torch tensors of int64 words (the u64 Montgomery limbs, SoA limb-major) that live where the
+process group can move them: device tensors under nccl (xGMI, no host bounce), CPU tensors under gloo.
+
+`compute(g1, g2, m) -> out` is the per-rank hot path on one contiguous chunk of m pairings: the HIP engine on the
+rank's own device and current stream by default (`hip_compute`), anything with the same signature in the CPU tests.
 """
 import importlib
-
-import numpy as np
+import os
 
 
 def shard_bounds(n, world, rank):
@@ -18,58 +21,138 @@ def shard_bounds(n, world, rank):
     return lo, hi
 
 
-def slice_soa(buf, words, n, lo, hi):
-    """Rows [lo, hi) of every limb plane of an SoA batch (plane-major: words*4... planes of length n)."""
-    planes = np.asarray(buf, dtype=np.uint64).reshape(words, n)
-    return np.ascontiguousarray(planes[:, lo:hi]).reshape(-1)
+def _cols(t, words, n, lo, hi):
+    """Columns [lo, hi) of every limb plane of an SoA batch, as a contiguous flat tensor (a device-side copy)."""
+    return t.view(words, n)[:, lo:hi].contiguous().view(-1)
 
 
-def _default_compute(g1, g2, n_local):
+def _run(dist, ops):
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+
+def hip_compute(device_index=None):
+    """The product path: bn254_pairing_batch_dev on this rank's device (LOCAL_RANK) and torch's current stream."""
+    import torch
     pkg = importlib.import_module("plonky2-bn254-pairing_amd")
-    return pkg.pairing_batch(g1, g2, n_local)
+    if device_index is None:
+        device_index = int(os.environ.get("LOCAL_RANK", "0"))
+
+    def compute(g1, g2, m):
+        assert g1.is_cuda and g1.device.index == device_index, "inputs must live on this rank's device"
+        out = torch.empty(48 * m, dtype=torch.int64, device=g1.device)
+        pkg.pairing_batch_dev(g1, g2, out, m, device=device_index, stream=torch.cuda.current_stream(g1.device))
+        return out
+
+    return compute
 
 
-def pairing_sharded(g1, g2, n, dist=None, compute=None, scatter_from_root=False, gather_to_root=True):
-    """Every rank returns its slice's result; rank 0 additionally returns the gathered SoA batch
-    (48*n u64) when gather_to_root.  g1/g2 must be valid on every rank unless scatter_from_root,
-    in which case only rank 0's are read and the slices travel by point-to-point send/recv."""
-    compute = compute or _default_compute
-    if dist is None or not dist.is_initialized():
-        out = compute(np.asarray(g1, dtype=np.uint64), np.asarray(g2, dtype=np.uint64), n)
-        return out, out
+def scatter_inputs(full_g1, full_g2, n, g1_local, g2_local, dist):
+    """Rank 0 holds the whole SoA batch (8n / 16n words); every rank receives its slice into g1_local / g2_local
+    (8 n_local / 16 n_local words).  Empty slices are skipped on both sides."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    lo, hi = shard_bounds(n, world, rank)
+    ops, keep = [], []
+    if rank == 0:
+        for r in range(1, world):
+            rlo, rhi = shard_bounds(n, world, r)
+            if rhi == rlo:
+                continue
+            for full, words in ((full_g1, 8), (full_g2, 16)):
+                s = _cols(full, words, n, rlo, rhi)
+                keep.append(s)
+                ops.append(dist.P2POp(dist.isend, s, r))
+        if hi > lo:
+            g1_local.view(8, hi - lo).copy_(full_g1.view(8, n)[:, lo:hi])
+            g2_local.view(16, hi - lo).copy_(full_g2.view(16, n)[:, lo:hi])
+    elif hi > lo:
+        ops = [dist.P2POp(dist.irecv, g1_local, 0), dist.P2POp(dist.irecv, g2_local, 0)]
+    _run(dist, ops)
+
+
+def gather_outputs(out_local, n, dist, device=None):
+    """Every rank's 48 n_local output words travel to rank 0, which returns the whole SoA batch (48 n words); other
+    ranks return None."""
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
     lo, hi = shard_bounds(n, world, rank)
+    if rank != 0:
+        if hi > lo:
+            _run(dist, [dist.P2POp(dist.isend, out_local, 0)])
+        return None
+    full = torch.empty(48 * n, dtype=torch.int64, device=device if device is not None else out_local.device)
+    ops, parts = [], []
+    for r in range(1, world):
+        rlo, rhi = shard_bounds(n, world, r)
+        if rhi == rlo:
+            continue
+        t = torch.empty(48 * (rhi - rlo), dtype=torch.int64, device=full.device)
+        parts.append((rlo, rhi, t))
+        ops.append(dist.P2POp(dist.irecv, t, r))
+    if hi > lo:
+        full.view(48, n)[:, lo:hi].copy_(out_local.view(48, hi - lo))
+    _run(dist, ops)
+    for rlo, rhi, t in parts:
+        full.view(48, n)[:, rlo:rhi].copy_(t.view(48, rhi - rlo))
+    return full
+
+
+def pairing_sharded(g1, g2, n, dist=None, compute=None, scatter_from_root=False, gather_to_root=True, chunk=1 << 19, device=None):
+    """n independent pairings over the ranks of `dist`.  Returns (local SoA result, gathered SoA result on rank 0 or None).
+
+    g1 / g2: SoA tensors of the WHOLE batch -- valid on every rank, or on rank 0 only with scatter_from_root (other ranks
+    may pass None).  Each rank walks its slice in chunks of `chunk` lanes; with gather_to_root a finished chunk is sent to
+    rank 0 while the next chunk computes (rank 0 posts all its receives up front as one grouped operation)."""
+    import torch
+    compute = compute or hip_compute()
+    if dist is None or not dist.is_initialized():
+        out = compute(g1, g2, n) if n else torch.empty(0, dtype=torch.int64, device=g1.device)
+        return out, out
+    world, rank = dist.get_world_size(), dist.get_rank()
+    lo, hi = shard_bounds(n, world, rank)
     n_local = hi - lo
+    if device is None:
+        device = g1.device if g1 is not None else torch.device("cpu")
     if scatter_from_root:
-        if rank == 0:
-            for r in range(1, world):
-                rlo, rhi = shard_bounds(n, world, r)
-                for buf, words in ((g1, 8), (g2, 16)):
-                    t = torch.from_numpy(slice_soa(buf, words, n, rlo, rhi).view(np.int64))
-                    dist.send(t, dst=r)
-            l1, l2 = slice_soa(g1, 8, n, lo, hi), slice_soa(g2, 16, n, lo, hi)
-        else:
-            t1 = torch.empty(8 * n_local, dtype=torch.int64)
-            t2 = torch.empty(16 * n_local, dtype=torch.int64)
-            dist.recv(t1, src=0)
-            dist.recv(t2, src=0)
-            l1, l2 = t1.numpy().view(np.uint64), t2.numpy().view(np.uint64)
+        l1 = torch.empty(8 * n_local, dtype=torch.int64, device=device)
+        l2 = torch.empty(16 * n_local, dtype=torch.int64, device=device)
+        scatter_inputs(g1, g2, n, l1, l2, dist)
     else:
-        l1, l2 = slice_soa(g1, 8, n, lo, hi), slice_soa(g2, 16, n, lo, hi)
-    local = compute(l1, l2, n_local) if n_local else np.zeros(0, dtype=np.uint64)
+        l1, l2 = _cols(g1, 8, n, lo, hi), _cols(g2, 16, n, lo, hi)
+
+    def chunks(a, b):
+        return [(c, min(c + chunk, b)) for c in range(a, b, chunk)]
+
+    # rank 0: one grouped launch of every receive (rank r's chunk c arrives in posting order on the (r, 0) pair)
+    pending, recv_parts = [], []
+    if gather_to_root and rank == 0:
+        full = torch.empty(48 * n, dtype=torch.int64, device=device)
+        ops = []
+        for r in range(1, world):
+            rlo, rhi = shard_bounds(n, world, r)
+            for a, b in chunks(rlo, rhi):
+                t = torch.empty(48 * (b - a), dtype=torch.int64, device=device)
+                recv_parts.append((a, b, t))
+                ops.append(dist.P2POp(dist.irecv, t, r))
+        pending = dist.batch_isend_irecv(ops) if ops else []
+    local = torch.empty(48 * n_local, dtype=torch.int64, device=device)
+    sends = []
+    for a, b in chunks(0, n_local):
+        m = b - a
+        o = compute(_cols(l1, 8, n_local, a, b), _cols(l2, 16, n_local, a, b), m)
+        local.view(48, n_local)[:, a:b].copy_(o.view(48, m))
+        if gather_to_root and rank != 0:
+            sends.append((o, dist.batch_isend_irecv([dist.P2POp(dist.isend, o, 0)])))      # travels while the next chunk computes
+    for _, ws in sends:
+        for w in ws:
+            w.wait()
     gathered = None
-    if gather_to_root:
-        if rank == 0:
-            full = np.zeros((48, n), dtype=np.uint64)
-            full[:, lo:hi] = np.asarray(local, dtype=np.uint64).reshape(48, n_local)
-            for r in range(1, world):
-                rlo, rhi = shard_bounds(n, world, r)
-                t = torch.empty(48 * (rhi - rlo), dtype=torch.int64)
-                if rhi > rlo:
-                    dist.recv(t, src=r)
-                    full[:, rlo:rhi] = t.numpy().view(np.uint64).reshape(48, rhi - rlo)
-            gathered = full.reshape(-1)
-        elif n_local:
-            dist.send(torch.from_numpy(np.asarray(local, dtype=np.uint64).view(np.int64).copy()), dst=0)
+    if gather_to_root and rank == 0:
+        for w in pending:
+            w.wait()
+        full.view(48, n)[:, lo:hi].copy_(local.view(48, n_local))
+        for a, b, t in recv_parts:
+            full.view(48, n)[:, a:b].copy_(t.view(48, b - a))
+        gathered = full
     return local, gathered

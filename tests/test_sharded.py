@@ -1,6 +1,15 @@
-"""world_size-2 gloo test (CPU) of the multi-GPU sharding driver: slices, scatter, gather.
-The per-rank compute is injected (the CPU oracle) -- the sharding logic is what is under test."""
+"""Multi-rank sharding: slices, scatter from rank 0, chunked compute with the gather of chunk i
+travelling under chunk i + 1, gather to rank 0.
+
+  * world_size-2 / 3 `gloo` runs on CPU tensors with an injected per-rank compute (the CPU oracle) -- the sharding logic is
+    what is under test here;
+  * `-m gpu`: the SAME function body under backend "nccl" (RCCL) on device tensors with the HIP engine as the compute, one
+    rank per visible GPU (world size 1 on a one-GPU box: every code path except the peer transfers);
+  * bench.py's own launcher (`--gpus 2` with no WORLD_SIZE in the environment) on CPU with a stand-in engine."""
+import importlib
+import json
 import os
+import subprocess
 import sys
 
 import numpy as np
@@ -14,55 +23,155 @@ import helpers as H
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _oracle_compute(g1, g2, n_local):
+def _sh():
+    sys.path.insert(0, ROOT)
+    return importlib.import_module("plonky2-bn254-pairing_amd.sharded")
+
+
+def _oracle_compute(g1, g2, m):
+    """Stand-in for the HIP engine in the CPU tests: same signature (SoA int64 tensors in, SoA int64 tensor out)."""
     pk = H.pkg()
-    out = H.oracle_pairing(pk.layout.to_aos(g1, 8), pk.layout.to_aos(g2, 16), n_local)
-    return pk.layout.to_soa(out, 48)
+    a = pk.layout.to_aos(g1.numpy().view(np.uint64), 8)
+    b = pk.layout.to_aos(g2.numpy().view(np.uint64), 16)
+    out = H.oracle_pairing(a, b, m)
+    return torch.from_numpy(pk.layout.to_soa(out, 48).view(np.int64).copy())
 
 
-def _worker(rank, world, port, n, g1, g2, want, scatter, q):
+def _worker(rank, world, port, n, g1, g2, want, scatter, chunk, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    sys.path.insert(0, ROOT)
-    import importlib
-    sh = importlib.import_module("plonky2-bn254-pairing_amd.sharded")
+    sh = _sh()
     a, b = (g1, g2) if (rank == 0 or not scatter) else (None, None)
-    local, gathered = sh.pairing_sharded(a, b, n, dist=dist, compute=_oracle_compute, scatter_from_root=scatter)
+    local, gathered = sh.pairing_sharded(a, b, n, dist=dist, compute=_oracle_compute, scatter_from_root=scatter, chunk=chunk,
+                                         device=torch.device("cpu"))
     lo, hi = sh.shard_bounds(n, world, rank)
-    ok = np.array_equal(np.asarray(local).reshape(48, hi - lo), want.reshape(48, n)[:, lo:hi])
+    ok = torch.equal(local.view(48, hi - lo), want.view(48, n)[:, lo:hi])
     if rank == 0:
-        ok = ok and np.array_equal(gathered, want)
+        ok = ok and torch.equal(gathered, want)
+    else:
+        ok = ok and gathered is None
+    # the stand-alone scatter / gather pair bench.py uses for configs[4]
+    l1 = torch.empty(8 * (hi - lo), dtype=torch.int64)
+    l2 = torch.empty(16 * (hi - lo), dtype=torch.int64)
+    sh.scatter_inputs(g1 if rank == 0 else None, g2 if rank == 0 else None, n, l1, l2, dist)
+    ok = ok and torch.equal(l1.view(8, hi - lo), g1.view(8, n)[:, lo:hi]) and torch.equal(l2.view(16, hi - lo), g2.view(16, n)[:, lo:hi])
+    full = sh.gather_outputs(local, n, dist)
+    ok = ok and (torch.equal(full, want) if rank == 0 else full is None)
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("scatter", [False, True])
-def test_sharded_two_ranks(scatter):
+def _spawn(world, n, scatter, chunk, seed):
     pk = H.pkg()
-    n = 5                                   # ragged: ranks get 2 and 3 pairings
-    P, Q = H.subgroup_points(n, seed=31)
-    g1a, g2a = H.g1_aos(P), H.g2_aos(Q)
-    want = pk.layout.to_soa(H.oracle_pairing(g1a, g2a, n), 48)
-    g1, g2 = pk.layout.to_soa(g1a, 8), pk.layout.to_soa(g2a, 16)
+    P, Q = H.subgroup_points(max(n, 1), seed=seed)
+    g1a, g2a = H.g1_aos(P[:n]), H.g2_aos(Q[:n])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64).copy())
+    want = t(pk.layout.to_soa(H.oracle_pairing(g1a, g2a, n), 48)) if n else torch.empty(0, dtype=torch.int64)
+    g1, g2 = t(pk.layout.to_soa(g1a, 8)), t(pk.layout.to_soa(g2a, 16))
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + (1 if scatter else 0)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, g1, g2, want, scatter, q)) for r in range(2)]
+    port = 29500 + (os.getpid() * 7 + n * 13 + world * 101 + (1 if scatter else 0)) % 3000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, g1, g2, want, scatter, chunk, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=180) for _ in procs)
+    res = sorted(q.get(timeout=240) for _ in procs)
     for p in procs:
         p.join(timeout=60)
-    assert res == [(0, True), (1, True)]
+    assert res == [(r, True) for r in range(world)]
+
+
+@pytest.mark.parametrize("scatter", [False, True])
+def test_sharded_two_ranks(scatter):
+    """ragged: ranks get 2 and 3 pairings; chunk = 2 lanes, so rank 1 sends a 2-lane and a 1-lane chunk"""
+    _spawn(2, 5, scatter, chunk=2, seed=31)
+
+
+def test_sharded_three_ranks_with_an_empty_slice():
+    """n = 2 over 3 ranks: rank 0's slice is empty (scatter and gather skip it consistently on both sides)"""
+    _spawn(3, 2, True, chunk=8, seed=32)
 
 
 def test_shard_bounds_cover_batch():
-    sys.path.insert(0, ROOT)
-    import importlib
-    sh = importlib.import_module("plonky2-bn254-pairing_amd.sharded")
-    for n in (0, 1, 7, 8, 65536):
-        for w in (1, 2, 4, 8):
+    sh = _sh()
+    for n in (0, 1, 7, 8, 65536, (1 << 24)):
+        for w in (1, 2, 3, 4, 8):
             b = [sh.shard_bounds(n, w, r) for r in range(w)]
             assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+    # BASELINE configs[4]: 2^24 over 8 GPUs = 2^21 each
+    assert [hi - lo for lo, hi in (sh.shard_bounds(1 << 24, 8, r) for r in range(8))] == [1 << 21] * 8
+
+
+def test_bench_launcher_two_ranks_cpu():
+    """`python bench.py --gpus 2` with no torch.distributed environment starts two ranks itself (a child torch.distributed.run,
+    before anything touches a GPU) and runs the configs[4] flow -- scatter from rank 0, timed compute on the shards, gather --
+    here over gloo with a stand-in engine (tests/fake_engine.py)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(BENCH_TEST_ENGINE="fake_engine:Engine", BENCH_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--log2-batch", "6"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["steps"] == 2 and rec["scaling"] == "weak"
+    assert rec["config"]["pairings_per_gpu"] == 64 and rec["config"]["pairings_total"] == 128
+    assert rec["exchange"]["bytes_scattered"] == 192 * 64 and rec["exchange"]["bytes_gathered"] == 384 * 64
+    assert "TEST ENGINE" in rec["data"]
+    # a world size that contradicts --gpus is an error, not a silent one-rank run
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env2,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
+
+
+# ------------------------------------------------------------------------------------------------ GPU: nccl = RCCL
+def _nccl_worker(rank, world, port, n, chunk, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    sh = _sh()
+    pk = H.pkg()
+    g1 = g2 = None
+    if rank == 0:
+        g1 = torch.zeros(8 * n, dtype=torch.int64, device=dev)
+        g2 = torch.zeros(16 * n, dtype=torch.int64, device=dev)
+        pk.generate_pairs_dev(0xB2540006, g1, g2, n, rank, torch.cuda.current_stream(dev))
+        pk.last_status(rank, torch.cuda.current_stream(dev))
+    local, gathered = sh.pairing_sharded(g1, g2, n, dist=dist, scatter_from_root=True, chunk=chunk, device=dev)
+    pk.last_status(rank, torch.cuda.current_stream(dev))
+    ok = True
+    if rank == 0:
+        ref = torch.empty(48 * n, dtype=torch.int64, device=dev)
+        pk.pairing_batch_dev(g1, g2, ref, n, rank, torch.cuda.current_stream(dev))
+        pk.last_status(rank, torch.cuda.current_stream(dev))
+        ok = torch.equal(gathered, ref)
+        pos = [0, n // 2, n - 1]
+        g1h = g1.view(8, n)[:, pos].cpu().numpy().view(np.uint64).reshape(-1).copy()
+        g2h = g2.view(16, n)[:, pos].cpu().numpy().view(np.uint64).reshape(-1).copy()
+        want = H.oracle_pairing(pk.layout.to_aos(g1h, 8), pk.layout.to_aos(g2h, 16), len(pos), threads=3)
+        got = gathered.view(48, n)[:, pos].cpu().numpy().view(np.uint64).reshape(-1).copy()
+        ok = ok and np.array_equal(pk.layout.to_aos(got, 48), want)
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_nccl_on_visible_gpus():
+    """backend nccl (RCCL), device tensors, the HIP engine on each rank's own device and stream: one rank per visible GPU."""
+    world = torch.cuda.device_count()
+    assert world >= 1
+    n = 3 * 4096 + 77
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31000 + os.getpid() % 2000
+    procs = [ctx.Process(target=_nccl_worker, args=(r, world, port, n, 4096, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(r, True) for r in range(world)]
