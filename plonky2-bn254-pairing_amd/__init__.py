@@ -304,6 +304,23 @@ def generate_pairs_dev(seed, g1_out, g2_out, n, device=0, stream=None):
     _check(load_library().bn254_generate_pairs_dev(seed, _dev(g1_out), _dev(g2_out), n, device, _stream(stream)), "generate_pairs")
 
 
+def generator_scalars(seed, i):
+    """The scalars (s_i, t_i) bn254_generate_pairs_dev uses for pair i: P_i = [s_i] G1, Q_i = [t_i] G2.  Four SplitMix64
+    draws from the state seed ^ (0xD1B54A32D192ED03 * (i + 1)): s = lo | (hi | 2^63) << 64, then t likewise -- 128-bit
+    scalars with the top bit set (never zero mod r; NOT uniform mod r: synthetic bench / test inputs, the pairing kernels
+    have no data-dependent control flow)."""
+    m64 = (1 << 64) - 1
+    st = (seed ^ (0xD1B54A32D192ED03 * (i + 1))) & m64
+    draws = []
+    for _ in range(4):
+        st = (st + 0x9E3779B97F4A7C15) & m64
+        z = st
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m64
+        draws.append(z ^ (z >> 31))
+    return draws[0] | ((draws[1] | (1 << 63)) << 64), draws[2] | ((draws[3] | (1 << 63)) << 64)
+
+
 def last_status(device=0, stream=None):
     """Synchronises the stream and raises where the reference would have panicked."""
     _check(load_library().bn254_last_status(device, _stream(stream)), "device status")

@@ -649,14 +649,24 @@ int bn254_frobenius_map_batch_dev(const uint64_t* a, size_t power, uint64_t* out
     return launch_op(OP_FROB, a, nullptr, out, n, power, nullptr, 0, device, stream);
 }
 int bn254_pow_batch_dev(const uint64_t* a, const uint64_t* exp, size_t exp_limbs, uint64_t* out, size_t n, int device, void* stream) {
-    if (!exp || exp_limbs == 0) return BN254_ERR_INVALID_ARG;
+    if (exp_limbs && !exp) return BN254_ERR_INVALID_ARG;
     std::vector<int8_t> naf(64 * exp_limbs + 1);
-    long len = get_naf_host(exp, exp_limbs, naf.data());
+    long len = exp_limbs ? get_naf_host(exp, exp_limbs, naf.data()) : 0;
     if (len < 0) return (int)len;
-    // pow_native asserts the first non-zero digit from the top is +1 (:77); a NAF's always is, unless exp == 0
     bool any = false;
     for (long t = 0; t < len; t++) any |= (naf[t] != 0);
-    if (!any) return BN254_ERR_INVALID_ARG;
+    if (!any) {
+        // pow_native (final_exp_native.rs:56-84) with an all-zero NAF (exp == 0 or an empty vector): `is_started` never
+        // becomes true, the loop body is skipped and the function returns `res`, which was initialised to `a`.
+        if (n == 0) return BN254_OK;
+        if (!a || !out) return BN254_ERR_INVALID_ARG;
+        int cnt = 0;
+        if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) return BN254_ERR_NO_DEVICE;
+        if (device < 0 || device >= cnt) return BN254_ERR_INVALID_ARG;
+        HIPCHK(hipSetDevice(device));
+        if (out != a) HIPCHK(hipMemcpyAsync(out, a, 48 * n * sizeof(uint64_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        return BN254_OK;
+    }
     return launch_op(OP_POW, a, nullptr, out, n, 0, naf.data(), (int)len, device, stream);
 }
 /* test hooks for the field layer (not part of the reference's surface) */
@@ -670,15 +680,9 @@ long bn254_get_naf(const uint64_t* exp, size_t exp_limbs, int8_t* naf) {
     return get_naf_host(exp, exp_limbs, naf);
 }
 
-static void mont_limbs_to_u64(const uint32_t* l, uint64_t* o) {
-    for (int i = 0; i < 4; i++) o[i] = (uint64_t)l[2 * i] | ((uint64_t)l[2 * i + 1] << 32);
-}
 int bn254_frob_coeffs(size_t index, uint64_t* out8) {
     if (index >= 12 || !out8) return BN254_ERR_INVALID_ARG;
-    uint32_t h[12][6][2][8];
-    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(BN254_FROB), sizeof(h), 0, hipMemcpyDeviceToHost) != hipSuccess) return BN254_ERR_HIP;
-    mont_limbs_to_u64(h[index][1][0], out8);
-    mont_limbs_to_u64(h[index][1][1], out8 + 4);
+    memcpy(out8, BN254_FROB_COEFFS_HOST[index], 8 * sizeof(uint64_t));      // host table: no device involved
     return BN254_OK;
 }
 const int8_t* bn254_six_u_plus_2_naf(void) {
@@ -833,7 +837,7 @@ int bn254_frobenius_map_batch(const uint64_t* a, size_t power, uint64_t* out, si
 }
 int bn254_pow_batch(const uint64_t* a, const uint64_t* exp, size_t exp_limbs, uint64_t* out, size_t n, int device, void* stream) {
     if (n == 0) return BN254_OK;
-    if (!a || !exp || !out) return BN254_ERR_INVALID_ARG;
+    if (!a || (!exp && exp_limbs) || !out) return BN254_ERR_INVALID_ARG;
     if (bn254_device_count() <= 0) return BN254_ERR_NO_DEVICE;
     if (hipSetDevice(device) != hipSuccess) return BN254_ERR_INVALID_ARG;
     Staged s; uint64_t *d1, *d3; int rc;

@@ -53,6 +53,19 @@ def test_host_logic_get_naf_and_constants(pk):
     assert lib.bn254_myfq12_to_ark_index(12) == -1
 
 
+def test_frob_coeffs_host_table(pk):
+    """frob_coeffs(index) (final_exp_native.rs:183-192) is served from a host-side table: no device needed."""
+    vec = H.load_golden("bn254_vectors.json")
+    for k in range(12):
+        got = pk.frob_coeffs(k)
+        want = [int(x, 16) for x in vec["consts"]["frob_coeffs"][str(k)]]
+        assert [R.from_mont(pk.layout.limbs_to_int(got[:4])), R.from_mont(pk.layout.limbs_to_int(got[4:]))] == want
+        assert want == list(R.frob_coeffs(k))
+    assert list(pk.frob_coeffs(13)) == list(pk.frob_coeffs(1))
+    out = np.zeros(8, dtype=np.uint64)
+    assert pk.load_library().bn254_frob_coeffs(12, out.ctypes.data_as(__import__("ctypes").c_void_p)) == pk.ERR_INVALID_ARG
+
+
 def test_conjugates(pk):
     x = (123456789, R.P - 5)
     arr = np.array(H.fq_words(x[0]) + H.fq_words(x[1]), dtype=np.uint64)

@@ -1,0 +1,17 @@
+"""The committed kernel header is exactly what the generator emits (deterministic label names, no hand edits):
+tools/gen_kernels.py is re-run in memory and compared byte for byte with plonky2-bn254-pairing_amd/csrc/pairing_asm_gen.h."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def test_committed_header_is_the_generator_output():
+    import gen_kernels
+    text, stats = gen_kernels.render(verbose=False)
+    with open(gen_kernels.OUT) as f:
+        committed = f.read()
+    assert text == committed, "pairing_asm_gen.h is stale: run python tools/gen_kernels.py"
+    text2, _ = gen_kernels.render(verbose=False)
+    assert text2 == text, "the generator is not deterministic"

@@ -359,3 +359,194 @@ def test_host_pipeline_chunk_edges():
         pk.last_status(0, st)
         got = pk.pairing_batch(g1.cpu().numpy().view(np.uint64).copy(), g2.cpu().numpy().view(np.uint64).copy(), n)
         assert np.array_equal(got, out.cpu().numpy().view(np.uint64)), n
+
+
+# ------------------------------------------------------------------------------------------------ full-size runs per entry point
+P_TOP = 0x30644e72e131a029
+
+
+def _rand_fq12_dev(n, seed, dev):
+    """n arbitrary (non-unitary) Fq12 elements on the device, SoA: every coefficient a uniform 256-bit pattern below p
+    (top limb below p's top limb), i.e. a valid Montgomery representation of some field element."""
+    import torch
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    t = torch.randint(-(1 << 63), (1 << 63) - 1, (48, n), dtype=torch.int64, device=dev, generator=g)
+    top = torch.randint(0, P_TOP, (12, n), dtype=torch.int64, device=dev, generator=g)
+    t[3::4] = top
+    return t.view(-1)
+
+
+def _take(t, words, n, pos):
+    return t.view(words, n)[:, pos].cpu().numpy().view(np.uint64).reshape(-1).copy()
+
+
+def test_miller_loop_full_size_vs_oracle():
+    """bn254_miller_loop_batch_dev (the bit-exact miller_loop_native value, miller_loop_native.rs:320-322, with the running line
+    scale divided out) over 3 x 2^16 + 300 lanes: every workgroup walks three or four 256-lane items of the persistent loop.
+    640 oracle spot checks spread over the first, second, third and ragged last items; determinism; guard words."""
+    import torch
+    pk = H.pkg()
+    n = 3 * (1 << 16) + 300
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev)
+    g1 = torch.zeros(8 * n, dtype=torch.int64, device=dev)
+    g2 = torch.zeros(16 * n, dtype=torch.int64, device=dev)
+    pk.generate_pairs_dev(0xB2540011, g1, g2, n, 0, st)
+    out = torch.full((48 * n + 64,), -1, dtype=torch.int64, device=dev)
+    out2 = torch.zeros(48 * n, dtype=torch.int64, device=dev)
+    pk.miller_loop_batch_dev(g1, g2, out, n, 0, st)
+    pk.miller_loop_batch_dev(g1, g2, out2, n, 0, st)
+    pk.last_status(0, st)
+    assert torch.equal(out[:48 * n], out2) and bool((out[48 * n:] == -1).all())
+    rng = np.random.default_rng(21)
+    pos = np.unique(np.concatenate([rng.choice(n, size=600, replace=False), [0, 255, 256, 65535, 65536, 65791, 131071, 131072, 196607, 196608, n - 301, n - 300, n - 1]]))
+    want = H.oracle_miller(pk.layout.to_aos(_take(g1, 8, n, pos), 8), pk.layout.to_aos(_take(g2, 16, n, pos), 16), len(pos))
+    got = pk.layout.to_aos(_take(out[:48 * n], 48, n, pos), 48)
+    assert np.array_equal(got, want)
+
+
+def test_final_exp_full_size_vs_oracle():
+    """bn254_final_exp_batch_dev (final_exp_native, final_exp_native.rs:209-213) on 2 x 2^16 + 77 arbitrary non-unitary Fq12
+    elements (the T4 shape, :274-285): 520 oracle spot checks incl. lanes of the second and third items; determinism."""
+    import torch
+    pk = H.pkg()
+    n = 2 * (1 << 16) + 77
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev)
+    a = _rand_fq12_dev(n, 5, dev)
+    out = torch.full((48 * n + 64,), -1, dtype=torch.int64, device=dev)
+    out2 = torch.zeros(48 * n, dtype=torch.int64, device=dev)
+    pk.final_exp_batch_dev(a, out, n, 0, st)
+    pk.final_exp_batch_dev(a, out2, n, 0, st)
+    pk.last_status(0, st)
+    assert torch.equal(out[:48 * n], out2) and bool((out[48 * n:] == -1).all())
+    rng = np.random.default_rng(22)
+    pos = np.unique(np.concatenate([rng.choice(n, size=500, replace=False), [0, 255, 256, 65535, 65536, 70000, 131071, 131072, n - 1]]))
+    rc, want = H.oracle_final_exp(pk.layout.to_aos(_take(a, 48, n, pos), 48), len(pos))
+    assert rc == 0
+    assert np.array_equal(pk.layout.to_aos(_take(out[:48 * n], 48, n, pos), 48), want)
+
+
+def test_pairing_2_20_vs_oracle():
+    """BASELINE.json configs[2]: 2^20 independent pairings in one launch (16 items per workgroup): determinism, guard words,
+    512 oracle spot checks over the whole index range."""
+    import os
+    import torch
+    pk = H.pkg()
+    n = 1 << 20
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev)
+    g1 = torch.zeros(8 * n, dtype=torch.int64, device=dev)
+    g2 = torch.zeros(16 * n, dtype=torch.int64, device=dev)
+    pk.generate_pairs_dev(0xB2540001, g1, g2, n, 0, st)
+    out = torch.full((48 * n + 64,), -1, dtype=torch.int64, device=dev)
+    out2 = torch.zeros(48 * n, dtype=torch.int64, device=dev)
+    pk.pairing_batch_dev(g1, g2, out, n, 0, st)
+    pk.pairing_batch_dev(g1, g2, out2, n, 0, st)
+    pk.last_status(0, st)
+    assert torch.equal(out[:48 * n], out2) and bool((out[48 * n:] == -1).all())
+    rng = np.random.default_rng(23)
+    pos = np.unique(np.concatenate([rng.choice(n, size=500, replace=False), [0, 65535, 65536, 524287, 524288, 983040, n - 256, n - 1]]))
+    want = H.oracle_pairing(pk.layout.to_aos(_take(g1, 8, n, pos), 8), pk.layout.to_aos(_take(g2, 16, n, pos), 16), len(pos),
+                            threads=min(32, len(os.sched_getaffinity(0))))
+    assert np.array_equal(pk.layout.to_aos(_take(out[:48 * n], 48, n, pos), 48), want)
+
+
+def _neg_fq_planes(y):
+    """p - y on u64 limb planes y[4][m] (Montgomery limbs negate like canonical ones; y != 0 for curve points)."""
+    P_LIMBS = [0x3c208c16d87cfd47, 0x97816a916871ca8d, 0xb85045b68181585d, 0x30644e72e131a029]
+    out = np.empty_like(y)
+    borrow = np.zeros(y.shape[1], dtype=np.uint64)
+    for l in range(4):
+        pl = np.uint64(P_LIMBS[l])
+        out[l] = pl - y[l] - borrow
+        borrow = ((y[l] + borrow > pl) | ((borrow == 1) & (y[l] == np.uint64(0xFFFFFFFFFFFFFFFF)))).astype(np.uint64)
+    return out
+
+
+def test_groth16_shape_2_18_groups():
+    """BASELINE.json configs[3]: 2^18 groups x 4 pairs, one shared-f multi-Miller loop + one final exponentiation per group
+    (multi_miller_loop_native, miller_loop_native.rs:324-326).  (a) generic groups: 96 oracle spot checks of the Fq12 value;
+    (b) size-independent property over ALL groups (T3 pattern, final_exp_native.rs:245-263): groups built as
+    (P, Q), (P, -Q), (P', Q'), (P', -Q') have product one -- checked with the on-device verdict."""
+    import torch
+    pk = H.pkg()
+    groups, k = 1 << 18, 4
+    n = groups * k
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev)
+    g1 = torch.zeros(8 * n, dtype=torch.int64, device=dev)
+    g2 = torch.zeros(16 * n, dtype=torch.int64, device=dev)
+    pk.generate_pairs_dev(0xB2540013, g1, g2, n, 0, st)
+    out = torch.full((48 * groups + 64,), -1, dtype=torch.int64, device=dev)
+    pk.multi_pairing_batch_dev(g1, g2, out, groups, k, True, 0, st)
+    pk.last_status(0, st)
+    assert bool((out[48 * groups:] == -1).all())
+    rng = np.random.default_rng(24)
+    gp = np.unique(np.concatenate([rng.choice(groups, size=90, replace=False), [0, 255, 256, 65535, 65536, groups - 1]]))
+    pairs = (gp[:, None] * k + np.arange(k)[None, :]).reshape(-1)
+    want = H.oracle_multi_pairing(pk.layout.to_aos(_take(g1, 8, n, pairs), 8), pk.layout.to_aos(_take(g2, 16, n, pairs), 16), len(gp), k)
+    assert np.array_equal(pk.layout.to_aos(_take(out[:48 * groups], 48, groups, gp), 48), want)
+    # (b) product-one groups over the whole batch
+    h1 = g1.cpu().numpy().view(np.uint64).reshape(8, n)[:, :n // 2]
+    h2 = g2.cpu().numpy().view(np.uint64).reshape(16, n)[:, :n // 2]
+    neg = h2.copy()
+    neg[8:12] = _neg_fq_planes(h2[8:12])
+    neg[12:16] = _neg_fq_planes(h2[12:16])
+    g1k = np.repeat(h1, 2, axis=1)                                  # pairs 2i, 2i+1 share P_i
+    g2k = np.empty((16, n), dtype=np.uint64)
+    g2k[:, 0::2], g2k[:, 1::2] = h2, neg
+    d1 = torch.from_numpy(g1k.reshape(-1).view(np.int64)).to(dev)
+    d2 = torch.from_numpy(g2k.reshape(-1).view(np.int64)).to(dev)
+    verdict = torch.zeros(groups, dtype=torch.uint8, device=dev)
+    pk.multi_pairing_check_batch_dev(d1, d2, verdict, groups, k, 0, st)
+    pk.last_status(0, st)
+    assert bool(verdict.all())
+    # breaking one pair of one group breaks exactly that group
+    d2.view(16, n)[:, 4 * 4321 + 3] = d2.view(16, n)[:, 4 * 4321 + 2]
+    pk.multi_pairing_check_batch_dev(d1, d2, verdict, groups, k, 0, st)
+    pk.last_status(0, st)
+    assert int(verdict.sum()) == groups - 1 and int(verdict[4321]) == 0
+
+
+def test_generated_pairs_are_the_stated_subgroup_points():
+    """bn254_generate_pairs_dev (stands in for G1Affine::rand / G2Affine::rand, /root/reference/src/pairing.rs:65-66):
+    P_i = [s_i] G1, Q_i = [t_i] G2 with the SplitMix64-derived scalars the header states -- the first 64 pairs (and a few at
+    the far end) against the big-integer restatement; every point of a full 2^16 batch is on its curve."""
+    import torch
+    pk = H.pkg()
+    n = 1 << 16
+    seed = 0xB2540001
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev)
+    g1 = torch.zeros(8 * n, dtype=torch.int64, device=dev)
+    g2 = torch.zeros(16 * n, dtype=torch.int64, device=dev)
+    pk.generate_pairs_dev(seed, g1, g2, n, 0, st)
+    pk.last_status(0, st)
+    h1 = pk.layout.to_aos(g1.cpu().numpy().view(np.uint64), 8).reshape(n, 2, 4)
+    h2 = pk.layout.to_aos(g2.cpu().numpy().view(np.uint64), 16).reshape(n, 4, 4)
+    val = lambda limbs: H.R.from_mont(sum(int(limbs[l]) << (64 * l) for l in range(4)))
+    for i in list(range(64)) + [255, 256, 40000, n - 1]:
+        s, t = pk.generator_scalars(seed, i)
+        P = H.R.g1_mul(H.R.G1_GEN, s % H.R.R_ORDER)
+        Q = H.R.g2_mul(H.R.G2_GEN, t % H.R.R_ORDER)
+        assert (val(h1[i, 0]), val(h1[i, 1])) == tuple(P), i
+        assert ((val(h2[i, 0]), val(h2[i, 1])), (val(h2[i, 2]), val(h2[i, 3]))) == (tuple(Q[0]), tuple(Q[1])), i
+    lib = H.oracle()
+    g1a, g2a = h1.reshape(-1), h2.reshape(-1)
+    for i in range(n):
+        assert lib.oracle_g1_on_curve(H.ptr(g1a[8 * i: 8 * i + 8])) == 1, i
+        assert lib.oracle_g2_on_curve(H.ptr(g2a[16 * i: 16 * i + 16])) == 1, i
+
+
+def test_pow_native_zero_and_empty_exponent():
+    """pow_native(a, [0]) and pow_native(a, []) return a (all-zero NAF: the loop never starts, final_exp_native.rs:56-84)."""
+    pk = H.pkg()
+    n = 5
+    a = H.to_soa(H.fq12_aos(H.rand_fq12(n, seed=3)), 48)
+    assert np.array_equal(pk.pow_batch(a, [0], n), a)
+    assert np.array_equal(pk.pow_batch(a, [0, 0], n), a)
+    assert np.array_equal(pk.pow_batch(a, [], n), a)
+    rc, want = H.oracle_pow_native(H.to_aos(a, 48), [0], n)
+    assert rc == 0 and np.array_equal(H.to_soa(want, 48), a)

@@ -1287,10 +1287,12 @@ class KernelBuilder3(KP.KernelBuilder):
         # exponent p - 2, canonical 32-bit words as literals in SGPR s61 per word
         ex = P_INT - 2
         words = [(ex >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
+        self._fqinv_uid = getattr(self, "_fqinv_uid", 0) + 1          # deterministic per-instance label suffix
+        uid = self._fqinv_uid
         for limb in range(7, -1, -1):
             top = 28 if limb == 7 else 31
-            lbl = self.lab(f"L_fqinv_{limb}_{id(p) & 0xffff}")
-            skip = self.lab(f"L_fqinv_skip_{limb}_{id(p) & 0xffff}")
+            lbl = self.lab(f"L_fqinv_{limb}_{uid}")
+            skip = self.lab(f"L_fqinv_skip_{limb}_{uid}")
             e.salu(f"s_mov_b32 s{S_TMP1}, 0x{words[limb]:x}")
             e.salu(f"s_mov_b32 s{S_TMP0}, {top}")
             e.label(lbl)

@@ -729,13 +729,15 @@ class KernelBuilder:
         p.tagA = p.tagB = None
         # exponent p-2: limb 0 differs from p by 2, the others are the modulus limbs already in SGPRs
         e.salu(f"s_sub_u32 s{S_TMP1}, s{S_P}, 2")
+        self._fqinv_uid = getattr(self, "_fqinv_uid", 0) + 1          # deterministic per-instance label suffix
+        uid = self._fqinv_uid
         for limb in range(7, -1, -1):
             top = 29 if limb == 7 else 31          # p < 2^254: bit 253 is the top bit; it is consumed by r = a
             if limb == 7:
                 top = 28                           # start below bit 253 (= bit 29 of limb 7)
             reg = f"s{S_TMP1}" if limb == 0 else f"s{S_P + limb}"
-            lbl = self.lab(f"L_fqinv_{limb}_{id(p) & 0xffff}")
-            skip = self.lab(f"L_fqinv_skip_{limb}_{id(p) & 0xffff}")
+            lbl = self.lab(f"L_fqinv_{limb}_{uid}")
+            skip = self.lab(f"L_fqinv_skip_{limb}_{uid}")
             e.salu(f"s_mov_b32 s{S_TMP0}, {top}")
             e.label(lbl)
             e.salu(f"s_call_b64 {S_RET1}, {self.labels['fqsqr']}")
