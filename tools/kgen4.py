@@ -1,0 +1,542 @@
+#!/usr/bin/env python3
+"""kgen4.py -- L1 field routines of the kernels: carry-free BALANCED signed limbs, radix 2^29, nine limbs.
+
+gfx950 issues one VALU instruction per 4 cycles for the single wave a SIMD can hold at this register / LDS footprint,
+whatever the instruction (tools/valu_calib.hip, profiles/valu_calib_r01.txt), so a pairing costs its dynamic instruction
+count; 69 % of the round-1 kernels' instructions were the limb products.  The representation is chosen to minimise those:
+
+  * an Fq element is NL = 9 signed 32-bit limbs in radix 2^29 (value = sum l_i 2^(29 i)), Montgomery form with
+    R' = 2^261: 81 limb products per Fq product instead of 100 (ten 27-bit limbs, round 1) or 64 + carry chains
+    (eight 32-bit limbs).  A limb product is ONE instruction, v_mad_i64_i32 acc64 += a_i * b_j;
+  * limbs are BALANCED: normalised limbs lie in [-2^28, 2^28) (the top limb is signed and carries the representative),
+    so |a_i b_j| <= 2^56 and a column of 54 products plus the 9 reduction products (the three-term fused multiply, six
+    Fq products per pass) stays below 2^63: 63 * 2^56 < 2^62; sums of two normalised values may enter a two-product pass
+    unnormalised (18 * 4 * 2^56 + 9 * 2^56 < 2^63).  Unsigned 29-bit limbs would overflow the signed accumulator;
+  * Montgomery reduction is fused column-wise (FIPS): m_k = balanced((lo(S) n0') mod 2^29), S += m_k p_0, S >>= 29; result
+    limbs are extracted balanced (v_bfe_i32) and the extracted digit is subtracted from the accumulator before the shift;
+  * R'/p = 2^7.4 only (round 1: 2^16.4): a reduction output is sum(a_i b_i)/R' +- p/2, so values must be kept small:
+    `redn` (normalise + subtract round(top limb * 2^232 / p) * p, one 64-bit carry chain) brings a value back to
+    (-0.51 p, 0.51 p); tools/kgen4_prog.py tracks value bounds and places it;
+  * x(9+u) of a normalised value would overflow int32 limb-wise (10 * 2^28 > 2^31): linear combinations with large
+    coefficients run on a 64-bit accumulator chain (`lincomb`: mads by inline constants, balanced digit extraction),
+    which normalises -- and optionally reduces -- in the same pass.
+
+Blocks: A = v[0:17] (c0 = v0..8, c1 = v9..17), B = v[18:35]; temporaries v[36:75].
+At the kernel boundary values are converted from/to ark's 4 x u64 Montgomery (R = 2^256) form.
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from asmcore import Emitter, Pool, P_INT  # noqa: E402
+
+NL = 9
+LB = 29
+MASK = (1 << LB) - 1
+HALF = 1 << (LB - 1)
+TOP_W = LB * (NL - 1)                                   # weight of the top limb: 2^232
+RP = 1 << (NL * LB)                                     # R' = 2^261
+N0P = (-pow(P_INT, -1, 1 << LB)) % (1 << LB)
+REDN_SHIFT = 52                                         # q = round(top limb * REDN_C / 2^52) ~ top limb * 2^232 / p
+REDN_C = (1 << (REDN_SHIFT + TOP_W)) // P_INT           # < 2^31: fits a signed multiply-high
+assert REDN_C < (1 << 31)
+
+A0, B0 = 0, 18
+TMP_FIRST, TMP_LAST = 36, 75
+V_LDS = 76          # v76, v77: LDS byte address of the lane's 16-byte chunks (+0, +64 KiB) ; v78: of its 8-byte tail chunks
+V_LTAIL = 78
+V_GOFF = 79         # lane * 72 (byte offset inside a global scratch slot)
+V_IDX8 = 80
+V_IDX = 81
+V_TID = 82
+V_FLAG = 83
+HOME0 = 84          # homes: v[84:245] = 9 x 18
+N_HOME = 9
+N_AGPR_SLOTS = 14   # a[0:251]
+N_LDS_SLOTS = 8     # 8 x 72 B x 256 lanes = 144 KiB
+SLOT_DW = 18
+SLOT_BYTES = 4 * SLOT_DW
+S_P = 36            # s36..s44: modulus limbs (balanced, radix 2^29)
+S_N0 = 46
+S_REDN = 47         # REDN_C
+S_M30 = 45          # the constant -30 (not an inline constant; used by the cyclotomic recombination chains)
+S_RET1 = "s[54:55]"
+S_RET2 = "s[56:57]"
+S_RET3 = "s[58:59]"
+
+
+def bal_limbs(x):
+    """Signed integer -> NL balanced limbs (limbs 0..NL-2 in [-2^28, 2^28), the top limb takes the rest)."""
+    out = []
+    for _ in range(NL - 1):
+        d = x & MASK
+        if d >= HALF:
+            d -= 1 << LB
+        out.append(d)
+        x = (x - d) >> LB
+    out.append(x)
+    return out
+
+
+def unsigned_limbs(x):
+    """Canonical non-negative integer -> NL limbs in [0, 2^29) (top limb: the rest)."""
+    return [(x >> (LB * i)) & MASK for i in range(NL - 1)] + [x >> (LB * (NL - 1))]
+
+
+def from_limbs(l):
+    return sum(int(v) << (LB * i) for i, v in enumerate(l))
+
+
+def mont4(x):
+    return x * RP % P_INT
+
+
+def hx(v):
+    """32-bit two's-complement literal of a signed limb."""
+    return "0x%x" % (v & 0xFFFFFFFF)
+
+
+P_L = bal_limbs(P_INT)
+P_U = unsigned_limbs(P_INT)
+
+
+class L1v4:
+    def __init__(self, e):
+        self.e = e
+        self.pool = Pool(TMP_FIRST, TMP_LAST)
+        self.p = [f"s{S_P + i}" for i in range(NL)]
+        self.n0 = f"s{S_N0}"
+
+    # ------------------------------------------------------------------ 64-bit accumulator helpers
+    def _acc(self):
+        a = self.pool.alloc_pair()
+        return a, f"v[{a}:{a + 1}]"
+
+    def _mad(self, acc, P, x, y, first):
+        """acc64 (+)= x * y ; x, y: VGPR numbers (int) or operand text (SGPR name / inline constant as str)"""
+        X = f"v{x}" if isinstance(x, int) else x
+        Y = f"v{y}" if isinstance(y, int) else y
+        self.e.emit(f"v_mad_i64_i32 {P}, vcc, {X}, {Y}, {0 if first else P}", w=["vcc"], vw=[acc, acc + 1])
+
+    @staticmethod
+    def _coef(c):
+        """operand text of a small integer coefficient: inline constant (-16..64) or the SGPR that holds it"""
+        if -16 <= c <= 64:
+            return str(c)
+        return {-30: f"s{S_M30}"}[c]
+
+    def _digit(self, acc, P, dst):
+        """dst <- balanced low digit of the accumulator; accumulator <- (accumulator - digit) >> 29."""
+        self.e.emit(f"v_bfe_i32 v{dst}, v{acc}, 0, {LB}", vw=[dst])
+        self.e.emit(f"v_mad_i64_i32 {P}, vcc, v{dst}, -1, {P}", w=["vcc"], vw=[acc, acc + 1])
+        self.e.emit(f"v_ashrrev_i64 {P}, {LB}, {P}", vw=[acc, acc + 1])
+
+    # ------------------------------------------------------------------ fused Montgomery column pass
+    def fips(self, prods, out, fillers=(), gap=8):
+        """out[0..NL-1] <- (sum over (a, b) in prods of a*b) / R' mod p, balanced limbs, value in sum/R' +- p/2.
+        a, b: lists of NL VGPR numbers.  Result limb j is written after column j + NL, when limb j of every operand is
+        dead, so `out` may be one of the first operands a (in place) but must not overlap a second operand b.
+
+        fillers: independent instructions [(text, vw, earliest column, latest column)] dropped into the multiply runs
+        (work that has to be done anyway -- negations, copies -- and whose operands die / are born inside the pass)."""
+        acc, P = self._acc()
+        m = [self.pool.alloc() for _ in range(NL)]
+        first = True
+        todo = list(fillers)
+        run = 0
+        col = 0
+
+        def fill(force_before=None):
+            nonlocal run
+            for j, (text, vw, lo, hi) in enumerate(todo):
+                if (force_before is None and lo <= col) or (force_before is not None and hi <= force_before):
+                    self.e.emit(text, vw=vw)
+                    del todo[j]
+                    run = 0
+                    return True
+            return False
+
+        def mad(x, y):
+            nonlocal first, run
+            self._mad(acc, P, x, y, first)
+            first = False
+            run += 1
+            if run >= gap:
+                fill()
+
+        for k in range(2 * NL - 1):
+            col = k
+            while fill(force_before=k):
+                pass
+            lo_i, hi_i = max(0, k - (NL - 1)), min(NL - 1, k)
+            for (a, b) in prods:
+                for i in range(lo_i, hi_i + 1):
+                    mad(a[i], b[k - i])
+            if k < NL:
+                for i in range(k):
+                    mad(m[i], self.p[k - i])
+                self.e.emit(f"v_mul_lo_u32 v{m[k]}, v{acc}, {self.n0}", vw=[m[k]])
+                self.e.emit(f"v_bfe_i32 v{m[k]}, v{m[k]}, 0, {LB}", vw=[m[k]])
+                run = 0
+                mad(m[k], self.p[0])
+                self.e.emit(f"v_ashrrev_i64 {P}, {LB}, {P}", vw=[acc, acc + 1])
+            else:
+                for i in range(k - (NL - 1), NL):
+                    mad(m[i], self.p[k - i])
+                self._digit(acc, P, out[k - NL])
+                run = 0
+        self.e.emit(f"v_mov_b32_e32 v{out[NL - 1]}, v{acc}", vw=[out[NL - 1]])
+        for (text, vw, lo, hi) in todo:
+            self.e.emit(text, vw=vw)
+        self.pool.free(acc, acc + 1, *m)
+
+    def lincomb(self, outs, termss, reduce=False):
+        """outs[j] <- sum of coef * vec over termss[j] (lists of (inline-constant coefficient, limb list)), NORMALISED
+        (balanced limbs; top limb: the rest), on one 64-bit carry chain per output, the chains interleaved limb by limb so
+        that outputs may overwrite inputs (limb i of every input is dead once limb i of every output is written).
+        reduce: also subtract q p with q = round(top limb of the combination * 2^232 / p): result in (-0.51 p, 0.51 p)."""
+        n = len(outs)
+        accs = [self._acc() for _ in range(n)]
+        qs = []
+        if reduce:
+            # quotient estimate from the top limbs alone: the lower limbs shift the combination's top limb by at most
+            # sum|coef| / 2 units of 2^232, i.e. the quotient by < 1e-5
+            for terms, (acc, P) in zip(termss, accs):
+                if len(terms) == 1 and terms[0][0] == 1:
+                    q = self.pool.alloc()
+                    self.e.emit(f"v_mov_b32_e32 v{q}, v{terms[0][1][NL - 1]}", vw=[q])
+                else:
+                    for t_, (coef, vec) in enumerate(terms):
+                        self._mad(acc, P, vec[NL - 1], self._coef(coef), t_ == 0)
+                    q = self.pool.alloc()
+                    self.e.emit(f"v_mov_b32_e32 v{q}, v{acc}", vw=[q])
+                self._quot(q)
+                qs.append(q)
+        for i in range(NL):
+            for j, terms in enumerate(termss):
+                acc, P = accs[j]
+                first = i == 0
+                for coef, vec in terms:
+                    self._mad(acc, P, vec[i], self._coef(coef), first)
+                    first = False
+                if reduce:
+                    self._mad(acc, P, qs[j], self.p[i], False)
+            for j in range(n):
+                acc, P = accs[j]
+                if i < NL - 1:
+                    self._digit(acc, P, outs[j][i])
+                else:
+                    self.e.emit(f"v_mov_b32_e32 v{outs[j][i]}, v{acc}", vw=[outs[j][i]])
+        for acc, _ in accs:
+            self.pool.free(acc, acc + 1)
+        self.pool.free(*qs)
+
+    def _quot(self, q):
+        """q <- -round(q * 2^232 / p)  (q holds a top limb on entry)"""
+        self.e.emit(f"v_mul_hi_i32 v{q}, v{q}, s{S_REDN}", vw=[q])
+        self.e.emit(f"v_add_u32_e32 v{q}, 0x{1 << (REDN_SHIFT - 33):x}, v{q}", vw=[q])
+        self.e.emit(f"v_ashrrev_i32_e32 v{q}, {REDN_SHIFT - 32}, v{q}", vw=[q])
+        self.e.emit(f"v_sub_u32_e32 v{q}, 0, v{q}", vw=[q])
+
+    # ------------------------------------------------------------------ blocks
+    @staticmethod
+    def blk(base, half):
+        return list(range(base + NL * half, base + NL * half + NL))
+
+    def fq2(self, base):
+        return (self.blk(base, 0), self.blk(base, 1))
+
+    def limbwise(self, op, dst, a, b):
+        for i in range(NL):
+            self.e.emit(f"{op} v{dst[i]}, v{a[i]}, v{b[i]}", vw=[dst[i]])
+
+    def _lw(self, op, d, a, b):
+        for h in range(2):
+            self.limbwise(op, d[h], a[h], b[h])
+
+    def _neg_into(self, dst, src):
+        for i in range(NL):
+            self.e.emit(f"v_sub_u32_e32 v{dst[i]}, 0, v{src[i]}", vw=[dst[i]])
+
+    def norm_limbs(self, a):
+        """One balanced carry pass: limbs 0..NL-2 -> [-2^28, 2^28), excess pushed up (the top limb keeps the rest).
+        Limbs must be below 2^31 - 2^28 in magnitude."""
+        c = self.pool.alloc()
+        for i in range(NL - 1):
+            self.e.emit(f"v_add_u32_e32 v{c}, 0x{HALF:x}, v{a[i]}", vw=[c])
+            self.e.emit(f"v_ashrrev_i32_e32 v{c}, {LB}, v{c}", vw=[c])
+            self.e.emit(f"v_bfe_i32 v{a[i]}, v{a[i]}, 0, {LB}", vw=[a[i]])
+            self.e.emit(f"v_add_u32_e32 v{a[i + 1]}, v{a[i + 1]}, v{c}", vw=[a[i + 1]])
+        self.pool.free(c)
+
+    def unorm_limbs(self, a):
+        """Unsigned carry pass: limbs 0..NL-2 -> [0, 2^29) (floor carries; the top limb carries the sign of the value)."""
+        c = self.pool.alloc()
+        for i in range(NL - 1):
+            self.e.emit(f"v_ashrrev_i32_e32 v{c}, {LB}, v{a[i]}", vw=[c])
+            self.e.emit(f"v_and_b32_e32 v{a[i]}, 0x{MASK:x}, v{a[i]}", vw=[a[i]])
+            self.e.emit(f"v_add_u32_e32 v{a[i + 1]}, v{a[i + 1]}, v{c}", vw=[a[i + 1]])
+        self.pool.free(c)
+
+    # ------------------------------------------------------------------ routines: A <- op(A, B)
+    def _fq2_mul(self, x, y, o):
+        """o <- x * y (Fq2; x, y, o = (c0 limbs, c1 limbs)); o may be x itself (in place) or a disjoint block."""
+        (x0, x1), (y0, y1), (o0, o1) = x, y, o
+        n = [self.pool.alloc() for _ in range(NL)]
+        self._neg_into(n, x1)
+        self.fips([(x1, y0), (x0, y1)], o1)
+        self.fips([(x0, y0), (n, y1)], o0)
+        self.pool.free(*n)
+
+    def r_mul(self):
+        """(a0 + a1 u)(b0 + b1 u): two fused two-product passes, both in place over A."""
+        self._fq2_mul(self.fq2(A0), self.fq2(B0), self.fq2(A0))
+
+    def r_mul3(self):
+        """A <- A*B + H0*H1 + H2*H3 (Fq2 products, H_k = home block k), ONE reduction per output component:
+        two fused six-product column passes.  H0 and H2 are destroyed (their c1 halves get negated).  All six operands
+        normalised (54 products of 2^56 per column)."""
+        blocks = [(A0, B0), (HOME0, HOME0 + SLOT_DW), (HOME0 + 2 * SLOT_DW, HOME0 + 3 * SLOT_DW)]
+        xs = [self.fq2(x) for x, _ in blocks]
+        ys = [self.fq2(y) for _, y in blocks]
+        t = [self.pool.alloc() for _ in range(NL)]
+        prods = []
+        for (x0, x1), (y0, y1) in zip(xs, ys):
+            prods += [(x0, y1), (x1, y0)]
+        # x1[i] is dead in pass 1 after column i + NL - 1: its negation (for pass 2) rides in the upper columns
+        neg = [(f"v_sub_u32_e32 v{x1[i]}, 0, v{x1[i]}", [x1[i]], NL + i, 99) for i in range(NL) for (x0, x1) in xs]
+        self.fips(prods, t, fillers=neg, gap=6)                      # c1
+        prods = []
+        for (x0, x1), (y0, y1) in zip(xs, ys):
+            prods += [(x0, y0), (x1, y1)]
+        # c1 (in t) moves into A.c1 as soon as pass 2 has read A.c1[i] for the last time (column i + NL - 1)
+        mov = [(f"v_mov_b32_e32 v{A0 + NL + i}, v{t[i]}", [A0 + NL + i], NL + i, 99) for i in range(NL)]
+        self.fips(prods, self.blk(A0, 0), fillers=mov)               # c0, in place over A.c0
+        self.pool.free(*t)
+
+    def r_sqr(self):
+        """(a0 + a1 u)^2 = (a0+a1)(a0-a1) + 2 a0 a1 u ; both passes write in place.  A normalised."""
+        a0, a1 = self.fq2(A0)
+        t = [self.pool.alloc() for _ in range(NL)]
+        u = [self.pool.alloc() for _ in range(NL)]
+        self.limbwise("v_add_u32_e32", t, a0, a1)
+        self.limbwise("v_sub_u32_e32", u, a0, a1)
+        for r in a0:
+            self.e.emit(f"v_lshlrev_b32_e32 v{r}, 1, v{r}", vw=[r])     # a0 <- 2 a0 (t, u already hold what c0 needs)
+        self.fips([(a1, a0)], a1)                                       # c1 = a1 * 2a0, in place over a1
+        self.fips([(t, u)], a0)                                         # c0 over (dead) a0; t, u are temporaries
+        self.pool.free(*t)
+        self.pool.free(*u)
+
+    def r_sqr4c(self, xi=False):
+        """One Fq4 squaring of the Granger-Scott cyclotomic squaring WITH its recombination, all in registers:
+        (a + b y)^2, y^2 = xi, a in block A, b in block B, zc in home block 3, zd in home block 4 (all normalised):
+            A <- 3 (a^2 + xi b^2) - 2 zc        B <- 3 (2 a b) + 2 zd      (xi variant: B <- 3 xi (2 a b) + 2 zd)
+        both NORMALISED AND REDUCED (values in (-0.51 p, 0.51 p)).
+        t = a b ; S = xi b + a (normalised on a 64-bit chain) ; P = (a + b) S ; a^2 + xi b^2 = P - t - xi t.
+        Scratch: home blocks 0..2, the pool."""
+        a, b = self.fq2(A0), self.fq2(B0)
+        t = self.fq2(HOME0)
+        u = self.fq2(HOME0 + SLOT_DW)
+        s = self.fq2(HOME0 + 2 * SLOT_DW)
+        zc = self.fq2(HOME0 + 3 * SLOT_DW)
+        zd = self.fq2(HOME0 + 4 * SLOT_DW)
+        self._fq2_mul(a, b, t)                                          # t = a b (a, b stay intact)
+        # S = xi b + a = (9 b0 - b1 + a0, 9 b1 + b0 + a1), normalised
+        self.lincomb([s[0], s[1]], [[(9, b[0]), (-1, b[1]), (1, a[0])], [(9, b[1]), (1, b[0]), (1, a[1])]])
+        self._lw("v_add_u32_e32", u, a, b)                              # u = a + b (two units)
+        self._fq2_mul(u, s, u)                                          # P = u S, in place
+        # A <- 3 (P - t - xi t) - 2 zc = 3 P - 30 t0 + 3 t1 - 2 zc | 3 P1 - 30 t1 - 3 t0 - 2 zc1
+        self.lincomb([a[0], a[1]], [[(3, u[0]), (-30, t[0]), (3, t[1]), (-2, zc[0])],
+                                    [(3, u[1]), (-30, t[1]), (-3, t[0]), (-2, zc[1])]], reduce=True)
+        if not xi:                                                      # B <- 6 t + 2 zd
+            self.lincomb([b[0], b[1]], [[(6, t[0]), (2, zd[0])], [(6, t[1]), (2, zd[1])]], reduce=True)
+        else:                                                           # B <- 6 xi t + 2 zd = (54 t0 - 6 t1, 54 t1 + 6 t0) + 2 zd
+            self.lincomb([b[0], b[1]], [[(54, t[0]), (-6, t[1]), (2, zd[0])], [(54, t[1]), (6, t[0]), (2, zd[1])]], reduce=True)
+
+    def r_sqr4cx(self):
+        self.r_sqr4c(xi=True)
+
+    # ------------------------------------------------------------------ fused Fq6 multiplication
+    def r_mul6(self):
+        """Fq6 multiplication (Fq2[v]/(v^3 - xi), Karatsuba: six Fq2 multiplications), fused: a = (a0, a1, a2) in home blocks
+        0..2, b in home blocks 3..5, all NORMALISED.  Results, normalised and reduced:  c0 -> home block 1,  c1 -> block A,
+        c2 -> home block 0.  Scratch: home blocks 6, 7, blocks A, B, the pool.  Every input block is destroyed.
+        The recombinations run on 64-bit chains (the x xi term would overflow 32-bit limbs), which also reduce."""
+        H = lambda k: self.fq2(HOME0 + SLOT_DW * k)
+        a, b = [H(0), H(1), H(2)], [H(3), H(4), H(5)]
+        v0, v1 = H(6), H(7)
+        A, B = self.fq2(A0), self.fq2(B0)
+        self._fq2_mul(a[0], b[0], v0)
+        self._fq2_mul(a[1], b[1], v1)
+        # m01 = (a0 + a1)(b0 + b1)
+        self._lw("v_add_u32_e32", A, a[0], a[1])
+        self._lw("v_add_u32_e32", B, b[0], b[1])
+        self._fq2_mul(A, B, A)
+        # m02 = (a0 + a2)(b0 + b2), in place over a0 / b0 (both dead afterwards)
+        self._lw("v_add_u32_e32", a[0], a[0], a[2])
+        self._lw("v_add_u32_e32", b[0], b[0], b[2])
+        self._fq2_mul(a[0], b[0], a[0])
+        # m12 = (a1 + a2)(b1 + b2), in place over a1 / b1
+        self._lw("v_add_u32_e32", a[1], a[1], a[2])
+        self._lw("v_add_u32_e32", b[1], b[1], b[2])
+        self._fq2_mul(a[1], b[1], a[1])
+        v2 = B
+        self._fq2_mul(a[2], b[2], v2)
+        m01, m02, m12 = A, a[0], a[1]
+        # c1 = m01 - v0 - v1 + xi v2  -> block A (in place over m01)
+        self.lincomb([A[0], A[1]], [[(1, m01[0]), (-1, v0[0]), (-1, v1[0]), (9, v2[0]), (-1, v2[1])],
+                                    [(1, m01[1]), (-1, v0[1]), (-1, v1[1]), (9, v2[1]), (1, v2[0])]], reduce=True)
+        # c2 = m02 - v0 - v2 + v1  -> home block 0 (in place over m02)
+        self.lincomb([m02[0], m02[1]], [[(1, m02[0]), (-1, v0[0]), (-1, v2[0]), (1, v1[0])],
+                                        [(1, m02[1]), (-1, v0[1]), (-1, v2[1]), (1, v1[1])]], reduce=True)
+        # c0 = v0 + xi (m12 - v1 - v2)  -> home block 1 (in place over m12); w = m12 - v1 - v2: c0 = v0 + (9 w0 - w1, 9 w1 + w0)
+        w0 = [(9, m12[0]), (-9, v1[0]), (-9, v2[0]), (-1, m12[1]), (1, v1[1]), (1, v2[1]), (1, v0[0])]
+        w1 = [(9, m12[1]), (-9, v1[1]), (-9, v2[1]), (1, m12[0]), (-1, v1[0]), (-1, v2[0]), (1, v0[1])]
+        self.lincomb([m12[0], m12[1]], [w0, w1], reduce=True)
+
+    def r_mulfq(self):
+        """A <- (A.c0 * B.c0, A.c1 * B.c0), in place"""
+        a0, a1, k = self.blk(A0, 0), self.blk(A0, 1), self.blk(B0, 0)
+        self.fips([(a0, k)], a0)
+        self.fips([(a1, k)], a1)
+
+    def r_fqmul(self):
+        a0, k = self.blk(A0, 0), self.blk(B0, 0)
+        self.fips([(a0, k)], a0)
+
+    def r_fqsqr(self):
+        a0 = self.blk(A0, 0)
+        self.fips([(a0, a0)], a0)            # result limb j lands after column j + NL, when a0[j] is dead
+
+    def r_add(self):
+        self._lw("v_add_u32_e32", self.fq2(A0), self.fq2(A0), self.fq2(B0))
+
+    def r_sub(self):
+        self._lw("v_sub_u32_e32", self.fq2(A0), self.fq2(A0), self.fq2(B0))
+
+    def r_rsub(self):
+        self._lw("v_sub_u32_e32", self.fq2(A0), self.fq2(B0), self.fq2(A0))
+
+    def home_variant(self, op, idx):
+        """A <- A op HOME[idx] with the operand read straight from its home registers (no marshalling)."""
+        h = self.fq2(HOME0 + SLOT_DW * idx)
+        a = self.fq2(A0)
+        if op == "add":
+            self._lw("v_add_u32_e32", a, a, h)
+        elif op == "sub":
+            self._lw("v_sub_u32_e32", a, a, h)
+        else:
+            self._lw("v_sub_u32_e32", a, h, a)
+
+    def r_dbl(self):
+        for h in range(2):
+            for r in self.blk(A0, h):
+                self.e.emit(f"v_lshlrev_b32_e32 v{r}, 1, v{r}", vw=[r])
+
+    def r_neg(self):
+        for h in range(2):
+            for r in self.blk(A0, h):
+                self.e.emit(f"v_sub_u32_e32 v{r}, 0, v{r}", vw=[r])
+
+    def r_negc1(self):
+        for r in self.blk(A0, 1):
+            self.e.emit(f"v_sub_u32_e32 v{r}, 0, v{r}", vw=[r])
+
+    def r_mulxi(self):
+        """A <- (9 a0 - a1, a0 + 9 a1), NORMALISED (64-bit chains: 10 * 2^28 does not fit an int32 limb)."""
+        a0, a1 = self.fq2(A0)
+        self.lincomb([a0, a1], [[(9, a0), (-1, a1)], [(9, a1), (1, a0)]])
+
+    def r_mulxir(self):
+        """as mulxi, also reduced"""
+        a0, a1 = self.fq2(A0)
+        self.lincomb([a0, a1], [[(9, a0), (-1, a1)], [(9, a1), (1, a0)]], reduce=True)
+
+    def r_norm(self):
+        self.norm_limbs(self.blk(A0, 0))
+        self.norm_limbs(self.blk(A0, 1))
+
+    def r_redn(self):
+        """Normalise AND reduce the representative: A <- A - q p, q = round(top limb * 2^232 / p) per component: limbs
+        0..NL-2 in [-2^28, 2^28), value in (-0.51 p, 0.51 p).  Limbs of any int32 magnitude (64-bit chain)."""
+        a0, a1 = self.fq2(A0)
+        self.lincomb([a0, a1], [[(1, a0)], [(1, a1)]], reduce=True)
+
+    # ------------------------------------------------------------------ boundary conversions
+    def r_cvtin(self):
+        """A.c0 <- internal form of the packed external value in v[0:7] (8 x u32, canonical, Montgomery R = 2^256):
+        unpack to 29-bit limbs, then one Montgomery multiplication by 2^266 mod p (x 2^256 * 2^266 / 2^261 = x 2^261)."""
+        w = list(range(A0, A0 + 8))
+        l = [self.pool.alloc() for _ in range(NL)]
+        for i in range(NL):
+            bit = LB * i
+            j, s = bit // 32, bit % 32
+            if i == NL - 1:
+                self.e.emit(f"v_lshrrev_b32_e32 v{l[i]}, {s}, v{w[j]}", vw=[l[i]])
+                continue
+            if s + LB <= 32:
+                self.e.emit(f"v_bfe_u32 v{l[i]}, v{w[j]}, {s}, {LB}", vw=[l[i]])
+            else:
+                self.e.emit(f"v_alignbit_b32 v{l[i]}, v{w[j + 1]}, v{w[j]}, {s}", vw=[l[i]])
+                self.e.emit(f"v_and_b32_e32 v{l[i]}, 0x{MASK:x}, v{l[i]}", vw=[l[i]])
+        c = [self.pool.alloc() for _ in range(NL)]
+        cin = bal_limbs(pow(2, 2 * NL * LB - 256, P_INT))
+        for i in range(NL):
+            self.e.emit(f"v_mov_b32_e32 v{c[i]}, {hx(cin[i])}", vw=[c[i]])
+        self.fips([(l, c)], self.blk(A0, 0))         # A.c0 region (v0..v8) overlaps w only after w is dead
+        self.pool.free(*l)
+        self.pool.free(*c)
+
+    def r_cvtout(self):
+        """v[0:7] <- canonical external form (8 x u32, Montgomery R = 2^256, in [0, p)) of internal A.c0 (|value| < 80 p)."""
+        a0 = self.blk(A0, 0)
+        c = [self.pool.alloc() for _ in range(NL)]
+        cout = bal_limbs(pow(2, 256, P_INT))
+        for i in range(NL):
+            self.e.emit(f"v_mov_b32_e32 v{c[i]}, {hx(cout[i])}", vw=[c[i]])
+        w = [self.pool.alloc() for _ in range(NL)]
+        self.fips([(a0, c)], w)                        # w == y 2^256 mod p, in (-p, p)
+        self.pool.free(*c)
+        self.unorm_limbs(w)                            # floor carries: the top limb now has the sign of the value
+        msk = self.pool.alloc()
+        t = self.pool.alloc()
+        self.e.emit(f"v_ashrrev_i32_e32 v{msk}, 31, v{w[NL - 1]}", vw=[msk])
+        for i in range(NL):                            # w += p if negative
+            self.e.emit(f"v_and_b32_e32 v{t}, 0x{P_U[i]:x}, v{msk}", vw=[t])
+            self.e.emit(f"v_add_u32_e32 v{w[i]}, v{w[i]}, v{t}", vw=[w[i]])
+        self.unorm_limbs(w)
+        d = [self.pool.alloc() for _ in range(NL)]     # d = w - p ; take d if d >= 0 (w was in [0, 2p))
+        for i in range(NL):
+            self.e.emit(f"v_subrev_u32_e32 v{d[i]}, 0x{P_U[i]:x}, v{w[i]}", vw=[d[i]])
+        self.unorm_limbs(d)
+        self.e.emit(f"v_cmp_gt_i32_e32 vcc, 0, v{d[NL - 1]}", w=["vcc"])      # vcc = (d < 0)
+        for i in range(NL):
+            self.e.emit(f"v_cndmask_b32_e32 v{w[i]}, v{d[i]}, v{w[i]}, vcc", r=["vcc"], vw=[w[i]])
+        # repack 9 x 29 -> 8 x 32
+        for j in range(8):
+            lo_bit = 32 * j
+            i, s = lo_bit // LB, lo_bit % LB
+            dst = A0 + j
+            self.e.emit(f"v_lshrrev_b32_e32 v{dst}, {s}, v{w[i]}", vw=[dst])
+            sh1 = LB - s
+            if i + 1 < NL and sh1 < 32:
+                self.e.emit(f"v_lshl_or_b32 v{dst}, v{w[i + 1]}, {sh1}, v{dst}", vw=[dst])
+            sh2 = 2 * LB - s
+            if i + 2 < NL and sh2 < 32:
+                self.e.emit(f"v_lshl_or_b32 v{dst}, v{w[i + 2]}, {sh2}, v{dst}", vw=[dst])
+        self.pool.free(msk, t, *w)
+        self.pool.free(*d)
+
+
+L1V4_NAMES = ["mul", "mul3", "mul6", "sqr", "sqr4c", "sqr4cx", "mulfq", "add", "sub", "rsub", "dbl", "neg", "negc1", "mulxi", "mulxir", "norm",
+              "redn", "fqmul", "fqsqr", "cvtin", "cvtout"]
+
+if __name__ == "__main__":
+    for n in L1V4_NAMES:
+        e = Emitter()
+        g = L1v4(e)
+        getattr(g, "r_" + n)()
+        lines = e.finalize()
+        print(n, len(lines), "mads", sum(1 for l in lines if l.startswith("v_mad_i64")), "nops", sum(1 for l in lines if l.startswith("s_nop")),
+              "max tmp", max(g.pool.used) if g.pool.used else None)
