@@ -1,0 +1,347 @@
+"""The generated gfx950 kernels (tools/kgen4.py: L1 field routines on balanced radix-2^29 limbs; tools/kgen4_prog.py: L2/L3)
+executed on ONE lane by the instruction-level simulator tools/ksim.py, against big-int arithmetic and the golden fixtures.
+This is the CPU-side check of the product's instruction stream (the GPU parity tests run the same text on the hardware):
+results, 64-bit operand alignment, uninitialised-register reads, the VALU-writes-SGPR -> VALU-reads hazard distance and any
+signed 64-bit overflow of a column accumulator are all trapped here."""
+import os
+import random
+import re
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import asmcore as AC  # noqa: E402
+import kgen4 as K4  # noqa: E402
+import kgen4_prog as K4P  # noqa: E402
+import ksim as S  # noqa: E402
+import helpers as H  # noqa: E402
+from helpers import R  # noqa: E402
+
+P = AC.P_INT
+NL, LB = K4.NL, K4.LB
+HX = lambda xs: [int(x, 16) for x in xs]  # noqa: E731
+G1B, G2B, FINB, OUTB, SCR, STAT = 0x100000, 0x200000, 0x300000, 0x400000, 0x1000000, 0x500000
+
+
+def _sval(limbs):
+    v = 0
+    for i, l in enumerate(limbs):
+        l = l - (1 << 32) if l >> 31 else l
+        v += l << (LB * i)
+    return v
+
+
+def _redundant(x, rng, slack, k_p=3):
+    """A signed redundant representation of x + k p with limb borrows of up to `slack` units of 2^29."""
+    y = x + (rng.randrange(-k_p, k_p + 1) if slack else 0) * P
+    l = K4.bal_limbs(y)
+    for i in range(NL - 1):
+        b = rng.randrange(-slack, slack + 1) if slack else 0
+        l[i] += b << LB
+        l[i + 1] -= b
+    return l
+
+
+def _m4(vals, rng, slack):
+    m = S.Machine()
+    for i in range(NL):
+        m.s[K4.S_P + i] = K4.P_L[i] & 0xFFFFFFFF
+    m.s[K4.S_N0] = K4.N0P
+    m.s[K4.S_REDN] = K4.REDN_C
+    m.s[K4.S_M30] = (-30) & 0xFFFFFFFF
+    for j, x in enumerate(vals):
+        for i, w in enumerate(_redundant(x, rng, slack)):
+            m.v[NL * j + i] = w & 0xFFFFFFFF
+    return m
+
+
+def _body(n):
+    e = AC.Emitter()
+    getattr(K4.L1v4(e), "r_" + n)()
+    return e.finalize()
+
+
+def _is_norm(m, regs):
+    return all(-K4.HALF <= _sval([m.v[r]]) < K4.HALF for r in regs[:-1])
+
+
+def test_l1_routines():
+    """Redundant signed operands (negative limbs, limbs beyond 29 bits, value offsets by multiples of p): results are
+    checked mod p; normalised / reduced outputs are checked as such."""
+    rng = random.Random(7)
+    RPI = pow(K4.RP, -1, P)
+    B = {n: _body(n) for n in K4.L1V4_NAMES}
+
+    def rnd():
+        return rng.choice([0, 1, P - 1, P - 2]) if rng.random() < 0.25 else rng.randrange(P)
+
+    def val(m, j):
+        return _sval([m.v[NL * j + i] for i in range(NL)])
+
+    for t in range(30):
+        a0, a1, b0, b1 = rnd(), rnd(), rnd(), rnd()
+        sl = [0, 1, 1][t % 3]          # limb borrows of up to one radix unit: |limb| <= 3 * 2^28
+        want = {"mulfq": (a0 * b0 * RPI, a1 * b0 * RPI), "fqmul": (a0 * b0 * RPI, None), "fqsqr": (a0 * a0 * RPI, None),
+                "add": (a0 + b0, a1 + b1), "sub": (a0 - b0, a1 - b1), "rsub": (b0 - a0, b1 - a1), "dbl": (2 * a0, 2 * a1),
+                "neg": (-a0, -a1), "negc1": (a0, -a1), "norm": (a0, a1), "redn": (a0, a1), "mulxi": (9 * a0 - a1, a0 + 9 * a1),
+                "mulxir": (9 * a0 - a1, a0 + 9 * a1)}
+        if sl <= 1:
+            want["mul"] = ((a0 * b0 - a1 * b1) * RPI, (a0 * b1 + a1 * b0) * RPI)
+        if sl == 0:
+            want["sqr"] = ((a0 * a0 - a1 * a1) * RPI, 2 * a0 * a1 * RPI)
+        for name, (w0, w1) in want.items():
+            m = _m4([a0, a1, b0, b1], rng, sl)
+            S.run_block(B[name], m)
+            assert (val(m, 0) - w0) % P == 0, name
+            if w1 is not None:
+                assert (val(m, 1) - w1) % P == 0, name
+            if name in ("norm", "redn", "mulxi", "mulxir", "mul", "sqr", "mulfq"):
+                assert _is_norm(m, list(range(NL))) and _is_norm(m, list(range(NL, 2 * NL))), name
+            if name in ("redn", "mulxir"):
+                assert all(abs(val(m, j)) < 0.52 * P for j in range(2)), name
+            if name in ("mul", "sqr", "mulfq") and sl == 0:
+                assert all(abs(val(m, j)) < 0.6 * P for j in range(2)), name          # inputs below p: sum/R' +- p/2
+    f2m = lambda x, y: ((x[0] * y[0] - x[1] * y[1]) % P, (x[0] * y[1] + x[1] * y[0]) % P)
+    f2a = lambda x, y: ((x[0] + y[0]) % P, (x[1] + y[1]) % P)
+    sub = lambda x, y: ((x[0] - y[0]) % P, (x[1] - y[1]) % P)
+    xi = lambda x: ((9 * x[0] - x[1]) % P, (9 * x[1] + x[0]) % P)
+
+    def put(m, blk, el, neg=False):
+        for h in range(2):
+            for i, w in enumerate(K4.bal_limbs(el[h] if el[h] < P // 2 or True else el[h] - P)):
+                m.v[blk + NL * h + i] = (-w if neg else w) & 0xFFFFFFFF
+
+    # mul3: A <- A*B + H0*H1 + H2*H3
+    for t in range(12):
+        ops = [(rnd(), rnd()) for _ in range(6)]
+        m = _m4([], rng, 0)
+        for blk, el in zip((K4.A0, K4.B0, K4.HOME0, K4.HOME0 + K4.SLOT_DW, K4.HOME0 + 2 * K4.SLOT_DW, K4.HOME0 + 3 * K4.SLOT_DW), ops):
+            put(m, blk, el)
+        S.run_block(B["mul3"], m)
+        w = f2a(f2a(f2m(ops[0], ops[1]), f2m(ops[2], ops[3])), f2m(ops[4], ops[5]))
+        for h in range(2):
+            assert (val(m, h) - w[h] * RPI) % P == 0, ("mul3", t, h)
+        assert _is_norm(m, list(range(NL))) and _is_norm(m, list(range(NL, 2 * NL)))
+    # sqr4c / sqr4cx: Fq4 squaring of the cyclotomic squaring with the Granger-Scott recombination (zc, zd in home blocks 3, 4)
+    for t in range(12):
+        a, b, zc, zd = [(rnd(), rnd()) for _ in range(4)]
+        for name in ("sqr4c", "sqr4cx"):
+            m = _m4([], rng, 0)
+            for r in range(K4.HOME0, K4.HOME0 + 3 * K4.SLOT_DW):
+                m.v[r] = rng.getrandbits(32)     # scratch blocks hold garbage
+            neg = t % 3 == 1                     # conjugates arrive as limb-wise negations
+            put(m, K4.A0, a, neg)
+            put(m, K4.B0, b, neg)
+            put(m, K4.HOME0 + 3 * K4.SLOT_DW, zc)
+            put(m, K4.HOME0 + 4 * K4.SLOT_DW, zd)
+            S.run_block(B[name], m)
+            r0 = f2a(f2m(a, a), xi(f2m(b, b)))
+            tt = f2m(a, b)
+            if name == "sqr4cx":
+                tt = xi(tt)
+            want = [3 * r0[0] * RPI - 2 * zc[0], 3 * r0[1] * RPI - 2 * zc[1], 6 * tt[0] * RPI + 2 * zd[0], 6 * tt[1] * RPI + 2 * zd[1]]
+            for j in range(4):
+                assert (val(m, j) - want[j]) % P == 0, (name, t, j)
+                assert _is_norm(m, list(range(NL * j, NL * j + NL))) and abs(val(m, j)) < 0.52 * P, (name, t, j)
+    # mul6 (fused Fq6 multiplication): normalised operands in home blocks 0..5
+    for t in range(10):
+        a = [(rnd(), rnd()) for _ in range(3)]
+        b = [(rnd(), rnd()) for _ in range(3)]
+        m = _m4([], rng, 0)
+        for r in list(range(K4.HOME0 + 6 * K4.SLOT_DW, K4.HOME0 + 8 * K4.SLOT_DW)) + list(range(0, 2 * K4.SLOT_DW)):
+            m.v[r] = rng.getrandbits(32)
+        for k, el in enumerate(a + b):
+            put(m, K4.HOME0 + K4.SLOT_DW * k, el, neg=False)
+        S.run_block(B["mul6"], m)
+        v = [f2m(a[i], b[i]) for i in range(3)]
+        cross = lambda i, j: f2m(f2a(a[i], a[j]), f2a(b[i], b[j]))
+        want = [f2a(v[0], xi(sub(sub(cross(1, 2), v[1]), v[2]))), f2a(sub(sub(cross(0, 1), v[0]), v[1]), xi(v[2])),
+                f2a(sub(sub(cross(0, 2), v[0]), v[2]), v[1])]
+        where = [K4.HOME0 + K4.SLOT_DW, K4.A0, K4.HOME0]            # c0 -> home 1, c1 -> A, c2 -> home 0
+        for c in range(3):
+            for h in range(2):
+                regs = list(range(where[c] + NL * h, where[c] + NL * h + NL))
+                x = _sval([m.v[r] for r in regs])
+                assert (x - want[c][h] * RPI) % P == 0, ("mul6", t, c, h)
+                assert _is_norm(m, regs) and abs(x) < 0.52 * P
+    # extreme operands: every limb at the largest magnitude the routines accept (the simulator traps any signed 64-bit overflow
+    # of a column accumulator; an int32 overflow shows up as a wrong residue elsewhere)
+    top = K4.HALF
+    for name, mag_, homes in (("mul6", 1, range(6)), ("sqr4c", 1, (3, 4)), ("sqr4cx", 1, (3, 4)), ("mul", 2.5, ()), ("mul3", 1, range(4)), ("sqr", 1.8, ())):
+        for pattern in (lambda i: 1, lambda i: -1, lambda i: 1 if i % 2 else -1, lambda i: 1 if (i // 2) % 2 else -1):
+            m = _m4([], rng, 0)
+            for r in range(0, K4.HOME0 + 9 * K4.SLOT_DW):
+                m.v[r] = rng.getrandbits(32) if r >= 2 * K4.SLOT_DW else 0
+            blocks = [K4.A0, K4.B0] + [K4.HOME0 + K4.SLOT_DW * k for k in homes]
+            for blk in blocks:
+                for i in range(K4.SLOT_DW):
+                    m.v[blk + i] = int(pattern(i) * mag_ * top) & 0xFFFFFFFF
+            S.run_block(B[name], m)
+            assert m.max_acc < (1 << 63)
+    # redn on large representatives (x + t p) with unnormalised limbs of any int32 magnitude
+    for t in range(40):
+        xs = [rnd() + rng.randrange(-300, 300) * P for _ in range(2)]
+        m = _m4([], rng, 0)
+        for j, x in enumerate(xs):
+            l = K4.bal_limbs(x)
+            for i in range(NL - 1):
+                bw = rng.randrange(-3, 4) if t % 2 else 0
+                l[i] += bw << LB
+                l[i + 1] -= bw
+            for i in range(NL):
+                m.v[NL * j + i] = l[i] & 0xFFFFFFFF
+        S.run_block(B["redn"], m)
+        for j in range(2):
+            assert (val(m, j) - xs[j]) % P == 0 and abs(val(m, j)) < 0.52 * P, (t, j)
+            assert _is_norm(m, list(range(NL * j, NL * j + NL)))
+    # boundary conversions: ark 4 x u64 Montgomery (R = 2^256) <-> internal; cvtout is canonical
+    for t in range(30):
+        x = rnd()
+        ext = (x << 256) % P
+        m = _m4([], rng, 0)
+        for i in range(8):
+            m.v[i] = (ext >> (32 * i)) & 0xFFFFFFFF
+        S.run_block(B["cvtin"], m)
+        assert (val(m, 0) - x * K4.RP) % P == 0 and _is_norm(m, list(range(NL)))
+        y = (x * K4.RP) % P + rng.randrange(-60, 61) * P          # any representative the kernels may hold
+        m2 = _m4([], rng, 0)
+        for i, w in enumerate(K4.bal_limbs(y)):
+            m2.v[i] = w & 0xFFFFFFFF
+        S.run_block(B["cvtout"], m2)
+        assert sum(m2.v[i] << (32 * i) for i in range(8)) == ext
+
+
+# ---------------------------------------------------------------- whole kernels on one lane
+def _concretize(lines):
+    ops = {"%0": "s[2:3]", "%1": "s[4:5]", "%2": "s[6:7]", "%3": "s[8:9]", "%4": "s10", "%5": "s11", "%6": "s[12:13]", "%7": "s14", "%8": "s[16:17]",
+           "%9": "v255", "%10": "s18", "%11": "s19"}
+    out = []
+    for l in lines:
+        l = re.sub(r"%(1[01]|\d)(?!\d)", lambda mo: ops["%" + mo.group(1)], l)
+        out.append(l.replace("_%=", "_0"))
+    return out
+
+
+def _first_diff(a, b):
+    for i, (x, y) in enumerate(zip(a, b)):
+        if x != y:
+            return f"call {i}: executed {a[max(0, i - 3):i + 3]} certified {b[max(0, i - 3):i + 3]}"
+    return f"lengths {len(a)} vs {len(b)}"
+
+
+def run_kernel(kb, g1=None, g2=None, fin=None, k=1, check_seq=True, profile=False):
+    lines = _concretize(kb.build()) + ["s_endpgm"]
+    m = S.Machine()
+
+    def put64(base, words):
+        for i, w in enumerate(words):
+            m.gmem[base + 8 * i] = w & 0xFFFFFFFF
+            m.gmem[base + 8 * i + 4] = (w >> 32) & 0xFFFFFFFF
+
+    for base, words in ((G1B, g1), (G2B, g2), (FINB, fin)):
+        if words is not None:
+            put64(base, words)
+    for name, val in (("s[2:3]", G1B), ("s[4:5]", G2B), ("s[6:7]", FINB), ("s[8:9]", OUTB), ("s10", 1), ("s11", k), ("s[12:13]", SCR),
+                      ("s14", 256 * K4.SLOT_BYTES), ("s[16:17]", STAT), ("s18", 0), ("s19", 1)):
+        m.sset(name, val)
+    m.v[255] = 0
+    m.call_log = []
+    if profile:
+        m.profile = {}
+    S.run(lines, m)
+    if check_seq:
+        # the statically certified call sequence (value bounds, tools/kgen4_prog.py: certify_values) is the one executed
+        rep = kb.certify_values(k_pairs=k)
+        log = [re.sub(r"_\d+$", "", x) for x in m.call_log]
+        assert log == rep["sequence"], _first_diff(log, rep["sequence"])
+        assert rep["max_stored"] <= K4P.V_CAP
+    out = []
+    for c in range(12):
+        v = 0
+        for l in range(4):
+            a = OUTB + (c * 4 + l) * 8
+            v |= (m.gmem[a] | (m.gmem[a + 4] << 32)) << (64 * l)
+        out.append(R.from_mont(v))
+    return out, m
+
+
+@pytest.fixture(scope="module")
+def vec():
+    return H.load_golden("bn254_vectors.json")
+
+
+def _inputs(vec, i):
+    g1 = [w for c in HX(vec["g1"][i]) for w in R.limbs4(R.to_mont(c))]
+    g2 = [w for c in HX(vec["g2"][i]) for w in R.limbs4(R.to_mont(c))]
+    return g1, g2
+
+
+def test_miller_kernel_exact(vec):
+    g1, g2 = _inputs(vec, 3)
+    out, m = run_kernel(K4P.KernelBuilder(do_miller=True, do_fexp=False, track=True), g1, g2)
+    assert out == HX(vec["miller"][3]) and STAT not in m.gmem
+    assert m.max_acc < (1 << 63)
+
+
+def test_final_exp_kernel(vec):
+    x = HX(vec["fq12_in"][2])
+    fin = [w for c in x for w in R.limbs4(R.to_mont(c))]
+    out, m = run_kernel(K4P.KernelBuilder(do_miller=False, do_fexp=True), fin=fin)
+    assert out == HX(vec["final_exp"][2])
+    out, m = run_kernel(K4P.KernelBuilder(do_miller=False, do_fexp=True), fin=[0] * 48)
+    assert m.gmem.get(STAT) == 1            # zero input: the reference panics
+
+
+def test_pairing_kernel_generators(vec):
+    """BASELINE.json configs[0]: e(G1gen, G2gen) through the fused default kernel."""
+    g1, g2 = _inputs(vec, 0)
+    out, m = run_kernel(K4P.KernelBuilder(do_miller=True, do_fexp=True), g1, g2)
+    assert out == HX(vec["pairing"][0])
+
+
+def test_multi_pairing_kernel(vec):
+    """k = 2 shared-f kernel: exact multi_miller_loop_native value (tracked scale)."""
+    g = vec["groups"][0]
+    k, idx = g["k"], g["idx"]
+
+    def soa(rows):
+        n = len(rows)
+        out = [0] * (len(rows[0]) * 4 * n)
+        for i, el in enumerate(rows):
+            for c, x in enumerate(el):
+                for l, w in enumerate(R.limbs4(R.to_mont(x))):
+                    out[(c * 4 + l) * n + i] = w
+        return out
+
+    g1, g2 = soa([HX(vec["g1"][i]) for i in idx]), soa([HX(vec["g2"][i]) for i in idx])
+    out, m = run_kernel(K4P.KernelBuilder(do_miller=True, do_fexp=False, track=True, multi=True), g1, g2, k=k)
+    assert out == HX(g["miller"])
+
+
+def test_helper_kernel(vec):
+    """k_op: MyFq12 Mul, frobenius_map_native and pow_native (general, non-unitary elements)."""
+    xs = [HX(x) for x in vec["fq12_in"]]
+    fq12_words = lambda x: [w for c in x for w in R.limbs4(R.to_mont(c))]
+    kb = K4P.KernelBuilder(helper=True)
+    a, b = xs[1], xs[2]
+    # Mul: a * b (golden fq12_mul[i] = fq12_in[i] * fq12_in[i + 1])
+    out, m = run_kernel(kb, g1=fq12_words(b), fin=fq12_words(a), k=kb.OP_MUL, check_seq=False)
+    assert out == HX(vec["fq12_mul"][1]) and STAT not in m.gmem
+    for power in (1, 2, 3, 6, 11):
+        out, m = run_kernel(kb, fin=fq12_words(a), k=kb.OP_FROB | power << 8, check_seq=False)
+        assert out == HX(vec["frobenius"][str(power)][1]), f"frobenius power {power}"
+    # pow_native(a, [BN_X]) with the reference's NAF (get_naf), -1 digits divide
+    naf = R.get_naf([R.BN_X])
+    while naf[-1] == 0:
+        naf.pop()
+    assert naf[-1] == 1
+    packed = bytes((d & 0xFF) for d in naf) + b"\0" * 8
+    words = [int.from_bytes(packed[8 * i: 8 * i + 8], "little") for i in range(len(packed) // 8)]
+    out, m = run_kernel(kb, g2=words, fin=fq12_words(a), k=kb.OP_POW | 1 << 8 | len(naf) << 16, check_seq=False)
+    assert out == HX(vec["pow_x"][1]) and STAT not in m.gmem
+    # an exponent without -1 digits never divides: a = 0 is not an error (0^5 = 0)
+    out, m = run_kernel(kb, g2=[0x0000000000010001], fin=[0] * 48, k=kb.OP_POW | 3 << 16, check_seq=False)
+    assert out == [0] * 12 and STAT not in m.gmem
+    kb.certify_helper()

@@ -1,0 +1,1923 @@
+#!/usr/bin/env python3
+"""kgen4_prog.py -- L2 (Fq12 arithmetic, curve steps) and L3 (kernels) of the generated gfx950 assembly.
+
+Everything a lane computes is emitted from here as ONE inline-asm blob per kernel on top of the L1 field routines of
+tools/kgen4.py (balanced signed radix-2^29 limbs, nine limbs, Montgomery R' = 2^261); hipcc only provides the kernel
+descriptor and hands the kernel arguments over in SGPRs.
+
+Model
+  * "accumulator machine" on Fq2 values: block A = v[0:17], block B = v[18:35]; an L1 routine computes A <- op(A, B).
+    Values live in SLOTS of 18 dwords (72 B): LDS (8 per lane: four ds_*_b128 chunks + one ds_*_b64 tail), VGPR homes
+    (9), AGPRs (14) and, for cold Fq12 registers of the final exponentiation and per-pair state of the multi-pairing
+    kernels, global scratch.  L2 code is a sequence of   p.A(x).mul(y).sub(v1).mulxi().add(v0).to(c0).
+  * STATIC BOUND TRACKER (class Prog): every value carries (a) an interval, in units of 2^28, that contains all of its
+    limbs, (b) a bound, in units of p, of the integer it represents.  Each multiplication asserts at generation time that
+    its signed 64-bit column sums cannot overflow, `norm` (one balanced carry pass) / `redn` (normalise and subtract the
+    right multiple of p) are inserted exactly where a bound would be exceeded, and KernelBuilder.certify_values() replays
+    every kernel's data-independent call sequence on per-slot bounds (tests/test_bounds.py).
+  * the same instruction stream is executed by tools/ksim.py (single-lane simulator) in the CPU tests.
+
+Reference functions implemented here (file:line under /root/reference/src):
+  miller_loop_native.rs:10-44 (line functions), :46-110 (sparse multiplications), :112-190 / :192-282 (Miller loops),
+  :298-312 (twisted Frobenius); final_exp_native.rs:17-54 (frobenius_map_native), :56-84 (pow_native), :130-169
+  (hard part), :171-181 (conjugate), :195-213 (easy part, final_exp_native).
+"""
+import math
+import os
+import re
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from asmcore import Emitter, P_INT, BN_X, SIX_U_PLUS_2_NAF, align_code, max_branch_distance  # noqa: E402
+from kgen4 import (A0, B0, HOME0, L1V4_NAMES, L1v4, LB, N0P, N_AGPR_SLOTS, N_HOME, N_LDS_SLOTS, NL, P_L, REDN_C, S_M30, S_N0, S_P, S_REDN,  # noqa: E402
+                   S_RET1, S_RET2, S_RET3, SLOT_DW, SLOT_BYTES, V_FLAG, V_GOFF, V_IDX, V_IDX8, V_LDS, V_LTAIL, V_TID, bal_limbs, hx, mont4)
+
+# ---- scalar registers used by L2/L3 (all inside the clobbered range s36..s101) ----------------
+S_TMP0, S_TMP1 = 60, 61
+S_GADDR = "s[62:63]"      # address of the global slot being accessed
+S_SCRATCH = "s[64:65]"    # scratch base of this workgroup
+S_GSTRIDE = 66            # bytes between consecutive global slots
+S_I = 67                  # Miller-loop digit index
+S_NAF_NZ = "s[68:69]"     # 6u+2 NAF: non-zero mask, negative mask (digits 0..63)
+S_NAF_NEG = "s[70:71]"
+S_XNAF_NZ = "s[72:73]"    # x-power digit masks
+S_XNAF_NEG = "s[74:75]"
+S_XNAF_RED = "s[48:49]"   # digits after which the accumulator's representative is reduced (L2_redF)
+S_XIDX0, S_XIDX1 = "s[50:51]", "s[52:53]"      # which power a non-zero digit selects (index into X_POWERS)
+S_J = 76                  # pow_x digit index
+S_GBASE = 77              # global Fq12 register operand of fq12_mul (slot number * stride, low 32 bits)
+S_ITEM = 78
+S_NITEMS = 79
+S_G1 = "s[80:81]"
+S_G2 = "s[82:83]"
+S_OUT = "s[84:85]"
+S_N = 86                  # batch size (u32)
+S_GRID = 87
+S_IOADDR = "s[88:89]"
+S_NSTRIDE = 90            # n * 8 (bytes between limbs in the SoA batch)
+S_PHASE = 91
+S_STATUS = "s[92:93]"
+S_FIN = "s[94:95]"
+S_K = 96
+S_JP = 97                 # pair counter of the multi-pairing kernels
+S_SAVE_EXEC = "s[98:99]"
+S_PB = 100                # byte offset of the base's scratch register during the x-power routine
+BLOCK = 256
+
+
+class Slot:
+    def __init__(self, kind, idx, name=""):
+        self.kind, self.idx, self.name = kind, idx, name
+
+    def __repr__(self):
+        return f"{self.kind}{self.idx}" + (f"({self.name})" if self.name else "")
+
+
+def LDS(i, name=""):
+    assert 0 <= i < N_LDS_SLOTS
+    return Slot("lds", i, name)
+
+
+def HOME(i, name=""):
+    assert 0 <= i < N_HOME
+    return Slot("home", i, name)
+
+
+def AGPR(i, name=""):
+    assert 0 <= i < N_AGPR_SLOTS
+    return Slot("agpr", i, name)
+
+
+def GLOB(i, name=""):
+    return Slot("glob", i, name)
+
+
+class GlobDyn:
+    """Global slot whose number is base register S_GBASE (bytes) + k * stride (runtime Fq12 operand)."""
+
+    def __init__(self, k):
+        self.kind, self.k = "globdyn", k
+
+
+class Const:
+    """Fq2 constant (canonical integers), materialised with literal moves."""
+
+    def __init__(self, c0, c1, name=""):
+        self.kind, self.c0, self.c1, self.name = "const", c0, c1, name
+
+
+def f2mul(a, b):
+    return ((a[0] * b[0] - a[1] * b[1]) % P_INT, (a[0] * b[1] + a[1] * b[0]) % P_INT)
+
+
+def f2pow(a, e):
+    r = (1, 0)
+    for bit in bin(e)[2:]:
+        r = f2mul(r, r)
+        if bit == "1":
+            r = f2mul(r, a)
+    return r
+
+
+def naf_masks(naf):
+    nz = sum(1 << i for i, d in enumerate(naf) if d != 0)
+    neg = sum(1 << i for i, d in enumerate(naf) if d < 0)
+    return nz, neg
+
+
+def _three_b():
+    xi_inv_n = pow(82, -1, P_INT)          # 1/(9+u) = (9 - u)/82
+    return Const(81 * xi_inv_n % P_INT, (-9 * xi_inv_n) % P_INT, "threeb")
+
+
+THREE_B = _three_b()        # 3 b' = 9 / xi (twist curve y^2 = x^3 + 3/xi)
+
+# ---- x-power schedule of the final exponentiation (F <- F^BN_X for cyclotomic F, three times per pairing).
+# pow_native (final_exp_native.rs:56-84) walks the NAF of BN_X: 62 squarings + 23 multiplications.  The value F^x does
+# not depend on the chain, so the kernels use a signed fixed-set recoding instead: digits in {0, +-1, +-5, +-9, +-13}
+# (found by exhaustive search over digit sets, tools/exp/xchain.py): 59 squarings + 12 multiplications in the loop and
+# b^4, b^5, b^9, b^13 from 2 squarings + 3 multiplications: 61 S + 15 M instead of 62 S + 23 M (a squaring costs a
+# third of a multiplication).  Negative digits multiply by the conjugate (= inverse of a unitary element).
+X_POWERS = (1, 5, 9, 13)
+X_DIGITS = (-13, -1, 0, 0, 0, 0, 0, 0, 0, 5, 0, 0, 0, 0, 0, 0, 9, 0, 0, 0, 0, -13, 0, 0, 0, 0, -13, 0, 0, 0, 0, 9, 0, 0, 0, 0, -5, 0, 0, 0, -13,
+            0, 0, 0, 0, 13, 0, 0, 0, 0, 0, 5, 0, 0, -13, 0, 0, 0, 0, 9)            # least significant first
+assert sum(d << i for i, d in enumerate(X_DIGITS)) == BN_X and X_DIGITS[-1] in X_POWERS
+assert all(d == 0 or abs(d) in X_POWERS for d in X_DIGITS)
+G_POW = {5: 8, 9: 9, 13: 10}     # scratch Fq12 registers of b^5, b^9, b^13 (b itself: the caller's register)
+G_B4 = 11                        # b^4 (only while the powers are built)
+N_GREG = 12                      # Fq12 scratch registers G0..G11 = slots 0..71
+GLOB_TMP0 = 6 * N_GREG           # eight overflow temporaries: slots 72..79
+N_GSLOTS = GLOB_TMP0 + 8         # scratch slots of the single-pairing kernels; pair j of a multi kernel: N_GSLOTS + 7 j + ...
+
+ALIGN_CODE = bool(int(os.environ.get("KGEN_ALIGN", "1")))     # keep 8-byte instructions 8-byte aligned (asmcore.align_code)
+
+# ---- static bound tracking -------------------------------------------------------------------------------------------
+# LIMB intervals are in units of U = 2^28 (the magnitude bound of a normalised balanced limb) and cover all limbs of both
+# Fq2 components; VALUE bounds are in units of p.
+#   * a column pass over n_terms limb products of magnitudes (ma, mb) plus the reduction's 9 products of balanced m and
+#     p limbs stays inside the signed 64-bit accumulator iff  n_terms ma mb + 9 + (carry) < 2^63 / 2^56 = 128;
+#   * a reduction maps sum(a_i b_i) to sum(a_i b_i) / R' +- p/2 and R'/p = 169.6: values contract only while they are small;
+#   * the top limb (weight 2^232) carries the representative: value v p <-> |top| = v / K_TOP units.
+COL_BUDGET = 118.0
+K_RP = float((1 << (NL * LB)) / P_INT)              # 169.6
+K_TOP = float((1 << (LB * (NL - 1) + LB - 1)) / P_INT)   # 84.8: value (in p) per unit of the top limb
+V_CAP = 84.0                # nothing larger is ever stored or multiplied: the top limb then stays within one unit
+V_STORE = 4.0               # contract: bound (in p) of a value another routine left in a slot (routine boundaries)
+V_REDN_AT = 4.0             # a store that has to normalise anyway reduces as well when the value bound exceeds this
+STORE_MAG = 2.05            # stored values may keep limbs of up to two units (sums / differences of two normalised values)
+LIMB_MAG = 6.9              # int32 limbs that `norm` may meet: |limb| + 2^28 < 2^31
+R_NORM = (-1.0, 1.0)
+
+
+def mag(r):
+    return max(abs(r[0]), abs(r[1]))
+
+
+def r_add(a, b):
+    return (a[0] + b[0], a[1] + b[1])
+
+
+def r_sub(a, b):
+    return (a[0] - b[1], a[1] - b[0])
+
+
+def r_neg(a):
+    return (-a[1], -a[0])
+
+
+def r_hull(a, b):
+    return (min(a[0], b[0]), max(a[1], b[1]))
+
+
+def x_red_mask(digits, run_len):
+    """Bit j set: digit j of the x-power loop (walked from the top, as L3_powx does) is zero and closes a run of
+    `run_len` squarings without a multiplication -> L2_redF is called there."""
+    mask, run = 0, 0
+    if not run_len:
+        return 0
+    for j in range(len(digits) - 1, -1, -1):
+        run += 1
+        if digits[j] != 0:
+            run = 0
+        elif run == run_len:
+            mask |= 1 << j
+            run = 0
+    return mask
+
+
+class Prog:
+    """Accumulator-machine program over slots with static limb / value bounds."""
+
+    UNKNOWN = (-STORE_MAG, STORE_MAG)      # contract for values stored by other routines
+    STORED_NORM = R_NORM                   # slots in `norm_keys` hold NORMALISED values on every routine boundary
+
+    def __init__(self, e, l1_labels):
+        self.e = e
+        self.l1 = l1_labels
+        self.tagA = None
+        self.tagB = None
+        self.free_tmp = []
+        self.lds_pending = False
+        self.vm_pending = False
+        self.stats = {}
+        self.rA = None
+        self.slot_r = {}
+        self.vA = V_STORE
+        self.slot_v = {}
+        self.max_v = 0.0
+        self.norm_keys = frozenset()
+        self.entry_v = {}           # certification: bounds of the values other routines left in the slots
+        self.default_v = V_STORE
+        self.read_keys = {}         # slot keys whose entry bound was used -> the bound
+        self.temp_keys = frozenset()
+        self.homes_free = False
+        self.cold = False
+        self._blocks_reserved = False
+
+    # ---------------------------------------------------------------- bounds
+    @staticmethod
+    def key(slot):
+        if slot.kind == "globdyn":
+            return ("globdyn", slot.k)
+        if slot.kind == "const":
+            return ("const", slot.name)
+        return (slot.kind, slot.idx)
+
+    def v_of(self, slot):
+        if slot.kind == "const":
+            return 1.0
+        k = self.key(slot)
+        if k in self.slot_v:
+            return self.slot_v[k]
+        v = self.entry_v.get(k, self.default_v)
+        self.read_keys[k] = v
+        return v
+
+    def r_of(self, slot):
+        if slot.kind == "const":
+            return R_NORM
+        k = self.key(slot)
+        return self.slot_r.get(k, self.STORED_NORM if k in self.norm_keys else self.UNKNOWN)
+
+    def r_norm(self, v=None):
+        """Limb interval of a normalised value: limbs 0..NL-2 in [-1, 1) units; the signed top limb carries the value."""
+        t = (self.vA if v is None else v) / K_TOP
+        return (-max(1.0, t), max(1.0, t))
+
+    def _need(self, ok, what):
+        if not ok:
+            raise AssertionError("bound violated: " + what)
+
+    def _count(self, k):
+        self.stats[k] = self.stats.get(k, 0) + 1
+
+    # ---------------------------------------------------------------- data movement (18-dword slots)
+    N_B128 = SLOT_DW // 4          # four 16-byte chunks ...
+    TAIL_DW = SLOT_DW % 4          # ... and one 8-byte tail
+
+    def _lds_addr(self, slot, c):
+        """(address VGPR, offset) of 16-byte chunk c of an LDS slot: [slot][chunk][lane] uint4"""
+        ci = slot.idx * self.N_B128 + c
+        return V_LDS + ci // 16, (ci % 16) * 4096
+
+    def _lds_tail(self, slot):
+        return V_LTAIL, slot.idx * 2048
+
+    def _glob_base(self, slot):
+        if slot.kind == "glob":
+            self.e.salu(f"s_mul_i32 s{S_TMP0}, s{S_GSTRIDE}, {slot.idx}")
+        else:
+            self.e.salu(f"s_mul_i32 s{S_TMP0}, s{S_GSTRIDE}, {slot.k}")
+            self.e.salu(f"s_add_u32 s{S_TMP0}, s{S_TMP0}, s{S_GBASE}")
+        self.e.salu(f"s_add_u32 s62, s64, s{S_TMP0}")
+        self.e.salu("s_addc_u32 s63, s65, 0")
+
+    def load(self, blk, slot):
+        e = self.e
+        if slot.kind == "lds":
+            for c in range(self.N_B128):
+                base, off = self._lds_addr(slot, c)
+                e.emit(f"ds_read_b128 v[{blk + 4 * c}:{blk + 4 * c + 3}], v{base} offset:{off}", kind="lds", vw=range(blk + 4 * c, blk + 4 * c + 4))
+            base, off = self._lds_tail(slot)
+            e.emit(f"ds_read_b64 v[{blk + 16}:{blk + 17}], v{base} offset:{off}", kind="lds", vw=[blk + 16, blk + 17])
+            self.lds_pending = True
+        elif slot.kind == "home":
+            r0 = HOME0 + SLOT_DW * slot.idx
+            for i in range(SLOT_DW):
+                e.emit(f"v_mov_b32_e32 v{blk + i}, v{r0 + i}", vw=[blk + i])
+        elif slot.kind == "agpr":
+            for i in range(SLOT_DW):
+                e.emit(f"v_accvgpr_read_b32 v{blk + i}, a{SLOT_DW * slot.idx + i}", vw=[blk + i])
+        elif slot.kind == "const":
+            w = bal_limbs(mont4(slot.c0)) + bal_limbs(mont4(slot.c1))
+            for i in range(SLOT_DW):
+                e.emit(f"v_mov_b32_e32 v{blk + i}, {hx(w[i])}", vw=[blk + i])
+        elif slot.kind in ("glob", "globdyn"):
+            self._glob_base(slot)
+            for c in range(self.N_B128):
+                e.emit(f"global_load_dwordx4 v[{blk + 4 * c}:{blk + 4 * c + 3}], v{V_GOFF}, {S_GADDR} offset:{16 * c}", kind="vmem",
+                       vw=range(blk + 4 * c, blk + 4 * c + 4))
+            e.emit(f"global_load_dwordx2 v[{blk + 16}:{blk + 17}], v{V_GOFF}, {S_GADDR} offset:64", kind="vmem", vw=[blk + 16, blk + 17])
+            self.vm_pending = True
+        else:
+            raise ValueError(slot.kind)
+        self._count("ld_" + slot.kind)
+
+    def store(self, blk, slot):
+        e = self.e
+        if slot.kind == "lds":
+            for c in range(self.N_B128):
+                base, off = self._lds_addr(slot, c)
+                e.emit(f"ds_write_b128 v{base}, v[{blk + 4 * c}:{blk + 4 * c + 3}] offset:{off}", kind="lds")
+            base, off = self._lds_tail(slot)
+            e.emit(f"ds_write_b64 v{base}, v[{blk + 16}:{blk + 17}] offset:{off}", kind="lds")
+        elif slot.kind == "home":
+            r0 = HOME0 + SLOT_DW * slot.idx
+            for i in range(SLOT_DW):
+                e.emit(f"v_mov_b32_e32 v{r0 + i}, v{blk + i}", vw=[r0 + i])
+        elif slot.kind == "agpr":
+            for i in range(SLOT_DW):
+                e.emit(f"v_accvgpr_write_b32 a{SLOT_DW * slot.idx + i}, v{blk + i}")
+        elif slot.kind in ("glob", "globdyn"):
+            self._glob_base(slot)
+            for c in range(self.N_B128):
+                e.emit(f"global_store_dwordx4 v{V_GOFF}, v[{blk + 4 * c}:{blk + 4 * c + 3}], {S_GADDR} offset:{16 * c}", kind="vmem",
+                       store=range(blk + 4 * c, blk + 4 * c + 4))
+            e.emit(f"global_store_dwordx2 v{V_GOFF}, v[{blk + 16}:{blk + 17}], {S_GADDR} offset:64", kind="vmem", store=[blk + 16, blk + 17])
+            e.raw("s_nop 1")        # wide-store data hazard: the next VALU write of the block may sit behind a call
+        else:
+            raise ValueError(slot.kind)
+        self._count("st_" + slot.kind)
+
+    def wait(self):
+        if self.lds_pending and self.vm_pending:
+            self.e.raw("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        elif self.lds_pending:
+            self.e.raw("s_waitcnt lgkmcnt(0)")
+        elif self.vm_pending:
+            self.e.raw("s_waitcnt vmcnt(0)")
+        self.lds_pending = self.vm_pending = False
+
+    # ---------------------------------------------------------------- accumulator machine
+    def reset_tags(self):
+        self.tagA = self.tagB = None
+        self.rA = None
+
+    def A(self, x):
+        if self.tagA is not x:
+            self.load(A0, x)
+            self.tagA = x
+            self.rA = self.r_of(x)
+            self.vA = self.v_of(x)
+        return self
+
+    def _B(self, y):
+        if self.tagB is not y:
+            self.load(B0, y)
+            self.tagB = y
+
+    def set_A_fresh(self, v=0.51):
+        """A was filled by hand-written code with a normalised value of at most v p."""
+        self.tagA = None
+        self.rA = R_NORM
+        self.vA = v
+
+    # a call/return pair costs a lone wave ~70 cycles (two taken branches, each refilling the instruction buffer):
+    # the short routines are inlined (cold routines keep calling the longer ones: code size)
+    INLINE_SET = ("add", "sub", "rsub", "dbl", "neg", "negc1", "norm", "mulxi", "mulxir", "redn")
+    INLINE_COLD = ("add", "sub", "rsub", "dbl", "neg", "negc1")
+
+    def _raw_call(self, name):
+        self.wait()
+        base = name.split("_h")[0]
+        if base in (self.INLINE_COLD if self.cold else self.INLINE_SET):
+            g = L1v4(self.e)
+            if "_h" in name:
+                g.home_variant(base, int(name.split("_h")[1]))
+            else:
+                getattr(g, "r_" + name)()
+        else:
+            self.e.salu(f"s_call_b64 {S_RET1}, {self.l1[name]}")
+        self.tagA = None
+        self._count(name)
+
+    def norm(self):
+        """A <- normalised A.  Limbs beyond what the 32-bit carry pass takes go through the 64-bit chain (redn)."""
+        rA = self.rA if self.rA is not None else self.UNKNOWN
+        if mag(rA) > LIMB_MAG or self.vA > V_REDN_AT:
+            return self.redn()
+        self._raw_call("norm")
+        self.rA = self.r_norm()
+        return self
+
+    def redn(self):
+        """Normalise and bring the representative back to (-0.51 p, 0.51 p) (L1 redn: quotient from the top limb)."""
+        self._need(self.vA <= 8 * V_CAP, f"redn of a value of {self.vA} p")       # |top limb| must fit an int32 with room
+        self._raw_call("redn")
+        self.vA = 0.51
+        self.rA = R_NORM
+        return self
+
+    @staticmethod
+    def cols(n_terms, ra, rb):
+        return n_terms * mag(ra) * mag(rb)
+
+    def call(self, name, rB=None, direct=None, vB=1.0, k=None):
+        vA = self.vA
+        rA = self.rA if self.rA is not None else self.UNKNOWN
+        if name in ("mul", "mulfq", "fqmul"):
+            n = 2 * NL if name == "mul" else NL
+            if self.cols(n, rA, rB) > COL_BUDGET or vA > V_CAP:
+                self.norm()
+                rA, vA = self.rA, self.vA
+            self._need(self.cols(n, rA, rB) <= COL_BUDGET, f"{name} {rA} {rB}")
+            v_out = (2 if name == "mul" else 1) * vA * vB / K_RP + 0.5
+            out = self.r_norm(v_out)
+        elif name in ("sqr", "fqsqr"):
+            t = r_add(rA, rA) if name == "sqr" else rA
+            if self.cols(NL, t, t) > COL_BUDGET or vA > V_CAP:
+                self.norm()
+                rA, vA = self.rA, self.vA
+                t = r_add(rA, rA) if name == "sqr" else rA
+            self._need(self.cols(NL, t, t) <= COL_BUDGET, f"{name} {rA}")
+            v_out = (4 if name == "sqr" else 1) * vA * vA / K_RP + 0.5
+            out = self.r_norm(v_out)
+        elif name in ("add", "sub", "rsub"):
+            f = {"add": r_add, "sub": r_sub, "rsub": lambda x, y: r_sub(y, x)}[name]
+            if mag(f(rA, rB)) > LIMB_MAG:
+                self.norm()
+                rA, vA = self.rA, self.vA
+            out = f(rA, rB)
+            self._need(mag(out) <= LIMB_MAG, f"{name} {rA} {rB}")
+            v_out = vA + vB
+        elif name == "dbl":
+            if 2 * mag(rA) > LIMB_MAG:
+                self.norm()
+                rA, vA = self.rA, self.vA
+            out = (2 * rA[0], 2 * rA[1])
+            v_out = 2 * vA
+        elif name == "neg":
+            out, v_out = r_neg(rA), vA
+        elif name == "negc1":
+            out, v_out = r_hull(rA, r_neg(rA)), vA
+        elif name == "scale":
+            # A <- k A on 64-bit chains (k: inline constant), normalised
+            self._need(mag(rA) <= 7.9 and -16 <= k <= 64, f"scale {k} {rA}")
+            v_out = abs(k) * vA
+            out = self.r_norm(v_out)
+            self.wait()
+            g = L1v4(self.e)
+            g.lincomb(list(g.fq2(A0)), [[(k, g.blk(A0, 0))], [(k, g.blk(A0, 1))]])
+            self.tagA = None
+            self._count("scale")
+            self.vA, self.rA = v_out, out
+            self._need(v_out <= V_CAP, f"scale: value {v_out}")
+            return self
+        elif name == "mulxi":
+            # 64-bit chains: any int32 limbs in, normalised out; values grow tenfold
+            self._need(mag(rA) <= 7.9, f"mulxi {rA}")
+            v_out = 10 * vA
+            if v_out > V_CAP / 2:
+                name = direct = "mulxir"
+                v_out = 0.51
+            out = self.r_norm(v_out)
+        else:
+            raise ValueError(name)
+        self._raw_call(direct or name)
+        self.vA = v_out
+        self.rA = out
+        return self
+
+    def _bin(self, name, y):
+        if y.kind == "home" and name in ("add", "sub", "rsub"):
+            return self.call(name, self.r_of(y), direct=f"{name}_h{y.idx}", vB=self.v_of(y))
+        self._B(y)
+        return self.call(name, self.r_of(y), vB=self.v_of(y))
+
+    def mul(self, y): return self._bin("mul", y)
+    def add(self, y): return self._bin("add", y)
+    def sub(self, y): return self._bin("sub", y)
+    def rsub(self, y): return self._bin("rsub", y)
+    def mulfq(self, y): return self._bin("mulfq", y)      # A * (Fq in y.c0)
+    def sqr(self): return self.call("sqr")
+    def dbl(self): return self.call("dbl")
+    def neg(self): return self.call("neg")
+    def conj(self): return self.call("negc1")
+    def mulxi(self): return self.call("mulxi")
+    def scale(self, k): return self.call("scale", k=k)
+
+    def v_limit(self, dst):
+        """Largest value bound (in p) that may be left in `dst`: routine temporaries up to the cap, everything that
+        crosses a routine boundary at most V_STORE (the bound every routine assumes for its inputs)."""
+        return V_CAP if self.key(dst) in self.temp_keys else V_STORE
+
+    def to(self, dst):
+        rA = self.rA if self.rA is not None else self.UNKNOWN
+        lim = 1.0 if self.key(dst) in self.norm_keys else STORE_MAG
+        if self.vA > self.v_limit(dst):
+            self.redn()
+        elif mag(rA) > max(lim, self.vA / K_TOP):
+            self.norm()
+        self.wait()
+        self.store(A0, dst)
+        self.slot_r[self.key(dst)] = self.rA if self.rA is not None else self.UNKNOWN
+        self._need(self.vA <= V_CAP, f"value bound {self.vA} p at store")
+        self.slot_v[self.key(dst)] = self.vA
+        self.max_v = max(self.max_v, self.vA)
+        self.tagA = dst
+        if self.tagB is dst:
+            self.tagB = None
+        return self
+
+    def mov(self, dst, src):
+        self.A(src).to(dst)
+
+    # ---------------------------------------------------------------- temp slots
+    def set_temps(self, slots):
+        self.free_tmp = list(slots)
+        self.temp_keys = frozenset(self.key(t) for t in slots)
+
+    def tmp(self):
+        return self.free_tmp.pop(0)
+
+    def rel(self, *slots):
+        for s in slots:
+            assert s not in self.free_tmp
+            self.free_tmp.insert(0, s)
+
+    # ---- operand blocks H0..H3 of the three-term multiply (home registers 0..3 used as raw blocks)
+    def reserve_blocks(self, count=4):
+        self._saved_tmp = self.free_tmp
+        self._n_reserved = count
+        self.free_tmp = [t for t in self.free_tmp if not (t.kind == "home" and t.idx < count)]
+        assert len(self._saved_tmp) - len(self.free_tmp) == count, f"home blocks 0..{count - 1} must be free"
+        self.tagH = [None] * 4
+        self.eH = [None] * 4
+        self.vH = [V_STORE] * 4
+        self._blocks_reserved = True
+
+    def release_blocks(self):
+        held = [t for t in self._saved_tmp if t.kind == "home" and t.idx < self._n_reserved]
+        self.free_tmp = held + self.free_tmp
+        self._blocks_reserved = False
+
+    def ldH(self, k, slot):
+        """home block k <- slot (straight ds_read for LDS slots)."""
+        if self.tagH[k] is slot:
+            return self
+        blk = HOME0 + SLOT_DW * k
+        self.load(blk, slot)
+        self.tagH[k] = slot
+        self.eH[k] = self.r_of(slot)
+        self.vH[k] = self.v_of(slot)
+        return self
+
+    def mul3(self, y):
+        """A <- A*y + H0*H1 + H2*H3"""
+        self._B(y)
+        rA = self.rA if self.rA is not None else self.UNKNOWN
+        worst = mag(rA) * mag(self.r_of(y)) + mag(self.eH[0]) * mag(self.eH[1]) + mag(self.eH[2]) * mag(self.eH[3])
+        self._need(2 * NL * worst <= COL_BUDGET, f"mul3 {worst}")
+        vs = (self.vA, self.v_of(y), *self.vH)
+        self._need(max(vs) <= V_CAP, f"mul3 operand value {vs}")
+        self.vA = 2 * (self.vA * self.v_of(y) + self.vH[0] * self.vH[1] + self.vH[2] * self.vH[3]) / K_RP + 0.5
+        self._raw_call("mul3")
+        self.rA = self.r_norm()
+        self.tagH[0] = self.tagH[2] = None          # destroyed
+        return self
+
+    # ================================================================ L2 algorithms: Fq6 / Fq12
+    def _load_norm_sum(self, blk, s1, s2):
+        """register block blk <- s1 (+ s2), NORMALISED limbs (the fused routines take one-unit operands)."""
+        m_ = mag(self.r_of(s1)) + (mag(self.r_of(s2)) if s2 is not None else 0.0)
+        v_ = self.v_of(s1) + (self.v_of(s2) if s2 is not None else 0.0)
+        if m_ > 1.0 or v_ > K_TOP:
+            self.A(s1)
+            if s2 is not None:
+                self.add(s2)
+            self.norm()
+            self.wait()
+            if blk != A0:
+                for i in range(SLOT_DW):
+                    self.e.emit(f"v_mov_b32_e32 v{blk + i}, v{A0 + i}", vw=[blk + i])
+            self.tagA = None
+            return self.vA
+        assert s2 is None
+        if blk == A0:
+            self.A(s1)
+        elif blk == B0:
+            self._B(s1)
+        else:
+            self.load(blk, s1)
+        return v_
+
+    def _mul6_regs(self, a, b, a_plus=None, b_plus=None):
+        """Fused Fq6 multiplication (L1 mul6) of (a + a_plus) by (b + b_plus), coefficient-wise sums formed (and normalised)
+        while the operands are loaded into the home blocks.  Returns the three result 'slots' [c0, c1, c2]: c0 = HOME(1),
+        c1 = block A (None), c2 = HOME(0), all normalised and reduced; every home block is clobbered."""
+        va = vb = 0.0
+        for base, slots, plus in ((0, a, a_plus), (3, b, b_plus)):
+            for k, s_ in enumerate(slots):
+                v_ = self._load_norm_sum(HOME0 + SLOT_DW * (base + k), s_, plus[k] if plus else None)
+                if base == 0:
+                    va = max(va, v_)
+                else:
+                    vb = max(vb, v_)
+        self._need(max(va, vb) <= V_CAP / 2, f"mul6 operand values {va} {vb}")
+        self._raw_call("mul6")
+        self.tagB = None
+        res = [HOME(1, "mul6.c0"), None, HOME(0, "mul6.c2")]
+        for slot in (res[0], res[2]):
+            self.slot_r[self.key(slot)] = R_NORM
+            self.slot_v[self.key(slot)] = 0.51
+        self.vA = 0.51
+        self.rA = R_NORM
+        self.tagA = None
+        return res
+
+    def fq6_mul(self, a, b, out, a_plus=None, b_plus=None):
+        """(a0, a1, a2)(b0, b1, b2) in Fq2[v]/(v^3 - xi): ONE fused L1 routine (mul6: operands in the home blocks) when the
+        routine keeps no temporary in the home registers; six calls plus glue otherwise."""
+        if not self.homes_free:
+            assert a_plus is None and b_plus is None
+            return self._fq6_mul_generic(a, b, out)
+        res = self._mul6_regs(a, b, a_plus, b_plus)
+        self.to(out[1])                                       # c1 sits in block A
+        self.A(res[0]).to(out[0])
+        self.A(res[2]).to(out[2])
+
+    def _fq6_mul_generic(self, a, b, out):
+        V0, V1, V2, S = self.tmp(), self.tmp(), self.tmp(), self.tmp()
+        self.A(a[0]).mul(b[0]).to(V0)
+        self.A(a[1]).mul(b[1]).to(V1)
+        self.A(a[2]).mul(b[2]).to(V2)
+        self.A(a[1]).add(a[2]).to(S)
+        self.A(b[1]).add(b[2]).mul(S).sub(V1).sub(V2).mulxi().add(V0).to(out[0])
+        self.A(a[0]).add(a[1]).to(S)
+        self.A(b[0]).add(b[1]).mul(S).sub(V0).sub(V1).to(S)
+        self.A(V2).mulxi().add(S).to(out[1])
+        self.A(a[0]).add(a[2]).to(S)
+        self.A(b[0]).add(b[2]).mul(S).sub(V0).sub(V2).add(V1).to(out[2])
+        self.rel(V0, V1, V2, S)
+
+    def fq12_mul(self, F, Bs, conj_b=False):
+        """F <- F * B (Karatsuba over Fq6) on the fused Fq6 multiplication: the sums of the third product are formed while
+        its operands are loaded and its results are combined straight from the registers (B is not modified)."""
+        if conj_b:
+            for k in (1, 3, 5):
+                self.A(Bs[k]).neg().to(Bs[k])
+        A_0, A_1 = [F[0], F[2], F[4]], [F[1], F[3], F[5]]
+        B_0, B_1 = [Bs[0], Bs[2], Bs[4]], [Bs[1], Bs[3], Bs[5]]
+        T0 = [self.tmp() for _ in range(3)]
+        T1 = [self.tmp() for _ in range(3)]
+        assert self.homes_free, "fq12_mul runs on the fused Fq6 multiplication (home blocks 0..7 must be free)"
+        if True:
+            self.fq6_mul(A_0, B_0, T0)
+            self.fq6_mul(A_1, B_1, T1)
+            M = self._mul6_regs(A_0, B_0, A_1, B_1)               # (A0 + A1)(B0 + B1)
+            self.sub(T0[1]).sub(T1[1]).to(F[3])                   # c1 is in block A
+            self.A(M[0]).sub(T0[0]).sub(T1[0]).to(F[1])
+            self.A(M[2]).sub(T0[2]).sub(T1[2]).to(F[5])
+        self.A(T1[2]).mulxi().add(T0[0]).to(F[0])
+        self.A(T0[1]).add(T1[0]).to(F[2])
+        self.A(T0[2]).add(T1[1]).to(F[4])
+        self.rel(*T0)
+        self.rel(*T1)
+
+    def fq12_sqr(self, F):
+        """F <- F^2 (complex squaring over Fq6: t = A0 A1, u = (A0 + A1)(A0 + v A1))."""
+        A_0, A_1 = [F[0], F[2], F[4]], [F[1], F[3], F[5]]
+        T = [self.tmp() for _ in range(3)]
+        S0 = self.tmp()
+        assert self.homes_free, "fq12_sqr runs on the fused Fq6 multiplication (home blocks 0..7 must be free)"
+        if True:
+            self.fq6_mul(A_0, A_1, T)
+            self.A(F[5]).mulxi().add(F[0]).to(S0)                 # first coefficient of A0 + v A1
+            U = self._mul6_regs(A_0, [S0, F[2], F[4]], A_1, [None, F[1], F[3]])
+            self.sub(T[1]).sub(T[0]).to(F[2])                     # u1 - t1 - t0   (u1 is in block A)
+            X = S0
+            self.A(T[2]).mulxi().to(X)
+            self.A(U[0]).sub(T[0]).sub(X).to(F[0])
+            self.A(U[2]).sub(T[2]).sub(T[1]).to(F[4])
+        self.A(T[0]).dbl().to(F[1])
+        self.A(T[1]).dbl().to(F[3])
+        self.A(T[2]).dbl().to(F[5])
+        self.rel(S0, *T)
+
+    def _sqr4c(self, a, b, zc, zd, out_a, out_b, xi=False):
+        """out_a <- 3 (a^2 + xi b^2) - 2 zc ; out_b <- 3 (2 a b) + 2 zd  (xi: 3 xi (2 a b) + 2 zd): one Fq4 squaring of the
+        Granger-Scott cyclotomic squaring with its recombination, in ONE L1 routine.  All four operands normalised;
+        both results normalised and reduced."""
+        vs = []
+        for blk, s_ in ((HOME0 + 3 * SLOT_DW, zc), (HOME0 + 4 * SLOT_DW, zd), (A0, a), (B0, b)):
+            self._need(mag(self.r_of(s_)) <= 1.0, f"sqr4c operand {s_} is not normalised")
+            vs.append(self._load_norm_sum(blk, s_, None))
+        self._need(max(vs) <= V_CAP / 12, f"sqr4c operand values {vs}")      # S = xi b + a enters a product
+        self._raw_call("sqr4cx" if xi else "sqr4c")
+        self.tagH = [None] * 4
+        self.set_A_fresh()
+        self.to(out_a)
+        self.wait()
+        self.store(B0, out_b)
+        k1 = self.key(out_b)
+        self.slot_v[k1] = 0.51
+        self.slot_r[k1] = R_NORM
+        self.tagB = out_b
+
+    def fq12_cyc_sqr(self, F):
+        """Granger-Scott squaring (F in the cyclotomic subgroup), in place: three fused Fq4 squarings with recombination."""
+        self.reserve_blocks(5)
+        t2, t5 = self.tmp(), self.tmp()
+        self._sqr4c(F[1], F[4], F[2], F[5], t2, t5)            # F2' = 3 t2 - 2 F2 ; F5' = 3 t3 + 2 F5  (kept aside: F2, F5 are read below)
+        self._sqr4c(F[0], F[3], F[0], F[3], F[0], F[3])        # F0' = 3 t0 - 2 F0 ; F3' = 3 t1 + 2 F3
+        self._sqr4c(F[2], F[5], F[4], F[1], F[4], F[1], xi=True)   # F4' = 3 t4 - 2 F4 ; F1' = 3 xi t5 + 2 F1
+        self.mov(F[2], t2)
+        self.mov(F[5], t5)
+        self.rel(t2, t5)
+        self.release_blocks()
+
+    # ================================================================ sparse multiplications (miller_loop_native.rs:46-110)
+    def mul_by_034(self, F, L0, L3, L4):
+        """f *= L0 + L3 w^3 + L4 w^4 with one reduction per output coefficient (xi folded into the line)."""
+        self.reserve_blocks()
+        L3x, L4x = self.tmp(), self.tmp()
+        self.A(L3).mulxi().to(L3x)
+        self.A(L4).mulxi().to(L4x)
+        c = [self.tmp() for _ in range(3)]
+        # c0 = a0 L0 + a3 xiL3 + a2 xiL4 ; c1 = a1 L0 + a4 xiL3 + a3 xiL4 ; c2 = a2 L0 + a5 xiL3 + a4 xiL4
+        for k, (i0, i3, i4) in enumerate(((0, 3, 2), (1, 4, 3), (2, 5, 4))):
+            self.ldH(1, L3x).ldH(3, L4x).ldH(0, F[i3]).ldH(2, F[i4])
+            self.A(F[i0]).mul3(L0).to(c[k])
+        # c3 = a3 L0 + a0 L3 + a5 xiL4   (a3 is not read again: the result goes straight to its place)
+        self.ldH(1, L3).ldH(3, L4x).ldH(0, F[0]).ldH(2, F[5])
+        self.A(F[3]).mul3(L0).to(F[3])
+        # c4 = a4 L0 + a1 L3 + a0 L4 ; c5 = a5 L0 + a2 L3 + a1 L4
+        self.ldH(1, L3).ldH(3, L4).ldH(0, F[1]).ldH(2, F[0])
+        self.A(F[4]).mul3(L0).to(F[4])
+        self.ldH(0, F[2]).ldH(2, F[1])
+        self.A(F[5]).mul3(L0).to(F[5])
+        for k in range(3):
+            self.mov(F[k], c[k])
+        self.rel(L3x, L4x, *c)
+        self.release_blocks()
+
+    def mul_by_235(self, F, L2, L3, L5):
+        """f *= L2 w^2 + L3 w^3 + L5 w^5, same scheme."""
+        self.reserve_blocks()
+        L2x, L3x, L5x = self.tmp(), self.tmp(), self.tmp()
+        self.A(L2).mulxi().to(L2x)
+        self.A(L3).mulxi().to(L3x)
+        self.A(L5).mulxi().to(L5x)
+        c = [self.tmp() for _ in range(4)]
+        # c0 = xi (a4 b2 + a3 b3 + a1 b5) ; c1 = xi (a5 b2 + a4 b3 + a2 b5)
+        for k, (i2, i3, i5) in enumerate(((4, 3, 1), (5, 4, 2))):
+            self.ldH(1, L3x).ldH(3, L5x).ldH(0, F[i3]).ldH(2, F[i5])
+            self.A(F[i2]).mul3(L2x).to(c[k])
+        # c2 = a0 b2 + xi (a5 b3 + a3 b5)
+        self.ldH(1, L3x).ldH(3, L5x).ldH(0, F[5]).ldH(2, F[3])
+        self.A(F[0]).mul3(L2).to(c[2])
+        # c3 = a1 b2 + a0 b3 + xi a4 b5 ; c4 = a2 b2 + a1 b3 + xi a5 b5
+        for k, (i2, i3, i5) in ((3, (1, 0, 4)), (4, (2, 1, 5))):
+            self.ldH(1, L3).ldH(3, L5x).ldH(0, F[i3]).ldH(2, F[i5])
+            self.A(F[i2]).mul3(L2).to(c[k] if k == 3 else F[4])           # a4 is not read after c3
+        # c5 = a3 b2 + a2 b3 + a0 b5
+        self.ldH(1, L3).ldH(3, L5).ldH(0, F[2]).ldH(2, F[0])
+        self.A(F[3]).mul3(L2).to(F[5])
+        for k in range(4):
+            self.mov(F[k], c[k])
+        self.rel(L2x, L3x, L5x, *c)
+        self.release_blocks()
+
+    # ================================================================ G2 steps (homogeneous projective, no inversions)
+    # The reference steps in affine coordinates with one Fq2 inversion each (miller_loop_native.rs:157,167,186); the
+    # projective line values are the reference's un-normalised affine line values (:10-44) times a known Fq2 factor (Z^2 for
+    # tangents, Z for chords), tracked in `scale` by the kernels that must return the exact miller_loop_native value.
+    def dbl_step(self, R, Pt, line, scale=None):
+        """R=(X,Y,Z) <- 2R ; line = (L0, L3, L4) of the tangent at the old R evaluated at P (Pt = (PX, PY) slots, scalar in c0).
+        scale: slot of the running line scale s <- s * Z^2 (the caller squares it with f)."""
+        X, Y, Z = R
+        L0, L3, L4 = line
+        Bq, C, E, Fv, H, T = [self.tmp() for _ in range(6)]
+        self.A(Y).sqr().to(Bq)
+        self.A(Z).sqr().to(C)
+        if scale is not None:
+            self.A(scale).mul(C).to(scale)
+        self.A(C).mul(THREE_B).to(E)
+        self.A(E).dbl().add(E).to(Fv)
+        self.A(Y).add(Z).sqr().sub(Bq).sub(C).to(H)            # H = 2 Y Z = (Y + Z)^2 - Y^2 - Z^2
+        # line
+        self.A(C).scale(9).to(T)                               # 9 C
+        self.A(Bq).mulxi().sub(T).to(L0)
+        self.A(H).mulfq(Pt[1]).to(L3)                          # H * Py
+        self.A(X).sqr().to(T)
+        self.A(T).dbl().add(T).mulfq(Pt[0]).neg().to(L4)       # -3 X^2 * Px
+        # point
+        self.A(Bq).sub(Fv).to(T)
+        self.A(X).mul(Y).dbl().mul(T).to(X)
+        self.A(E).sqr().to(T)
+        self.A(T).scale(12).to(T)                              # 12 E^2
+        self.A(Bq).add(Fv).sqr().sub(T).to(Y)
+        self.A(Bq).mul(H).scale(4).to(Z)
+        self.rel(Bq, C, E, Fv, H, T)
+
+    def add_step(self, R, Q, Pt, line, scale=None, update=True):
+        """R <- R + Q (Q = (x2, y2) affine slots); line = (L2, L3, L5) of the chord through old R and Q at P."""
+        X, Y, Z = R
+        x2, y2 = Q
+        L2, L3, L5 = line
+        th, mu, T, U = [self.tmp() for _ in range(4)]
+        if scale is not None:
+            self.A(scale).mul(Z).to(scale)
+        self.A(y2).mul(Z).rsub(Y).to(th)                      # theta = Y - y2 Z
+        self.A(x2).mul(Z).rsub(X).to(mu)                      # mu = X - x2 Z
+        self.A(mu).mulfq(Pt[1]).neg().to(L2)                  # -mu * Py
+        self.A(th).mulfq(Pt[0]).to(L3)                        # theta * Px
+        self.A(x2).mul(Y).to(T)
+        self.A(X).mul(y2).sub(T).to(L5)                       # X y2 - x2 Y
+        if update:
+            Cc, D, E = self.tmp(), self.tmp(), self.tmp()
+            self.A(th).sqr().to(Cc)
+            self.A(mu).sqr().to(D)
+            self.A(mu).mul(D).to(E)
+            self.A(Z).mul(Cc).to(Cc)                          # F = Z * C
+            self.A(X).mul(D).to(D)                            # G = X * D
+            self.A(D).dbl().to(T)
+            self.A(E).add(Cc).sub(T).to(T)                    # H = E + F - 2G
+            self.A(mu).mul(T).to(X)                           # X3 = mu H
+            self.A(E).mul(Y).to(U)                            # E * Y
+            self.A(D).sub(T).mul(th).sub(U).to(Y)             # Y3 = theta (G - H) - E Y
+            self.A(Z).mul(E).to(Z)                            # Z3 = Z E
+            self.rel(Cc, D, E)
+        self.rel(th, mu, T, U)
+
+
+# ======================================================================================================================
+class _PhaseList(list):
+    """The builder's section list: remembers in which phase (Miller loop / final exponentiation) a section was added."""
+
+    def __init__(self, kb):
+        super().__init__()
+        self.kb = kb
+
+    def append(self, e):
+        self.kb.section_phase[id(e)] = self.kb._phase
+        super().append(e)
+
+
+class KernelBuilder:
+    """Assembles one kernel blob.  Operand order of the asm statement (all inputs):
+       %0 g1 (s64)  %1 g2 (s64)  %2 f_in (s64)  %3 out (s64)  %4 n (s32)  %5 k (s32)  %6 scratch (s64)
+       %7 scratch slot stride in bytes (s32)  %8 status (s64)  %9 tid (v32)  %10 block id (s32)  %11 grid size (s32)"""
+
+    # slot map -------------------------------------------------------------------------------------
+    F = [LDS(i, f"F{i}") for i in range(6)]                  # the running Fq12 accumulator: LDS
+    R = [LDS(6, "RX"), LDS(7, "RY"), AGPR(9, "RZ")]          # RZ shares AGPR 9 with the Fq-inversion base (R is dead by then)
+    SCALE = AGPR(11, "scale")
+    QX, QY, PX, PY = AGPR(0, "QX"), AGPR(1, "QY"), AGPR(2, "PX"), AGPR(3, "PY")
+    SX, SY = AGPR(4, "SX"), AGPR(5, "SY")                    # the affine point of the current addition step
+    LINE = [AGPR(6, "La"), AGPR(7, "Lb"), AGPR(8, "Lc")]
+    FQINV_BASE = AGPR(9, "fqinv_base")
+    BOP = [AGPR(i, f"B{i}") for i in (0, 1, 2, 3, 4, 5)]      # fq12_mul operand copy (final exponentiation only)
+    PAIR_SLOT0 = N_GSLOTS               # scratch slots of pair j: PAIR_SLOT0 + 7 j + {PX, PY, QX, QY, RX, RY, RZ}
+
+    COLD = ("L2_inv", "L2_frob1", "L2_frob2", "L2_frob3", "L2_dblfirst", "L2_addmul_last", "L2_descale", "L2_fqinv")
+
+    def __init__(self, do_miller=True, do_fexp=True, track=False, multi=False, helper=False):
+        """track: keep the running line scale and divide it out (the exact miller_loop_native value).
+        multi: k pairs per lane with a shared f (multi_miller_loop_native, miller_loop_native.rs:192-282).
+        helper: the batched public helpers of the reference on Fq12 batches -- MyFq12 `Mul`, frobenius_map_native
+        (final_exp_native.rs:17-54), pow_native (:56-84) -- selected at run time by the kernel's `k` argument."""
+        if helper:
+            do_miller, do_fexp, track, multi = False, True, False, False
+        self.do_miller, self.do_fexp, self.track = do_miller, do_fexp, track
+        self.multi = multi
+        self.helper = helper
+        self.labels = {n: f"L1_{n}_%=" for n in L1V4_NAMES}
+        for op in ("add", "sub", "rsub"):
+            for i in range(N_HOME):
+                self.labels[f"{op}_h{i}"] = f"L1_{op}_h{i}_%="
+        self.sections = []
+        self._phase = "miller"
+        self._cold = False
+        self._uid = 0
+
+    def lab(self, name):
+        return f"{name}_%="
+
+    def uid(self):
+        self._uid += 1
+        return self._uid
+
+    # ---------------------------------------------------------------------------------------------
+    def norm_keys(self, phase):
+        """Slots that hold normalised values on every routine boundary of `phase` (Prog.norm_keys)."""
+        keys = [Prog.key(s_) for s_ in self.F]
+        if phase == "fexp":
+            keys += [Prog.key(s_) for s_ in self.BOP] + [("globdyn", i) for i in range(6)]
+        return frozenset(keys)
+
+    def new_prog(self, temps, phase=None):
+        if not hasattr(self, "l2_bodies"):
+            self.l2_bodies, self.l2_exit, self.l2_maxv, self.l2_phase = {}, {}, {}, {}
+        e = Emitter()
+        p = Prog(e, self.labels)
+        p.set_temps(temps)
+        p.norm_keys = self.norm_keys(phase or self._phase)
+        p.homes_free = not any(t.kind == "home" and t.idx < 8 for t in temps)      # mul6's workspace: home blocks 0..7
+        p.cold = self._cold
+        return e, p
+
+    def l2_routine(self, name, body, temps):
+        """Also records the value bounds (units of p) the routine leaves in every non-temporary slot, given that all
+        its inputs were below V_STORE p: the basis of the inductive certification in certify_values()."""
+        self._cold = name in self.COLD
+        e, p = self.new_prog(temps)
+        e.label(self.lab(name))
+        body(p)
+        p.wait()
+        e.salu(f"s_setpc_b64 {S_RET2}")
+        self.sections.append(e)
+        self._cold = False
+        tk = {Prog.key(t) for t in temps}
+        self.l2_bodies[name] = (body, temps)
+        self.l2_phase[name] = self._phase
+        self.l2_exit[name] = {k: v for k, v in p.slot_v.items() if k not in tk}
+        self.l2_maxv[name] = p.max_v
+        return p
+
+    def miller_temps(self, extra=(), no_homes=False):
+        """Fast temporaries of the Miller-loop routines: the home registers (only block 8 in routines built on the fused
+        Fq6 multiplication, whose workspace is blocks 0..7), the free AGPR slots, routine-specific dead slots; global
+        scratch slots only as overflow."""
+        homes = [HOME(8)] if no_homes else [HOME(i) for i in range(N_HOME)]
+        return (homes + [AGPR(10), AGPR(12), AGPR(13)] + ([] if self.track else [AGPR(11)]) + [AGPR(i) for i in extra]
+                + [GLOB(GLOB_TMP0 + i) for i in range(8)])
+
+    def fexp_temps(self, no_homes=False):
+        # fastest first: home registers, then AGPR slots (72 cycles either way), then LDS (a slot store costs 130-270 cycles)
+        homes = [HOME(8)] if no_homes else [HOME(i) for i in range(N_HOME)]
+        return homes + [AGPR(i) for i in (6, 7, 8, 10, 11, 12, 13)] + [LDS(6), LDS(7)] + [GLOB(GLOB_TMP0 + i) for i in range(8)]
+
+    # ---------------------------------------------------------------------------------------------
+    def build(self):
+        main = Emitter()
+        self.prologue(main)
+        l1 = {}                                  # one section per leaf routine: their order is chosen below
+        for n in L1V4_NAMES:
+            l1[n] = Emitter()
+            l1[n].label(self.labels[n])
+            getattr(L1v4(l1[n]), "r_" + n)()
+            l1[n].salu(f"s_setpc_b64 {S_RET1}")
+        for op in ("add", "sub", "rsub"):
+            for i in range(N_HOME):
+                n = f"{op}_h{i}"
+                l1[n] = Emitter()
+                l1[n].label(self.labels[n])
+                L1v4(l1[n]).home_variant(op, i)
+                l1[n].salu(f"s_setpc_b64 {S_RET1}")
+        self.sections = _PhaseList(self)
+        self.section_phase = {}
+        self.control_sections = []
+        self._phase = "miller"
+        if self.do_miller:
+            sc = self.SCALE if self.track else None
+            # during f^2 the line (AGPR 6..8) and the addition point (AGPR 4, 5) are dead
+            self.l2_routine("L2_sqr", lambda p: p.fq12_sqr(self.F), self.miller_temps(extra=(4, 5, 6, 7, 8), no_homes=True))
+            self.l2_routine("L2_dblmul", lambda p: (p.dbl_step(self.R, (self.PX, self.PY), self.LINE, scale=sc),
+                                                    p.mul_by_034(self.F, *self.LINE)), self.miller_temps(extra=(4, 5)))
+            self.l2_routine("L2_dblfirst", lambda p: self._dbl_first(p), self.miller_temps())
+
+            def addmul(p, update):
+                p.add_step(self.R, (self.SX, self.SY), (self.PX, self.PY), self.LINE, scale=sc, update=update)
+                glob = [t for t in p.free_tmp if t.kind == "glob"]
+                p.free_tmp = [t for t in p.free_tmp if t.kind != "glob"] + [self.SX, self.SY] + glob    # S is dead now
+                p.temp_keys = p.temp_keys | {Prog.key(self.SX), Prog.key(self.SY)}
+                p.mul_by_235(self.F, *self.LINE)
+
+            self.l2_routine("L2_addmul", lambda p: addmul(p, True), self.miller_temps())
+            self.l2_routine("L2_addmul_last", lambda p: addmul(p, False), self.miller_temps())
+            if self.track:
+                self.l2_routine("L2_fqinv", self._fq_inv, self.miller_temps())
+                self.l2_routine("L2_descale", self._descale, self.miller_temps())
+                self.l2_routine("L2_sqscale", lambda p: p.A(self.SCALE).sqr().to(self.SCALE), self.miller_temps())
+        self._phase = "fexp"
+        if self.do_fexp:
+            if not (self.do_miller and self.track):
+                self.l2_routine("L2_fqinv", self._fq_inv, self.fexp_temps())
+            self.l2_routine("L2_cyc", lambda p: p.fq12_cyc_sqr(self.F), self.fexp_temps())
+            self.l2_routine("L2_redF", self._reduce_f, self.fexp_temps())
+            self._mulG_routines()
+            for k in (1, 2, 3):
+                self.l2_routine(f"L2_frob{k}", lambda p, k=k: self._frobenius(p, k), self.fexp_temps())
+            self.l2_routine("L2_inv", self._fq12_inv, self.fexp_temps())
+            self.l2_routine("L2_stG", lambda p: [p.A(self.F[i]).to(GlobDyn(i)) for i in range(6)], self.fexp_temps())
+            self.l2_routine("L2_ldG", lambda p: self.batch_load_globdyn(p.e, p, range(6), self.F), self.fexp_temps())
+            self.l2_routine("L2_ldGc", lambda p: (self.batch_load_globdyn(p.e, p, range(6), self.F),
+                                                  [p.A(self.F[i]).neg().to(self.F[i]) for i in (1, 3, 5)]), self.fexp_temps())
+            self.l2_routine("L2_conjF", lambda p: [p.A(self.F[i]).neg().to(self.F[i]) for i in (1, 3, 5)], self.fexp_temps())
+            self._powx_routine()
+            if self.helper:
+                for k in range(4, 12):
+                    self.l2_routine(f"L2_frob{k}", lambda p, k=k: self._frobenius(p, k), self.fexp_temps())
+                self.l2_routine("L2_sqrF", lambda p: p.fq12_sqr(self.F), self.fexp_temps(no_homes=True))
+        self._phase = "miller"              # the main program only touches F
+        self.main_body(main)
+        # Layout: s_call_b64 / s_branch reach +-128 KB.  The leaf routines (called from everywhere) and the main control
+        # code sit in the middle; Miller-loop routines in front of that block, final-exponentiation routines behind it, the
+        # small ones (called from the main program) nearest to the middle, the big cold ones (Fq12 inversion) at the far ends.
+        size = {id(e): len(e.finalize()) for e in self.sections}
+        first = sorted([e for e in self.sections if self.section_phase[id(e)] == "miller"], key=lambda e: -size[id(e)])
+        second = sorted([e for e in self.sections if self.section_phase[id(e)] == "fexp"], key=lambda e: size[id(e)])
+        tot = lambda lst: sum(size[id(e)] for e in lst)
+        while second and tot(second) - tot(first) > size[id(second[-1])]:      # one-phase kernels: balance the two sides
+            first.insert(0, second.pop())
+        while first and tot(first) - tot(second) > size[id(first[0])]:
+            second.append(first.pop(0))
+        main.salu(f"s_branch {self.lab('L_exit_hop')}")   # main is not the last section; the end is out of reach in one hop
+        hop = Emitter()
+        hop.label(self.lab("L_exit_hop"))
+        hop.salu(f"s_branch {self.lab('L_exit')}")
+        tail = Emitter()
+        tail.label(self.lab("L_exit"))
+
+        # leaf routines nobody calls are dropped; the others are ordered by where their callers sit: routines called only
+        # from the sections in front of the block come first, those called only from behind last
+        def calls(secs_, lbl):
+            return sum(1 for e_ in secs_ for it in e_.ins if it["text"].startswith("s_call_b64") and it["text"].endswith(lbl))
+        front, back = first + [main] + self.control_sections, second
+        order = []
+        for n, e_ in l1.items():
+            nf, nb = calls(front, self.labels[n]), calls(back, self.labels[n])
+            if nf + nb:
+                order.append((nb / (nf + nb), -len(e_.ins) if nb <= nf else len(e_.ins), n))
+        order.sort()
+        out = []
+        for e in [self._pro] + first + [main] + self.control_sections + [l1[n] for _, _, n in order] + [hop] + second + [tail]:
+            out.extend(e.finalize())
+        out = [".p2align 3"] + align_code(out) if ALIGN_CODE else out
+        worst = max_branch_distance(out)
+        assert worst < 131072 - 512, f"branch of {worst} bytes: s_call_b64 / s_branch reach +-128 KB (re-balance the layout)"
+        return out
+
+    # ------------------------------------------------------------------ value-bound certification
+    # Limb bounds are closed per routine (every store enforces its limit, every multiplication its column sums).
+    # VALUE bounds cross routine boundaries through one contract: every routine is generated assuming that whatever it
+    # finds in a slot is below V_STORE p, and Prog.to() makes it leave at most V_STORE p in every slot that outlives it
+    # (its temporaries may hold up to V_CAP p).  Bounds are monotone in the inputs, so the shipped code is safe whenever
+    # the contract holds at every call: certify_values() walks the kernel's data-independent call sequence (NAF digits
+    # only), checks the recorded exit bounds of every routine on it against the contract and returns the sequence, which
+    # tests/test_kgen4.py compares with the simulator's call log.
+    def _check_routine(self, name):
+        for k_, v_ in self.l2_exit[name].items():
+            assert v_ <= V_STORE, f"{name} leaves {v_} p in {k_}"
+        assert self.l2_maxv[name] <= V_CAP, f"{name} stores {self.l2_maxv[name]} p"
+        return self.l2_maxv[name]
+
+    def certify_values(self, k_pairs=1):
+        """Returns a report dict (call sequence, largest stored bound); raises on any contract violation."""
+        worst, calls, seq = 0.0, 0, []
+
+        def run(name, label=None):
+            nonlocal worst, calls
+            worst = max(worst, self._check_routine(name))
+            calls += 1
+            seq.append(label or name)
+            if name in ("L2_descale", "L2_inv"):
+                seq.append("L2_fqinv")           # nested: the Fq inversion (fixed exponent)
+
+        assert self.main_prog.max_v <= V_STORE, "the main program stores across routine boundaries only"
+        if self.do_miller:
+            run("L2_dblfirst")
+            for _ in range(k_pairs - 1):
+                run("L2_dblmul")
+            for i in range(63, -1, -1):
+                if i != 63:
+                    run("L2_sqr")
+                    if self.track:
+                        run("L2_sqscale")
+                    for _ in range(k_pairs):
+                        run("L2_dblmul")
+                if SIX_U_PLUS_2_NAF[i] != 0:
+                    for _ in range(k_pairs):
+                        run("L2_addmul")
+            for _ in range(k_pairs):                                    # per pair: + Q1, then - Q2
+                run("L2_addmul")
+                run("L2_addmul_last")
+            if self.track:
+                run("L2_descale")
+        if self.do_fexp and not self.helper:
+            def mul_by(conj=False):
+                run("L2_mul_body", label="L2_mulGc" if conj else "L2_mulG")
+
+            for op in self.fexp_trace:
+                if op[0] == "st":
+                    seq.append("L2_stG")
+                elif op[0] == "ld":
+                    seq.append("L2_ldGc" if op[2] else "L2_ldG")
+                elif op[0] == "mul":
+                    mul_by(op[2])
+                elif op[0] == "powx":
+                    seq.append("L2_stG")
+                    run("L2_cyc"); run("L2_cyc"); seq.append("L2_stG")
+                    for _ in range(3):
+                        mul_by()
+                        seq.append("L2_stG")
+                    if X_DIGITS[-1] != 13:
+                        seq.append("L2_ldG")
+                    xd = X_DIGITS[:-1]
+                    for d in range(len(xd) - 1, -1, -1):
+                        run("L2_cyc")
+                        if xd[d] != 0:
+                            mul_by(conj=xd[d] < 0)
+                else:
+                    run(op[1])
+        return {"max_stored": worst, "calls": calls, "sequence": seq}
+
+    def certify_helper(self):
+        """The helper kernel's loops are data dependent (NAF of the caller's exponent): the contract must hold for ANY order
+        of squarings and multiplications, which is exactly what the per-routine check gives."""
+        worst = 0.0
+        for name in ["L2_inv", "L2_sqrF", "L2_mul_body", "L2_stG", "L2_ldG"] + [f"L2_frob{k}" for k in range(1, 12)]:
+            worst = max(worst, self._check_routine(name))
+        return {"fixed_point": V_STORE, "max_stored": worst}
+
+    def _reduce_f(self, p):
+        """F <- the same residues with representatives back in (-0.51 p, 0.51 p) (L1 redn)."""
+        for k in range(6):
+            p.A(self.F[k]).redn().to(self.F[k])
+
+    def _powx_routine(self):
+        """F <- F^BN_X for cyclotomic F (base b = F on entry, S_GBASE = its scratch register): the X_DIGITS schedule.
+        Same value as pow_native(a, [BN_X]) (final_exp_native.rs:56-84) for unitary a."""
+        e = Emitter()
+        L = self.lab
+
+        def c2(name):
+            e.salu(f"s_call_b64 {S_RET2}, {L(name)}")
+
+        def greg(j):
+            e.salu(f"s_mul_i32 s{S_GBASE}, s{S_GSTRIDE}, {6 * j}")
+
+        e.label(L("L3_powx"))
+        e.salu(f"s_mov_b32 s{S_PB}, s{S_GBASE}")
+        c2("L2_stG")                                                  # G[base] = b
+        c2("L2_cyc"); c2("L2_cyc"); greg(G_B4); c2("L2_stG")          # b^4
+        e.salu(f"s_mov_b32 s{S_GBASE}, s{S_PB}")
+        c2("L2_mulG"); greg(G_POW[5]); c2("L2_stG")                   # b^5 = b^4 b
+        greg(G_B4); c2("L2_mulG"); greg(G_POW[9]); c2("L2_stG")       # b^9 = b^5 b^4
+        greg(G_B4); c2("L2_mulG"); greg(G_POW[13]); c2("L2_stG")      # b^13 = b^9 b^4
+        top = X_DIGITS[-1]
+        if top == 1:
+            e.salu(f"s_mov_b32 s{S_GBASE}, s{S_PB}")
+        else:
+            greg(G_POW[top])
+        if top != 13:
+            c2("L2_ldG")
+        e.salu(f"s_mov_b32 s{S_J}, {self.x_top - 1}")
+        e.label(L("L3_powx_loop"))
+        c2("L2_cyc")
+        e.salu(f"s_bitcmp1_b64 {S_XNAF_NZ}, s{S_J}")
+        e.salu(f"s_cbranch_scc0 {L('L3_powx_next')}")
+        # select the power: S_GBASE <- register of b^(X_POWERS[idx])
+        e.salu(f"s_mov_b32 s{S_GBASE}, s{S_PB}")
+        for bit, mask in ((0, S_XIDX0), (1, S_XIDX1)):
+            e.salu(f"s_bitcmp1_b64 {mask}, s{S_J}")
+            e.salu(f"s_cselect_b32 s{S_TMP0}, {1 << bit}, 0")
+            e.salu(f"s_{'mov' if bit == 0 else 'or'}_b32 s{S_TMP1}, s{S_TMP0}" + (f", s{S_TMP1}" if bit else ""))
+        e.salu(f"s_cmp_eq_u32 s{S_TMP1}, 0")
+        e.salu(f"s_cbranch_scc1 {L('L3_powx_sel')}")
+        # registers of b^5, b^9, b^13 are consecutive: G_POW[5] + (idx - 1)
+        e.salu(f"s_add_u32 s{S_TMP1}, s{S_TMP1}, {G_POW[5] - 1}")
+        e.salu(f"s_mul_i32 s{S_TMP1}, s{S_TMP1}, 6")
+        e.salu(f"s_mul_i32 s{S_GBASE}, s{S_GSTRIDE}, s{S_TMP1}")
+        e.label(L("L3_powx_sel"))
+        e.salu(f"s_bitcmp1_b64 {S_XNAF_NEG}, s{S_J}")
+        e.salu(f"s_cbranch_scc1 {L('L3_powx_neg')}")
+        c2("L2_mulG")
+        e.salu(f"s_branch {L('L3_powx_next')}")
+        e.label(L("L3_powx_neg"))
+        c2("L2_mulGc")
+        e.label(L("L3_powx_next"))
+        e.salu(f"s_sub_u32 s{S_J}, s{S_J}, 1")
+        e.salu(f"s_cbranch_scc0 {L('L3_powx_loop')}")
+        e.salu(f"s_setpc_b64 {S_RET3}")
+        self.control_sections.append(e)           # control code: placed next to the main program (it calls L2 routines of both halves)
+
+    def batch_load_globdyn(self, e, p, ks, dests):
+        """dests[i] <- scratch slot (S_GBASE + ks[i]): all global loads issued back to back into landing registers
+        (blocks A, B and the home registers -- every temporary is dead at a routine boundary), ONE wait, then the
+        stores.  A dependent load->wait->store round trip per slot costs ~2 us each."""
+        land = [A0, B0] + [HOME0 + SLOT_DW * i for i in range(N_HOME)]
+        assert len(ks) <= len(land)
+        p.reset_tags()
+        p.wait()
+        for n, k in enumerate(ks):
+            e.salu(f"s_mul_i32 s{S_TMP0}, s{S_GSTRIDE}, {k}")
+            e.salu(f"s_add_u32 s{S_TMP0}, s{S_TMP0}, s{S_GBASE}")
+            e.salu(f"s_add_u32 s62, s64, s{S_TMP0}")
+            e.salu("s_addc_u32 s63, s65, 0")
+            for c in range(Prog.N_B128):
+                r = land[n] + 4 * c
+                e.emit(f"global_load_dwordx4 v[{r}:{r + 3}], v{V_GOFF}, {S_GADDR} offset:{16 * c}", kind="vmem", vw=range(r, r + 4))
+            r = land[n] + 16
+            e.emit(f"global_load_dwordx2 v[{r}:{r + 1}], v{V_GOFF}, {S_GADDR} offset:64", kind="vmem", vw=[r, r + 1])
+        e.raw("s_waitcnt vmcnt(0)")
+        for n, d in enumerate(dests):
+            p.store(land[n], d) if d.kind != "home" or HOME0 + SLOT_DW * d.idx != land[n] else None
+            p.slot_r.pop(p.key(d), None)
+            p.slot_v.pop(p.key(d), None)
+        p.reset_tags()
+
+    def _mulG_routines(self):
+        """F <- F * G (G = Fq12 in scratch at S_GBASE); L2_mulGc multiplies by conjugate_fp12(G)."""
+        e, p = self.new_prog(self.fexp_temps(no_homes=True))
+        e.label(self.lab("L2_mulGc"))
+        self.batch_load_globdyn(e, p, range(6), self.BOP)
+        for i in (1, 3, 5):
+            p.A(self.BOP[i]).neg().to(self.BOP[i])
+        p.wait()
+        e.salu(f"s_branch {self.lab('L2_mul_body')}")
+        e.label(self.lab("L2_mulG"))
+        p.reset_tags()
+        self.batch_load_globdyn(e, p, range(6), self.BOP)
+        e.label(self.lab("L2_mul_body"))
+        p.reset_tags()
+        p.slot_r.clear()
+        p.slot_v.clear()
+        p.fq12_mul(self.F, self.BOP)
+        p.wait()
+        e.salu(f"s_setpc_b64 {S_RET2}")
+        self.sections.append(e)
+        self.l2_exit["L2_mul_body"] = {k: v for k, v in p.slot_v.items() if k not in p.temp_keys}
+        self.l2_maxv["L2_mul_body"] = p.max_v
+
+    # ---------------------------------------------------------------------------------------------
+    def prologue(self, main):
+        e = Emitter()
+        self._pro = e
+        e.salu(f"s_mov_b64 {S_G1}, %0")
+        e.salu(f"s_mov_b64 {S_G2}, %1")
+        e.salu(f"s_mov_b64 {S_FIN}, %2")
+        e.salu(f"s_mov_b64 {S_OUT}, %3")
+        e.salu(f"s_mov_b32 s{S_N}, %4")
+        e.salu(f"s_mov_b32 s{S_K}, %5")
+        e.salu(f"s_mov_b32 s{S_GSTRIDE}, %7")
+        e.salu(f"s_mov_b64 {S_STATUS}, %8")
+        e.salu(f"s_mov_b32 s{S_ITEM}, %10")
+        e.salu(f"s_mov_b32 s{S_GRID}, %11")
+        # scratch base of this workgroup: scratch + block * 256 * 72 ; lane offset = tid * 72
+        e.salu(f"s_mul_i32 s{S_TMP0}, %10, {BLOCK * SLOT_BYTES}")
+        e.salu(f"s_mov_b64 {S_SCRATCH}, %6")
+        e.salu(f"s_add_u32 s64, s64, s{S_TMP0}")
+        e.salu("s_addc_u32 s65, s65, 0")
+        e.emit(f"v_mul_u32_u24_e32 v{V_GOFF}, {SLOT_BYTES}, %9", vw=[V_GOFF])
+        e.emit(f"v_lshlrev_b32_e32 v{V_LDS}, 4, %9", vw=[V_LDS])
+        e.emit(f"v_add_u32_e32 v{V_LDS + 1}, 0x10000, v{V_LDS}", vw=[V_LDS + 1])
+        e.emit(f"v_lshlrev_b32_e32 v{V_LTAIL}, 3, %9", vw=[V_LTAIL])
+        e.emit(f"v_add_u32_e32 v{V_LTAIL}, 0x{N_LDS_SLOTS * Prog.N_B128 * 4096:x}, v{V_LTAIL}", vw=[V_LTAIL])
+        e.emit(f"v_mov_b32_e32 v{V_TID}, %9", vw=[V_TID])
+        for i in range(NL):
+            e.salu(f"s_mov_b32 s{S_P + i}, {hx(P_L[i])}")
+        e.salu(f"s_mov_b32 s{S_N0}, 0x{N0P:x}")
+        e.salu(f"s_mov_b32 s{S_REDN}, 0x{REDN_C:x}")
+        e.salu(f"s_mov_b32 s{S_M30}, -30")
+        nz, neg = naf_masks(SIX_U_PLUS_2_NAF[:64])
+        e.salu(f"s_mov_b32 s68, 0x{nz & 0xFFFFFFFF:x}")
+        e.salu(f"s_mov_b32 s69, 0x{nz >> 32:x}")
+        e.salu(f"s_mov_b32 s70, 0x{neg & 0xFFFFFFFF:x}")
+        e.salu(f"s_mov_b32 s71, 0x{neg >> 32:x}")
+        xd = list(X_DIGITS[:-1])                       # the top digit is the initial value of the accumulator
+        nz, neg = naf_masks([(d > 0) - (d < 0) for d in xd])
+        self.x_top = len(xd)
+        idx = [X_POWERS.index(abs(d)) if d else 0 for d in xd]
+        for reg, val in ((72, nz), (74, neg), (50, sum((i & 1) << j for j, i in enumerate(idx))),
+                         (52, sum((i >> 1) << j for j, i in enumerate(idx)))):
+            e.salu(f"s_mov_b32 s{reg}, 0x{val & 0xFFFFFFFF:x}")
+            e.salu(f"s_mov_b32 s{reg + 1}, 0x{val >> 32:x}")
+        e.salu(f"s_lshl_b32 s{S_NSTRIDE}, s{S_N}, 3")
+        e.salu(f"s_add_u32 s{S_NITEMS}, s{S_N}, 255")
+        e.salu(f"s_lshr_b32 s{S_NITEMS}, s{S_NITEMS}, 8")
+        e.emit(f"v_mov_b32_e32 v{V_FLAG}, 0", vw=[V_FLAG])
+        e.salu(f"s_branch {self.lab('L_main')}")
+
+    # ---------------------------------------------------------------------------------------------
+    def io_walk_begin(self, e, base):
+        e.salu(f"s_mov_b64 {S_IOADDR}, {base}")
+
+    def io_walk_next(self, e):
+        e.salu(f"s_add_u32 s88, s88, s{S_NSTRIDE}")
+        e.salu("s_addc_u32 s89, s89, 0")
+
+    def io_load_fq(self, e, reg0):
+        """Loads one Fq (4 u64 limbs of the SoA batch at the walking address) into v[reg0:reg0+7]."""
+        for l in range(4):
+            e.emit(f"global_load_dwordx2 v[{reg0 + 2 * l}:{reg0 + 2 * l + 1}], v{V_IDX8}, {S_IOADDR}", kind="vmem", vw=[reg0 + 2 * l, reg0 + 2 * l + 1])
+            self.io_walk_next(e)
+
+    def io_store_fq(self, e, reg0):
+        for l in range(4):
+            e.emit(f"global_store_dwordx2 v{V_IDX8}, v[{reg0 + 2 * l}:{reg0 + 2 * l + 1}], {S_IOADDR}", kind="vmem")
+            self.io_walk_next(e)
+
+    def zero_block(self, e, blk, n=SLOT_DW):
+        for i in range(n):
+            e.emit(f"v_mov_b32_e32 v{blk + i}, 0", vw=[blk + i])
+
+    def one_into_A(self, e):
+        w = bal_limbs(mont4(1))
+        for i in range(NL):
+            e.emit(f"v_mov_b32_e32 v{A0 + i}, {hx(w[i])}", vw=[A0 + i])
+        self.zero_block(e, A0 + NL, NL)
+
+    def cvt_call(self, e, name):
+        e.salu(f"s_call_b64 {S_RET1}, {self.labels[name]}")
+
+    def gsel(self, e, j):
+        """S_GBASE <- byte offset of Fq12 scratch register j."""
+        e.salu(f"s_mul_i32 s{S_GBASE}, s{S_GSTRIDE}, {6 * j}")
+
+    def call2(self, e, name):
+        e.salu(f"s_call_b64 {S_RET2}, {self.lab(name)}")
+
+    def io_load_fq2_into_A(self, e, p, c1_present=True):
+        """Loads c0 (and c1) of the SoA batch at the walking address, converts to internal form -> block A."""
+        if c1_present:
+            self.io_load_fq(e, B0)                 # c0 packed -> v[18:25] (block B as staging)
+            self.io_load_fq(e, A0)                 # c1 packed -> v[0:7]
+            e.raw("s_waitcnt vmcnt(0)")
+            self.cvt_call(e, "cvtin")              # A.c0 <- internal(c1)
+            for i in range(NL):
+                e.emit(f"v_mov_b32_e32 v{A0 + NL + i}, v{A0 + i}", vw=[A0 + NL + i])
+            for i in range(8):
+                e.emit(f"v_mov_b32_e32 v{A0 + i}, v{B0 + i}", vw=[A0 + i])
+            self.cvt_call(e, "cvtin")
+        else:
+            self.io_load_fq(e, A0)
+            e.raw("s_waitcnt vmcnt(0)")
+            self.cvt_call(e, "cvtin")
+            self.zero_block(e, A0 + NL, NL)
+        p.set_A_fresh()
+        p.tagB = None
+
+    def _dbl_first(self, p):
+        """i = 63: R = Q -> 2Q, f = dense(tangent line) (miller_loop_native.rs:127-149); scale stays 1."""
+        p.dbl_step(self.R, (self.PX, self.PY), self.LINE, scale=None)
+        p.mov(self.F[0], self.LINE[0])
+        p.mov(self.F[3], self.LINE[1])
+        p.mov(self.F[4], self.LINE[2])
+        p.wait()
+        self.zero_block(p.e, A0)
+        p.set_A_fresh(0.0)
+        for k in (1, 2, 5):
+            p.to(self.F[k])
+
+    def _fq_inv(self, p):
+        """A.c0 <- A.c0^(p-2) (Fermat; fixed exponent, uniform control flow).  Input / output normalised.
+        Called with S_RET2; uses S_RET1 for the multiplies and s[60:61] as scratch."""
+        e = p.e
+        base = self.FQINV_BASE
+        p.wait()
+        p.store(A0, base)
+        p.load(B0, base)
+        p.tagA = p.tagB = None
+        ex = P_INT - 2
+        words = [(ex >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
+        uid = self.uid()
+        for limb in range(7, -1, -1):
+            top = 28 if limb == 7 else 31              # p < 2^254: bit 253 (= bit 29 of limb 7) is consumed by r = a
+            lbl = self.lab(f"L_fqinv_{limb}_{uid}")
+            skip = self.lab(f"L_fqinv_skip_{limb}_{uid}")
+            e.salu(f"s_mov_b32 s{S_TMP1}, 0x{words[limb]:x}")
+            e.salu(f"s_mov_b32 s{S_TMP0}, {top}")
+            e.label(lbl)
+            e.salu(f"s_call_b64 {S_RET1}, {self.labels['fqsqr']}")
+            e.salu(f"s_bitcmp1_b32 s{S_TMP1}, s{S_TMP0}")
+            e.salu(f"s_cbranch_scc0 {skip}")
+            e.salu(f"s_call_b64 {S_RET1}, {self.labels['fqmul']}")
+            e.label(skip)
+            e.salu(f"s_sub_u32 s{S_TMP0}, s{S_TMP0}, 1")
+            e.salu(f"s_cbranch_scc0 {lbl}")
+        p.set_A_fresh()
+
+    def _fq2_inv_inline(self, p, src, dst):
+        """dst <- 1/src (Fq2): conj(src) / (c0^2 + c1^2); sets the zero-divisor flag when the norm is 0."""
+        e = p.e
+        n0, tmp = p.tmp(), p.tmp()
+        p.A(src)
+        p.call("fqsqr")
+        p.to(n0)                                                  # n0.c0 = c0^2
+        p.A(src)
+        p.wait()
+        for i in range(NL):
+            e.emit(f"v_mov_b32_e32 v{A0 + i}, v{A0 + NL + i}", vw=[A0 + i])
+        rS, vS = p.rA, p.vA
+        p.tagA = None
+        p.rA, p.vA = rS, vS
+        p.call("fqsqr")
+        p.add(n0).redn()                                         # A.c0 = c0^2 + c1^2, reduced (the Fermat loop squares it unchecked)
+        # zero test needs the canonical representative: convert a copy out (value zero <-> all words zero)
+        p.to(tmp)
+        p.wait()
+        self.cvt_call(e, "cvtout")
+        e.emit(f"v_or3_b32 v{V_TID}, v{A0}, v{A0 + 1}, v{A0 + 2}", vw=[V_TID])
+        e.emit(f"v_or3_b32 v{V_TID}, v{V_TID}, v{A0 + 3}, v{A0 + 4}", vw=[V_TID])
+        e.emit(f"v_or3_b32 v{V_TID}, v{V_TID}, v{A0 + 5}, v{A0 + 6}", vw=[V_TID])
+        e.emit(f"v_or_b32_e32 v{V_TID}, v{V_TID}, v{A0 + 7}", vw=[V_TID])
+        e.emit(f"v_cmp_eq_u32_e32 vcc, 0, v{V_TID}", w=["vcc"])
+        e.emit(f"v_cndmask_b32_e64 v{V_TID}, 0, 1, vcc", r=["vcc"], vw=[V_TID])
+        e.emit(f"v_or_b32_e32 v{V_FLAG}, v{V_FLAG}, v{V_TID}", vw=[V_FLAG])
+        p.tagA = None
+        p.A(tmp)
+        p.wait()
+        e.salu(f"s_mov_b64 {S_RET3}, {S_RET2}")
+        e.salu(f"s_call_b64 {S_RET2}, {self.lab('L2_fqinv')}")
+        e.salu(f"s_mov_b64 {S_RET2}, {S_RET3}")
+        p.set_A_fresh()
+        p.tagB = None
+        p.to(tmp)
+        p.A(src).mulfq(tmp).conj().to(dst)
+        p.rel(n0, tmp)
+
+    def _descale(self, p):
+        """F <- F / scale  (exact miller_loop_native value)."""
+        inv = p.tmp()
+        self._fq2_inv_inline(p, self.SCALE, inv)
+        for i in range(6):
+            p.A(self.F[i]).mul(inv).to(self.F[i])
+        p.rel(inv)
+
+    def _frobenius(self, p, k):
+        """F <- frobenius_map_native(F, k) (final_exp_native.rs:17-54): conj^k on each coefficient, times frob_coeffs(k)^i."""
+        xi = (9, 1)
+        fc = f2pow(xi, (P_INT ** k - 1) // 6)
+        for i in range(6):
+            g = f2pow(fc, i)
+            p.A(self.F[i])
+            if k % 2:
+                p.conj()
+            if g == (1, 0):
+                pass
+            elif g[1] == 0:
+                p.mulfq(Const(g[0], 0, f"frob{k}_{i}"))
+            else:
+                p.mul(Const(g[0], g[1], f"frob{k}_{i}"))
+            p.to(self.F[i])
+
+    def _fq12_inv(self, p):
+        """F <- 1/F (ark Fq12 inverse, through Fq6 and Fq2 norms)."""
+        F = self.F
+        A_0, A_1 = [F[0], F[2], F[4]], [F[1], F[3], F[5]]
+        S0 = [p.tmp() for _ in range(3)]
+        S1 = [p.tmp() for _ in range(3)]
+        p.fq6_mul(A_0, A_0, S0)
+        p.fq6_mul(A_1, A_1, S1)
+        # d = S0 - v*S1 = (s00 - xi s12, s01 - s10, s02 - s11)
+        p.A(S1[2]).mulxi().rsub(S0[0]).to(S0[0])
+        p.A(S0[1]).sub(S1[0]).to(S0[1])
+        p.A(S0[2]).sub(S1[1]).to(S0[2])
+        d = S0
+        t = S1
+        # Fq6 inverse of d
+        X = p.tmp()
+        p.A(d[1]).mul(d[2]).mulxi().to(X)
+        p.A(d[0]).sqr().sub(X).to(t[0])                       # t0 = d0^2 - xi d1 d2
+        p.A(d[0]).mul(d[1]).to(X)
+        p.A(d[2]).sqr().mulxi().sub(X).to(t[1])               # t1 = xi d2^2 - d0 d1
+        p.A(d[0]).mul(d[2]).to(X)
+        p.A(d[1]).sqr().sub(X).to(t[2])                       # t2 = d1^2 - d0 d2
+        Y = p.tmp()
+        p.A(d[2]).mul(t[1]).to(X)
+        p.A(d[1]).mul(t[2]).add(X).mulxi().to(X)
+        p.A(d[0]).mul(t[0]).add(X).to(Y)                      # norm in Fq2
+        self._fq2_inv_inline(p, Y, X)
+        for i in range(3):
+            p.A(t[i]).mul(X).to(d[i])                         # d <- d^-1 (Fq6)
+        p.rel(X, Y)
+        # result = (A0 * dinv) - (A1 * dinv) w : even coefficients <- r0, odd <- -r1
+        r0, r1 = t, [p.tmp() for _ in range(3)]
+        p.fq6_mul(A_0, d, r0)
+        p.fq6_mul(A_1, d, r1)
+        for i in range(3):
+            p.mov(F[2 * i], r0[i])
+            p.A(r1[i]).neg().to(F[2 * i + 1])
+        p.rel(*S0)
+        p.rel(*S1)
+        p.rel(*r1)
+
+    # ---------------------------------------------------------------------------------------------
+    def main_body(self, e):
+        L = self.lab
+        e.label(L("L_main"))
+        e.label(L("L_item"))
+        e.salu(f"s_cmp_ge_u32 s{S_ITEM}, s{S_NITEMS}")
+        e.salu(f"s_cbranch_scc1 {L('L_done')}")
+        e.salu(f"s_lshl_b32 s{S_TMP0}, s{S_ITEM}, 8")
+        e.emit(f"v_add_u32_e32 v{V_IDX}, s{S_TMP0}, v{V_TID}", vw=[V_IDX])
+        e.salu(f"s_sub_u32 s{S_TMP1}, s{S_N}, 1")
+        e.emit(f"v_min_u32_e32 v{V_IDX8}, s{S_TMP1}, v{V_IDX}", vw=[V_IDX8])
+        e.emit(f"v_lshlrev_b32_e32 v{V_IDX8}, 3, v{V_IDX8}", vw=[V_IDX8])
+        e.emit(f"v_mov_b32_e32 v{V_FLAG}, 0", vw=[V_FLAG])
+        p = Prog(e, self.labels)
+        p.set_temps(self.miller_temps())
+        p.temp_keys = frozenset()            # the main program's stores all cross routine boundaries
+        p.norm_keys = self.norm_keys("miller")
+        self.main_prog = p
+        if self.do_miller and self.multi:
+            self.miller_main_multi(e, p)
+        elif self.do_miller:
+            self.miller_main(e, p)
+        else:
+            self.load_fq12_into_F(e, p, S_FIN)
+        if self.helper:
+            self.helper_main(e, p)
+        elif self.do_fexp:
+            self.fexp_main(e, p)
+        self.store_out(e, p)
+        e.salu(f"s_add_u32 s{S_ITEM}, s{S_ITEM}, s{S_GRID}")
+        e.salu(f"s_branch {L('L_item')}")
+        e.label(L("L_done"))
+
+    def load_fq12_into_F(self, e, p, ptr):
+        """F <- the lane's MyFq12 of the SoA batch at `ptr` (components 0..5 are the c0 parts of w^0..w^5, 6..11 the c1
+        parts): two passes over the planes, c0 parts first into AGPR staging (the operand slots, free at that point)."""
+        self.io_walk_begin(e, ptr)
+        for k in range(6):
+            self.io_load_fq(e, A0)
+            e.raw("s_waitcnt vmcnt(0)")
+            self.cvt_call(e, "cvtin")
+            for i in range(NL):
+                e.emit(f"v_accvgpr_write_b32 a{NL * k + i}, v{A0 + i}")       # c0 of coefficient k
+        for k in range(6):
+            self.io_load_fq(e, A0)
+            e.raw("s_waitcnt vmcnt(0)")
+            self.cvt_call(e, "cvtin")
+            for i in range(NL):
+                e.emit(f"v_mov_b32_e32 v{A0 + NL + i}, v{A0 + i}", vw=[A0 + NL + i])
+            for i in range(NL):
+                e.emit(f"v_accvgpr_read_b32 v{A0 + i}, a{NL * k + i}", vw=[A0 + i])
+            p.set_A_fresh()
+            p.to(self.F[k])
+        p.reset_tags()
+
+    # ---------------------------------------------------------------------------------------------
+    # batched helpers: k argument = op | power << 8 | naf_len << 16
+    OP_MUL, OP_FROB, OP_POW = 0, 1, 2
+
+    def helper_main(self, e, p):
+        L = self.lab
+
+        def gsel(j):
+            self.gsel(e, j)
+
+        def c2(name):
+            self.call2(e, name)
+
+        e.salu(f"s_and_b32 s{S_TMP0}, s{S_K}, 0xff")
+        e.salu(f"s_cmp_eq_u32 s{S_TMP0}, {self.OP_FROB}")
+        e.salu(f"s_cbranch_scc1 {L('L_h_frob')}")
+        e.salu(f"s_cmp_eq_u32 s{S_TMP0}, {self.OP_POW}")
+        e.salu(f"s_cbranch_scc1 {L('L_h_pow')}")
+        # ---- MyFq12 Mul: F holds a; b comes from the g1 pointer
+        gsel(0); c2("L2_stG")
+        self.load_fq12_into_F(e, p, S_G1)
+        gsel(0); c2("L2_mulG")
+        e.salu(f"s_branch {L('L_h_done')}")
+        # ---- frobenius_map_native(a, power), power = 0..11
+        e.label(L("L_h_frob"))
+        e.salu(f"s_lshr_b32 s{S_TMP0}, s{S_K}, 8")
+        e.salu(f"s_and_b32 s{S_TMP0}, s{S_TMP0}, 0xf")
+        for k in range(1, 12):
+            e.salu(f"s_cmp_eq_u32 s{S_TMP0}, {k}")
+            e.salu(f"s_cbranch_scc0 {L(f'L_h_nf{k}')}")
+            c2(f"L2_frob{k}")
+            e.salu(f"s_branch {L('L_h_done')}")
+            e.label(L(f"L_h_nf{k}"))
+        e.salu(f"s_branch {L('L_h_done')}")                      # power 0: identity
+        # ---- pow_native(a, exp): NAF digits (int8, least significant first) at the g2 pointer, top digit = +1
+        e.label(L("L_h_pow"))
+        gsel(0); c2("L2_stG")                                     # G0 = a
+        e.salu(f"s_bitcmp1_b32 s{S_K}, 8")                        # bit 8: the NAF has a -1 digit (only then is 1/a formed: the
+        e.salu(f"s_cbranch_scc0 {L('L_h_noinv')}")                 # reference divides -- and panics on a = 0 -- only on such a digit)
+        c2("L2_inv")
+        gsel(1); c2("L2_stG")                                     # G1 = 1/a   (`res / a` on a -1 digit, final_exp_native.rs:72-75)
+        gsel(0); c2("L2_ldG")                                     # res = a (the top digit)
+        e.label(L("L_h_noinv"))
+        e.salu(f"s_lshr_b32 s{S_J}, s{S_K}, 16")
+        e.salu(f"s_sub_u32 s{S_J}, s{S_J}, 2")
+        e.salu(f"s_cbranch_scc1 {L('L_h_done')}")                 # a single digit: a^1
+        e.label(L("L_h_ploop"))
+        c2("L2_sqrF")
+        e.salu(f"s_and_b32 s{S_TMP0}, s{S_J}, 0xfffffffc")
+        e.salu(f"s_load_dword s{S_TMP1}, {S_G2}, s{S_TMP0}")
+        e.salu(f"s_and_b32 s{S_TMP0}, s{S_J}, 3")
+        e.salu(f"s_lshl_b32 s{S_TMP0}, s{S_TMP0}, 3")
+        e.raw("s_waitcnt lgkmcnt(0)")
+        e.salu(f"s_lshr_b32 s{S_TMP1}, s{S_TMP1}, s{S_TMP0}")
+        e.salu(f"s_sext_i32_i8 s{S_TMP1}, s{S_TMP1}")
+        e.salu(f"s_cmp_eq_i32 s{S_TMP1}, 0")
+        e.salu(f"s_cbranch_scc1 {L('L_h_pnext')}")
+        e.salu(f"s_cmp_gt_i32 s{S_TMP1}, 0")
+        e.salu(f"s_cselect_b32 s{S_TMP1}, 0, 1")                   # register 0 (a) for +1, 1 (1/a) for -1
+        e.salu(f"s_mul_i32 s{S_TMP1}, s{S_TMP1}, 6")
+        e.salu(f"s_mul_i32 s{S_GBASE}, s{S_GSTRIDE}, s{S_TMP1}")
+        c2("L2_mulG")
+        e.label(L("L_h_pnext"))
+        e.salu(f"s_sub_u32 s{S_J}, s{S_J}, 1")
+        e.salu(f"s_cbranch_scc0 {L('L_h_ploop')}")
+        e.label(L("L_h_done"))
+        p.reset_tags()
+
+    def _twist_consts(self):
+        xi = (9, 1)
+        c = f2pow(xi, (P_INT - 1) // 6)
+        c2 = f2mul(c, c)
+        c3 = f2mul(c2, c)
+        return Const(c2[0], c2[1], "c2"), Const(c3[0], c3[1], "c3")
+
+    def _frobenius_points(self, p):
+        """Q1 = pi(Q) = (c2 conj(x), c3 conj(y)) -> S ; -Q2 = (c2 conj(Q1.x), c3 neg_conj(Q1.y)) -> the Q slots, which are dead
+        from here on (miller_loop_native.rs:298-312).  (The sparse multiplication inside L2_addmul uses the S slots as
+        temporaries, so -Q2 must exist before the first call.)"""
+        C2, C3 = self._twist_consts()
+        p.reset_tags()
+        p.A(self.QX).conj().mul(C2).to(self.SX)
+        p.A(self.QY).conj().mul(C3).to(self.SY)
+        p.A(self.SX).conj().mul(C2).to(self.QX)
+        p.A(self.SY).conj().neg().mul(C3).to(self.QY)
+
+    def _select_pm_q(self, e, p):
+        """S <- +-Q by the sign of the current digit"""
+        L = self.lab
+        p.reset_tags()
+        p.mov(self.SX, self.QX)
+        p.A(self.QY)
+        p.wait()
+        e.salu(f"s_bitcmp1_b64 {S_NAF_NEG}, s{S_I}")
+        e.salu(f"s_cbranch_scc0 {L('L_mpos')}")
+        e.salu(f"s_call_b64 {S_RET1}, {self.labels['neg']}")
+        e.label(L("L_mpos"))
+        p.tagA = None
+        p.to(self.SY)
+
+    def miller_main(self, e, p):
+        L = self.lab
+        self.io_walk_begin(e, S_G1)
+        self.io_load_fq2_into_A(e, p, c1_present=False)          # Px
+        p.to(self.PX)
+        self.io_load_fq2_into_A(e, p, c1_present=False)          # Py
+        p.to(self.PY)
+        self.io_walk_begin(e, S_G2)
+        self.io_load_fq2_into_A(e, p)                            # Q.x
+        p.to(self.QX)
+        p.to(self.R[0])
+        self.io_load_fq2_into_A(e, p)                            # Q.y
+        p.to(self.QY)
+        p.to(self.R[1])
+        self.one_into_A(e)
+        p.set_A_fresh()
+        p.to(self.R[2])
+        if self.track:
+            p.to(self.SCALE)
+        p.reset_tags()
+        self.call2(e, "L2_dblfirst")
+        e.salu(f"s_mov_b32 s{S_I}, 63")
+        e.label(L("L_mloop"))
+        e.salu(f"s_cmp_eq_u32 s{S_I}, 63")
+        e.salu(f"s_cbranch_scc1 {L('L_mskip')}")
+        self.call2(e, "L2_sqr")
+        if self.track:
+            self.call2(e, "L2_sqscale")
+        self.call2(e, "L2_dblmul")
+        e.label(L("L_mskip"))
+        e.salu(f"s_bitcmp1_b64 {S_NAF_NZ}, s{S_I}")
+        e.salu(f"s_cbranch_scc0 {L('L_mnoadd')}")
+        self._select_pm_q(e, p)
+        self.call2(e, "L2_addmul")
+        e.label(L("L_mnoadd"))
+        e.salu(f"s_sub_u32 s{S_I}, s{S_I}, 1")
+        e.salu(f"s_cbranch_scc0 {L('L_mloop')}")
+        self._frobenius_points(p)
+        self.call2(e, "L2_addmul")
+        p.reset_tags()
+        p.mov(self.SX, self.QX)
+        p.mov(self.SY, self.QY)
+        self.call2(e, "L2_addmul_last")
+        if self.track:
+            self.call2(e, "L2_descale")
+        p.reset_tags()
+
+    # ---------------------------------------------------------------------------------------------
+    # multi-pairing: shared f, k pairs per lane (multi_miller_loop_native, miller_loop_native.rs:192-282).
+    # Pair state (P, Q converted; R projective) lives in scratch and is swapped through the resident slots.
+    def pair_select(self, e):
+        """S_GBASE <- byte offset of pair S_JP's scratch block."""
+        e.salu(f"s_mul_i32 s{S_TMP0}, s{S_JP}, 7")
+        e.salu(f"s_add_u32 s{S_TMP0}, s{S_TMP0}, {self.PAIR_SLOT0}")
+        e.salu(f"s_mul_i32 s{S_GBASE}, s{S_TMP0}, s{S_GSTRIDE}")
+
+    def pair_in(self, e, p, with_q):
+        """Resident slots <- scratch block of the selected pair: all loads issued back to back, one wait."""
+        dests = [self.PX, self.PY] + ([self.QX, self.QY] if with_q else []) + list(self.R)
+        srcs = [0, 1] + ([2, 3] if with_q else []) + [4, 5, 6]
+        self.batch_load_globdyn(e, p, srcs, dests)
+
+    def pair_out(self, e, p):
+        """scratch block of the selected pair <- R (the only state a step changes)."""
+        p.reset_tags()
+        for k, src in zip((4, 5, 6), self.R):
+            p.A(src).to(GlobDyn(k))
+        p.reset_tags()
+
+    def pair_loop(self, e, name, body):
+        """for S_JP in 0..k-1: body()"""
+        L = self.lab
+        e.salu(f"s_mov_b32 s{S_JP}, 0")
+        e.label(L(f"L_pl_{name}"))
+        self.pair_select(e)
+        body()
+        e.salu(f"s_add_u32 s{S_JP}, s{S_JP}, 1")
+        e.salu(f"s_cmp_lt_u32 s{S_JP}, s{S_K}")
+        e.salu(f"s_cbranch_scc1 {L(f'L_pl_{name}')}")
+
+    def miller_main_multi(self, e, p):
+        L = self.lab
+        # ---- init: convert P_j, Q_j into scratch, R_j = (Q_j, 1)
+        e.salu(f"s_mul_i32 s{S_NSTRIDE}, s{S_N}, s{S_K}")
+        e.salu(f"s_lshl_b32 s{S_NSTRIDE}, s{S_NSTRIDE}, 3")          # bytes between limb planes of the PAIR batches
+        e.emit(f"v_lshrrev_b32_e32 v{V_IDX8}, 3, v{V_IDX8}", vw=[V_IDX8])   # clamped group index
+        e.emit(f"v_mul_lo_u32 v{V_IDX8}, v{V_IDX8}, s{S_K}", vw=[V_IDX8])
+        e.emit(f"v_lshlrev_b32_e32 v{V_IDX8}, 3, v{V_IDX8}", vw=[V_IDX8])   # byte offset of the group's first pair
+
+        def init_pair():
+            # element offset of pair j = (group*k + j) * 8
+            e.salu(f"s_lshl_b32 s{S_TMP1}, s{S_JP}, 3")
+            e.emit(f"v_add_u32_e32 v{V_IDX8}, s{S_TMP1}, v{V_IDX8}", vw=[V_IDX8])
+            self.io_walk_begin(e, S_G1)
+            self.io_load_fq2_into_A(e, p, c1_present=False)
+            p.to(GlobDyn(0))
+            self.io_load_fq2_into_A(e, p, c1_present=False)
+            p.to(GlobDyn(1))
+            self.io_walk_begin(e, S_G2)
+            self.io_load_fq2_into_A(e, p)
+            p.to(GlobDyn(2))
+            p.to(GlobDyn(4))
+            self.io_load_fq2_into_A(e, p)
+            p.to(GlobDyn(3))
+            p.to(GlobDyn(5))
+            self.one_into_A(e)
+            p.set_A_fresh()
+            p.to(GlobDyn(6))
+            p.wait()
+            e.salu(f"s_lshl_b32 s{S_TMP1}, s{S_JP}, 3")
+            e.emit(f"v_subrev_u32_e32 v{V_IDX8}, s{S_TMP1}, v{V_IDX8}", vw=[V_IDX8])
+            p.reset_tags()
+
+        self.pair_loop(e, "init", init_pair)
+        if self.track:
+            self.one_into_A(e)
+            p.set_A_fresh()
+            p.to(self.SCALE)
+            p.reset_tags()
+
+        # ---- top digit: f = product of the tangent lines at Q_j
+        def first_step():
+            self.pair_in(e, p, with_q=False)
+            e.salu(f"s_cmp_eq_u32 s{S_JP}, 0")
+            e.salu(f"s_cbranch_scc0 {L('L_mf_rest')}")
+            self.call2(e, "L2_dblfirst")
+            e.salu(f"s_branch {L('L_mf_done')}")
+            e.label(L("L_mf_rest"))
+            self.call2(e, "L2_dblmul")
+            e.label(L("L_mf_done"))
+            self.pair_out(e, p)
+
+        self.pair_loop(e, "first", first_step)
+        e.salu(f"s_mov_b32 s{S_I}, 63")
+        e.label(L("L_mloop"))
+        e.salu(f"s_cmp_eq_u32 s{S_I}, 63")
+        e.salu(f"s_cbranch_scc1 {L('L_mskip')}")
+        self.call2(e, "L2_sqr")
+        if self.track:
+            self.call2(e, "L2_sqscale")
+
+        def dbl_pair():
+            self.pair_in(e, p, with_q=False)
+            self.call2(e, "L2_dblmul")
+            self.pair_out(e, p)
+
+        self.pair_loop(e, "dbl", dbl_pair)
+        e.label(L("L_mskip"))
+        e.salu(f"s_bitcmp1_b64 {S_NAF_NZ}, s{S_I}")
+        e.salu(f"s_cbranch_scc0 {L('L_mnoadd')}")
+
+        def add_pair():
+            self.pair_in(e, p, with_q=True)
+            self._select_pm_q(e, p)
+            self.call2(e, "L2_addmul")
+            self.pair_out(e, p)
+
+        self.pair_loop(e, "add", add_pair)
+        e.label(L("L_mnoadd"))
+        e.salu(f"s_sub_u32 s{S_I}, s{S_I}, 1")
+        e.salu(f"s_cbranch_scc0 {L('L_mloop')}")
+
+        def end_pair():
+            self.pair_in(e, p, with_q=True)
+            self._frobenius_points(p)
+            self.call2(e, "L2_addmul")
+            p.reset_tags()
+            p.mov(self.SX, self.QX)
+            p.mov(self.SY, self.QY)
+            self.call2(e, "L2_addmul_last")
+            p.reset_tags()
+
+        self.pair_loop(e, "end", end_pair)
+        if self.track:
+            self.call2(e, "L2_descale")
+        p.reset_tags()
+        # output indexing is per group again
+        e.salu(f"s_lshl_b32 s{S_NSTRIDE}, s{S_N}, 3")
+        e.salu(f"s_sub_u32 s{S_TMP1}, s{S_N}, 1")
+        e.emit(f"v_min_u32_e32 v{V_IDX8}, s{S_TMP1}, v{V_IDX}", vw=[V_IDX8])
+        e.emit(f"v_lshlrev_b32_e32 v{V_IDX8}, 3, v{V_IDX8}", vw=[V_IDX8])
+
+    # ---------------------------------------------------------------------------------------------
+    def fexp_main(self, e, p):
+        """final_exp_native on F (LDS), F-centric schedule (tests/sched_model.py: final_exp_gpu)."""
+        G0, GM, G2, G3, G4, G5, G6, G7 = range(8)
+        tr = self.fexp_trace = []         # the straight-line call sequence, replayed by the bound certification
+
+        def st(j):
+            tr.append(("st", j))
+            self.gsel(e, j)
+            self.call2(e, "L2_stG")
+
+        def ld(j, conj=False):
+            tr.append(("ld", j, conj))
+            self.gsel(e, j)
+            self.call2(e, "L2_ldGc" if conj else "L2_ldG")
+
+        def mul(j, conj=False):
+            tr.append(("mul", j, conj))
+            self.gsel(e, j)
+            self.call2(e, "L2_mulGc" if conj else "L2_mulG")
+
+        def powx(j):
+            tr.append(("powx", j))
+            self.gsel(e, j)
+            e.salu(f"s_call_b64 {S_RET3}, {self.lab('L3_powx')}")
+
+        def c2(n):
+            tr.append(("call", n))
+            self.call2(e, n)
+        # easy part (:195-206)
+        st(G0); c2("L2_inv"); mul(G0, conj=True); st(G0); c2("L2_frob2"); mul(G0)
+        # hard part (:130-169)
+        st(GM)
+        c2("L2_frob1"); st(G2)
+        ld(GM); c2("L2_frob2"); st(G3)
+        ld(GM); c2("L2_frob3"); mul(G3); mul(G2); st(G2)              # y0
+        ld(GM); powx(GM); st(G3)                                      # mx
+        powx(G3); st(G4)                                              # mx2
+        powx(G4); st(G5)                                              # mx3
+        ld(G3); c2("L2_frob1"); st(G6)                                # mxp
+        ld(G4); c2("L2_frob1"); mul(G3); st(G7)                       # mx * mx2p
+        ld(G4); c2("L2_frob2"); st(G3)                                # y2
+        ld(G5); c2("L2_frob1"); mul(G5); c2("L2_conjF")               # y6
+        c2("L2_cyc")                                                  # T0 = y6^2
+        mul(G7, conj=True)                                            # * y4
+        mul(G4, conj=True)                                            # * y5
+        st(G0)
+        ld(G6, conj=True); mul(G4, conj=True)                         # T1 = y3 * y5
+        mul(G0); st(G5)                                               # T1 *= T0
+        ld(G0); mul(G3); st(G0)                                       # T0 = y2 * T0
+        ld(G5); c2("L2_cyc"); mul(G0); c2("L2_cyc"); st(G5)           # T1 = (T1^2 * T0)^2
+        mul(GM, conj=True); st(G0)                                    # T0 = T1 * y1
+        ld(G5); mul(G2); st(G5)                                       # T1 = T1 * y0
+        ld(G0); c2("L2_cyc"); mul(G5)                                 # T0 = T0^2 * T1
+
+    def store_out(self, e, p):
+        p.reset_tags()
+        e.emit(f"v_cmp_gt_u32_e32 vcc, s{S_N}, v{V_IDX}", w=["vcc"])      # lanes past the end of the batch do not store
+        e.raw("s_nop 1")
+        e.salu(f"s_and_saveexec_b64 {S_SAVE_EXEC}, vcc")
+        self.io_walk_begin(e, S_OUT)
+        for half in range(2):
+            for k in range(6):
+                p.load(A0, self.F[k])
+                p.wait()
+                if half == 1:
+                    for i in range(NL):
+                        e.emit(f"v_mov_b32_e32 v{A0 + i}, v{A0 + NL + i}", vw=[A0 + i])
+                self.cvt_call(e, "cvtout")
+                self.io_store_fq(e, A0)
+                e.raw("s_nop 1")
+        e.emit(f"v_cmp_ne_u32_e32 vcc, 0, v{V_FLAG}", w=["vcc"])          # zero-divisor flag -> status word
+        e.raw("s_nop 1")
+        e.salu("s_and_saveexec_b64 s[60:61], vcc")
+        e.emit(f"v_mov_b32_e32 v{V_IDX8}, 1", vw=[V_IDX8])
+        e.emit("v_mov_b32_e32 v36, 0", vw=[36])
+        e.emit(f"global_store_dword v36, v{V_IDX8}, {S_STATUS}", kind="vmem")
+        e.salu(f"s_mov_b64 exec, {S_SAVE_EXEC}")
+        e.raw("s_waitcnt vmcnt(0)")
+        e.emit(f"v_lshrrev_b32_e32 v{V_TID}, 4, v{V_LDS}", vw=[V_TID])

@@ -232,6 +232,11 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None):
             elif op == "v_subrev_u32_e32":
                 m.vset(a[0], m.vsrc(a[2]) - m.vsrc(a[1]))
                 m.count_valu += 1
+            elif op == "v_bfe_i32":
+                w = m.vsrc(a[3]) & 31
+                x = (m.vsrc(a[1]) >> (m.vsrc(a[2]) & 31)) & ((1 << w) - 1)
+                m.vset(a[0], x - (1 << w) if w and (x >> (w - 1)) else x)
+                m.count_valu += 1
             elif op == "v_bfe_u32":
                 m.vset(a[0], (m.vsrc(a[1]) >> (m.vsrc(a[2]) & 31)) & ((1 << (m.vsrc(a[3]) & 31)) - 1))
                 m.count_valu += 1
@@ -418,7 +423,8 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None):
                 m.count += 1
                 return
             # ------------------------------------------------------------ memory
-            elif op in ("ds_read_b128", "ds_write_b128"):
+            elif op in ("ds_read_b128", "ds_write_b128", "ds_read_b64", "ds_write_b64"):
+                ndw = 4 if op.endswith("b128") else 2
                 off = 0
                 regs = None
                 addr = None
@@ -429,10 +435,12 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None):
                 toks = [t.split()[0] for t in a]
                 if off < 0 or off > 65535:
                     raise SimError("DS offset out of range: " + text)
-                if op == "ds_read_b128":
+                if op.startswith("ds_read"):
                     lo = int(re.match(r"v\[(\d+):", toks[0]).group(1))
+                    if lo % 2:
+                        raise SimError("odd-aligned DS destination tuple")
                     base = m.vsrc(toks[1])
-                    for k in range(4):
+                    for k in range(ndw):
                         x = m.lds.get(base + off + 4 * k)
                         if x is None:
                             raise SimError(f"LDS read of unwritten address {base + off + 4 * k}: {text}")
@@ -440,9 +448,9 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None):
                 else:
                     base = m.vsrc(toks[0])
                     lo = int(re.match(r"v\[(\d+):", toks[1]).group(1))
-                    if (base + off) % 16:
-                        raise SimError("misaligned ds_write_b128")
-                    for k in range(4):
+                    if (base + off) % (4 * ndw):
+                        raise SimError("misaligned ds_write")
+                    for k in range(ndw):
                         if v[lo + k] is None:
                             raise SimError("store of uninitialised register: " + text)
                         if m.exec:
