@@ -222,18 +222,15 @@ k_pairing(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in, uint64_t
                        "v"(tid), "s"(bid), "s"(grid)                                                                       \
                      : BN254_ASM_CLOBBERS);                                                                                \
     }
-BN254_ASM_KERNEL(k2_pairing, BN254_ASM_PAIRING)
-BN254_ASM_KERNEL(k2_miller, BN254_ASM_MILLER)
-BN254_ASM_KERNEL(k2_fexp, BN254_ASM_FEXP)
-// v3: carry-free signed radix-2^27 limbs (tools/kgen3*.py); 80-byte scratch slots
-BN254_ASM_KERNEL(k3_pairing, BN254_ASM3_PAIRING)
-BN254_ASM_KERNEL(k3_miller, BN254_ASM3_MILLER)
-BN254_ASM_KERNEL(k3_fexp, BN254_ASM3_FEXP)
-BN254_ASM_KERNEL(k3_mpairing, BN254_ASM3_MPAIRING)   // k pairs per lane, shared f (multi_miller_loop_native) + final exp
-BN254_ASM_KERNEL(k3_mmiller, BN254_ASM3_MMILLER)     // k pairs per lane, exact multi_miller_loop_native value
-BN254_ASM_KERNEL(k3_op, BN254_ASM3_OP)               // batched helpers: MyFq12 Mul / frobenius_map_native / pow_native (k = op | power << 8 | naf_len << 16)
-constexpr int V3_GSLOTS = 80;         // twelve Fq12 registers + eight overflow temporaries (+ 7 per pair in the multi kernels)
-constexpr int V3_SLOT_BYTES = 80;
+// balanced signed radix-2^29 limbs, nine limbs (tools/kgen4*.py); 72-byte slots
+BN254_ASM_KERNEL(k3_pairing, BN254_ASM_PAIRING)
+BN254_ASM_KERNEL(k3_miller, BN254_ASM_MILLER)
+BN254_ASM_KERNEL(k3_fexp, BN254_ASM_FEXP)
+BN254_ASM_KERNEL(k3_mpairing, BN254_ASM_MPAIRING)   // k pairs per lane, shared f (multi_miller_loop_native) + final exp
+BN254_ASM_KERNEL(k3_mmiller, BN254_ASM_MMILLER)     // k pairs per lane, exact multi_miller_loop_native value
+BN254_ASM_KERNEL(k3_op, BN254_ASM_OP)               // batched helpers: MyFq12 Mul / frobenius_map_native / pow_native (k = op | power << 8 | naf_len << 16)
+constexpr int V3_GSLOTS = BN254_GSLOTS;         // twelve Fq12 registers + eight overflow temporaries (+ 7 per pair in the multi kernels)
+constexpr int V3_SLOT_BYTES = BN254_SLOT_BYTES;
 
 enum { OP_MUL = 0, OP_FROB = 1, OP_POW = 2, OP_INV = 3, OP_SQR = 4, OP_CYC_SQR = 5 };
 
@@ -414,8 +411,7 @@ int ctx_get(int device, void* stream, size_t k, LaunchCtx* out, uint32_t* grid_o
         HIPCHK(hipGetDeviceProperties(&prop, device));
         c.n_cu = prop.multiProcessorCount;
         const void* kernels[] = {(const void*)k_pairing<true, true>, (const void*)k_pairing<true, false>, (const void*)k_pairing<false, true>,
-                                 (const void*)k_fq12_op, (const void*)k_generate, (const void*)k2_pairing, (const void*)k2_miller,
-                                 (const void*)k2_fexp, (const void*)k3_pairing, (const void*)k3_miller, (const void*)k3_fexp,
+                                 (const void*)k_fq12_op, (const void*)k_generate, (const void*)k3_pairing, (const void*)k3_miller, (const void*)k3_fexp,
                                  (const void*)k3_mpairing, (const void*)k3_mmiller, (const void*)k3_op};
         for (const void* f : kernels) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
         c.init = true;
@@ -473,18 +469,6 @@ int launch_pairing(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in,
                                   (uint32_t)n_groups, (uint32_t)k, c->scratch, stride, c->status);
         else hipLaunchKernelGGL(k3_mmiller, dim3(grid), dim3(BLOCK), LDS_BYTES, (hipStream_t)stream, g1, g2, f_in, out,
                                 (uint32_t)n_groups, (uint32_t)k, c->scratch, stride, c->status);
-        HIPCHK(hipGetLastError());
-        return BN254_OK;
-    }
-    if (k == 1 && !use_v1) {
-        if (n_groups >= (1ull << 29)) return BN254_ERR_INVALID_ARG;   // 32-bit element offsets in the asm kernels
-        uint32_t stride = grid * BLOCK * 64;                            // bytes between scratch slots
-        if (M && F) hipLaunchKernelGGL(k2_pairing, dim3(grid), dim3(BLOCK), LDS_BYTES, (hipStream_t)stream, g1, g2, f_in, out,
-                                       (uint32_t)n_groups, 1u, c->scratch, stride, c->status);
-        else if (M) hipLaunchKernelGGL(k2_miller, dim3(grid), dim3(BLOCK), LDS_BYTES, (hipStream_t)stream, g1, g2, f_in, out,
-                                       (uint32_t)n_groups, 1u, c->scratch, stride, c->status);
-        else hipLaunchKernelGGL(k2_fexp, dim3(grid), dim3(BLOCK), LDS_BYTES, (hipStream_t)stream, g1, g2, f_in, out,
-                                (uint32_t)n_groups, 1u, c->scratch, stride, c->status);
         HIPCHK(hipGetLastError());
         return BN254_OK;
     }

@@ -1,13 +1,13 @@
-"""Static bound certification of the v3 kernels (signed radix-2^27 limbs, tools/kgen3*.py).
+"""Static bound certification of the shipped kernels (balanced radix-2^29 limbs, tools/kgen4*.py).
 
-Limb bounds are closed per routine: every store enforces |limb| <= 3.05 units of 2^27 and every multiplication
-asserts its signed 64-bit column sums when the code is generated.  VALUE bounds (which representative of a residue
-a slot holds -- it lives in the top limb) cross routine boundaries: a cyclotomic squaring 3t - 2z roughly doubles
-the representative and only a Montgomery multiplication contracts it again.  KernelBuilder3.certify_values()
-replays the kernel's real, data-independent call sequence (NAF digits of 6u+2 and of BN_X, the y-chain of
-hard_part_BN_native) through the generator's own transfer functions, re-generating every routine under the true
-entry bounds: all generation-time checks must still pass and the emitted code must be identical to what ships.
-tests/test_kgen.py cross-checks that the replayed sequence is exactly what the instruction simulator executes."""
+LIMB bounds are closed per routine: every multiplication asserts at generation time that its signed 64-bit column sums
+cannot overflow (n_terms * |a| * |b| + 9 below 118 units of 2^56) and every store enforces its limb limit.  VALUE bounds
+(which representative of a residue a slot holds -- with R'/p = 169.6 a Montgomery reduction contracts only small values)
+cross routine boundaries through one contract: whatever a routine finds in a slot is below V_STORE p, and it leaves at
+most V_STORE p in every slot that outlives it; its own temporaries stay below V_CAP p, which keeps the top limb (weight
+2^232) inside one unit.  KernelBuilder.certify_values() walks the kernel's real, data-independent call sequence (NAF digits
+of 6u+2, the x-power digits, the y-chain of hard_part_BN_native) and checks every routine on it against the contract;
+tests/test_kgen4.py cross-checks that the walked sequence is exactly what the instruction simulator executes."""
 import os
 import sys
 
@@ -15,47 +15,62 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-import kgen3_prog as K3P  # noqa: E402
-from gen_kernels import V3_KERNELS  # noqa: E402
+import kgen4 as K4  # noqa: E402
+import kgen4_prog as K4P  # noqa: E402
+from asmcore import Emitter, P_INT  # noqa: E402
+from gen_kernels import KERNELS  # noqa: E402
 
 
-@pytest.mark.parametrize("name,kw", V3_KERNELS, ids=[n for n, _ in V3_KERNELS])
-def test_value_bounds_of_shipped_kernels(name, kw):
-    kb = K3P.KernelBuilder3(**kw)
+@pytest.mark.parametrize("name,kw", KERNELS, ids=[n for n, _ in KERNELS])
+def test_value_contract_of_shipped_kernels(name, kw):
+    kb = K4P.KernelBuilder(**kw)
     kb.build()
-    for k_pairs in ((1, 2, 3, 8) if kw.get("multi") else (1,)):
-        rep = kb.certify_values(k_pairs)
-        assert rep["max_stored"] <= K3P.V_CAP
-        # top limb (weight 2^243) of the largest stored value: below one unit (2^27), inside every limb interval
-        assert rep["max_stored"] * K3P.P_INT / 2 ** 243 < 2 ** 27
-        if kw["do_miller"]:
-            assert rep["miller_f_out"] < 2.0            # the Miller loop hands over a freshly reduced f
-        if kw["do_fexp"]:
-            assert rep["fexp_f_out"] < 4096.0          # cvtout (one more Montgomery multiplication) canonicalises any representative
+    if kw.get("helper"):
+        rep = kb.certify_helper()
+    else:
+        for k_pairs in ((1, 2, 3, 8) if kw.get("multi") else (1,)):
+            rep = kb.certify_values(k_pairs)
+    assert rep["max_stored"] <= K4P.V_CAP
+    # top limb (weight 2^232) of the largest temporary: within one unit (2^28), inside every limb interval
+    assert rep["max_stored"] * P_INT / 2 ** 232 <= 2 ** 28
+    for routine, exits in kb.l2_exit.items():
+        assert all(v <= K4P.V_STORE for v in exits.values()), routine
+    # cvtout (one more Montgomery multiplication) canonicalises any representative below 84 p: (84 p * p / R') / p + 1/2 < 1
+    assert K4P.V_STORE * 1.0 / K4P.K_RP + 0.5 < 1.0
 
 
-def test_reduction_schedule_of_the_x_power_loop():
-    """No more than RED_RUN cyclotomic squarings in a row without a multiplication or a representative reduction."""
-    naf = K3P.X_DIGITS[:-1]                                # the shipped x-power schedule (digits in {0, +-1, +-5, +-9, +-13})
-    red = K3P.x_red_mask(naf)
-    run = longest = 0
-    for j in range(len(naf) - 1, -1, -1):
-        run += 1
-        longest = max(longest, run)
-        if naf[j] != 0 or red >> j & 1:
-            run = 0
-        assert not (naf[j] != 0 and red >> j & 1)
-    assert longest == K3P.RED_RUN
-    assert 0 < bin(red).count("1") <= 12                 # ~500 instructions each (L1 redn): < 0.5 % of the final exponentiation
+def test_constants_of_the_tracker():
+    assert abs(K4P.K_RP - (1 << 261) / P_INT) < 1e-6 and 169 < K4P.K_RP < 170
+    assert K4P.V_CAP <= K4P.K_TOP                          # a stored value's top limb stays within one unit
+    # a column of the three-term multiplication: 54 products of normalised limbs + 9 reduction products, far below 2^63
+    assert (54 + 9) * (1 << 56) < (1 << 63) and 2 * K4.NL * 3 <= K4P.COL_BUDGET
+    assert (K4P.COL_BUDGET + K4.NL) * (1 << 56) + (1 << 35) < (1 << 63)       # products + reduction products + carry-in
 
 
-def test_certification_has_teeth():
-    """Unreduced squarings in a row make the worst-case representative diverge: the replay must reject them."""
-    kb = K3P.KernelBuilder3(do_miller=False, do_fexp=True)
-    kb.build()
-    kb.certify_values()
-    state = {}
+def test_tracker_has_teeth():
+    """The generator refuses what it cannot prove: a three-term multiplication of unnormalised operands, a multiplication
+    whose column sums could overflow, a store beyond the value cap."""
+    def prog():
+        p = K4P.Prog(Emitter(), {n: f"L1_{n}" for n in K4.L1V4_NAMES})
+        p.set_temps([K4P.HOME(i) for i in range(9)])
+        return p
+    p = prog()
+    p.reserve_blocks()
+    for k in range(4):
+        p.ldH(k, K4P.AGPR(k))                                # unknown stored values: up to two units per limb
     with pytest.raises(AssertionError):
-        for _ in range(9):
-            ex, _ = kb._eval("L2_cyc", state)
-            state.update(ex)
+        p.A(K4P.AGPR(4)).mul3(K4P.AGPR(5))                   # 18 * (4 + 4 + 4) > 118
+    p = prog()
+    p.A(K4P.AGPR(0))
+    p.rA = (-6.0, 6.0)
+    p.mul(K4P.AGPR(1))                                       # the tracker inserts a normalisation by itself ...
+    assert p.stats.get("norm", 0) + p.stats.get("redn", 0) == 1
+    p = prog()
+    p.slot_r[("agpr", 1)] = (-8.0, 8.0)
+    with pytest.raises(AssertionError):
+        p.A(K4P.AGPR(0)).mul(K4P.AGPR(1))                    # ... but cannot fix an operand that sits in a slot
+    p = prog()
+    p.A(K4P.AGPR(0))
+    p.vA = 400.0
+    with pytest.raises(AssertionError):
+        p.store(K4.A0, K4P.AGPR(2)) or p._need(p.vA <= K4P.V_CAP, "value bound at store")

@@ -11,7 +11,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from kgen import align_code  # noqa: E402
+from asmcore import align_code  # noqa: E402
 
 P_L = [0x7cfd47, 0x1842c36, 0x2e5346f, 0x68ddb52, 0x455f06d, 0x360ab71, 0x7316de1, 0x4a028d7, 0x6131a02, 0x30644e7 >> 0]
 

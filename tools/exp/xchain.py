@@ -3,7 +3,7 @@
 
 Cost model: a cyclotomic squaring = 18 fqmul, an Fq12 multiplication = 54.  For every digit set
 D = {1} + up to three odd powers, the optimal signed recoding x = sum d_i 2^i with d_i in +-D (dynamic programming) and the
-cheapest addition chain producing b^d for d in D (depth-first search) are computed.  Result used by tools/kgen3_prog.py
+cheapest addition chain producing b^d for d in D (depth-first search) are computed.  Result used by tools/kgen4_prog.py
 (X_POWERS, X_DIGITS): D = {1, 5, 9, 13}: 61 squarings + 15 multiplications = 1908 against 2358 for the plain NAF of
 pow_native (final_exp_native.rs:56-84).  The value b^x does not depend on the chain, so results stay bit-identical."""
 import itertools, functools, sys

@@ -32,7 +32,7 @@ from asmcore import Emitter, P_INT, BN_X, SIX_U_PLUS_2_NAF, align_code, max_bran
 from kgen4 import (A0, B0, HOME0, L1V4_NAMES, L1v4, LB, N0P, N_AGPR_SLOTS, N_HOME, N_LDS_SLOTS, NL, P_L, REDN_C, S_M30, S_N0, S_P, S_REDN,  # noqa: E402
                    S_RET1, S_RET2, S_RET3, SLOT_DW, SLOT_BYTES, V_FLAG, V_GOFF, V_IDX, V_IDX8, V_LDS, V_LTAIL, V_TID, bal_limbs, hx, mont4)
 
-# ---- scalar registers used by L2/L3 (all inside the clobbered range s36..s101) ----------------
+# ---- scalar registers used by L2/L3 (all inside the clobbered range s36..s99) ----------------
 S_TMP0, S_TMP1 = 60, 61
 S_GADDR = "s[62:63]"      # address of the global slot being accessed
 S_SCRATCH = "s[64:65]"    # scratch base of this workgroup
@@ -42,7 +42,6 @@ S_NAF_NZ = "s[68:69]"     # 6u+2 NAF: non-zero mask, negative mask (digits 0..63
 S_NAF_NEG = "s[70:71]"
 S_XNAF_NZ = "s[72:73]"    # x-power digit masks
 S_XNAF_NEG = "s[74:75]"
-S_XNAF_RED = "s[48:49]"   # digits after which the accumulator's representative is reduced (L2_redF)
 S_XIDX0, S_XIDX1 = "s[50:51]", "s[52:53]"      # which power a non-zero digit selects (index into X_POWERS)
 S_J = 76                  # pow_x digit index
 S_GBASE = 77              # global Fq12 register operand of fq12_mul (slot number * stride, low 32 bits)
@@ -61,7 +60,7 @@ S_FIN = "s[94:95]"
 S_K = 96
 S_JP = 97                 # pair counter of the multi-pairing kernels
 S_SAVE_EXEC = "s[98:99]"
-S_PB = 100                # byte offset of the base's scratch register during the x-power routine
+S_PB = 48                 # byte offset of the base's scratch register during the x-power routine (s49: free)
 BLOCK = 256
 
 
