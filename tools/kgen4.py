@@ -358,11 +358,16 @@ class L1v4:
         self.r_sqr4c(xi=True)
 
     # ------------------------------------------------------------------ fused Fq6 multiplication
+    MUL6_REDUCE = bool(int(os.environ.get("KGEN_MUL6_REDUCE", "0")))
+
     def r_mul6(self):
         """Fq6 multiplication (Fq2[v]/(v^3 - xi), Karatsuba: six Fq2 multiplications), fused: a = (a0, a1, a2) in home blocks
-        0..2, b in home blocks 3..5, all NORMALISED.  Results, normalised and reduced:  c0 -> home block 1,  c1 -> block A,
-        c2 -> home block 0.  Scratch: home blocks 6, 7, blocks A, B, the pool.  Every input block is destroyed.
-        The recombinations run on 64-bit chains (the x xi term would overflow 32-bit limbs), which also reduce."""
+        0..2, b in home blocks 3..5, all NORMALISED.  Results, normalised (value bounds: kgen4_prog.Prog._mul6_regs):
+        c0 -> home block 1,  c1 -> block A,  c2 -> home block 0.  Scratch: home blocks 6, 7, blocks A, B, the pool.  Every
+        input block is destroyed.  The recombinations run on 64-bit chains (the x xi term would overflow 32-bit limbs).
+        The results are NOT reduced: their consumers (the Fq12 recombinations) add and subtract them first and reduce once
+        per Fq12 coefficient instead of once per Fq6 coefficient."""
+        red = self.MUL6_REDUCE
         H = lambda k: self.fq2(HOME0 + SLOT_DW * k)
         a, b = [H(0), H(1), H(2)], [H(3), H(4), H(5)]
         v0, v1 = H(6), H(7)
@@ -386,14 +391,14 @@ class L1v4:
         m01, m02, m12 = A, a[0], a[1]
         # c1 = m01 - v0 - v1 + xi v2  -> block A (in place over m01)
         self.lincomb([A[0], A[1]], [[(1, m01[0]), (-1, v0[0]), (-1, v1[0]), (9, v2[0]), (-1, v2[1])],
-                                    [(1, m01[1]), (-1, v0[1]), (-1, v1[1]), (9, v2[1]), (1, v2[0])]], reduce=True)
+                                    [(1, m01[1]), (-1, v0[1]), (-1, v1[1]), (9, v2[1]), (1, v2[0])]], reduce=red)
         # c2 = m02 - v0 - v2 + v1  -> home block 0 (in place over m02)
         self.lincomb([m02[0], m02[1]], [[(1, m02[0]), (-1, v0[0]), (-1, v2[0]), (1, v1[0])],
-                                        [(1, m02[1]), (-1, v0[1]), (-1, v2[1]), (1, v1[1])]], reduce=True)
+                                        [(1, m02[1]), (-1, v0[1]), (-1, v2[1]), (1, v1[1])]], reduce=red)
         # c0 = v0 + xi (m12 - v1 - v2)  -> home block 1 (in place over m12); w = m12 - v1 - v2: c0 = v0 + (9 w0 - w1, 9 w1 + w0)
         w0 = [(9, m12[0]), (-9, v1[0]), (-9, v2[0]), (-1, m12[1]), (1, v1[1]), (1, v2[1]), (1, v0[0])]
         w1 = [(9, m12[1]), (-9, v1[1]), (-9, v2[1]), (1, m12[0]), (-1, v1[0]), (-1, v2[0]), (1, v0[1])]
-        self.lincomb([m12[0], m12[1]], [w0, w1], reduce=True)
+        self.lincomb([m12[0], m12[1]], [w0, w1], reduce=red)
 
     def r_mulfq(self):
         """A <- (A.c0 * B.c0, A.c1 * B.c0), in place"""

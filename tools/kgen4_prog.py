@@ -613,7 +613,7 @@ class Prog:
     def _mul6_regs(self, a, b, a_plus=None, b_plus=None):
         """Fused Fq6 multiplication (L1 mul6) of (a + a_plus) by (b + b_plus), coefficient-wise sums formed (and normalised)
         while the operands are loaded into the home blocks.  Returns the three result 'slots' [c0, c1, c2]: c0 = HOME(1),
-        c1 = block A (None), c2 = HOME(0), all normalised and reduced; every home block is clobbered."""
+        c1 = block A (None), c2 = HOME(0), all normalised; every home block is clobbered."""
         va = vb = 0.0
         for base, slots, plus in ((0, a, a_plus), (3, b, b_plus)):
             for k, s_ in enumerate(slots):
@@ -626,11 +626,22 @@ class Prog:
         self._raw_call("mul6")
         self.tagB = None
         res = [HOME(1, "mul6.c0"), None, HOME(0, "mul6.c2")]
-        for slot in (res[0], res[2]):
-            self.slot_r[self.key(slot)] = R_NORM
-            self.slot_v[self.key(slot)] = 0.51
-        self.vA = 0.51
-        self.rA = R_NORM
+        if L1v4.MUL6_REDUCE:
+            v0 = v1 = v2 = 0.51
+        else:
+            # Fq2 products of operands below va, vb: 2 va vb / K + 1/2; of the Karatsuba sums: 8 va vb / K + 1/2
+            v_prod, v_sum = 2 * va * vb / K_RP + 0.5, 8 * va * vb / K_RP + 0.5
+            v0 = 10 * v_sum + 21 * v_prod         # c0 = v0 + xi (m12 - v1 - v2)
+            v1 = v_sum + 12 * v_prod              # c1 = m01 - v0 - v1 + xi v2
+            v2 = v_sum + 3 * v_prod               # c2 = m02 - v0 - v2 + v1
+        for slot, v in ((res[0], v0), (res[2], v2)):
+            self._need(v <= V_CAP, f"mul6 result value {v}")
+            self.slot_r[self.key(slot)] = self.r_norm(v)
+            self.slot_v[self.key(slot)] = v
+            self.max_v = max(self.max_v, v)
+        self._need(v1 <= V_CAP, f"mul6 result value {v1}")
+        self.vA = v1
+        self.rA = self.r_norm()
         self.tagA = None
         return res
 
@@ -940,7 +951,8 @@ class KernelBuilder:
         tk = {Prog.key(t) for t in temps}
         self.l2_bodies[name] = (body, temps)
         self.l2_phase[name] = self._phase
-        self.l2_exit[name] = {k: v for k, v in p.slot_v.items() if k not in tk}
+        # (home registers never carry a value across a routine boundary: they are every routine's workspace)
+        self.l2_exit[name] = {k: v for k, v in p.slot_v.items() if k not in tk and k[0] != "home"}
         self.l2_maxv[name] = p.max_v
         return p
 
@@ -1247,7 +1259,7 @@ class KernelBuilder:
         p.wait()
         e.salu(f"s_setpc_b64 {S_RET2}")
         self.sections.append(e)
-        self.l2_exit["L2_mul_body"] = {k: v for k, v in p.slot_v.items() if k not in p.temp_keys}
+        self.l2_exit["L2_mul_body"] = {k: v for k, v in p.slot_v.items() if k not in p.temp_keys and k[0] != "home"}
         self.l2_maxv["L2_mul_body"] = p.max_v
 
     # ---------------------------------------------------------------------------------------------
