@@ -306,9 +306,10 @@ def generate_pairs_dev(seed, g1_out, g2_out, n, device=0, stream=None):
 
 def generator_scalars(seed, i):
     """The scalars (s_i, t_i) bn254_generate_pairs_dev uses for pair i: P_i = [s_i] G1, Q_i = [t_i] G2.  Four SplitMix64
-    draws from the state seed ^ (0xD1B54A32D192ED03 * (i + 1)): s = lo | (hi | 2^63) << 64, then t likewise -- 128-bit
-    scalars with the top bit set (never zero mod r; NOT uniform mod r: synthetic bench / test inputs, the pairing kernels
-    have no data-dependent control flow)."""
+    draws from the state seed ^ (0xD1B54A32D192ED03 * (i + 1)) give two 128-bit strings (low word first); each is read as 32
+    radix-16 digits, a zero digit counting as 1, so s = sum d_k 16^k with every d_k in 1..15 (the fixed-base window method
+    of the generator kernel then performs exactly one table addition per digit).  Never zero mod r; NOT uniform mod r:
+    synthetic bench / test inputs -- the pairing kernels have no data-dependent control flow."""
     m64 = (1 << 64) - 1
     st = (seed ^ (0xD1B54A32D192ED03 * (i + 1))) & m64
     draws = []
@@ -318,7 +319,11 @@ def generator_scalars(seed, i):
         z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m64
         z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m64
         draws.append(z ^ (z >> 31))
-    return draws[0] | ((draws[1] | (1 << 63)) << 64), draws[2] | ((draws[3] | (1 << 63)) << 64)
+
+    def digits(v):
+        return sum(max((v >> (4 * k)) & 15, 1) << (4 * k) for k in range(32))
+
+    return digits(draws[0] | (draws[1] << 64)), digits(draws[2] | (draws[3] << 64))
 
 
 def last_status(device=0, stream=None):

@@ -345,3 +345,40 @@ def test_helper_kernel(vec):
     out, m = run_kernel(kb, g2=[0x0000000000010001], fin=[0] * 48, k=kb.OP_POW | 3 << 16, check_seq=False)
     assert out == [0] * 12 and STAT not in m.gmem
     kb.certify_helper()
+
+
+def test_generate_kernel():
+    """k_generate on one lane: P = [s] G1, Q = [t] G2 by the fixed-base radix-16 method (table of tools/gen_tables.py), scalars
+    from SplitMix64 as plonky2-bn254-pairing_amd.generator_scalars states; affine canonical output."""
+    import gen_tables as GT
+    pk = H.pkg()
+    kb = K4P.KernelBuilder(generate=True)
+    lines = _concretize(kb.build()) + ["s_endpgm"]
+    TAB = 0x600000
+    seed, n = 0xB2540001, 300
+    words = GT.all_words()
+    for item, tid in ((1, 1),):                          # second work item, lane 1
+        m = S.Machine()
+        for i, w in enumerate(words):
+            m.gmem[TAB + 4 * i] = w & 0xFFFFFFFF
+        for name, val in (("s[2:3]", G1B), ("s[4:5]", G2B), ("s[6:7]", TAB), ("s[8:9]", seed), ("s10", n), ("s11", 1), ("s[12:13]", SCR),
+                          ("s14", 256 * K4.SLOT_BYTES), ("s[16:17]", STAT), ("s18", item), ("s19", 4)):
+            m.sset(name, val)
+        m.v[255] = tid
+        S.run(lines, m)
+        idx = item * 256 + tid
+        s, t = pk.generator_scalars(seed, idx)
+        P_, Q_ = R.g1_mul(R.G1_GEN, s % R.R_ORDER), R.g2_mul(R.G2_GEN, t % R.R_ORDER)
+
+        def rd(base, planes):
+            out = []
+            for c in range(planes):
+                v = 0
+                for l in range(4):
+                    a = base + ((c * 4 + l) * n + idx) * 8
+                    v |= (m.gmem[a] | (m.gmem[a + 4] << 32)) << (64 * l)
+                out.append(R.from_mont(v))
+            return out
+        assert rd(G1B, 2) == list(P_)
+        assert rd(G2B, 4) == [Q_[0][0], Q_[0][1], Q_[1][0], Q_[1][1]]
+        print("generate kernel:", m.count, "instructions per pair")

@@ -118,6 +118,19 @@ def f2pow(a, e):
     return r
 
 
+def frob_const(k, i):
+    """frob_coeffs(k)^i = xi^(i (p^k - 1)/6): the factor frobenius_map_native(a, k) puts on the coefficient of w^i
+    (final_exp_native.rs:27,33-42)"""
+    return f2pow(f2pow((9, 1), (P_INT ** k - 1) // 6), i)
+
+
+def twist_consts():
+    """c2 = xi^((p-1)/3), c3 = xi^((p-1)/2)   (miller_loop_native.rs:176-181)"""
+    c = f2pow((9, 1), (P_INT - 1) // 6)
+    c2 = f2mul(c, c)
+    return c2, f2mul(c2, c)
+
+
 def naf_masks(naf):
     nz = sum(1 << i for i, d in enumerate(naf) if d != 0)
     neg = sum(1 << i for i, d in enumerate(naf) if d < 0)
@@ -861,6 +874,27 @@ class Prog:
         self.rel(th, mu, T, U)
 
 
+    def pt_add(self, R, Q):
+        """R <- R + Q (Q affine), the point part of add_step alone (fixed-base scalar multiplication of the input generator)."""
+        X, Y, Z = R
+        x2, y2 = Q
+        th, mu, T, U, Cc, D, E = [self.tmp() for _ in range(7)]
+        self.A(y2).mul(Z).rsub(Y).to(th)
+        self.A(x2).mul(Z).rsub(X).to(mu)
+        self.A(th).sqr().to(Cc)
+        self.A(mu).sqr().to(D)
+        self.A(mu).mul(D).to(E)
+        self.A(Z).mul(Cc).to(Cc)
+        self.A(X).mul(D).to(D)
+        self.A(D).dbl().to(T)
+        self.A(E).add(Cc).sub(T).to(T)
+        self.A(mu).mul(T).to(X)
+        self.A(E).mul(Y).to(U)
+        self.A(D).sub(T).mul(th).sub(U).to(Y)
+        self.A(Z).mul(E).to(Z)
+        self.rel(th, mu, T, U, Cc, D, E)
+
+
 # ======================================================================================================================
 class _PhaseList(list):
     """The builder's section list: remembers in which phase (Miller loop / final exponentiation) a section was added."""
@@ -892,13 +926,16 @@ class KernelBuilder:
 
     COLD = ("L2_inv", "L2_frob1", "L2_frob2", "L2_frob3", "L2_dblfirst", "L2_addmul_last", "L2_descale", "L2_fqinv")
 
-    def __init__(self, do_miller=True, do_fexp=True, track=False, multi=False, helper=False):
+    def __init__(self, do_miller=True, do_fexp=True, track=False, multi=False, helper=False, generate=False):
         """track: keep the running line scale and divide it out (the exact miller_loop_native value).
         multi: k pairs per lane with a shared f (multi_miller_loop_native, miller_loop_native.rs:192-282).
         helper: the batched public helpers of the reference on Fq12 batches -- MyFq12 `Mul`, frobenius_map_native
         (final_exp_native.rs:17-54), pow_native (:56-84) -- selected at run time by the kernel's `k` argument."""
         if helper:
             do_miller, do_fexp, track, multi = False, True, False, False
+        if generate:
+            do_miller, do_fexp, track, multi = False, False, False, False
+        self.generate = generate
         self.do_miller, self.do_fexp, self.track = do_miller, do_fexp, track
         self.multi = multi
         self.helper = helper
@@ -1011,6 +1048,11 @@ class KernelBuilder:
                 self.l2_routine("L2_fqinv", self._fq_inv, self.miller_temps())
                 self.l2_routine("L2_descale", self._descale, self.miller_temps())
                 self.l2_routine("L2_sqscale", lambda p: p.A(self.SCALE).sqr().to(self.SCALE), self.miller_temps())
+        if self.generate:
+            gt = self.gen_temps()
+            self.l2_routine("L2_fqinv", self._fq_inv, gt)
+            self.l2_routine("L2_ptadd", lambda p: p.pt_add(self.R, (self.SX, self.SY)), gt)
+            self.l2_routine("L2_affine", self._to_affine, gt)
         self._phase = "fexp"
         if self.do_fexp:
             if not (self.do_miller and self.track):
@@ -1459,10 +1501,8 @@ class KernelBuilder:
 
     def _frobenius(self, p, k):
         """F <- frobenius_map_native(F, k) (final_exp_native.rs:17-54): conj^k on each coefficient, times frob_coeffs(k)^i."""
-        xi = (9, 1)
-        fc = f2pow(xi, (P_INT ** k - 1) // 6)
         for i in range(6):
-            g = f2pow(fc, i)
+            g = frob_const(k, i)
             p.A(self.F[i])
             if k % 2:
                 p.conj()
@@ -1533,6 +1573,12 @@ class KernelBuilder:
         p.temp_keys = frozenset()            # the main program's stores all cross routine boundaries
         p.norm_keys = self.norm_keys("miller")
         self.main_prog = p
+        if self.generate:
+            self.generate_main(e, p)
+            e.salu(f"s_add_u32 s{S_ITEM}, s{S_ITEM}, s{S_GRID}")
+            e.salu(f"s_branch {L('L_item')}")
+            e.label(L("L_done"))
+            return
         if self.do_miller and self.multi:
             self.miller_main_multi(e, p)
         elif self.do_miller:
@@ -1639,10 +1685,7 @@ class KernelBuilder:
         p.reset_tags()
 
     def _twist_consts(self):
-        xi = (9, 1)
-        c = f2pow(xi, (P_INT - 1) // 6)
-        c2 = f2mul(c, c)
-        c3 = f2mul(c2, c)
+        c2, c3 = twist_consts()
         return Const(c2[0], c2[1], "c2"), Const(c3[0], c3[1], "c3")
 
     def _frobenius_points(self, p):
@@ -1851,6 +1894,150 @@ class KernelBuilder:
         e.salu(f"s_sub_u32 s{S_TMP1}, s{S_N}, 1")
         e.emit(f"v_min_u32_e32 v{V_IDX8}, s{S_TMP1}, v{V_IDX}", vw=[V_IDX8])
         e.emit(f"v_lshlrev_b32_e32 v{V_IDX8}, 3, v{V_IDX8}", vw=[V_IDX8])
+
+
+    # ---------------------------------------------------------------------------------------------
+    # synthetic inputs: P = [s] G1, Q = [t] G2 by the fixed-base radix-16 method over the table of tools/gen_tables.py
+    # (stands in for G1Affine::rand / G2Affine::rand, /root/reference/src/pairing.rs:65-66).
+    # kernel arguments: %0 g1_out  %1 g2_out  %2 table  %3 seed (64-bit value)  %4 n
+    GEN_WORDS = HOME0 + SLOT_DW * 8            # v[228:235]: the scalars s (4 dwords) and t (4 dwords) ; v[236:243]: SplitMix64 scratch
+    GEN_ENTRY_BYTES = 4 * 4 * NL               # x.c0, x.c1, y.c0, y.c1
+
+    def gen_temps(self):
+        return [HOME(i) for i in range(8)] + [AGPR(i) for i in (6, 7, 8, 10, 11, 12, 13)] + [GLOB(GLOB_TMP0 + i) for i in range(8)]
+
+    def _to_affine(self, p):
+        """S <- (X / Z, Y / Z)"""
+        inv, z = p.tmp(), p.tmp()
+        p.mov(z, self.R[2])                       # RZ shares its AGPR slot with the Fq-inversion base
+        self._fq2_inv_inline(p, z, inv)
+        p.rel(z)
+        p.A(self.R[0]).mul(inv).to(self.SX)
+        p.A(self.R[1]).mul(inv).to(self.SY)
+        p.rel(inv)
+
+    def _splitmix(self, e, st, z, t, dst):
+        """dst (one VGPR pair: 64 bits) <- next SplitMix64 output; st: the state pair, z / t: scratch pairs (all even-aligned)"""
+        P2 = lambda r: f"v[{r}:{r + 1}]"
+
+        def mul64(c):
+            e.salu(f"s_mov_b32 s{S_TMP0}, 0x{c & 0xFFFFFFFF:x}")
+            e.salu(f"s_mov_b32 s{S_TMP1}, 0x{c >> 32:x}")
+            e.emit(f"v_mul_lo_u32 v{t}, v{z + 1}, s{S_TMP0}", vw=[t])
+            e.emit(f"v_mul_lo_u32 v{t + 1}, v{z}, s{S_TMP1}", vw=[t + 1])
+            e.emit(f"v_mad_u64_u32 {P2(z)}, vcc, v{z}, s{S_TMP0}, 0", w=["vcc"], vw=[z, z + 1])
+            e.emit(f"v_add3_u32 v{z + 1}, v{z + 1}, v{t}, v{t + 1}", vw=[z + 1])
+
+        def xorshift(k):
+            e.emit(f"v_lshrrev_b64 {P2(t)}, {k}, {P2(z)}", vw=[t, t + 1])
+            e.emit(f"v_xor_b32_e32 v{z}, v{z}, v{t}", vw=[z])
+            e.emit(f"v_xor_b32_e32 v{z + 1}, v{z + 1}, v{t + 1}", vw=[z + 1])
+
+        e.emit(f"v_add_co_u32_e32 v{st}, vcc, 0x7f4a7c15, v{st}", w=["vcc"], vw=[st])
+        e.emit(f"v_mov_b32_e32 v{t}, 0x9e3779b9", vw=[t])                 # (a literal next to the VCC carry-in would need two constant-bus reads)
+        e.emit(f"v_addc_co_u32_e32 v{st + 1}, vcc, v{t}, v{st + 1}, vcc", r=["vcc"], w=["vcc"], vw=[st + 1])
+        e.emit(f"v_mov_b32_e32 v{z}, v{st}", vw=[z])
+        e.emit(f"v_mov_b32_e32 v{z + 1}, v{st + 1}", vw=[z + 1])
+        xorshift(30)
+        mul64(0xBF58476D1CE4E5B9)
+        xorshift(27)
+        mul64(0x94D049BB133111EB)
+        xorshift(31)
+        e.emit(f"v_mov_b32_e32 v{dst}, v{z}", vw=[dst])
+        e.emit(f"v_mov_b32_e32 v{dst + 1}, v{z + 1}", vw=[dst + 1])
+
+    def _gen_load_entry(self, e, p, word, first):
+        """S <- table entry of the digit at (scalar word VGPR `word`, nibble S_J) in window S_I of the current curve
+        (S_PHASE = byte offset of the curve's sub-table); first: into R = (x, y, 1) instead."""
+        off, d = V_IDX8, V_FLAG            # free here: the output index is recomputed before the stores
+        e.salu(f"s_lshl_b32 s{S_TMP0}, s{S_J}, 2")
+        e.emit(f"v_lshrrev_b32_e32 v{d}, s{S_TMP0}, v{word}", vw=[d])
+        e.emit(f"v_and_b32_e32 v{d}, 15, v{d}", vw=[d])
+        e.emit(f"v_max_u32_e32 v{d}, 1, v{d}", vw=[d])                       # digits are 1..15 (a zero nibble counts as 1)
+        # entry = (window * 15 + digit - 1) ; byte offset = entry * 144 + curve offset
+        e.salu(f"s_mul_i32 s{S_TMP1}, s{S_I}, {15 * self.GEN_ENTRY_BYTES}")
+        e.salu(f"s_add_u32 s{S_TMP1}, s{S_TMP1}, s{S_PHASE}")
+        e.salu(f"s_sub_u32 s{S_TMP1}, s{S_TMP1}, {self.GEN_ENTRY_BYTES}")
+        e.emit(f"v_mul_u32_u24_e32 v{off}, {self.GEN_ENTRY_BYTES}, v{d}", vw=[off])
+        e.emit(f"v_add_u32_e32 v{off}, s{S_TMP1}, v{off}", vw=[off])
+        for blk, base in ((A0, 0), (B0, 4 * SLOT_DW)):
+            for c in range(Prog.N_B128):
+                e.emit(f"global_load_dwordx4 v[{blk + 4 * c}:{blk + 4 * c + 3}], v{off}, {S_FIN} offset:{base + 16 * c}", kind="vmem",
+                       vw=range(blk + 4 * c, blk + 4 * c + 4))
+            e.emit(f"global_load_dwordx2 v[{blk + 16}:{blk + 17}], v{off}, {S_FIN} offset:{base + 64}", kind="vmem", vw=[blk + 16, blk + 17])
+        e.raw("s_waitcnt vmcnt(0)")
+        p.set_A_fresh()
+        p.tagB = None
+        p.to(self.R[0] if first else self.SX)
+        p.wait()
+        for i in range(SLOT_DW):
+            e.emit(f"v_mov_b32_e32 v{A0 + i}, v{B0 + i}", vw=[A0 + i])
+        p.set_A_fresh()
+        p.to(self.R[1] if first else self.SY)
+        p.reset_tags()
+
+    def generate_main(self, e, p):
+        L = self.lab
+        W = self.GEN_WORDS
+        st, z, t = W + 8, W + 10, W + 12
+        # SplitMix64 state = seed ^ (0xD1B54A32D192ED03 * (index + 1))
+        e.emit(f"v_lshrrev_b32_e32 v{z}, 3, v{V_IDX8}", vw=[z])           # V_IDX8 = clamped index * 8
+        e.emit(f"v_add_u32_e32 v{z}, 1, v{z}", vw=[z])
+        e.salu(f"s_mov_b32 s{S_TMP0}, 0xd192ed03")
+        e.salu(f"s_mov_b32 s{S_TMP1}, 0xd1b54a32")
+        e.emit(f"v_mul_lo_u32 v{t}, v{z}, s{S_TMP1}", vw=[t])
+        e.emit(f"v_mad_u64_u32 v[{st}:{st + 1}], vcc, v{z}, s{S_TMP0}, 0", w=["vcc"], vw=[st, st + 1])
+        e.emit(f"v_add_u32_e32 v{st + 1}, v{st + 1}, v{t}", vw=[st + 1])
+        e.emit(f"v_xor_b32_e32 v{st}, s84, v{st}", vw=[st])                # seed: the `out` argument (s[84:85])
+        e.emit(f"v_xor_b32_e32 v{st + 1}, s85, v{st + 1}", vw=[st + 1])
+        for k in range(4):                                                 # s = draws 0, 1 ; t = draws 2, 3 (low word first)
+            self._splitmix(e, st, z, t, W + 2 * k)
+        for curve in range(2):
+            e.salu(f"s_mov_b32 s{S_PHASE}, {curve * 32 * 15 * self.GEN_ENTRY_BYTES}")
+            e.salu(f"s_mov_b32 s{S_I}, 0")
+            for w in range(4):
+                word = W + 4 * curve + w
+                e.salu(f"s_mov_b32 s{S_J}, 0")
+                if w == 0:                                                 # window 0: R = (entry, 1)
+                    self._gen_load_entry(e, p, word, first=True)
+                    self.one_into_A(e)
+                    p.set_A_fresh()
+                    p.to(self.R[2])
+                    p.reset_tags()
+                    e.salu(f"s_mov_b32 s{S_J}, 1")
+                    e.salu(f"s_mov_b32 s{S_I}, 1")
+                e.label(L(f"L_gen_{curve}_{w}"))
+                self._gen_load_entry(e, p, word, first=False)
+                self.call2(e, "L2_ptadd")
+                e.salu(f"s_add_u32 s{S_I}, s{S_I}, 1")
+                e.salu(f"s_add_u32 s{S_J}, s{S_J}, 1")
+                e.salu(f"s_cmp_lt_u32 s{S_J}, 8")
+                e.salu(f"s_cbranch_scc1 {L(f'L_gen_{curve}_{w}')}")
+            self.call2(e, "L2_affine")
+            # store: canonical external form, SoA planes of this curve's output batch
+            e.salu(f"s_sub_u32 s{S_TMP1}, s{S_N}, 1")
+            e.emit(f"v_min_u32_e32 v{V_IDX8}, s{S_TMP1}, v{V_IDX}", vw=[V_IDX8])
+            e.emit(f"v_lshlrev_b32_e32 v{V_IDX8}, 3, v{V_IDX8}", vw=[V_IDX8])
+            e.emit(f"v_cmp_gt_u32_e32 vcc, s{S_N}, v{V_IDX}", w=["vcc"])
+            e.raw("s_nop 1")
+            e.salu(f"s_and_saveexec_b64 {S_SAVE_EXEC}, vcc")
+            self.io_walk_begin(e, S_G1 if curve == 0 else S_G2)
+            p.reset_tags()
+            for src in (self.SX, self.SY):
+                for half in range(1 if curve == 0 else 2):
+                    p.load(A0, src)
+                    p.wait()
+                    if half == 1:
+                        for i in range(NL):
+                            e.emit(f"v_mov_b32_e32 v{A0 + i}, v{A0 + NL + i}", vw=[A0 + i])
+                    self.cvt_call(e, "cvtout")
+                    self.io_store_fq(e, A0)
+                    e.raw("s_nop 1")
+            e.salu(f"s_mov_b64 exec, {S_SAVE_EXEC}")
+            e.raw("s_waitcnt vmcnt(0)")
+            e.emit(f"v_mov_b32_e32 v{V_FLAG}, 0", vw=[V_FLAG])
+        e.emit(f"v_lshrrev_b32_e32 v{V_TID}, 4, v{V_LDS}", vw=[V_TID])
+        p.reset_tags()
 
     # ---------------------------------------------------------------------------------------------
     def fexp_main(self, e, p):

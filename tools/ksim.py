@@ -285,6 +285,26 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None):
                 c = m.carry_in(a[3])
                 m.vset(a[0], m.vsrc(a[2]) if c else m.vsrc(a[1]))
                 m.count_valu += 1
+            elif op == "v_xor_b32_e32":
+                m.vset(a[0], m.vsrc(a[1]) ^ m.vsrc(a[2]))
+                m.count_valu += 1
+            elif op == "v_max_u32_e32":
+                m.vset(a[0], max(m.vsrc(a[1]), m.vsrc(a[2])))
+                m.count_valu += 1
+            elif op == "v_add3_u32":
+                m.vset(a[0], m.vsrc(a[1]) + m.vsrc(a[2]) + m.vsrc(a[3]))
+                m.count_valu += 1
+            elif op == "v_mad_u32_u24":
+                m.vset(a[0], (m.vsrc(a[1]) & 0xFFFFFF) * (m.vsrc(a[2]) & 0xFFFFFF) + m.vsrc(a[3]))
+                m.count_valu += 1
+            elif op == "v_lshrrev_b64":
+                r = m.vsrc64(a[2]) >> (m.vsrc(a[1]) & 63)
+                lo = int(re.match(r"v\[(\d+):", a[0]).group(1))
+                if lo % 2:
+                    raise SimError("odd-aligned 64-bit VGPR dest")
+                v[lo] = r & M32
+                v[lo + 1] = (r >> 32) & M32
+                m.count_valu += 1
             elif op == "v_and_b32_e32":
                 m.vset(a[0], m.vsrc(a[1]) & m.vsrc(a[2]))
                 m.count_valu += 1
