@@ -145,7 +145,8 @@ def test_l1_routines():
             for j in range(4):
                 assert (val(m, j) - want[j]) % P == 0, (name, t, j)
                 assert _is_norm(m, list(range(NL * j, NL * j + NL))) and abs(val(m, j)) < 0.52 * P, (name, t, j)
-    # mul6 (fused Fq6 multiplication): normalised operands in home blocks 0..5
+    # mul6 (fused Fq6 multiplication, schoolbook with lazy reduction): a in home blocks 0..2 (also as unnormalised sums of two
+    # normalised values), b normalised in home blocks 3..5
     for t in range(10):
         a = [(rnd(), rnd()) for _ in range(3)]
         b = [(rnd(), rnd()) for _ in range(3)]
@@ -153,29 +154,39 @@ def test_l1_routines():
         for r in list(range(K4.HOME0 + 6 * K4.SLOT_DW, K4.HOME0 + 8 * K4.SLOT_DW)) + list(range(0, 2 * K4.SLOT_DW)):
             m.v[r] = rng.getrandbits(32)
         for k, el in enumerate(a + b):
-            put(m, K4.HOME0 + K4.SLOT_DW * k, el, neg=False)
+            blk = K4.HOME0 + K4.SLOT_DW * k
+            if t % 2 and k < 3:                  # a sum of two normalised values, limb by limb
+                part = (rng.randrange(P), rng.randrange(P))
+                put(m, blk, part)
+                rest = K4.bal_limbs((el[0] - part[0]) % P) + K4.bal_limbs((el[1] - part[1]) % P)
+                for i in range(K4.SLOT_DW):
+                    m.v[blk + i] = (m.v[blk + i] + rest[i]) & 0xFFFFFFFF
+            else:
+                put(m, blk, el)
         S.run_block(B["mul6"], m)
-        v = [f2m(a[i], b[i]) for i in range(3)]
-        cross = lambda i, j: f2m(f2a(a[i], a[j]), f2a(b[i], b[j]))
-        want = [f2a(v[0], xi(sub(sub(cross(1, 2), v[1]), v[2]))), f2a(sub(sub(cross(0, 1), v[0]), v[1]), xi(v[2])),
-                f2a(sub(sub(cross(0, 2), v[0]), v[2]), v[1])]
-        where = [K4.HOME0 + K4.SLOT_DW, K4.A0, K4.HOME0]            # c0 -> home 1, c1 -> A, c2 -> home 0
+        v = lambda i, j: f2m(a[i], b[j])
+        want = [f2a(v(0, 0), xi(f2a(v(1, 2), v(2, 1)))), f2a(f2a(v(0, 1), v(1, 0)), xi(v(2, 2))), f2a(f2a(v(0, 2), v(1, 1)), v(2, 0))]
+        where = [K4.HOME0 + K4.SLOT_DW, K4.HOME0 + 2 * K4.SLOT_DW, K4.A0]            # c0 -> home 1, c1 -> home 2, c2 -> A
         for c in range(3):
             for h in range(2):
                 regs = list(range(where[c] + NL * h, where[c] + NL * h + NL))
                 x = _sval([m.v[r] for r in regs])
                 assert (x - want[c][h] * RPI) % P == 0, ("mul6", t, c, h)
-                assert _is_norm(m, regs) and abs(x) < (0.52 if K4.L1v4.MUL6_REDUCE else (17, 8, 3)[c]) * P      # Prog._mul6_regs' bounds
+                assert _is_norm(m, regs) and abs(x) < (1.6, 1.2, 0.6)[c] * P       # Prog._mul6_regs' bounds for operands below p, 2 p
     # extreme operands: every limb at the largest magnitude the routines accept (the simulator traps any signed 64-bit overflow
     # of a column accumulator; an int32 overflow shows up as a wrong residue elsewhere)
     top = K4.HALF
-    for name, mag_, homes in (("mul6", 1, range(6)), ("sqr4c", 1, (3, 4)), ("sqr4cx", 1, (3, 4)), ("mul", 2.5, ()), ("mul3", 1, range(4)), ("sqr", 1.8, ())):
+    H_ = lambda k: K4.HOME0 + K4.SLOT_DW * k
+    cases = (("mul6", {**{H_(k): 2 for k in range(3)}, **{H_(k): 1 for k in range(3, 6)}}),
+             ("sqr4c", {K4.A0: 1, K4.B0: 1, H_(3): 1, H_(4): 1}), ("sqr4cx", {K4.A0: 1, K4.B0: 1, H_(3): 1, H_(4): 1}),
+             ("mul", {K4.A0: 2.5, K4.B0: 2.5}), ("mul3", {K4.A0: 1, K4.B0: 1, H_(0): 1, H_(1): 1, H_(2): 1, H_(3): 1}),
+             ("mul3", {K4.A0: 2, K4.B0: 1, H_(0): 2, H_(1): 1, H_(2): 2, H_(3): 1}), ("sqr", {K4.A0: 1.8}))
+    for name, mags in cases:
         for pattern in (lambda i: 1, lambda i: -1, lambda i: 1 if i % 2 else -1, lambda i: 1 if (i // 2) % 2 else -1):
             m = _m4([], rng, 0)
             for r in range(0, K4.HOME0 + 9 * K4.SLOT_DW):
                 m.v[r] = rng.getrandbits(32) if r >= 2 * K4.SLOT_DW else 0
-            blocks = [K4.A0, K4.B0] + [K4.HOME0 + K4.SLOT_DW * k for k in homes]
-            for blk in blocks:
+            for blk, mag_ in mags.items():
                 for i in range(K4.SLOT_DW):
                     m.v[blk + i] = int(pattern(i) * mag_ * top) & 0xFFFFFFFF
             S.run_block(B[name], m)

@@ -132,13 +132,15 @@ class L1v4:
         self.e.emit(f"v_ashrrev_i64 {P}, {LB}, {P}", vw=[acc, acc + 1])
 
     # ------------------------------------------------------------------ fused Montgomery column pass
-    def fips(self, prods, out, fillers=(), gap=8):
+    def fips(self, prods, out, fillers=(), gap=8, balanced=True):
         """out[0..NL-1] <- (sum over (a, b) in prods of a*b) / R' mod p, balanced limbs, value in sum/R' +- p/2.
         a, b: lists of NL VGPR numbers.  Result limb j is written after column j + NL, when limb j of every operand is
         dead, so `out` may be one of the first operands a (in place) but must not overlap a second operand b.
 
         fillers: independent instructions [(text, vw, earliest column, latest column)] dropped into the multiply runs
-        (work that has to be done anyway -- negations, copies -- and whose operands die / are born inside the pass)."""
+        (work that has to be done anyway -- negations, copies -- and whose operands die / are born inside the pass).
+        balanced=False: result limbs in [0, 2^29) instead (one instruction less per limb) -- for results that only feed the
+        64-bit linear-combination chains, never a product."""
         acc, P = self._acc()
         m = [self.pool.alloc() for _ in range(NL)]
         first = True
@@ -183,7 +185,11 @@ class L1v4:
             else:
                 for i in range(k - (NL - 1), NL):
                     mad(m[i], self.p[k - i])
-                self._digit(acc, P, out[k - NL])
+                if balanced:
+                    self._digit(acc, P, out[k - NL])
+                else:
+                    self.e.emit(f"v_and_b32_e32 v{out[k - NL]}, 0x{MASK:x}, v{acc}", vw=[out[k - NL]])
+                    self.e.emit(f"v_ashrrev_i64 {P}, {LB}, {P}", vw=[acc, acc + 1])
                 run = 0
         self.e.emit(f"v_mov_b32_e32 v{out[NL - 1]}, v{acc}", vw=[out[NL - 1]])
         for (text, vw, lo, hi) in todo:
@@ -279,13 +285,13 @@ class L1v4:
         self.pool.free(c)
 
     # ------------------------------------------------------------------ routines: A <- op(A, B)
-    def _fq2_mul(self, x, y, o):
+    def _fq2_mul(self, x, y, o, balanced=True):
         """o <- x * y (Fq2; x, y, o = (c0 limbs, c1 limbs)); o may be x itself (in place) or a disjoint block."""
         (x0, x1), (y0, y1), (o0, o1) = x, y, o
         n = [self.pool.alloc() for _ in range(NL)]
         self._neg_into(n, x1)
-        self.fips([(x1, y0), (x0, y1)], o1)
-        self.fips([(x0, y0), (n, y1)], o0)
+        self.fips([(x1, y0), (x0, y1)], o1, balanced=balanced)
+        self.fips([(x0, y0), (n, y1)], o0, balanced=balanced)
         self.pool.free(*n)
 
     def r_mul(self):
@@ -341,11 +347,11 @@ class L1v4:
         s = self.fq2(HOME0 + 2 * SLOT_DW)
         zc = self.fq2(HOME0 + 3 * SLOT_DW)
         zd = self.fq2(HOME0 + 4 * SLOT_DW)
-        self._fq2_mul(a, b, t)                                          # t = a b (a, b stay intact)
+        self._fq2_mul(a, b, t, balanced=False)                          # t = a b (a, b stay intact); t and P only feed the chains
         # S = xi b + a = (9 b0 - b1 + a0, 9 b1 + b0 + a1), normalised
         self.lincomb([s[0], s[1]], [[(9, b[0]), (-1, b[1]), (1, a[0])], [(9, b[1]), (1, b[0]), (1, a[1])]])
         self._lw("v_add_u32_e32", u, a, b)                              # u = a + b (two units)
-        self._fq2_mul(u, s, u)                                          # P = u S, in place
+        self._fq2_mul(u, s, u, balanced=False)                          # P = u S, in place
         # A <- 3 (P - t - xi t) - 2 zc = 3 P - 30 t0 + 3 t1 - 2 zc | 3 P1 - 30 t1 - 3 t0 - 2 zc1
         self.lincomb([a[0], a[1]], [[(3, u[0]), (-30, t[0]), (3, t[1]), (-2, zc[0])],
                                     [(3, u[1]), (-30, t[1]), (-3, t[0]), (-2, zc[1])]], reduce=True)
@@ -358,47 +364,49 @@ class L1v4:
         self.r_sqr4c(xi=True)
 
     # ------------------------------------------------------------------ fused Fq6 multiplication
-    MUL6_REDUCE = bool(int(os.environ.get("KGEN_MUL6_REDUCE", "0")))
+    def _pass3(self, out, terms, imag):
+        """out <- one component of x0 y0 + x1 y1 + x2 y2 (three Fq2 products, terms = [(x, y)] with x, y = (c0 limbs, c1 limbs)),
+        ONE reduction: the real component sum(x.0 y.0 - x.1 y.1) or the imaginary one sum(x.0 y.1 + x.1 y.0)."""
+        if imag:
+            prods = []
+            for x, y in terms:
+                prods += [(x[0], y[1]), (x[1], y[0])]
+            self.fips(prods, out)
+            return
+        negs, prods = [], []
+        for x, y in terms:
+            n = [self.pool.alloc() for _ in range(NL)]
+            self._neg_into(n, x[1])
+            negs.append(n)
+            prods += [(x[0], y[0]), (n, y[1])]
+        self.fips(prods, out)
+        for n in negs:
+            self.pool.free(*n)
 
     def r_mul6(self):
-        """Fq6 multiplication (Fq2[v]/(v^3 - xi), Karatsuba: six Fq2 multiplications), fused: a = (a0, a1, a2) in home blocks
-        0..2, b in home blocks 3..5, all NORMALISED.  Results, normalised (value bounds: kgen4_prog.Prog._mul6_regs):
-        c0 -> home block 1,  c1 -> block A,  c2 -> home block 0.  Scratch: home blocks 6, 7, blocks A, B, the pool.  Every
-        input block is destroyed.  The recombinations run on 64-bit chains (the x xi term would overflow 32-bit limbs).
-        The results are NOT reduced: their consumers (the Fq12 recombinations) add and subtract them first and reduce once
-        per Fq12 coefficient instead of once per Fq6 coefficient."""
-        red = self.MUL6_REDUCE
+        """Fq6 multiplication in Fq2[v]/(v^3 - xi), schoolbook with LAZY REDUCTION: nine Fq2 products, but each of the six
+        output components is ONE column pass over six Fq products with one Montgomery reduction (Karatsuba: six Fq2 products
+        = 24 Fq products, but 12 reductions and three recombination chains -- 4 % more instructions):
+            c0 = a0 b0 + (xi a1) b2 + (xi a2) b1     c1 = a0 b1 + a1 b0 + (xi a2) b2     c2 = a0 b2 + a1 b1 + a2 b0
+        a = (a0, a1, a2) in home blocks 0..2 (limbs of up to two units: unnormalised sums are fine), b in home blocks 3..5
+        (normalised).  Results (reduction outputs: normalised, values per kgen4_prog.Prog._mul6_regs):
+            c0 -> home block 1,  c1 -> home block 2,  c2 -> block A.
+        Scratch: home blocks 6, 7 (xi a1, xi a2), the pool.  a1, a2 are destroyed; a0 and b survive."""
         H = lambda k: self.fq2(HOME0 + SLOT_DW * k)
         a, b = [H(0), H(1), H(2)], [H(3), H(4), H(5)]
-        v0, v1 = H(6), H(7)
-        A, B = self.fq2(A0), self.fq2(B0)
-        self._fq2_mul(a[0], b[0], v0)
-        self._fq2_mul(a[1], b[1], v1)
-        # m01 = (a0 + a1)(b0 + b1)
-        self._lw("v_add_u32_e32", A, a[0], a[1])
-        self._lw("v_add_u32_e32", B, b[0], b[1])
-        self._fq2_mul(A, B, A)
-        # m02 = (a0 + a2)(b0 + b2), in place over a0 / b0 (both dead afterwards)
-        self._lw("v_add_u32_e32", a[0], a[0], a[2])
-        self._lw("v_add_u32_e32", b[0], b[0], b[2])
-        self._fq2_mul(a[0], b[0], a[0])
-        # m12 = (a1 + a2)(b1 + b2), in place over a1 / b1
-        self._lw("v_add_u32_e32", a[1], a[1], a[2])
-        self._lw("v_add_u32_e32", b[1], b[1], b[2])
-        self._fq2_mul(a[1], b[1], a[1])
-        v2 = B
-        self._fq2_mul(a[2], b[2], v2)
-        m01, m02, m12 = A, a[0], a[1]
-        # c1 = m01 - v0 - v1 + xi v2  -> block A (in place over m01)
-        self.lincomb([A[0], A[1]], [[(1, m01[0]), (-1, v0[0]), (-1, v1[0]), (9, v2[0]), (-1, v2[1])],
-                                    [(1, m01[1]), (-1, v0[1]), (-1, v1[1]), (9, v2[1]), (1, v2[0])]], reduce=red)
-        # c2 = m02 - v0 - v2 + v1  -> home block 0 (in place over m02)
-        self.lincomb([m02[0], m02[1]], [[(1, m02[0]), (-1, v0[0]), (-1, v2[0]), (1, v1[0])],
-                                        [(1, m02[1]), (-1, v0[1]), (-1, v2[1]), (1, v1[1])]], reduce=red)
-        # c0 = v0 + xi (m12 - v1 - v2)  -> home block 1 (in place over m12); w = m12 - v1 - v2: c0 = v0 + (9 w0 - w1, 9 w1 + w0)
-        w0 = [(9, m12[0]), (-9, v1[0]), (-9, v2[0]), (-1, m12[1]), (1, v1[1]), (1, v2[1]), (1, v0[0])]
-        w1 = [(9, m12[1]), (-9, v1[1]), (-9, v2[1]), (1, m12[0]), (-1, v1[0]), (-1, v2[0]), (1, v0[1])]
-        self.lincomb([m12[0], m12[1]], [w0, w1], reduce=red)
+        xa1, xa2 = H(6), H(7)
+        A = self.fq2(A0)
+        for src, dst in ((a[1], xa1), (a[2], xa2)):                      # xi a = (9 a.0 - a.1, 9 a.1 + a.0), normalised
+            self.lincomb([dst[0], dst[1]], [[(9, src[0]), (-1, src[1])], [(9, src[1]), (1, src[0])]])
+        t2 = [(a[0], b[2]), (a[1], b[1]), (a[2], b[0])]
+        self._pass3(A[1], t2, imag=True)                                  # c2 -> block A (the only user of a2 itself)
+        self._pass3(A[0], t2, imag=False)
+        t1 = [(a[0], b[1]), (a[1], b[0]), (xa2, b[2])]
+        self._pass3(a[2][1], t1, imag=True)                               # c1 over a2 (dead by now)
+        self._pass3(a[2][0], t1, imag=False)
+        t0 = [(a[0], b[0]), (xa1, b[2]), (xa2, b[1])]
+        self._pass3(a[1][1], t0, imag=True)                               # c0 over a1 (dead by now)
+        self._pass3(a[1][0], t0, imag=False)
 
     def r_mulfq(self):
         """A <- (A.c0 * B.c0, A.c1 * B.c0), in place"""

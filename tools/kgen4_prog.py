@@ -623,37 +623,56 @@ class Prog:
             self.load(blk, s1)
         return v_
 
+    def _load_sum(self, blk, s1, s2, limit):
+        """register block blk <- s1 (+ s2); limbs of at most `limit` units: the raw limb-wise sum when it fits, normalised
+        otherwise.  Returns (limb magnitude, value bound)."""
+        m_ = mag(self.r_of(s1)) + (mag(self.r_of(s2)) if s2 is not None else 0.0)
+        v_ = self.v_of(s1) + (self.v_of(s2) if s2 is not None else 0.0)
+        if m_ > limit or v_ > K_TOP:
+            v_ = self._load_norm_sum(blk, s1, s2)
+            return 1.0, v_
+        if s2 is None:
+            if blk == A0:
+                self.A(s1)
+            elif blk == B0:
+                self._B(s1)
+            else:
+                self.load(blk, s1)
+            return m_, v_
+        self.load(blk, s1)
+        self.load(A0, s2)
+        self.tagA = None
+        self.wait()
+        for i in range(SLOT_DW):
+            self.e.emit(f"v_add_u32_e32 v{blk + i}, v{blk + i}, v{A0 + i}", vw=[blk + i])
+        return m_, v_
+
     def _mul6_regs(self, a, b, a_plus=None, b_plus=None):
-        """Fused Fq6 multiplication (L1 mul6) of (a + a_plus) by (b + b_plus), coefficient-wise sums formed (and normalised)
-        while the operands are loaded into the home blocks.  Returns the three result 'slots' [c0, c1, c2]: c0 = HOME(1),
-        c1 = block A (None), c2 = HOME(0), all normalised; every home block is clobbered."""
-        va = vb = 0.0
-        for base, slots, plus in ((0, a, a_plus), (3, b, b_plus)):
-            for k, s_ in enumerate(slots):
-                v_ = self._load_norm_sum(HOME0 + SLOT_DW * (base + k), s_, plus[k] if plus else None)
-                if base == 0:
-                    va = max(va, v_)
-                else:
-                    vb = max(vb, v_)
-        self._need(max(va, vb) <= V_CAP / 2, f"mul6 operand values {va} {vb}")
+        """Fused Fq6 multiplication (L1 mul6, schoolbook with one reduction per output component) of (a + a_plus) by
+        (b + b_plus), coefficient-wise sums formed while the operands are loaded into the home blocks: the a side may stay
+        an unnormalised sum (two units), the b side is normalised.  Returns the three result 'slots' [c0, c1, c2]:
+        c0 = HOME(1), c1 = HOME(2), c2 = block A (None), all normalised; home blocks 1, 2, 6, 7 and block A are clobbered."""
+        ma = mb = va = vb = 0.0
+        for k, s_ in enumerate(b):
+            m_, v_ = self._load_sum(HOME0 + SLOT_DW * (3 + k), s_, b_plus[k] if b_plus else None, 1.0)
+            mb, vb = max(mb, m_), max(vb, v_)
+        for k, s_ in enumerate(a):
+            m_, v_ = self._load_sum(HOME0 + SLOT_DW * k, s_, a_plus[k] if a_plus else None, 2.0)
+            ma, va = max(ma, m_), max(va, v_)
+        # worst column: a0 b2 + a1 b1 + a2 b0 (three products of ma x mb); the xi a terms are normalised
+        self._need(2 * NL * 3 * ma * mb <= COL_BUDGET, f"mul6 operand limbs {ma} {mb}")
+        self._need(10 * va <= V_CAP and vb <= V_CAP, f"mul6 operand values {va} {vb}")
         self._raw_call("mul6")
-        self.tagB = None
-        res = [HOME(1, "mul6.c0"), None, HOME(0, "mul6.c2")]
-        if L1v4.MUL6_REDUCE:
-            v0 = v1 = v2 = 0.51
-        else:
-            # Fq2 products of operands below va, vb: 2 va vb / K + 1/2; of the Karatsuba sums: 8 va vb / K + 1/2
-            v_prod, v_sum = 2 * va * vb / K_RP + 0.5, 8 * va * vb / K_RP + 0.5
-            v0 = 10 * v_sum + 21 * v_prod         # c0 = v0 + xi (m12 - v1 - v2)
-            v1 = v_sum + 12 * v_prod              # c1 = m01 - v0 - v1 + xi v2
-            v2 = v_sum + 3 * v_prod               # c2 = m02 - v0 - v2 + v1
-        for slot, v in ((res[0], v0), (res[2], v2)):
+        res = [HOME(1, "mul6.c0"), HOME(2, "mul6.c1"), None]
+        v0 = 42 * va * vb / K_RP + 0.5            # c0 = a0 b0 + (xi a1) b2 + (xi a2) b1: 2 (1 + 10 + 10) va vb / K + 1/2
+        v1 = 24 * va * vb / K_RP + 0.5            # c1 = a0 b1 + a1 b0 + (xi a2) b2
+        v2 = 6 * va * vb / K_RP + 0.5             # c2 = a0 b2 + a1 b1 + a2 b0
+        for slot, v in ((res[0], v0), (res[1], v1)):
             self._need(v <= V_CAP, f"mul6 result value {v}")
             self.slot_r[self.key(slot)] = self.r_norm(v)
             self.slot_v[self.key(slot)] = v
             self.max_v = max(self.max_v, v)
-        self._need(v1 <= V_CAP, f"mul6 result value {v1}")
-        self.vA = v1
+        self.vA = v2
         self.rA = self.r_norm()
         self.tagA = None
         return res
@@ -665,9 +684,9 @@ class Prog:
             assert a_plus is None and b_plus is None
             return self._fq6_mul_generic(a, b, out)
         res = self._mul6_regs(a, b, a_plus, b_plus)
-        self.to(out[1])                                       # c1 sits in block A
+        self.to(out[2])                                       # c2 sits in block A
         self.A(res[0]).to(out[0])
-        self.A(res[2]).to(out[2])
+        self.A(res[1]).to(out[1])
 
     def _fq6_mul_generic(self, a, b, out):
         V0, V1, V2, S = self.tmp(), self.tmp(), self.tmp(), self.tmp()
@@ -698,9 +717,9 @@ class Prog:
             self.fq6_mul(A_0, B_0, T0)
             self.fq6_mul(A_1, B_1, T1)
             M = self._mul6_regs(A_0, B_0, A_1, B_1)               # (A0 + A1)(B0 + B1)
-            self.sub(T0[1]).sub(T1[1]).to(F[3])                   # c1 is in block A
+            self.sub(T0[2]).sub(T1[2]).to(F[5])                   # c2 is in block A
             self.A(M[0]).sub(T0[0]).sub(T1[0]).to(F[1])
-            self.A(M[2]).sub(T0[2]).sub(T1[2]).to(F[5])
+            self.A(M[1]).sub(T0[1]).sub(T1[1]).to(F[3])
         self.A(T1[2]).mulxi().add(T0[0]).to(F[0])
         self.A(T0[1]).add(T1[0]).to(F[2])
         self.A(T0[2]).add(T1[1]).to(F[4])
@@ -717,11 +736,11 @@ class Prog:
             self.fq6_mul(A_0, A_1, T)
             self.A(F[5]).mulxi().add(F[0]).to(S0)                 # first coefficient of A0 + v A1
             U = self._mul6_regs(A_0, [S0, F[2], F[4]], A_1, [None, F[1], F[3]])
-            self.sub(T[1]).sub(T[0]).to(F[2])                     # u1 - t1 - t0   (u1 is in block A)
+            self.sub(T[2]).sub(T[1]).to(F[4])                     # u2 - t2 - t1   (u2 is in block A)
             X = S0
             self.A(T[2]).mulxi().to(X)
             self.A(U[0]).sub(T[0]).sub(X).to(F[0])
-            self.A(U[2]).sub(T[2]).sub(T[1]).to(F[4])
+            self.A(U[1]).sub(T[1]).sub(T[0]).to(F[2])
         self.A(T[0]).dbl().to(F[1])
         self.A(T[1]).dbl().to(F[3])
         self.A(T[2]).dbl().to(F[5])
