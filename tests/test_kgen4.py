@@ -393,3 +393,76 @@ def test_generate_kernel():
         assert rd(G1B, 2) == list(P_)
         assert rd(G2B, 4) == [Q_[0][0], Q_[0][1], Q_[1][0], Q_[1][1]]
         print("generate kernel:", m.count, "instructions per pair")
+
+
+def _fq2(x):
+    return (x[0] % P, x[1] % P)
+
+
+def test_l1_fused_point_steps():
+    """dblstep / addstep (fused G2 steps + line coefficients) against the projective formulas in big integers."""
+    rng = random.Random(11)
+    RPI = pow(K4.RP, -1, P)
+    f2m = lambda x, y: ((x[0] * y[0] - x[1] * y[1]) % P, (x[0] * y[1] + x[1] * y[0]) % P)
+    f2a = lambda x, y: ((x[0] + y[0]) % P, (x[1] + y[1]) % P)
+    f2s = lambda x, y: ((x[0] - y[0]) % P, (x[1] - y[1]) % P)
+    f2k = lambda x, k: (x[0] * k % P, x[1] * k % P)
+    xi = lambda x: ((9 * x[0] - x[1]) % P, (9 * x[1] + x[0]) % P)
+    inv82 = pow(82, -1, P)
+    three_b = (81 * inv82 % P, (-9 * inv82) % P)
+    H_ = lambda k: K4.HOME0 + K4.SLOT_DW * k
+
+    def put(m, blk, el):
+        for h in range(2):
+            for i, w in enumerate(K4.bal_limbs(K4.mont4(el[h]))):
+                m.v[blk + NL * h + i] = w & 0xFFFFFFFF
+
+    def get(m, blk):
+        return tuple(_sval([m.v[blk + NL * h + i] for i in range(NL)]) * RPI % P for h in range(2))
+
+    B = {n: _body(n) for n in ("dblstep", "addstep")}
+    for t in range(6):
+        X, Y, Z = [(rng.randrange(P), rng.randrange(P)) for _ in range(3)]
+        px, py = rng.randrange(P), rng.randrange(P)
+        m = _m4([], rng, 0)
+        for r in range(0, K4.HOME0 + 9 * K4.SLOT_DW):
+            m.v[r] = rng.getrandbits(32)
+        put(m, H_(0), X); put(m, H_(1), Y); put(m, H_(2), Z)
+        put(m, K4.B0, (px, 0))
+        for i, w in enumerate(K4.bal_limbs(K4.mont4(py))):
+            m.v[K4.B0 + NL + i] = w & 0xFFFFFFFF
+        S.run_block(B["dblstep"], m)
+        Bq, C = f2m(Y, Y), f2m(Z, Z)
+        E = f2m(C, three_b)
+        Fv = f2k(E, 3)
+        Hh = f2k(f2m(Y, Z), 2)
+        want = {"X3": f2m(f2k(f2m(X, Y), 2), f2s(Bq, Fv)), "Y3": f2s(f2m(f2a(Bq, Fv), f2a(Bq, Fv)), f2k(f2m(E, E), 12)),
+                "Z3": f2k(f2m(Bq, Hh), 4), "L0": f2s(xi(Bq), f2k(C, 9)), "L3": f2k(Hh, py), "L4": f2k(f2m(X, X), (-3 * px) % P)}
+        where = {"X3": H_(0), "Y3": H_(1), "Z3": H_(2), "L0": H_(7), "L3": H_(4), "L4": H_(5)}
+        for k_, w in want.items():
+            assert get(m, where[k_]) == w, ("dblstep", t, k_)
+            assert _is_norm(m, list(range(where[k_], where[k_] + NL))) and _is_norm(m, list(range(where[k_] + NL, where[k_] + 2 * NL)))
+        assert m.max_acc < (1 << 63)
+    for t in range(6):
+        X, Y, Z, x2, y2 = [(rng.randrange(P), rng.randrange(P)) for _ in range(5)]
+        px, py = rng.randrange(P), rng.randrange(P)
+        m = _m4([], rng, 0)
+        for r in range(0, K4.HOME0 + 9 * K4.SLOT_DW):
+            m.v[r] = rng.getrandbits(32)
+        for k_, el in enumerate((X, Y, Z, x2, y2)):
+            put(m, H_(k_), el)
+        put(m, K4.B0, (px, 0))
+        for i, w in enumerate(K4.bal_limbs(K4.mont4(py))):
+            m.v[K4.B0 + NL + i] = w & 0xFFFFFFFF
+        S.run_block(B["addstep"], m)
+        th, mu = f2s(Y, f2m(y2, Z)), f2s(X, f2m(x2, Z))
+        Cc, D = f2m(th, th), f2m(mu, mu)
+        E, Fz, G = f2m(mu, D), f2m(Z, Cc), f2m(X, D)
+        Hh = f2s(f2a(E, Fz), f2k(G, 2))
+        want = {"X3": f2m(mu, Hh), "Y3": f2s(f2m(th, f2s(G, Hh)), f2m(E, Y)), "Z3": f2m(Z, E),
+                "L2": f2k(mu, (-py) % P), "L3": f2k(th, px), "L5": f2s(f2m(X, y2), f2m(x2, Y))}
+        where = {"X3": H_(6), "Y3": H_(4), "Z3": H_(2), "L2": H_(7), "L3": H_(8), "L5": K4.A0}
+        for k_, w in want.items():
+            assert get(m, where[k_]) == w, ("addstep", t, k_)
+            assert _is_norm(m, list(range(where[k_], where[k_] + NL))) and _is_norm(m, list(range(where[k_] + NL, where[k_] + 2 * NL)))
+        assert m.max_acc < (1 << 63)

@@ -172,18 +172,26 @@ def _to_e64(text):
     return base + "_e64" + text[len(op):]
 
 
-def align_code(lines):
+def align_code(lines, src_map=None):
+    """src_map (optional, an empty list): receives, for every output line, the index of the input line it is (None for an
+    inserted s_nop); re-encoded lines keep their index."""
     out, off, last = [], 0, None            # last: index in `out` of the previous instruction if it may be re-encoded
-    for ln in lines:
+    src = [] if src_map is None else src_map
+
+    def put(line, i):
+        out.append(line)
+        src.append(i)
+
+    for i, ln in enumerate(lines):
         t = ln.strip()
         if not t or t.startswith((";", "//", ".")):
-            out.append(ln)
+            put(ln, i)
             continue
         if t.endswith(":"):
             if off % 8:
-                out.append("s_nop 0")
+                put("s_nop 0", None)
                 off += 4
-            out.append(ln)
+            put(ln, i)
             last = None
             continue
         size = insn_size(t)
@@ -192,9 +200,9 @@ def align_code(lines):
             if conv is not None:
                 out[last] = conv
             else:
-                out.append("s_nop 0")
+                put("s_nop 0", None)
             off += 4
-        out.append(ln)
+        put(ln, i)
         off += size
         last = len(out) - 1 if size == 4 else None
     return out
@@ -220,3 +228,62 @@ def max_branch_distance(lines):
             if tgt in lab:
                 worst = max(worst, abs(lab[tgt] - (o + 4)))
     return worst
+
+
+def branch_table(lines):
+    """(label -> byte offset, [(byte offset, line index, opcode, target label)]) of all label-targeted branches / calls"""
+    off, lab, ins = 0, {}, []
+    for idx, l in enumerate(lines):
+        t = l.strip()
+        if not t or t.startswith((";", "//", ".")):
+            continue
+        if t.endswith(":"):
+            lab[t[:-1]] = off
+            continue
+        op = t.split()[0]
+        if op in ("s_call_b64", "s_branch") or op.startswith("s_cbranch"):
+            tgt = t.split(",")[-1].strip() if op == "s_call_b64" else t.split()[-1]
+            ins.append((off, idx, op, tgt))
+        off += insn_size(t)
+    return lab, ins
+
+
+
+
+def place_with_islands(blocks, reach, mk_label):
+    """Concatenates code blocks (lists of lines; no block falls through into the next) and makes every s_call_b64 / s_branch /
+    s_cbranch reach its target within `reach` bytes: a transfer that cannot is retargeted to a one-instruction trampoline
+    (`label: s_branch target`) in an island between two blocks near the midpoint; trampolines hop again if needed.  A
+    trampoline costs one extra taken branch and leaves the return address untouched.  Returns (lines, trampolines)."""
+    islands = [[] for _ in range(len(blocks) + 1)]
+    blocks = [list(b) for b in blocks]
+    n_hops = 0
+    for _ in range(400):
+        flat, where = [], []                  # the concatenation and, per line, (collection, index) it came from
+        for i in range(len(blocks) + 1):
+            flat.append(mk_label(f"L_isl{i}") + ":")
+            where.append(None)
+            for j, l in enumerate(islands[i]):
+                flat.append(l)
+                where.append((islands[i], j))
+            if i < len(blocks):
+                for j, l in enumerate(blocks[i]):
+                    flat.append(l)
+                    where.append((blocks[i], j))
+        src = []
+        out = align_code(flat, src)
+        lab, ins = branch_table(out)
+        bad = [(abs(lab[t] - (o + 4)), o, idx, t) for o, idx, op, t in ins if t in lab and abs(lab[t] - (o + 4)) >= reach]
+        if not bad:
+            return [".p2align 3"] + out, n_hops
+        _, o, idx, t = max(bad)
+        mid = (o + lab[t]) // 2
+        k = min(range(len(blocks) + 1), key=lambda i: abs(lab[mk_label(f"L_isl{i}")] - mid))
+        hop = mk_label(f"L_hop{n_hops}")
+        n_hops += 1
+        coll, j = where[src[idx]]
+        line = coll[j]
+        assert line.rstrip().endswith(t), (line, t)
+        coll[j] = line[: line.rfind(t)] + hop
+        islands[k] += [hop + ":", f"s_branch {t}"]
+    raise RuntimeError("island placement did not converge")

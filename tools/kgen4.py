@@ -408,6 +408,155 @@ class L1v4:
         self._pass3(a[1][1], t0, imag=True)                               # c0 over a1 (dead by now)
         self._pass3(a[1][0], t0, imag=False)
 
+
+    # ------------------------------------------------------------------ fused G2 steps of the Miller loop
+    # A point step is ~20 Fq2 operations on a dozen values; as separate accumulator-machine calls every operand crosses a
+    # slot <-> block boundary (18 moves each way) and every call costs two taken branches.  Fused, everything stays in named
+    # register blocks: X, Y, Z in home blocks 0..2, the evaluation point in block B (Px limbs in B.c0, Py limbs in B.c1).
+    def _fq2_sqr(self, x, o):
+        """o <- x^2 (x normalised); o may be x itself or a disjoint block"""
+        (x0, x1), (o0, o1) = x, o
+        t = [self.pool.alloc() for _ in range(NL)]
+        u = [self.pool.alloc() for _ in range(NL)]
+        d = [self.pool.alloc() for _ in range(NL)]
+        self.limbwise("v_add_u32_e32", t, x0, x1)
+        self.limbwise("v_sub_u32_e32", u, x0, x1)
+        for i in range(NL):
+            self.e.emit(f"v_lshlrev_b32_e32 v{d[i]}, 1, v{x0[i]}", vw=[d[i]])
+        self.fips([(x1, d)], o1)                       # 2 x0 x1
+        self.fips([(t, u)], o0)                        # (x0 + x1)(x0 - x1)
+        self.pool.free(*t)
+        self.pool.free(*u)
+        self.pool.free(*d)
+
+    def _fq2_mulfq(self, x, k, o):
+        """o <- (x.0 k, x.1 k) with k in Fq (one limb list)"""
+        self.fips([(x[0], k)], o[0])
+        self.fips([(x[1], k)], o[1])
+
+    def _pass2(self, out, terms, imag):
+        """out <- one component of sum of x y over terms = [(x, y, sign)] (Fq2 products, sign = +-1), ONE reduction."""
+        prods, negs = [], []
+
+        def neg(v):
+            n = [self.pool.alloc() for _ in range(NL)]
+            self._neg_into(n, v)
+            negs.append(n)
+            return n
+        for x, y, sg in terms:
+            if imag:       # x0 y1 + x1 y0
+                prods += [(x[0], y[1]), (x[1], y[0])] if sg > 0 else [(neg(x[0]), y[1]), (neg(x[1]), y[0])]
+            else:          # x0 y0 - x1 y1
+                prods += [(x[0], y[0]), (neg(x[1]), y[1])] if sg > 0 else [(neg(x[0]), y[0]), (x[1], y[1])]
+        self.fips(prods, out)
+        for n in negs:
+            self.pool.free(*n)
+
+    def _load_const(self, blk, c0, c1):
+        w = bal_limbs(mont4(c0)) + bal_limbs(mont4(c1))
+        for i in range(SLOT_DW):
+            self.e.emit(f"v_mov_b32_e32 v{blk + i}, {hx(w[i])}", vw=[blk + i])
+
+    THREE_B = (81 * pow(82, -1, P_INT) % P_INT, (-9 * pow(82, -1, P_INT)) % P_INT)      # 3 b' = 9 / (9 + u)
+
+    def r_dblstep(self):
+        """R = (X, Y, Z) <- 2 R on y^2 = x^3 + 3/xi (homogeneous projective) and the tangent line at the old R evaluated at P:
+        L0 = xi Y^2 - 9 Z^2,  L3 = 2 Y Z Py,  L4 = -3 X^2 Px   (the reference's sparse_line_function_equal_native value,
+        miller_loop_native.rs:30-44, times Z^2).  In: X, Y, Z normalised in home blocks 0, 1, 2; Px in B.c0, Py in B.c1.
+        Out: X3 -> home 0, Y3 -> home 1 (reduced), Z3 -> home 2, L0 -> home 7, L3 -> home 4, L4 -> home 5, all normalised.
+        Scratch: home blocks 3, 6, 8, block A, the pool."""
+        H = lambda k: self.fq2(HOME0 + SLOT_DW * k)
+        X, Y, Z, Bq, L3, L4, C, Hh, E = [H(k) for k in range(9)]
+        A = self.fq2(A0)
+        Px, Py = self.blk(B0, 0), self.blk(B0, 1)
+        self._fq2_sqr(Y, Bq)
+        self._fq2_sqr(Z, C)
+        self._lw("v_add_u32_e32", Hh, Y, Z)
+        self.norm_limbs(Hh[0])                          # (the squaring forms x0 + x1: two units in would be four)
+        self.norm_limbs(Hh[1])
+        self._fq2_sqr(Hh, Hh)
+        self._lw("v_sub_u32_e32", Hh, Hh, Bq)
+        self._lw("v_sub_u32_e32", Hh, Hh, C)            # H = 2 Y Z (three units)
+        self._fq2_mul(Bq, Hh, A)
+        self.lincomb([Z[0], Z[1]], [[(4, A[0])], [(4, A[1])]])                                  # Z3 = 4 Y^2 H
+        self._fq2_mulfq(Hh, Py, L3)                                                             # L3 = H Py
+        self._load_const(A0, *self.THREE_B)
+        self._fq2_mul(C, A, E)                                                                  # E = 3 b' Z^2
+        L0 = Hh                                                                                 # (H is dead)
+        self.lincomb([L0[0], L0[1]], [[(9, Bq[0]), (-1, Bq[1]), (-9, C[0])], [(9, Bq[1]), (1, Bq[0]), (-9, C[1])]])
+        self._fq2_sqr(X, C)                                                                     # X^2 (C is dead)
+        for h in range(2):
+            for r in C[h]:
+                self.e.emit(f"v_lshl_add_u32 v{r}, v{r}, 1, v{r}", vw=[r])                      # 3 X^2
+        nPx = [self.pool.alloc() for _ in range(NL)]
+        self._neg_into(nPx, Px)
+        self._fq2_mulfq(C, nPx, L4)                                                             # L4 = -3 X^2 Px
+        self.pool.free(*nPx)
+        Fv = C
+        for h in range(2):
+            for i in range(NL):
+                self.e.emit(f"v_lshl_add_u32 v{Fv[h][i]}, v{E[h][i]}, 1, v{E[h][i]}", vw=[Fv[h][i]])   # F = 3 E
+        self._lw("v_sub_u32_e32", A, Bq, Fv)                                                    # T = Y^2 - F (four units)
+        self.norm_limbs(A[0])
+        self.norm_limbs(A[1])
+        self._fq2_mul(X, Y, X)                                                                  # X Y, in place over X
+        for h in range(2):
+            for r in X[h]:
+                self.e.emit(f"v_lshlrev_b32_e32 v{r}, 1, v{r}", vw=[r])
+        self._fq2_mul(X, A, X)                                                                  # X3 = 2 X Y T
+        self._lw("v_add_u32_e32", Y, Bq, Fv)                                                    # (Y is dead) Y^2 + F
+        self.norm_limbs(Y[0])
+        self.norm_limbs(Y[1])
+        self._fq2_sqr(Y, Y)
+        self._fq2_sqr(E, E)
+        self.lincomb([Y[0], Y[1]], [[(1, Y[0]), (-12, E[0])], [(1, Y[1]), (-12, E[1])]], reduce=True)   # Y3 = (Y^2 + F)^2 - 12 E^2
+
+    def r_addstep(self):
+        """R <- R + Q (mixed addition, Q = (x2, y2) affine) and the chord through the old R and Q evaluated at P:
+        L2 = -mu Py,  L3 = theta Px,  L5 = X y2 - x2 Y   with theta = Y - y2 Z, mu = X - x2 Z   (the reference's
+        sparse_line_function_unequal_native value, miller_loop_native.rs:10-28, times Z).  In: X, Y, Z in home blocks 0, 1, 2,
+        x2, y2 in home blocks 3, 4 (all normalised); Px in B.c0, Py in B.c1.
+        Out: X3 -> home 6, Y3 -> home 4, Z3 -> home 2;  L2 -> home 7,  L3 -> home 8,  L5 -> block A; all normalised.
+        Scratch: home blocks 0, 3, 5, block B, the pool.
+        theta^2 = C, mu^2 = D, E = mu D, F = Z C, G = X D, H = E + F - 2 G:  X3 = mu H, Y3 = theta (G - H) - E Y, Z3 = Z E."""
+        H = lambda k: self.fq2(HOME0 + SLOT_DW * k)
+        X, Y, Z, x2, y2, th, mu, L2, L3 = [H(k) for k in range(9)]
+        A, Bk = self.fq2(A0), self.fq2(B0)
+        Px, Py = self.blk(B0, 0), self.blk(B0, 1)
+        self._fq2_mul(y2, Z, th)
+        self._lw("v_sub_u32_e32", th, Y, th)                           # theta = Y - y2 Z
+        self._fq2_mul(x2, Z, mu)
+        self._lw("v_sub_u32_e32", mu, X, mu)                           # mu = X - x2 Z
+        for v in (th, mu):
+            self.norm_limbs(v[0])
+            self.norm_limbs(v[1])
+        nPy = [self.pool.alloc() for _ in range(NL)]
+        self._neg_into(nPy, Py)
+        self._fq2_mulfq(mu, nPy, L2)                                    # L2 = -mu Py
+        self.pool.free(*nPy)
+        self._fq2_mulfq(th, Px, L3)                                     # L3 = theta Px
+        t5 = [(X, y2, 1), (x2, Y, -1)]                                  # L5 = X y2 - x2 Y: one reduction per component
+        self._pass2(A[1], t5, imag=True)
+        self._pass2(A[0], t5, imag=False)
+        Cc, D, E = x2, y2, Bk                                           # (the affine point and P are dead)
+        self._fq2_sqr(th, Cc)
+        self._fq2_sqr(mu, D)
+        self._fq2_mul(mu, D, E)
+        self._fq2_mul(Cc, Z, Cc)                                        # F = Z C, in place over C
+        self._fq2_mul(D, X, D)                                          # G = X D, in place over D
+        Hh = X                                                          # (X is dead)
+        for h in range(2):
+            for i in range(NL):
+                self.e.emit(f"v_add_u32_e32 v{Hh[h][i]}, v{E[h][i]}, v{Cc[h][i]}", vw=[Hh[h][i]])
+                self.e.emit(f"v_sub_u32_e32 v{Hh[h][i]}, v{Hh[h][i]}, v{D[h][i]}", vw=[Hh[h][i]])
+                self.e.emit(f"v_sub_u32_e32 v{Hh[h][i]}, v{Hh[h][i]}, v{D[h][i]}", vw=[Hh[h][i]])      # H = E + F - 2 G (four units)
+        self._fq2_mul(mu, Hh, mu)                                       # X3 = mu H, in place over mu
+        self._lw("v_sub_u32_e32", Hh, D, Hh)                            # W = G - H (five units)
+        ty = [(th, Hh, 1), (E, Y, -1)]                                  # Y3 = theta W - E Y: one reduction per component
+        self._pass2(D[1], ty, imag=True)                                # (G is dead)
+        self._pass2(D[0], ty, imag=False)
+        self._fq2_mul(Z, E, Z)                                          # Z3 = Z E, in place
+
     def r_mulfq(self):
         """A <- (A.c0 * B.c0, A.c1 * B.c0), in place"""
         a0, a1, k = self.blk(A0, 0), self.blk(A0, 1), self.blk(B0, 0)
@@ -542,7 +691,7 @@ class L1v4:
         self.pool.free(*d)
 
 
-L1V4_NAMES = ["mul", "mul3", "mul6", "sqr", "sqr4c", "sqr4cx", "mulfq", "add", "sub", "rsub", "dbl", "neg", "negc1", "mulxi", "mulxir", "norm",
+L1V4_NAMES = ["mul", "mul3", "mul6", "dblstep", "addstep", "sqr", "sqr4c", "sqr4cx", "mulfq", "add", "sub", "rsub", "dbl", "neg", "negc1", "mulxi", "mulxir", "norm",
               "redn", "fqmul", "fqsqr", "cvtin", "cvtout"]
 
 if __name__ == "__main__":

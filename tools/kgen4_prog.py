@@ -28,7 +28,7 @@ import re
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from asmcore import Emitter, P_INT, BN_X, SIX_U_PLUS_2_NAF, align_code, max_branch_distance  # noqa: E402
+from asmcore import Emitter, P_INT, BN_X, SIX_U_PLUS_2_NAF, align_code, max_branch_distance, place_with_islands  # noqa: E402
 from kgen4 import (A0, B0, HOME0, L1V4_NAMES, L1v4, LB, N0P, N_AGPR_SLOTS, N_HOME, N_LDS_SLOTS, NL, P_L, REDN_C, S_M30, S_N0, S_P, S_REDN,  # noqa: E402
                    S_RET1, S_RET2, S_RET3, SLOT_DW, SLOT_BYTES, V_FLAG, V_GOFF, V_IDX, V_IDX8, V_LDS, V_LTAIL, V_TID, bal_limbs, hx, mont4)
 
@@ -396,7 +396,7 @@ class Prog:
 
     # a call/return pair costs a lone wave ~70 cycles (two taken branches, each refilling the instruction buffer):
     # the short routines are inlined (cold routines keep calling the longer ones: code size)
-    INLINE_SET = ("add", "sub", "rsub", "dbl", "neg", "negc1", "norm", "mulxi", "mulxir", "redn")
+    INLINE_SET = ("add", "sub", "rsub", "dbl", "neg", "negc1", "norm", "mulxi", "mulxir", "redn", "dblstep", "addstep")   # (the fused steps have one call site each)
     INLINE_COLD = ("add", "sub", "rsub", "dbl", "neg", "negc1")
 
     def _raw_call(self, name):
@@ -834,11 +834,91 @@ class Prog:
     # The reference steps in affine coordinates with one Fq2 inversion each (miller_loop_native.rs:157,167,186); the
     # projective line values are the reference's un-normalised affine line values (:10-44) times a known Fq2 factor (Z^2 for
     # tangents, Z for chords), tracked in `scale` by the kernels that must return the exact miller_loop_native value.
+    # ---- fused point steps (L1 dblstep / addstep: everything in named register blocks, no marshalling between the ~20 field
+    # operations of a step); used when all nine home blocks are this routine's temporaries
+    FUSED_STEPS = bool(int(os.environ.get("KGEN_FUSED_STEPS", "1")))
+
+    def _fused_ok(self):
+        homes = {t.idx for t in self.free_tmp if t.kind == "home"}
+        return self.FUSED_STEPS and homes == set(range(N_HOME)) and not self.cold
+
+    def _load_fq(self, reg0, slot):
+        """v[reg0 : reg0 + NL] <- the c0 component (an Fq value) of a register-resident slot"""
+        self._need(mag(self.r_of(slot)) <= 1.0, f"{slot} is not normalised")
+        for i in range(NL):
+            if slot.kind == "agpr":
+                self.e.emit(f"v_accvgpr_read_b32 v{reg0 + i}, a{SLOT_DW * slot.idx + i}", vw=[reg0 + i])
+            elif slot.kind == "home":
+                self.e.emit(f"v_mov_b32_e32 v{reg0 + i}, v{HOME0 + SLOT_DW * slot.idx + i}", vw=[reg0 + i])
+            else:
+                raise ValueError(slot.kind)
+        return self.v_of(slot)
+
+    def _step_in(self, slots):
+        vs = []
+        for k, s_ in enumerate(slots):
+            self._need(mag(self.r_of(s_)) <= 1.0, f"fused step operand {s_} is not normalised")
+            self.load(HOME0 + SLOT_DW * k, s_)
+            vs.append(self.v_of(s_))
+        return max(vs)
+
+    def _step_out(self, k, dst, v):
+        """dst <- home block k (a normalised result of value bound v)"""
+        self._need(v <= self.v_limit(dst) and v <= V_CAP, f"fused step result {dst}: {v} p")
+        self.store(HOME0 + SLOT_DW * k, dst)
+        self.slot_r[self.key(dst)] = self.r_norm(v)
+        self.slot_v[self.key(dst)] = v
+        self.max_v = max(self.max_v, v)
+
+    def _dbl_step_fused(self, R, Pt, line):
+        v = self._step_in(R)
+        vp = max(self._load_fq(B0, Pt[0]), self._load_fq(B0 + NL, Pt[1]))
+        self.tagA = self.tagB = None
+        self._raw_call("dblstep")
+        sq = lambda x: 4 * x * x / K_RP + 0.5
+        ml = lambda x, y: 2 * x * y / K_RP + 0.5
+        bq = c = sq(v)
+        hh = sq(2 * v) + bq + c
+        e_ = ml(c, 1.0)
+        fv = 3 * e_
+        self._step_out(0, R[0], ml(2 * ml(v, v), bq + fv))
+        self._step_out(1, R[1], 0.51)
+        self._step_out(2, R[2], 4 * ml(bq, hh))
+        self._step_out(7, line[0], 10 * bq + 9 * c)
+        self._step_out(4, line[1], hh * vp / K_RP + 0.5)
+        self._step_out(5, line[2], 3 * sq(v) * vp / K_RP + 0.5)
+        self.wait()
+
+    def _add_step_fused(self, R, Q, Pt, line):
+        v = self._step_in(list(R) + list(Q))
+        vp = max(self._load_fq(B0, Pt[0]), self._load_fq(B0 + NL, Pt[1]))
+        self.tagA = self.tagB = None
+        self._raw_call("addstep")
+        sq = lambda x: 4 * x * x / K_RP + 0.5
+        ml = lambda x, y: 2 * x * y / K_RP + 0.5
+        th = mu = v + ml(v, v)
+        cc = d = sq(th)
+        e_, fz, g = ml(mu, d), ml(v, cc), ml(v, d)
+        hh = e_ + fz + 2 * g
+        self.vA, self.rA, self.tagA = 2 * ml(v, v) - 0.5, None, None          # L5 = X y2 - x2 Y (one reduction): block A
+        self.rA = self.r_norm()
+        self.to(line[2])
+        self._step_out(6, R[0], ml(mu, hh))
+        self._step_out(4, R[1], 2 * (th * (g + hh) + e_ * v) / K_RP + 0.5)
+        self._step_out(2, R[2], ml(v, e_))
+        self._step_out(7, line[0], mu * vp / K_RP + 0.5)
+        self._step_out(8, line[1], th * vp / K_RP + 0.5)
+        self.wait()
+
     def dbl_step(self, R, Pt, line, scale=None):
         """R=(X,Y,Z) <- 2R ; line = (L0, L3, L4) of the tangent at the old R evaluated at P (Pt = (PX, PY) slots, scalar in c0).
         scale: slot of the running line scale s <- s * Z^2 (the caller squares it with f)."""
         X, Y, Z = R
         L0, L3, L4 = line
+        if self._fused_ok():
+            if scale is not None:
+                self.A(Z).sqr().mul(scale).to(scale)
+            return self._dbl_step_fused(R, Pt, line)
         Bq, C, E, Fv, H, T = [self.tmp() for _ in range(6)]
         self.A(Y).sqr().to(Bq)
         self.A(Z).sqr().to(C)
@@ -867,6 +947,10 @@ class Prog:
         X, Y, Z = R
         x2, y2 = Q
         L2, L3, L5 = line
+        if update and self._fused_ok():
+            if scale is not None:
+                self.A(scale).mul(Z).to(scale)
+            return self._add_step_fused(R, Q, Pt, line)
         th, mu, T, U = [self.tmp() for _ in range(4)]
         if scale is not None:
             self.A(scale).mul(Z).to(scale)
@@ -980,6 +1064,9 @@ class KernelBuilder:
         keys = [Prog.key(s_) for s_ in self.F]
         if phase == "fexp":
             keys += [Prog.key(s_) for s_ in self.BOP] + [("globdyn", i) for i in range(6)]
+        else:       # the point state of the Miller loop (and its per-pair copies in scratch): operands of the fused steps
+            keys += [Prog.key(s_) for s_ in (*self.R, self.QX, self.QY, self.PX, self.PY, self.SX, self.SY)]
+            keys += [("globdyn", i) for i in range(7)]
         return frozenset(keys)
 
     def new_prog(self, temps, phase=None):
@@ -993,18 +1080,20 @@ class KernelBuilder:
         p.cold = self._cold
         return e, p
 
-    def l2_routine(self, name, body, temps):
+    def l2_routine(self, name, body, temps, local=()):
         """Also records the value bounds (units of p) the routine leaves in every non-temporary slot, given that all
         its inputs were below V_STORE p: the basis of the inductive certification in certify_values()."""
         self._cold = name in self.COLD
         e, p = self.new_prog(temps)
+        # `local`: named slots that are written and consumed inside this routine (the line coefficients): no contract at its exit
+        p.temp_keys = p.temp_keys | {Prog.key(s_) for s_ in local}
         e.label(self.lab(name))
         body(p)
         p.wait()
         e.salu(f"s_setpc_b64 {S_RET2}")
         self.sections.append(e)
         self._cold = False
-        tk = {Prog.key(t) for t in temps}
+        tk = {Prog.key(t) for t in temps} | {Prog.key(s_) for s_ in local}
         self.l2_bodies[name] = (body, temps)
         self.l2_phase[name] = self._phase
         # (home registers never carry a value across a routine boundary: they are every routine's workspace)
@@ -1051,8 +1140,8 @@ class KernelBuilder:
             # during f^2 the line (AGPR 6..8) and the addition point (AGPR 4, 5) are dead
             self.l2_routine("L2_sqr", lambda p: p.fq12_sqr(self.F), self.miller_temps(extra=(4, 5, 6, 7, 8), no_homes=True))
             self.l2_routine("L2_dblmul", lambda p: (p.dbl_step(self.R, (self.PX, self.PY), self.LINE, scale=sc),
-                                                    p.mul_by_034(self.F, *self.LINE)), self.miller_temps(extra=(4, 5)))
-            self.l2_routine("L2_dblfirst", lambda p: self._dbl_first(p), self.miller_temps())
+                                                    p.mul_by_034(self.F, *self.LINE)), self.miller_temps(extra=(4, 5)), local=self.LINE)
+            self.l2_routine("L2_dblfirst", lambda p: self._dbl_first(p), self.miller_temps(), local=self.LINE)
 
             def addmul(p, update):
                 p.add_step(self.R, (self.SX, self.SY), (self.PX, self.PY), self.LINE, scale=sc, update=update)
@@ -1061,8 +1150,8 @@ class KernelBuilder:
                 p.temp_keys = p.temp_keys | {Prog.key(self.SX), Prog.key(self.SY)}
                 p.mul_by_235(self.F, *self.LINE)
 
-            self.l2_routine("L2_addmul", lambda p: addmul(p, True), self.miller_temps())
-            self.l2_routine("L2_addmul_last", lambda p: addmul(p, False), self.miller_temps())
+            self.l2_routine("L2_addmul", lambda p: addmul(p, True), self.miller_temps(), local=self.LINE)
+            self.l2_routine("L2_addmul_last", lambda p: addmul(p, False), self.miller_temps(), local=self.LINE)
             if self.track:
                 self.l2_routine("L2_fqinv", self._fq_inv, self.miller_temps())
                 self.l2_routine("L2_descale", self._descale, self.miller_temps())
@@ -1105,10 +1194,7 @@ class KernelBuilder:
             first.insert(0, second.pop())
         while first and tot(first) - tot(second) > size[id(first[0])]:
             second.append(first.pop(0))
-        main.salu(f"s_branch {self.lab('L_exit_hop')}")   # main is not the last section; the end is out of reach in one hop
-        hop = Emitter()
-        hop.label(self.lab("L_exit_hop"))
-        hop.salu(f"s_branch {self.lab('L_exit')}")
+        main.salu(f"s_branch {self.lab('L_exit')}")
         tail = Emitter()
         tail.label(self.lab("L_exit"))
 
@@ -1123,12 +1209,10 @@ class KernelBuilder:
             if nf + nb:
                 order.append((nb / (nf + nb), -len(e_.ins) if nb <= nf else len(e_.ins), n))
         order.sort()
-        out = []
-        for e in [self._pro] + first + [main] + self.control_sections + [l1[n] for _, _, n in order] + [hop] + second + [tail]:
-            out.extend(e.finalize())
-        out = [".p2align 3"] + align_code(out) if ALIGN_CODE else out
-        worst = max_branch_distance(out)
-        assert worst < 131072 - 512, f"branch of {worst} bytes: s_call_b64 / s_branch reach +-128 KB (re-balance the layout)"
+        secs = [self._pro] + first + [main] + self.control_sections + [l1[n] for _, _, n in order] + second + [tail]
+        # transfers that cannot reach their target (+-128 KB) go through one-instruction trampolines between the sections
+        out, self.n_trampolines = place_with_islands([e.finalize() for e in secs], 131072 - 1024, self.lab)
+        assert max_branch_distance(out) < 131072 - 512
         return out
 
     # ------------------------------------------------------------------ value-bound certification

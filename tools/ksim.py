@@ -169,7 +169,7 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None):
         if region is not None:
             k_ = (region[pc], op)
             m.profile[k_] = m.profile.get(k_, 0) + 1
-            if op == "s_call_b64" and a[1].startswith("L2_"):
+            if op == "s_call_b64" and (a[1].startswith("L2_") or (a[1].startswith("L_hop") and prog[labels[a[1]]][1][0].startswith("L2_"))):
                 m.l2_stack.append(a[1])
             elif op == "s_setpc_b64" and a[0] == "s[56:57]" and m.l2_stack:
                 m.l2_stack.pop()
@@ -428,8 +428,11 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None):
                 pc = labels[a[0]]
             elif op == "s_call_b64":
                 m.sset(a[0], pc)          # "return address" = next instruction index
-                if m.call_log is not None and a[1].startswith("L2_"):
-                    m.call_log.append(a[1].replace("_%=", ""))
+                tgt = a[1]
+                while prog[labels[tgt]][0] == "s_branch" and tgt.startswith("L_hop"):      # trampolines of out-of-range calls
+                    tgt = prog[labels[tgt]][1][0]
+                if m.call_log is not None and tgt.startswith("L2_"):
+                    m.call_log.append(tgt.replace("_%=", ""))
                 pc = labels[a[1]]
             elif op == "s_setpc_b64":
                 pc = m.sget(a[0])
