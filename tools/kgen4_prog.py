@@ -1017,14 +1017,37 @@ class KernelBuilder:
        %7 scratch slot stride in bytes (s32)  %8 status (s64)  %9 tid (v32)  %10 block id (s32)  %11 grid size (s32)"""
 
     # slot map -------------------------------------------------------------------------------------
-    F = [LDS(i, f"F{i}") for i in range(6)]                  # the running Fq12 accumulator: LDS
-    R = [LDS(6, "RX"), LDS(7, "RY"), AGPR(9, "RZ")]          # RZ shares AGPR 9 with the Fq-inversion base (R is dead by then)
-    SCALE = AGPR(11, "scale")
-    QX, QY, PX, PY = AGPR(0, "QX"), AGPR(1, "QY"), AGPR(2, "PX"), AGPR(3, "PY")
-    SX, SY = AGPR(4, "SX"), AGPR(5, "SY")                    # the affine point of the current addition step
-    LINE = [AGPR(6, "La"), AGPR(7, "Lb"), AGPR(8, "Lc")]
+    # The Miller loop touches the Fq12 accumulator f in every routine (18 + 6 slot accesses per sparse multiplication): there
+    # it lives in AGPR slots (72 issue cycles per access, no wait) and the cold point coordinates in LDS; the final
+    # exponentiation needs the AGPR slots for the multiplication operand, so f moves to LDS at the phase boundary.
+    F_IN_AGPR = bool(int(os.environ.get("KGEN_F_AGPR", "1")))
+    F_LDS = [LDS(i, f"F{i}") for i in range(6)]
+    F_AGPR = [AGPR(i, f"F{i}") for i in range(6)]
+    F_AGPR_FEXP = bool(int(os.environ.get("KGEN_F_AGPR_FEXP", "1")))
+    BOP = [AGPR(i, f"B{i}") for i in ((6, 7, 8, 10, 11, 12) if (F_IN_AGPR and F_AGPR_FEXP) else (0, 1, 2, 3, 4, 5))]      # fq12_mul operand copy (final exponentiation only)
     FQINV_BASE = AGPR(9, "fqinv_base")
-    BOP = [AGPR(i, f"B{i}") for i in (0, 1, 2, 3, 4, 5)]      # fq12_mul operand copy (final exponentiation only)
+    LINE = [AGPR(6, "La"), AGPR(7, "Lb"), AGPR(8, "Lc")]
+    if F_IN_AGPR:
+        R = [LDS(6, "RX"), LDS(7, "RY"), AGPR(9, "RZ")]          # RZ shares AGPR 9 with the Fq-inversion base (R is dead by then)
+        QX, QY = LDS(0, "QX"), LDS(1, "QY")
+        PX, PY = AGPR(10, "PX"), AGPR(11, "PY")
+        SX, SY = AGPR(12, "SX"), AGPR(13, "SY")                  # the affine point of the current addition step
+        SCALE = LDS(2, "scale")
+        MILLER_FREE = ([], [LDS(3), LDS(4), LDS(5)])             # free (AGPR, LDS) slots of the Miller phase (+ the scale slot when untracked)
+    else:
+        R = [LDS(6, "RX"), LDS(7, "RY"), AGPR(9, "RZ")]
+        SCALE = AGPR(11, "scale")
+        QX, QY, PX, PY = AGPR(0, "QX"), AGPR(1, "QY"), AGPR(2, "PX"), AGPR(3, "PY")
+        SX, SY = AGPR(4, "SX"), AGPR(5, "SY")
+        MILLER_FREE = ([AGPR(10), AGPR(12), AGPR(13)], [])
+
+    @property
+    def F(self):
+        """the running Fq12 accumulator: AGPR slots in the Miller phase, LDS in the final exponentiation"""
+        if self.F_IN_AGPR and self.F_AGPR_FEXP:
+            return self.F_AGPR
+        return self.F_AGPR if (self.F_IN_AGPR and self.do_miller and self._phase == "miller") else self.F_LDS
+
     PAIR_SLOT0 = N_GSLOTS               # scratch slots of pair j: PAIR_SLOT0 + 7 j + {PX, PY, QX, QY, RX, RY, RZ}
 
     COLD = ("L2_inv", "L2_frob1", "L2_frob2", "L2_frob3", "L2_dblfirst", "L2_addmul_last", "L2_descale", "L2_fqinv")
@@ -1106,12 +1129,15 @@ class KernelBuilder:
         Fq6 multiplication, whose workspace is blocks 0..7), the free AGPR slots, routine-specific dead slots; global
         scratch slots only as overflow."""
         homes = [HOME(8)] if no_homes else [HOME(i) for i in range(N_HOME)]
-        return (homes + [AGPR(10), AGPR(12), AGPR(13)] + ([] if self.track else [AGPR(11)]) + [AGPR(i) for i in extra]
-                + [GLOB(GLOB_TMP0 + i) for i in range(8)])
+        fa, fl = self.MILLER_FREE
+        return (homes + fa + ([] if self.track else ([self.SCALE] if self.SCALE.kind == "agpr" else [])) + list(extra) + fl
+                + ([] if self.track or self.SCALE.kind == "agpr" else [self.SCALE]) + [GLOB(GLOB_TMP0 + i) for i in range(8)])
 
     def fexp_temps(self, no_homes=False):
         # fastest first: home registers, then AGPR slots (72 cycles either way), then LDS (a slot store costs 130-270 cycles)
         homes = [HOME(8)] if no_homes else [HOME(i) for i in range(N_HOME)]
+        if self.F_IN_AGPR and self.F_AGPR_FEXP:      # f: AGPR 0..5, the multiplication operand: AGPR 6..8, 10..12 (9: the Fq-inversion base)
+            return homes + [AGPR(13)] + [LDS(i) for i in range(N_LDS_SLOTS)] + [GLOB(GLOB_TMP0 + i) for i in range(8)]
         return homes + [AGPR(i) for i in (6, 7, 8, 10, 11, 12, 13)] + [LDS(6), LDS(7)] + [GLOB(GLOB_TMP0 + i) for i in range(8)]
 
     # ---------------------------------------------------------------------------------------------
@@ -1138,9 +1164,9 @@ class KernelBuilder:
         if self.do_miller:
             sc = self.SCALE if self.track else None
             # during f^2 the line (AGPR 6..8) and the addition point (AGPR 4, 5) are dead
-            self.l2_routine("L2_sqr", lambda p: p.fq12_sqr(self.F), self.miller_temps(extra=(4, 5, 6, 7, 8), no_homes=True))
+            self.l2_routine("L2_sqr", lambda p: p.fq12_sqr(self.F), self.miller_temps(extra=(self.SX, self.SY, *self.LINE), no_homes=True))
             self.l2_routine("L2_dblmul", lambda p: (p.dbl_step(self.R, (self.PX, self.PY), self.LINE, scale=sc),
-                                                    p.mul_by_034(self.F, *self.LINE)), self.miller_temps(extra=(4, 5)), local=self.LINE)
+                                                    p.mul_by_034(self.F, *self.LINE)), self.miller_temps(extra=(self.SX, self.SY)), local=self.LINE)
             self.l2_routine("L2_dblfirst", lambda p: self._dbl_first(p), self.miller_temps(), local=self.LINE)
 
             def addmul(p, update):
@@ -1688,11 +1714,20 @@ class KernelBuilder:
             self.miller_main(e, p)
         else:
             self.load_fq12_into_F(e, p, S_FIN)
+        if self.do_miller and self.do_fexp and self.F_IN_AGPR and not self.F_AGPR_FEXP:      # phase boundary: f moves from the AGPR slots to LDS
+            p.reset_tags()
+            src = self.F
+            self._phase = "fexp"
+            p.norm_keys = self.norm_keys("fexp")
+            for a_, l_ in zip(src, self.F):
+                p.mov(l_, a_)
+            p.reset_tags()
         if self.helper:
             self.helper_main(e, p)
         elif self.do_fexp:
             self.fexp_main(e, p)
         self.store_out(e, p)
+        self._phase = "miller"
         e.salu(f"s_add_u32 s{S_ITEM}, s{S_ITEM}, s{S_GRID}")
         e.salu(f"s_branch {L('L_item')}")
         e.label(L("L_done"))
@@ -1700,13 +1735,14 @@ class KernelBuilder:
     def load_fq12_into_F(self, e, p, ptr):
         """F <- the lane's MyFq12 of the SoA batch at `ptr` (components 0..5 are the c0 parts of w^0..w^5, 6..11 the c1
         parts): two passes over the planes, c0 parts first into AGPR staging (the operand slots, free at that point)."""
+        stage = SLOT_DW * self.BOP[0].idx
         self.io_walk_begin(e, ptr)
         for k in range(6):
             self.io_load_fq(e, A0)
             e.raw("s_waitcnt vmcnt(0)")
             self.cvt_call(e, "cvtin")
             for i in range(NL):
-                e.emit(f"v_accvgpr_write_b32 a{NL * k + i}, v{A0 + i}")       # c0 of coefficient k
+                e.emit(f"v_accvgpr_write_b32 a{stage + NL * k + i}, v{A0 + i}")       # c0 of coefficient k
         for k in range(6):
             self.io_load_fq(e, A0)
             e.raw("s_waitcnt vmcnt(0)")
@@ -1714,7 +1750,7 @@ class KernelBuilder:
             for i in range(NL):
                 e.emit(f"v_mov_b32_e32 v{A0 + NL + i}, v{A0 + i}", vw=[A0 + NL + i])
             for i in range(NL):
-                e.emit(f"v_accvgpr_read_b32 v{A0 + i}, a{NL * k + i}", vw=[A0 + i])
+                e.emit(f"v_accvgpr_read_b32 v{A0 + i}, a{stage + NL * k + i}", vw=[A0 + i])
             p.set_A_fresh()
             p.to(self.F[k])
         p.reset_tags()
