@@ -11,7 +11,7 @@ import json
 import os
 import sys
 
-KERNEL = os.environ.get("PROF_KERNEL", "k3_pairing")
+KERNEL = os.environ.get("PROF_KERNEL", "::k_pairing(")
 LOG2_BATCH = int(os.environ.get("PROF_LOG2_BATCH", "20"))
 
 
