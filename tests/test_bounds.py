@@ -74,3 +74,27 @@ def test_tracker_has_teeth():
     p.vA = 400.0
     with pytest.raises(AssertionError):
         p.store(K4.A0, K4P.AGPR(2)) or p._need(p.vA <= K4P.V_CAP, "value bound at store")
+
+
+def test_trampolines_for_out_of_range_transfers():
+    """asmcore.place_with_islands: a call whose target is farther than the branch reach goes through trampolines placed
+    between the blocks (possibly more than one hop), everything else is untouched, and the shipped pairing kernel -- 330 KB of
+    code against a reach of +-128 KB -- ends up with every transfer in range."""
+    from asmcore import branch_table, max_branch_distance, place_with_islands
+    filler = lambda n: ["v_mad_i64_i32 v[0:1], vcc, v2, v3, v[0:1]"] * n          # 8 bytes each
+    blocks = [["L_a_%=:", "s_call_b64 s[54:55], L_far_%=", "s_branch L_near_%="] + filler(50), ["L_near_%=:"] + filler(900),
+              ["L_mid_%=:"] + filler(900), ["L_far_%=:", "s_setpc_b64 s[54:55]"]]
+    out, hops = place_with_islands(blocks, 8192, lambda n: n + "_%=")
+    assert hops >= 1 and max_branch_distance(out) < 8192
+    lab, ins = branch_table(out)
+    # the near branch still goes straight to its label; the far call reaches L_far through L_hop labels only
+    assert any(op == "s_branch" and t == "L_near_%=" for _, _, op, t in ins)
+    tgt = [t for _, _, op, t in ins if op == "s_call_b64"][0]
+    seen = 0
+    while tgt.startswith("L_hop"):
+        i = out.index(tgt + ":")
+        tgt = out[i + 1].split()[-1]
+        seen += 1
+    assert tgt == "L_far_%=" and seen == hops
+    kb = K4P.KernelBuilder(do_miller=True, do_fexp=True)
+    assert max_branch_distance(kb.build()) < 131072 - 512 and kb.n_trampolines < 32
