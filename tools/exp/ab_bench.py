@@ -18,6 +18,7 @@ def main():
     import helpers as H
     libs = sys.argv[1:]
     log2 = int(os.environ.get("AB_LOG2", "20"))
+    k = int(os.environ.get("AB_K", "1"))               # AB_K=4: the Groth16 shape (2^(log2) pairs in groups of k, shared final exponentiation)
     reps = int(os.environ.get("AB_REPS", "4"))
     n = 1 << log2
     dev = torch.device("cuda:0")
@@ -35,25 +36,36 @@ def main():
     g1h = g1.view(8, n)[:, pos].cpu().numpy().view(np.uint64).reshape(-1).copy()
     g2h = g2.view(16, n)[:, pos].cpu().numpy().view(np.uint64).reshape(-1).copy()
     want = H.oracle_pairing(pkg.layout.to_aos(g1h, 8), pkg.layout.to_aos(g2h, 16), len(pos), threads=4)
+    groups = n // k
+    if k > 1:
+        gp = [0, 77, groups // 2, groups - 1]
+        pairs = [g * k + j for g in gp for j in range(k)]
+        g1h = g1.view(8, n)[:, pairs].cpu().numpy().view(np.uint64).reshape(-1).copy()
+        g2h = g2.view(16, n)[:, pairs].cpu().numpy().view(np.uint64).reshape(-1).copy()
+        want = H.oracle_multi_pairing(pkg.layout.to_aos(g1h, 8), pkg.layout.to_aos(g2h, 16), len(gp), k)
+        pos = gp
     times = {p: [] for p in libs}
     for r in range(reps + 1):
         for p, h in zip(libs, handles):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(st)
-            assert h.bn254_pairing_batch_dev(P(g1), P(g2), P(out), n, 0, S) == 0
+            if k == 1:
+                assert h.bn254_pairing_batch_dev(P(g1), P(g2), P(out), n, 0, S) == 0
+            else:
+                assert h.bn254_multi_pairing_batch_dev(P(g1), P(g2), P(out), groups, k, 1, 0, S) == 0
             b.record(st)
             torch.cuda.synchronize()
             if r:
                 times[p].append(a.elapsed_time(b))
             else:
-                got = out.view(48, n)[:, pos].cpu().numpy().view(np.uint64).reshape(-1).copy()
+                got = out[:48 * groups].view(48, groups)[:, pos].cpu().numpy().view(np.uint64).reshape(-1).copy()
                 assert np.array_equal(pkg.layout.to_aos(got, 48), want), f"{p}: wrong results"
     base = None
     for p in libs:
         t = sorted(times[p])
         med = t[len(t) // 2]
         base = base or med
-        print(f"{os.path.basename(p):40s} median {med:8.3f} ms  min {t[0]:8.3f}  {n / med / 1e3:7.3f} M pairings/s  ({100 * (base / med - 1):+.2f} % vs first)")
+        print(f"{os.path.basename(p):40s} median {med:8.3f} ms  min {t[0]:8.3f}  {n / med / 1e3:7.3f} M pair(ing)s/s  ({100 * (base / med - 1):+.2f} % vs first)")
 
 
 if __name__ == "__main__":

@@ -870,10 +870,14 @@ class Prog:
         self.slot_v[self.key(dst)] = v
         self.max_v = max(self.max_v, v)
 
-    def _dbl_step_fused(self, R, Pt, line):
+    def _dbl_step_fused(self, R, Pt, line, out=None, after_load=None):
         v = self._step_in(R)
         vp = max(self._load_fq(B0, Pt[0]), self._load_fq(B0 + NL, Pt[1]))
         self.tagA = self.tagB = None
+        if after_load:
+            self.wait()
+            after_load()
+        R = out or R
         self._raw_call("dblstep")
         sq = lambda x: 4 * x * x / K_RP + 0.5
         ml = lambda x, y: 2 * x * y / K_RP + 0.5
@@ -889,10 +893,14 @@ class Prog:
         self._step_out(5, line[2], 3 * sq(v) * vp / K_RP + 0.5)
         self.wait()
 
-    def _add_step_fused(self, R, Q, Pt, line):
+    def _add_step_fused(self, R, Q, Pt, line, out=None, after_load=None):
         v = self._step_in(list(R) + list(Q))
         vp = max(self._load_fq(B0, Pt[0]), self._load_fq(B0 + NL, Pt[1]))
         self.tagA = self.tagB = None
+        if after_load:
+            self.wait()
+            after_load()
+        R = out or R
         self._raw_call("addstep")
         sq = lambda x: 4 * x * x / K_RP + 0.5
         ml = lambda x, y: 2 * x * y / K_RP + 0.5
@@ -910,7 +918,7 @@ class Prog:
         self._step_out(8, line[1], th * vp / K_RP + 0.5)
         self.wait()
 
-    def dbl_step(self, R, Pt, line, scale=None):
+    def dbl_step(self, R, Pt, line, scale=None, out=None, after_load=None):
         """R=(X,Y,Z) <- 2R ; line = (L0, L3, L4) of the tangent at the old R evaluated at P (Pt = (PX, PY) slots, scalar in c0).
         scale: slot of the running line scale s <- s * Z^2 (the caller squares it with f)."""
         X, Y, Z = R
@@ -918,7 +926,8 @@ class Prog:
         if self._fused_ok():
             if scale is not None:
                 self.A(Z).sqr().mul(scale).to(scale)
-            return self._dbl_step_fused(R, Pt, line)
+            return self._dbl_step_fused(R, Pt, line, out, after_load)
+        assert out is None and after_load is None
         Bq, C, E, Fv, H, T = [self.tmp() for _ in range(6)]
         self.A(Y).sqr().to(Bq)
         self.A(Z).sqr().to(C)
@@ -942,7 +951,7 @@ class Prog:
         self.A(Bq).mul(H).scale(4).to(Z)
         self.rel(Bq, C, E, Fv, H, T)
 
-    def add_step(self, R, Q, Pt, line, scale=None, update=True):
+    def add_step(self, R, Q, Pt, line, scale=None, update=True, out=None, after_load=None):
         """R <- R + Q (Q = (x2, y2) affine slots); line = (L2, L3, L5) of the chord through old R and Q at P."""
         X, Y, Z = R
         x2, y2 = Q
@@ -950,7 +959,8 @@ class Prog:
         if update and self._fused_ok():
             if scale is not None:
                 self.A(scale).mul(Z).to(scale)
-            return self._add_step_fused(R, Q, Pt, line)
+            return self._add_step_fused(R, Q, Pt, line, out, after_load)
+        assert out is None and after_load is None
         th, mu, T, U = [self.tmp() for _ in range(4)]
         if scale is not None:
             self.A(scale).mul(Z).to(scale)
@@ -1073,6 +1083,8 @@ class KernelBuilder:
         self._phase = "miller"
         self._cold = False
         self._uid = 0
+        if multi:       # the resident-slot step routines only run for the first and the last steps of a multi kernel
+            self.COLD = self.COLD + ("L2_dblmul", "L2_addmul")
 
     def lab(self, name):
         return f"{name}_%="
@@ -1164,7 +1176,9 @@ class KernelBuilder:
         if self.do_miller:
             sc = self.SCALE if self.track else None
             # during f^2 the line (AGPR 6..8) and the addition point (AGPR 4, 5) are dead
-            self.l2_routine("L2_sqr", lambda p: p.fq12_sqr(self.F), self.miller_temps(extra=(self.SX, self.SY, *self.LINE), no_homes=True))
+            # during f^2 the line and the addition point are dead (in the multi kernels the S slots hold the prefetched pair)
+            self.l2_routine("L2_sqr", lambda p: p.fq12_sqr(self.F),
+                            self.miller_temps(extra=(tuple(self.LINE) if self.multi else (self.SX, self.SY, *self.LINE)), no_homes=True))
             self.l2_routine("L2_dblmul", lambda p: (p.dbl_step(self.R, (self.PX, self.PY), self.LINE, scale=sc),
                                                     p.mul_by_034(self.F, *self.LINE)), self.miller_temps(extra=(self.SX, self.SY)), local=self.LINE)
             self.l2_routine("L2_dblfirst", lambda p: self._dbl_first(p), self.miller_temps(), local=self.LINE)
@@ -1178,6 +1192,8 @@ class KernelBuilder:
 
             self.l2_routine("L2_addmul", lambda p: addmul(p, True), self.miller_temps(), local=self.LINE)
             self.l2_routine("L2_addmul_last", lambda p: addmul(p, False), self.miller_temps(), local=self.LINE)
+            if self.multi:
+                self._stream_routines(sc)
             if self.track:
                 self.l2_routine("L2_fqinv", self._fq_inv, self.miller_temps())
                 self.l2_routine("L2_descale", self._descale, self.miller_temps())
@@ -1272,16 +1288,19 @@ class KernelBuilder:
             run("L2_dblfirst")
             for _ in range(k_pairs - 1):
                 run("L2_dblmul")
+            dn, an = ("L2_dblmul_s", "L2_addmul_s") if self.multi else ("L2_dblmul", "L2_addmul")
+            if self.multi:
+                run("L2_prefetch")
             for i in range(63, -1, -1):
                 if i != 63:
                     run("L2_sqr")
                     if self.track:
                         run("L2_sqscale")
                     for _ in range(k_pairs):
-                        run("L2_dblmul")
+                        run(dn)
                 if SIX_U_PLUS_2_NAF[i] != 0:
                     for _ in range(k_pairs):
-                        run("L2_addmul")
+                        run(an)
             for _ in range(k_pairs):                                    # per pair: + Q1, then - Q2
                 run("L2_addmul")
                 run("L2_addmul_last")
@@ -1985,6 +2004,8 @@ class KernelBuilder:
             self.pair_out(e, p)
 
         self.pair_loop(e, "first", first_step)
+        e.salu(f"s_mul_i32 s{self.S_GNEXT}, s{S_GSTRIDE}, {self.PAIR_SLOT0}")      # prime the stream: pair 0
+        self.call2(e, "L2_prefetch")
         e.salu(f"s_mov_b32 s{S_I}, 63")
         e.label(L("L_mloop"))
         e.salu(f"s_cmp_eq_u32 s{S_I}, 63")
@@ -1994,9 +2015,8 @@ class KernelBuilder:
             self.call2(e, "L2_sqscale")
 
         def dbl_pair():
-            self.pair_in(e, p, with_q=False)
-            self.call2(e, "L2_dblmul")
-            self.pair_out(e, p)
+            self.pair_select_next(e)
+            self.call2(e, "L2_dblmul_s")
 
         self.pair_loop(e, "dbl", dbl_pair)
         e.label(L("L_mskip"))
@@ -2004,10 +2024,8 @@ class KernelBuilder:
         e.salu(f"s_cbranch_scc0 {L('L_mnoadd')}")
 
         def add_pair():
-            self.pair_in(e, p, with_q=True)
-            self._select_pm_q(e, p)
-            self.call2(e, "L2_addmul")
-            self.pair_out(e, p)
+            self.pair_select_next(e)
+            self.call2(e, "L2_addmul_s")
 
         self.pair_loop(e, "add", add_pair)
         e.label(L("L_mnoadd"))
@@ -2177,6 +2195,73 @@ class KernelBuilder:
             e.emit(f"v_mov_b32_e32 v{V_FLAG}, 0", vw=[V_FLAG])
         e.emit(f"v_lshrrev_b32_e32 v{V_TID}, 4, v{V_LDS}", vw=[V_TID])
         p.reset_tags()
+
+
+    # ---------------------------------------------------------------------------------------------
+    # multi-pairing main loop: STREAMED pair state.  The k pairs of a group share f, so their points take turns; their
+    # state (P, Q, R) lives in scratch.  Swapping it through resident slots (load, wait, compute, store) leaves the global
+    # latency exposed twice per pair and step -- 14 % of the Groth16-shape kernel's time.  Instead the NEXT pair's P and R are
+    # fetched straight into five AGPR slots (global loads can target AGPRs, no VGPR is needed) while the current pair's step
+    # and its sparse multiplication run; the fused step reads its operands from that buffer and writes the new R from its
+    # register blocks straight back to scratch.  (Q is only needed by the 27 addition steps: fetched synchronously there.)
+    S_GNEXT = 49               # byte offset of the NEXT pair's scratch block
+
+    @property
+    def BUF(self):
+        return {"PX": AGPR(10, "bPX"), "PY": AGPR(11, "bPY"), "RX": AGPR(12, "bRX"), "RY": AGPR(13, "bRY"), "RZ": AGPR(9, "bRZ")}
+
+    def _emit_prefetch(self, e):
+        """buffer <- {PX, PY, RX, RY, RZ} of the pair whose scratch block starts at S_GNEXT; nobody waits here"""
+        for name, k in (("PX", 0), ("PY", 1), ("RX", 4), ("RY", 5), ("RZ", 6)):
+            a0 = SLOT_DW * self.BUF[name].idx
+            e.salu(f"s_mul_i32 s{S_TMP0}, s{S_GSTRIDE}, {k}")
+            e.salu(f"s_add_u32 s{S_TMP0}, s{S_TMP0}, s{self.S_GNEXT}")
+            e.salu(f"s_add_u32 s62, s64, s{S_TMP0}")
+            e.salu("s_addc_u32 s63, s65, 0")
+            for c in range(Prog.N_B128):
+                e.emit(f"global_load_dwordx4 a[{a0 + 4 * c}:{a0 + 4 * c + 3}], v{V_GOFF}, {S_GADDR} offset:{16 * c}", kind="vmem")
+            e.emit(f"global_load_dwordx2 a[{a0 + 16}:{a0 + 17}], v{V_GOFF}, {S_GADDR} offset:64", kind="vmem")
+
+    def _stream_routines(self, sc):
+        buf = self.BUF
+        Rb, Pb = [buf["RX"], buf["RY"], buf["RZ"]], (buf["PX"], buf["PY"])
+        Rout = [GlobDyn(4), GlobDyn(5), GlobDyn(6)]
+        temps = [HOME(i) for i in range(N_HOME)] + self.MILLER_FREE[1] + [GLOB(GLOB_TMP0 + i) for i in range(8)]
+        L = self.lab
+
+        def dbl_s(p):
+            p.e.raw("s_waitcnt vmcnt(0)")                       # the prefetch of this pair has landed
+            p.dbl_step(Rb, Pb, self.LINE, scale=sc, out=Rout, after_load=lambda: self._emit_prefetch(p.e))
+            p.mul_by_034(self.F, *self.LINE)
+
+        def add_s(p):
+            e = p.e
+            e.raw("s_waitcnt vmcnt(0)")
+
+            def after():
+                # S = +-Q by the sign of the current digit: y2 sits in home block 4
+                e.salu(f"s_bitcmp1_b64 {S_NAF_NEG}, s{S_I}")
+                e.salu(f"s_cbranch_scc0 {L('L_as_pos')}")
+                for i in range(SLOT_DW):
+                    r = HOME0 + SLOT_DW * 4 + i
+                    e.emit(f"v_sub_u32_e32 v{r}, 0, v{r}", vw=[r])
+                e.label(L("L_as_pos"))
+                self._emit_prefetch(e)
+            p.add_step(Rb, (GlobDyn(2), GlobDyn(3)), Pb, self.LINE, scale=sc, out=Rout, after_load=after)
+            p.mul_by_235(self.F, *self.LINE)
+
+        self.l2_routine("L2_dblmul_s", dbl_s, temps, local=self.LINE)
+        self.l2_routine("L2_addmul_s", add_s, temps, local=self.LINE)
+        self.l2_routine("L2_prefetch", lambda p: self._emit_prefetch(p.e), temps)
+
+    def pair_select_next(self, e):
+        """S_GNEXT <- byte offset of the scratch block of pair (S_JP + 1) mod k"""
+        e.salu(f"s_add_u32 s{S_TMP0}, s{S_JP}, 1")
+        e.salu(f"s_cmp_lt_u32 s{S_TMP0}, s{S_K}")
+        e.salu(f"s_cselect_b32 s{S_TMP0}, s{S_TMP0}, 0")
+        e.salu(f"s_mul_i32 s{S_TMP0}, s{S_TMP0}, 7")
+        e.salu(f"s_add_u32 s{S_TMP0}, s{S_TMP0}, {self.PAIR_SLOT0}")
+        e.salu(f"s_mul_i32 s{self.S_GNEXT}, s{S_TMP0}, s{S_GSTRIDE}")
 
     # ---------------------------------------------------------------------------------------------
     def fexp_main(self, e, p):
