@@ -22,13 +22,11 @@ Reference functions implemented here (file:line under /root/reference/src):
   :298-312 (twisted Frobenius); final_exp_native.rs:17-54 (frobenius_map_native), :56-84 (pow_native), :130-169
   (hard part), :171-181 (conjugate), :195-213 (easy part, final_exp_native).
 """
-import math
 import os
-import re
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from asmcore import Emitter, P_INT, BN_X, SIX_U_PLUS_2_NAF, align_code, max_branch_distance, place_with_islands  # noqa: E402
+from asmcore import Emitter, P_INT, BN_X, SIX_U_PLUS_2_NAF, max_branch_distance, place_with_islands  # noqa: E402
 from kgen4 import (A0, B0, HOME0, L1V4_NAMES, L1v4, LB, N0P, N_AGPR_SLOTS, N_HOME, N_LDS_SLOTS, NL, P_L, REDN_C, S_M30, S_N0, S_P, S_REDN,  # noqa: E402
                    S_RET1, S_RET2, S_RET3, SLOT_DW, SLOT_BYTES, V_FLAG, V_GOFF, V_IDX, V_IDX8, V_LDS, V_LTAIL, V_TID, bal_limbs, hx, mont4)
 
@@ -199,22 +197,6 @@ def r_neg(a):
 
 def r_hull(a, b):
     return (min(a[0], b[0]), max(a[1], b[1]))
-
-
-def x_red_mask(digits, run_len):
-    """Bit j set: digit j of the x-power loop (walked from the top, as L3_powx does) is zero and closes a run of
-    `run_len` squarings without a multiplication -> L2_redF is called there."""
-    mask, run = 0, 0
-    if not run_len:
-        return 0
-    for j in range(len(digits) - 1, -1, -1):
-        run += 1
-        if digits[j] != 0:
-            run = 0
-        elif run == run_len:
-            mask |= 1 << j
-            run = 0
-    return mask
 
 
 class Prog:
