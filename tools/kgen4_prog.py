@@ -1309,9 +1309,11 @@ class KernelBuilder:
                         seq.append("L2_ldG")
                     xd = X_DIGITS[:-1]
                     for d in range(len(xd) - 1, -1, -1):
+                        if xd[d] != 0:
+                            seq.append("L2_pfB")
                         run("L2_cyc")
                         if xd[d] != 0:
-                            mul_by(conj=xd[d] < 0)
+                            run("L2_mul_body", label="L2_mulGc_w" if xd[d] < 0 else "L2_mulG_w")
                 else:
                     run(op[1])
         return {"max_stored": worst, "calls": calls, "sequence": seq}
@@ -1358,10 +1360,12 @@ class KernelBuilder:
             c2("L2_ldG")
         e.salu(f"s_mov_b32 s{S_J}, {self.x_top - 1}")
         e.label(L("L3_powx_loop"))
-        c2("L2_cyc")
         e.salu(f"s_bitcmp1_b64 {S_XNAF_NZ}, s{S_J}")
-        e.salu(f"s_cbranch_scc0 {L('L3_powx_next')}")
-        # select the power: S_GBASE <- register of b^(X_POWERS[idx])
+        e.salu(f"s_cbranch_scc1 {L('L3_powx_nz')}")
+        c2("L2_cyc")
+        e.salu(f"s_branch {L('L3_powx_next')}")
+        e.label(L("L3_powx_nz"))
+        # select the power: S_GBASE <- register of b^(X_POWERS[idx]); fetch it under the squaring
         e.salu(f"s_mov_b32 s{S_GBASE}, s{S_PB}")
         for bit, mask in ((0, S_XIDX0), (1, S_XIDX1)):
             e.salu(f"s_bitcmp1_b64 {mask}, s{S_J}")
@@ -1374,12 +1378,14 @@ class KernelBuilder:
         e.salu(f"s_mul_i32 s{S_TMP1}, s{S_TMP1}, 6")
         e.salu(f"s_mul_i32 s{S_GBASE}, s{S_GSTRIDE}, s{S_TMP1}")
         e.label(L("L3_powx_sel"))
+        c2("L2_pfB")
+        c2("L2_cyc")
         e.salu(f"s_bitcmp1_b64 {S_XNAF_NEG}, s{S_J}")
         e.salu(f"s_cbranch_scc1 {L('L3_powx_neg')}")
-        c2("L2_mulG")
+        c2("L2_mulG_w")
         e.salu(f"s_branch {L('L3_powx_next')}")
         e.label(L("L3_powx_neg"))
-        c2("L2_mulGc")
+        c2("L2_mulGc_w")
         e.label(L("L3_powx_next"))
         e.salu(f"s_sub_u32 s{S_J}, s{S_J}, 1")
         e.salu(f"s_cbranch_scc0 {L('L3_powx_loop')}")
@@ -1411,18 +1417,46 @@ class KernelBuilder:
             p.slot_v.pop(p.key(d), None)
         p.reset_tags()
 
+    def _emit_load_bop(self, e, p):
+        """multiplication operand (AGPR slots BOP) <- the Fq12 scratch register at S_GBASE: global loads straight into the
+        AGPRs (no landing VGPRs, no moves); nobody waits here."""
+        p.reset_tags()
+        p.wait()
+        for k, dst in enumerate(self.BOP):
+            a0 = SLOT_DW * dst.idx
+            e.salu(f"s_mul_i32 s{S_TMP0}, s{S_GSTRIDE}, {k}")
+            e.salu(f"s_add_u32 s{S_TMP0}, s{S_TMP0}, s{S_GBASE}")
+            e.salu(f"s_add_u32 s62, s64, s{S_TMP0}")
+            e.salu("s_addc_u32 s63, s65, 0")
+            for c in range(Prog.N_B128):
+                e.emit(f"global_load_dwordx4 a[{a0 + 4 * c}:{a0 + 4 * c + 3}], v{V_GOFF}, {S_GADDR} offset:{16 * c}", kind="vmem")
+            e.emit(f"global_load_dwordx2 a[{a0 + 16}:{a0 + 17}], v{V_GOFF}, {S_GADDR} offset:64", kind="vmem")
+            p.slot_r.pop(p.key(dst), None)
+            p.slot_v.pop(p.key(dst), None)
+
     def _mulG_routines(self):
-        """F <- F * G (G = Fq12 in scratch at S_GBASE); L2_mulGc multiplies by conjugate_fp12(G)."""
+        """F <- F * G (G = Fq12 in scratch at S_GBASE); L2_mulGc multiplies by conjugate_fp12(G).  Entry points:
+        L2_pfB issues the operand loads and returns (the x-power loop calls it BEFORE the cyclotomic squaring that precedes
+        the multiplication: the ~3 us of a 27 KB-per-wave fetch that every wave of the chip issues at about the same time
+        run under the squaring); L2_mulG_w / L2_mulGc_w wait for them and multiply; L2_mulG / L2_mulGc do both."""
         e, p = self.new_prog(self.fexp_temps(no_homes=True))
+        e.label(self.lab("L2_pfB"))
+        self._emit_load_bop(e, p)
+        e.salu(f"s_setpc_b64 {S_RET2}")
         e.label(self.lab("L2_mulGc"))
-        self.batch_load_globdyn(e, p, range(6), self.BOP)
+        self._emit_load_bop(e, p)
+        e.label(self.lab("L2_mulGc_w"))
+        e.raw("s_waitcnt vmcnt(0)")
+        p.reset_tags()
         for i in (1, 3, 5):
             p.A(self.BOP[i]).neg().to(self.BOP[i])
         p.wait()
         e.salu(f"s_branch {self.lab('L2_mul_body')}")
         e.label(self.lab("L2_mulG"))
         p.reset_tags()
-        self.batch_load_globdyn(e, p, range(6), self.BOP)
+        self._emit_load_bop(e, p)
+        e.label(self.lab("L2_mulG_w"))
+        e.raw("s_waitcnt vmcnt(0)")
         e.label(self.lab("L2_mul_body"))
         p.reset_tags()
         p.slot_r.clear()
