@@ -550,3 +550,27 @@ def test_pow_native_zero_and_empty_exponent():
     assert np.array_equal(pk.pow_batch(a, [], n), a)
     rc, want = H.oracle_pow_native(H.to_aos(a, 48), [0], n)
     assert rc == 0 and np.array_equal(H.to_soa(want, 48), a)
+
+
+def test_fused_and_split_kernels_agree_on_every_lane():
+    """pairing = final_exp_native(miller_loop_native) (/root/reference/src/pairing.rs:20-22) over ALL 2^20 lanes, through
+    different kernels: k_pairing (untracked projective lines: any Fq2 factor dies in the easy part) must equal k_fexp applied
+    to k_miller's exact miller_loop_native value (tracked line scale, divided out by an Fq2 inversion) limb for limb on every
+    lane -- a size-independent cross-check of the whole 2^20 batch (the oracle only spot-checks 512 lanes of it)."""
+    import torch
+    pk = H.pkg()
+    n = 1 << 20
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev)
+    g1 = torch.zeros(8 * n, dtype=torch.int64, device=dev)
+    g2 = torch.zeros(16 * n, dtype=torch.int64, device=dev)
+    pk.generate_pairs_dev(0xB2540021, g1, g2, n, 0, st)
+    a = torch.zeros(48 * n, dtype=torch.int64, device=dev)
+    m = torch.zeros(48 * n, dtype=torch.int64, device=dev)
+    b = torch.zeros(48 * n, dtype=torch.int64, device=dev)
+    pk.pairing_batch_dev(g1, g2, a, n, 0, st)
+    pk.miller_loop_batch_dev(g1, g2, m, n, 0, st)
+    pk.final_exp_batch_dev(m, b, n, 0, st)
+    pk.last_status(0, st)
+    assert torch.equal(a, b)
+    assert not torch.equal(a, m)
