@@ -327,7 +327,7 @@ def run_rank(args):
         notes = pmc_summary()
         same_cfg = notes.get("log2_batch") == log2
         traffic = notes.get("hbm_bytes_per_launch_corrected") if same_cfg else None
-        insts_per_wave = notes.get("valu_insts_per_wave")
+        insts_per_pairing = notes.get("valu_wave_insts_per_pairing")       # wave-instructions per 64-lane work item
         cfg_name = "configs[2]" if (world == 1 and log2 == 20) else ("configs[4]" if (world > 1 and log2 == 21) else "custom size")
         rec = {
             "metric": "BN254 pairings/sec (whole node)", "value": value, "unit": "pairings/s", "n_gpus": world,
@@ -347,11 +347,12 @@ def run_rank(args):
                          "kernel": "k_pairing", "kernel_ms_avg": kern_avg_ms, "kernel_ms_min": kern_ms[0],
                          "work_per_unit": f"{W_MUL32_PER_PAIRING} mul32 = {W_FQMUL_PER_PAIRING} fqmul x 136 per pairing (SURVEY.md 8d)",
                          "frac_of_nominal_quarter_rate_peak": achieved / NOMINAL_PEAK_MUL32_PER_S,
-                         "valu_issue": None if not insts_per_wave else {
-                             "source": "SQ_INSTS_VALU per wave from the committed PMC summary x this run's kernel time",
-                             "wave_instr_per_s": insts_per_wave * (n / 64) / (kern_avg_ms * 1e-3), "peak_wave_instr_per_s": 1024 * 2.4e9 / 4,
-                             "frac": insts_per_wave * (n / 64) / (kern_avg_ms * 1e-3) / (1024 * 2.4e9 / 4),
-                             "note": "all VALU instructions the kernel issues against 1024 SIMDs x 2.4 GHz / 4 cycles"},
+                         "valu_issue": None if not insts_per_pairing else {
+                             "source": "SQ_INSTS_VALU per 64-lane work item from the committed PMC summary x this run's kernel time",
+                             "wave_instr_per_pairing": insts_per_pairing,
+                             "wave_instr_per_s": insts_per_pairing * (n / 64) / (kern_avg_ms * 1e-3), "peak_wave_instr_per_s": 1024 * 2.4e9 / 4,
+                             "frac": insts_per_pairing * (n / 64) / (kern_avg_ms * 1e-3) / (1024 * 2.4e9 / 4),
+                             "note": "all VALU instructions the kernel issues against 1024 SIMDs x 2.4 GHz (nominal) / 4 cycles"},
                          "hbm": {"bound": "hbm", "achieved": 576 * n / (kern_avg_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                                  "frac": 576 * n / (kern_avg_ms * 1e-3) / 8e12, "traffic": traffic,
                                  "note": "the schema's HBM view of the same kernel: algorithmic bytes (576 B/pairing) over the launch time "

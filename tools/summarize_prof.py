@@ -43,6 +43,8 @@ def main():
         notes["valu_busy_fraction_of_wave_cycles"] = s["SQ_ACTIVE_INST_VALU"] / s["SQ_WAVE_CYCLES"]
         notes["cycles_per_valu_instruction_active"] = 4 * s["SQ_ACTIVE_INST_VALU"] / s["SQ_INSTS_VALU"]      # counters tick every 4 cycles
         notes["valu_insts_per_wave"] = s["SQ_INSTS_VALU"] / s["SQ_WAVES"]
+        notes["valu_wave_insts_per_launch"] = s["SQ_INSTS_VALU"]
+        notes["valu_wave_insts_per_pairing"] = s["SQ_INSTS_VALU"] / ((1 << LOG2_BATCH) / 64)
     if "SQ_WAIT_ANY" in s and "SQ_WAVE_CYCLES" in s:
         notes["wait_fraction"] = s["SQ_WAIT_ANY"] / s["SQ_WAVE_CYCLES"]
     if "SQ_ACTIVE_INST_LDS" in s and "SQ_WAVE_CYCLES" in s:
