@@ -45,7 +45,8 @@ A0, B0 = 0, 18
 TMP_FIRST, TMP_LAST = 36, 75
 V_LDS = 76          # v76, v77: LDS byte address of the lane's 16-byte chunks (+0, +64 KiB) ; v78: of its 8-byte tail chunks
 V_LTAIL = 78
-V_GOFF = 79         # lane * 72 (byte offset inside a global scratch slot)
+V_GOFF = 79         # byte offset of the lane's 16-byte chunks inside a global scratch slot: wave * 4608 + lane * 16 (V_GOFF8 = 246: ... + lane * 8, the tail)
+V_GOFF8 = 246
 V_IDX8 = 80
 V_IDX = 81
 V_TID = 82

@@ -28,7 +28,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from asmcore import Emitter, P_INT, BN_X, SIX_U_PLUS_2_NAF, max_branch_distance, place_with_islands  # noqa: E402
 from kgen4 import (A0, B0, HOME0, L1V4_NAMES, L1v4, LB, N0P, N_AGPR_SLOTS, N_HOME, N_LDS_SLOTS, NL, P_L, REDN_C, S_M30, S_N0, S_P, S_REDN,  # noqa: E402
-                   S_RET1, S_RET2, S_RET3, SLOT_DW, SLOT_BYTES, V_FLAG, V_GOFF, V_IDX, V_IDX8, V_LDS, V_LTAIL, V_TID, bal_limbs, hx, mont4)
+                   S_RET1, S_RET2, S_RET3, SLOT_DW, SLOT_BYTES, V_FLAG, V_GOFF, V_GOFF8, V_IDX, V_IDX8, V_LDS, V_LTAIL, V_TID, bal_limbs, hx, mont4)
 
 # ---- scalar registers used by L2/L3 (all inside the clobbered range s36..s99) ----------------
 S_TMP0, S_TMP1 = 60, 61
@@ -158,6 +158,7 @@ G_B4 = 11                        # b^4 (only while the powers are built)
 N_GREG = 12                      # Fq12 scratch registers G0..G11 = slots 0..71
 GLOB_TMP0 = 6 * N_GREG           # eight overflow temporaries: slots 72..79
 N_GSLOTS = GLOB_TMP0 + 8         # scratch slots of the single-pairing kernels; pair j of a multi kernel: N_GSLOTS + 7 j + ...
+GCHUNK0 = 512                    # byte offset of the first 16-byte chunk plane inside a wave's part of a scratch slot (after the tails)
 
 ALIGN_CODE = bool(int(os.environ.get("KGEN_ALIGN", "1")))     # keep 8-byte instructions 8-byte aligned (asmcore.align_code)
 
@@ -309,9 +310,9 @@ class Prog:
         elif slot.kind in ("glob", "globdyn"):
             self._glob_base(slot)
             for c in range(self.N_B128):
-                e.emit(f"global_load_dwordx4 v[{blk + 4 * c}:{blk + 4 * c + 3}], v{V_GOFF}, {S_GADDR} offset:{16 * c}", kind="vmem",
+                e.emit(f"global_load_dwordx4 v[{blk + 4 * c}:{blk + 4 * c + 3}], v{V_GOFF}, {S_GADDR} offset:{GCHUNK0 + 1024 * c}", kind="vmem",
                        vw=range(blk + 4 * c, blk + 4 * c + 4))
-            e.emit(f"global_load_dwordx2 v[{blk + 16}:{blk + 17}], v{V_GOFF}, {S_GADDR} offset:64", kind="vmem", vw=[blk + 16, blk + 17])
+            e.emit(f"global_load_dwordx2 v[{blk + 16}:{blk + 17}], v{V_GOFF8}, {S_GADDR} offset:0", kind="vmem", vw=[blk + 16, blk + 17])
             self.vm_pending = True
         else:
             raise ValueError(slot.kind)
@@ -335,9 +336,9 @@ class Prog:
         elif slot.kind in ("glob", "globdyn"):
             self._glob_base(slot)
             for c in range(self.N_B128):
-                e.emit(f"global_store_dwordx4 v{V_GOFF}, v[{blk + 4 * c}:{blk + 4 * c + 3}], {S_GADDR} offset:{16 * c}", kind="vmem",
+                e.emit(f"global_store_dwordx4 v{V_GOFF}, v[{blk + 4 * c}:{blk + 4 * c + 3}], {S_GADDR} offset:{GCHUNK0 + 1024 * c}", kind="vmem",
                        store=range(blk + 4 * c, blk + 4 * c + 4))
-            e.emit(f"global_store_dwordx2 v{V_GOFF}, v[{blk + 16}:{blk + 17}], {S_GADDR} offset:64", kind="vmem", store=[blk + 16, blk + 17])
+            e.emit(f"global_store_dwordx2 v{V_GOFF8}, v[{blk + 16}:{blk + 17}], {S_GADDR} offset:0", kind="vmem", store=[blk + 16, blk + 17])
             e.raw("s_nop 1")        # wide-store data hazard: the next VALU write of the block may sit behind a call
         else:
             raise ValueError(slot.kind)
@@ -1407,9 +1408,9 @@ class KernelBuilder:
             e.salu("s_addc_u32 s63, s65, 0")
             for c in range(Prog.N_B128):
                 r = land[n] + 4 * c
-                e.emit(f"global_load_dwordx4 v[{r}:{r + 3}], v{V_GOFF}, {S_GADDR} offset:{16 * c}", kind="vmem", vw=range(r, r + 4))
+                e.emit(f"global_load_dwordx4 v[{r}:{r + 3}], v{V_GOFF}, {S_GADDR} offset:{GCHUNK0 + 1024 * c}", kind="vmem", vw=range(r, r + 4))
             r = land[n] + 16
-            e.emit(f"global_load_dwordx2 v[{r}:{r + 1}], v{V_GOFF}, {S_GADDR} offset:64", kind="vmem", vw=[r, r + 1])
+            e.emit(f"global_load_dwordx2 v[{r}:{r + 1}], v{V_GOFF8}, {S_GADDR} offset:0", kind="vmem", vw=[r, r + 1])
         e.raw("s_waitcnt vmcnt(0)")
         for n, d in enumerate(dests):
             p.store(land[n], d) if d.kind != "home" or HOME0 + SLOT_DW * d.idx != land[n] else None
@@ -1429,8 +1430,8 @@ class KernelBuilder:
             e.salu(f"s_add_u32 s62, s64, s{S_TMP0}")
             e.salu("s_addc_u32 s63, s65, 0")
             for c in range(Prog.N_B128):
-                e.emit(f"global_load_dwordx4 a[{a0 + 4 * c}:{a0 + 4 * c + 3}], v{V_GOFF}, {S_GADDR} offset:{16 * c}", kind="vmem")
-            e.emit(f"global_load_dwordx2 a[{a0 + 16}:{a0 + 17}], v{V_GOFF}, {S_GADDR} offset:64", kind="vmem")
+                e.emit(f"global_load_dwordx4 a[{a0 + 4 * c}:{a0 + 4 * c + 3}], v{V_GOFF}, {S_GADDR} offset:{GCHUNK0 + 1024 * c}", kind="vmem")
+            e.emit(f"global_load_dwordx2 a[{a0 + 16}:{a0 + 17}], v{V_GOFF8}, {S_GADDR} offset:0", kind="vmem")
             p.slot_r.pop(p.key(dst), None)
             p.slot_v.pop(p.key(dst), None)
 
@@ -1487,7 +1488,15 @@ class KernelBuilder:
         e.salu(f"s_mov_b64 {S_SCRATCH}, %6")
         e.salu(f"s_add_u32 s64, s64, s{S_TMP0}")
         e.salu("s_addc_u32 s65, s65, 0")
-        e.emit(f"v_mul_u32_u24_e32 v{V_GOFF}, {SLOT_BYTES}, %9", vw=[V_GOFF])
+        # scratch slot of a workgroup = 4 waves x 4608 B; inside a wave's part the 64 lanes' 8-byte tails come first (512 B),
+        # then the four 16-byte chunks as [chunk][lane] (1 KiB each): every slot access instruction touches ONE contiguous
+        # 1 KiB (16 cache lines) instead of 64 lines at a 72-byte lane stride
+        e.emit(f"v_lshrrev_b32_e32 v{V_GOFF}, 6, %9", vw=[V_GOFF])
+        e.emit(f"v_mul_u32_u24_e32 v{V_GOFF}, {64 * SLOT_BYTES}, v{V_GOFF}", vw=[V_GOFF])
+        e.emit(f"v_and_b32_e32 v{V_GOFF8}, 63, %9", vw=[V_GOFF8])
+        e.emit(f"v_lshl_add_u32 v{V_GOFF8}, v{V_GOFF8}, 3, v{V_GOFF}", vw=[V_GOFF8])
+        e.emit(f"v_and_b32_e32 v{V_IDX}, 63, %9", vw=[V_IDX])
+        e.emit(f"v_lshl_add_u32 v{V_GOFF}, v{V_IDX}, 4, v{V_GOFF}", vw=[V_GOFF])
         e.emit(f"v_lshlrev_b32_e32 v{V_LDS}, 4, %9", vw=[V_LDS])
         e.emit(f"v_add_u32_e32 v{V_LDS + 1}, 0x10000, v{V_LDS}", vw=[V_LDS + 1])
         e.emit(f"v_lshlrev_b32_e32 v{V_LTAIL}, 3, %9", vw=[V_LTAIL])
@@ -2235,8 +2244,8 @@ class KernelBuilder:
             e.salu(f"s_add_u32 s62, s64, s{S_TMP0}")
             e.salu("s_addc_u32 s63, s65, 0")
             for c in range(Prog.N_B128):
-                e.emit(f"global_load_dwordx4 a[{a0 + 4 * c}:{a0 + 4 * c + 3}], v{V_GOFF}, {S_GADDR} offset:{16 * c}", kind="vmem")
-            e.emit(f"global_load_dwordx2 a[{a0 + 16}:{a0 + 17}], v{V_GOFF}, {S_GADDR} offset:64", kind="vmem")
+                e.emit(f"global_load_dwordx4 a[{a0 + 4 * c}:{a0 + 4 * c + 3}], v{V_GOFF}, {S_GADDR} offset:{GCHUNK0 + 1024 * c}", kind="vmem")
+            e.emit(f"global_load_dwordx2 a[{a0 + 16}:{a0 + 17}], v{V_GOFF8}, {S_GADDR} offset:0", kind="vmem")
 
     def _stream_routines(self, sc):
         buf = self.BUF
