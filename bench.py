@@ -209,6 +209,17 @@ def extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n):
     out["configs[3]: Groth16 shape, 2^18 groups x 4 pairs, shared final exp"] = {
         "ms": ms, "groups_per_s": groups / (ms * 1e-3), "pairs_per_s": groups * k / (ms * 1e-3),
         "roofline_frac": groups / (ms * 1e-3) * W_MUL32_PER_GROTH16_GROUP / PEAK_MUL32_PER_S}
+    # data formats either side of the path: element-major <-> limb-major on the device (HBM-bound: every word read once, written once)
+    HBM_PEAK = 8.0e12
+    lay = {}
+    o3 = torch.empty(48 * n, dtype=torch.int64, device=dev)
+    for name, src, words, fn, order in (("G1 elems -> planes", g1, 8, pkg.soa_from_elems_dev, 0), ("G2 elems -> planes", g2, 16, pkg.soa_from_elems_dev, 0),
+                                        ("Fq12 planes -> ark Fq12 elems", o3, 48, pkg.soa_to_elems_dev, pkg.FQ12_ARK)):
+        dst = torch.empty(words * n, dtype=torch.int64, device=dev)
+        ms = timed(lambda: fn(src, dst, words, n, order, local_rank, stream), 20)
+        lay[name] = {"ms": ms, "GB_per_s": 2 * 8 * words * n / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": 2 * 8 * words * n / (ms * 1e-3) / HBM_PEAK}
+        del dst
+    out["layout kernels at 2^20 elements (roofline bound: hbm, 8 TB/s)"] = lay
     pkg.last_status(local_rank, stream)
     return out
 

@@ -129,6 +129,32 @@ uint64_t bn254_bn_x(void);
  * ark_flat[j] = myfq12.coeffs[bn254_myfq12_to_ark_index(j)], j = 0..11 */
 int bn254_myfq12_to_ark_index(int j);
 
+/* ---- element-major data ("elems") ------------------------------------------------------
+ * The reference's callers hold `G1Affine` / `G2Affine` / `MyFq12` / `Fq12` values one after the other
+ * (pairing.rs:20 takes them by value, miller_loop_native.rs:324 as `Vec<(&G1Affine, &G2Affine)>`):
+ *   elems[i*W + w], W = 8 (G1: x, y), 16 (G2: x.c0, x.c1, y.c0, y.c1), 48 (Fq12), 4 limbs per Fq as above.
+ * These entry points take / return that order, so a binding copies fields sequentially and never transposes on
+ * the host; the limb-major planes are made on the device (one HBM pass).  For W = 48, `fq12_order` selects the
+ * coefficient order of the element-major side:
+ *   BN254_FQ12_MYFQ12  MyFq12.coeffs[0..12]
+ *   BN254_FQ12_ARK     ark Fq12 (c0.c0.c0, c0.c0.c1, c0.c1.c0, ... c1.c2.c1): MyFq12 `From`/`Into<Fq12>`,
+ *                      the `.into()` of src/pairing.rs:21 -- what pairing() returns. */
+#define BN254_FQ12_MYFQ12 0
+#define BN254_FQ12_ARK 1
+/* device pointers; src != dst; words = 8, 16 or 48 (fq12_order is ignored unless words = 48) */
+int bn254_soa_from_elems_dev(const uint64_t* elems, uint64_t* soa, size_t words, size_t n, int fq12_order, int device, void* stream);
+int bn254_soa_to_elems_dev(const uint64_t* soa, uint64_t* elems, size_t words, size_t n, int fq12_order, int device, void* stream);
+/* host pointers, element-major in and out: pairing() (src/pairing.rs:20-22), miller_loop_native (:320),
+ * multi_miller_loop_native (:324; pair j of group g = element g*k + j) and final_exp_native (final_exp_native.rs:209) */
+int bn254_pairing_batch_elems(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n, int out_order, int device, void* stream);
+int bn254_miller_loop_batch_elems(const uint64_t* g1, const uint64_t* g2, uint64_t* f_out, size_t n, int device, void* stream);
+int bn254_multi_pairing_batch_elems(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_groups, size_t k, int do_final_exp,
+                                    int out_order, int device, void* stream);
+int bn254_final_exp_batch_elems(const uint64_t* f_in, uint64_t* out, size_t n, int in_order, int out_order, int device, void* stream);
+/* the product-of-pairings check (final_exp_native.rs:245-263) on element-major pairs: one byte per group */
+int bn254_multi_pairing_check_batch_elems(const uint64_t* g1, const uint64_t* g2, uint8_t* verdict, size_t n_groups, size_t k, int device,
+                                          void* stream);
+
 /* ---- synthetic inputs (bench / tests): on-device subgroup points ------------------------ */
 /* P_i = [s_i] G1, Q_i = [t_i] G2 with s_i, t_i from SplitMix64(seed, i) (non-zero, < 2^128);
  * affine, Montgomery, SoA.  Device pointers. */

@@ -116,19 +116,53 @@ inline Fq fq_neg(const Fq& a) {
 inline Fq2 conjugate_fp2(const Fq2& x) { return Fq2{x.c0, fq_neg(x.c1)}; }
 inline Fq2 neg_conjugate_fp2(const Fq2& x) { return Fq2{fq_neg(x.c0), x.c1}; }
 
-// ---- batch forms (the reason the engine exists): SoA buffers, see bn254_pairing.h ------------
+// ---- batch forms (the reason the engine exists).  std::vector<G1Affine> etc. ARE the element-major layout of
+// bn254_pairing.h (8 / 16 / 48 words per element), so the vectors go to the engine as they are: no packing on the host.
+static_assert(sizeof(G1Affine) == 64 && sizeof(G2Affine) == 128 && sizeof(MyFq12) == 384 && sizeof(Fq12) == 384, "element-major layout");
+namespace detail {
+inline const uint64_t* words(const void* p) { return static_cast<const uint64_t*>(p); }
+inline uint64_t* words(void* p) { return static_cast<uint64_t*>(p); }
+}  // namespace detail
+
 inline std::vector<MyFq12> pairing_batch(const std::vector<G1Affine>& ps, const std::vector<G2Affine>& qs, int device = 0) {
     const size_t n = ps.size();
     if (qs.size() != n) throw Panic(BN254_ERR_INVALID_ARG);
-    std::vector<uint64_t> g1(8 * n), g2(16 * n), out(48 * n);
-    for (size_t i = 0; i < n; i++) { detail::pack_g1(ps[i], g1.data(), n, i); detail::pack_g2(qs[i], g2.data(), n, i); }
-    check(bn254_pairing_batch(g1.data(), g2.data(), out.data(), n, device, nullptr));
     std::vector<MyFq12> r(n);
-    for (size_t i = 0; i < n; i++) r[i] = detail::unpack_fq12(out.data(), n, i);
+    check(bn254_pairing_batch_elems(detail::words(ps.data()), detail::words(qs.data()), detail::words(r.data()), n, BN254_FQ12_MYFQ12, device, nullptr));
+    return r;
+}
+// n x pairing(p, q) -> Fq12 exactly as src/pairing.rs:20-22 returns it (ark coefficient order)
+inline std::vector<Fq12> pairing_batch_fq12(const std::vector<G1Affine>& ps, const std::vector<G2Affine>& qs, int device = 0) {
+    const size_t n = ps.size();
+    if (qs.size() != n) throw Panic(BN254_ERR_INVALID_ARG);
+    std::vector<Fq12> r(n);
+    check(bn254_pairing_batch_elems(detail::words(ps.data()), detail::words(qs.data()), detail::words(r.data()), n, BN254_FQ12_ARK, device, nullptr));
+    return r;
+}
+inline std::vector<MyFq12> miller_loop_batch(const std::vector<G2Affine>& qs, const std::vector<G1Affine>& ps, int device = 0) {
+    const size_t n = ps.size();
+    if (qs.size() != n) throw Panic(BN254_ERR_INVALID_ARG);
+    std::vector<MyFq12> r(n);
+    check(bn254_miller_loop_batch_elems(detail::words(ps.data()), detail::words(qs.data()), detail::words(r.data()), n, device, nullptr));
+    return r;
+}
+inline std::vector<MyFq12> final_exp_batch(const std::vector<MyFq12>& fs, int device = 0) {
+    std::vector<MyFq12> r(fs.size());
+    check(bn254_final_exp_batch_elems(detail::words(fs.data()), detail::words(r.data()), fs.size(), BN254_FQ12_MYFQ12, BN254_FQ12_MYFQ12, device, nullptr));
+    return r;
+}
+// groups of k pairs: multi_miller_loop_native per group (+ final_exp_native when do_final_exp)
+inline std::vector<MyFq12> multi_pairing_batch(const std::vector<G1Affine>& ps, const std::vector<G2Affine>& qs, size_t k, bool do_final_exp = true,
+                                               int device = 0) {
+    const size_t np = ps.size();
+    if (qs.size() != np || k == 0 || np % k != 0) throw Panic(BN254_ERR_INVALID_ARG);
+    std::vector<MyFq12> r(np / k);
+    check(bn254_multi_pairing_batch_elems(detail::words(ps.data()), detail::words(qs.data()), detail::words(r.data()), np / k, k, do_final_exp ? 1 : 0,
+                                          BN254_FQ12_MYFQ12, device, nullptr));
     return r;
 }
 
-// One process, several GPUs: contiguous slices per device (bn254_pairing_sharded).
+// One process, several GPUs: contiguous slices per device (bn254_pairing_sharded; limb-major host arrays).
 inline std::vector<MyFq12> pairing_sharded(const std::vector<G1Affine>& ps, const std::vector<G2Affine>& qs, int n_devices) {
     const size_t n = ps.size();
     if (qs.size() != n) throw Panic(BN254_ERR_INVALID_ARG);
@@ -145,10 +179,8 @@ inline std::vector<MyFq12> pairing_sharded(const std::vector<G1Affine>& ps, cons
 inline std::vector<uint8_t> multi_pairing_check_batch(const std::vector<G1Affine>& ps, const std::vector<G2Affine>& qs, size_t k, int device = 0) {
     const size_t np = ps.size();
     if (qs.size() != np || k == 0 || np % k != 0) throw Panic(BN254_ERR_INVALID_ARG);
-    std::vector<uint64_t> g1(8 * np), g2(16 * np);
-    for (size_t i = 0; i < np; i++) { detail::pack_g1(ps[i], g1.data(), np, i); detail::pack_g2(qs[i], g2.data(), np, i); }
     std::vector<uint8_t> verdict(np / k);
-    check(bn254_multi_pairing_check_batch(g1.data(), g2.data(), verdict.data(), np / k, k, device, nullptr));
+    check(bn254_multi_pairing_check_batch_elems(detail::words(ps.data()), detail::words(qs.data()), verdict.data(), np / k, k, device, nullptr));
     return verdict;
 }
 

@@ -44,6 +44,7 @@ SIX_U_PLUS_2_NAF = [
 ]
 
 G1_WORDS, G2_WORDS, FQ12_WORDS = 8, 16, 48
+FQ12_MYFQ12, FQ12_ARK = 0, 1          # coefficient order of element-major Fq12 data (include/bn254_pairing.h)
 
 
 class Bn254Error(RuntimeError):
@@ -87,6 +88,13 @@ _PROTOS = {
     "bn254_bn_x": (ctypes.c_uint64, []),
     "bn254_myfq12_to_ark_index": (ctypes.c_int, [ctypes.c_int]),
     "bn254_generate_pairs_dev": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_soa_from_elems_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_soa_to_elems_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_pairing_batch_elems": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_miller_loop_batch_elems": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_multi_pairing_batch_elems": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_multi_pairing_check_batch_elems": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_final_exp_batch_elems": (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
 }
 # symbols include/bn254_pairing.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = sorted(_PROTOS)
@@ -263,7 +271,60 @@ def pow_batch(a, exp, n, device=0):
     return out
 
 
+# ----------------------------------------------------------------------------- element-major API (host numpy buffers)
+# elems[i*W + w]: the order the reference's callers hold &[G1Affine] / Vec<MyFq12> / Vec<Fq12> in; the planes are made on the device.
+def pairing_batch_elems(g1, g2, n, out_order=FQ12_MYFQ12, device=0):
+    """n x pairing(p, q); out_order = FQ12_ARK gives ark `Fq12` words, the value src/pairing.rs:20-22 returns."""
+    lib = load_library()
+    g1, g2 = _np_in(g1, G1_WORDS, n), _np_in(g2, G2_WORDS, n)
+    out = np.empty(FQ12_WORDS * n, dtype=np.uint64)
+    _check(lib.bn254_pairing_batch_elems(_ptr(g1), _ptr(g2), _ptr(out), n, out_order, device, None), "pairing")
+    return out
+
+
+def miller_loop_batch_elems(g1, g2, n, device=0):
+    lib = load_library()
+    g1, g2 = _np_in(g1, G1_WORDS, n), _np_in(g2, G2_WORDS, n)
+    out = np.empty(FQ12_WORDS * n, dtype=np.uint64)
+    _check(lib.bn254_miller_loop_batch_elems(_ptr(g1), _ptr(g2), _ptr(out), n, device, None), "miller_loop_native")
+    return out
+
+
+def multi_pairing_batch_elems(g1, g2, n_groups, k, do_final_exp=True, out_order=FQ12_MYFQ12, device=0):
+    lib = load_library()
+    g1, g2 = _np_in(g1, G1_WORDS, n_groups * k), _np_in(g2, G2_WORDS, n_groups * k)
+    out = np.empty(FQ12_WORDS * n_groups, dtype=np.uint64)
+    _check(lib.bn254_multi_pairing_batch_elems(_ptr(g1), _ptr(g2), _ptr(out), n_groups, k, 1 if do_final_exp else 0, out_order, device, None),
+           "multi_miller_loop_native")
+    return out
+
+
+def multi_pairing_check_batch_elems(g1, g2, n_groups, k, device=0):
+    lib = load_library()
+    g1, g2 = _np_in(g1, G1_WORDS, n_groups * k), _np_in(g2, G2_WORDS, n_groups * k)
+    out = np.empty(n_groups, dtype=np.uint8)
+    _check(lib.bn254_multi_pairing_check_batch_elems(_ptr(g1), _ptr(g2), _ptr(out), n_groups, k, device, None), "multi-pairing check")
+    return out
+
+
+def final_exp_batch_elems(f, n, in_order=FQ12_MYFQ12, out_order=FQ12_MYFQ12, device=0):
+    lib = load_library()
+    f = _np_in(f, FQ12_WORDS, n)
+    out = np.empty(FQ12_WORDS * n, dtype=np.uint64)
+    _check(lib.bn254_final_exp_batch_elems(_ptr(f), _ptr(out), n, in_order, out_order, device, None), "final_exp_native")
+    return out
+
+
 # ----------------------------------------------------------------------------- device-pointer API (torch tensors / raw pointers)
+def soa_from_elems_dev(elems, soa, words, n, fq12_order=FQ12_MYFQ12, device=0, stream=None):
+    _check(load_library().bn254_soa_from_elems_dev(_dev(elems), _dev(soa), words, n, fq12_order, device, _stream(stream)), "soa_from_elems")
+
+
+def soa_to_elems_dev(soa, elems, words, n, fq12_order=FQ12_MYFQ12, device=0, stream=None):
+    _check(load_library().bn254_soa_to_elems_dev(_dev(soa), _dev(elems), words, n, fq12_order, device, _stream(stream)), "soa_to_elems")
+
+
+
 def _dev(t):
     return ctypes.c_void_p(t.data_ptr()) if hasattr(t, "data_ptr") else ctypes.c_void_p(int(t))
 

@@ -59,6 +59,40 @@ __global__ void __launch_bounds__(256) k_is_one(const uint64_t* __restrict__ f, 
 
 enum { OP_MUL = 0, OP_FROB = 1, OP_POW = 2 };
 
+// Element-major <-> limb-major.  The reference's callers hold `&[G1Affine]`, `Vec<(&G1Affine, &G2Affine)>`, `Vec<MyFq12>`,
+// `Vec<Fq12>`: one element after the other, W = 8 / 16 / 48 words each; the pairing kernels want plane (c, l) of all
+// elements contiguous.  HBM-bound: every word is read once and written once, both sides in runs of >= 512 B per wave
+// (a tile of T elements goes through LDS, rows padded by one word so that the transposed reads are conflict-free).
+// W = 48 with order = BN254_FQ12_ARK also applies the MyFq12 <-> ark Fq12 coefficient permutation (`.into()`, pairing.rs:21).
+__device__ __forceinline__ int fq12_plane(int w, int order) {      // SoA plane of word w of an element
+    if (order == 0) return w;
+    int j = w >> 2, h = j / 6, k = (j % 6) >> 1, e = j & 1;        // ark flat coefficient j = ((h*3 + k)*2 + e)
+    return (((2 * k + h) + 6 * e) << 2) | (w & 3);
+}
+template <int W, int T, bool TO_SOA>
+__global__ void __launch_bounds__(256) k_layout(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, size_t n, int order) {
+    __shared__ uint64_t tile[T][W + 1];
+    size_t i0 = (size_t)blockIdx.x * T;
+    int cnt = (int)(n - i0 < (size_t)T ? n - i0 : (size_t)T);
+    if (TO_SOA) {
+        const uint64_t* in = src + i0 * W;
+        for (int idx = threadIdx.x; idx < cnt * W; idx += 256) tile[idx / W][idx % W] = in[idx];
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < T * W; idx += 256) {
+            int w = idx / T, e = idx % T;
+            if (e < cnt) dst[(size_t)(W == 48 ? fq12_plane(w, order) : w) * n + i0 + e] = tile[e][w];
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < T * W; idx += 256) {
+            int w = idx / T, e = idx % T;
+            if (e < cnt) tile[e][w] = src[(size_t)(W == 48 ? fq12_plane(w, order) : w) * n + i0 + e];
+        }
+        __syncthreads();
+        uint64_t* out = dst + i0 * W;
+        for (int idx = threadIdx.x; idx < cnt * W; idx += 256) out[idx] = tile[idx / W][idx % W];
+    }
+}
+
 // ------------------------------------------------------------------ host side
 // Scratch, the status word and the staging buffers of the host-pointer entry points are kept per (device, stream): calls on
 // different streams of one device are independent ("library is re-entrant, one HIP stream per call").  Calls on
@@ -69,7 +103,7 @@ struct Buf {
 };
 struct StreamCtx {
     Buf scratch, naf, tmp;
-    Buf stage[4];              // device staging of the host-pointer entry points (inputs / outputs), grown on demand
+    Buf stage[8];              // device staging of the host-pointer entry points (inputs / outputs), grown on demand
     int* status = nullptr;
 };
 struct DeviceCtx {
@@ -199,6 +233,22 @@ int launch_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_
     return BN254_OK;
 }
 
+int launch_layout(bool to_soa, const uint64_t* src, uint64_t* dst, size_t words, size_t n, int order, int device, void* stream) {
+    if (n == 0) return BN254_OK;
+    if (!src || !dst || src == dst || (words != 8 && words != 16 && words != 48) || (order != BN254_FQ12_MYFQ12 && order != BN254_FQ12_ARK) ||
+        n >= (1ull << 29))
+        return BN254_ERR_INVALID_ARG;
+    int rc = check_device(device);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    auto go = [&](auto kern, size_t tile) { hipLaunchKernelGGL(kern, dim3((uint32_t)((n + tile - 1) / tile)), dim3(256), 0, st, src, dst, n, order); };
+    if (words == 8) { if (to_soa) go(k_layout<8, 256, true>, 256); else go(k_layout<8, 256, false>, 256); }
+    else if (words == 16) { if (to_soa) go(k_layout<16, 128, true>, 128); else go(k_layout<16, 128, false>, 128); }
+    else { if (to_soa) go(k_layout<48, 64, true>, 64); else go(k_layout<48, 64, false>, 64); }
+    HIPCHK(hipGetLastError());
+    return BN254_OK;
+}
+
 // get_naf -- final_exp_native.rs:86-128 (host logic, identical control flow)
 long get_naf_host(const uint64_t* exp_in, size_t n, int8_t* naf) {
     std::vector<uint64_t> exp(exp_in, exp_in + n);
@@ -238,7 +288,7 @@ struct Stage {
         return BN254_OK;
     }
     int up(const void* h, size_t bytes, uint64_t** d) {
-        if (used >= 4) return BN254_ERR_INVALID_ARG;
+        if (used >= 8) return BN254_ERR_INVALID_ARG;
         Buf& b = sc->stage[used++];
         int rc = ensure(b, bytes ? bytes : 8, st);
         if (rc) return rc;
@@ -254,8 +304,12 @@ struct Stage {
 extern "C" {
 
 constexpr size_t PIPE_CHUNK = 2 * 65536;      // lanes per chunk of the host-pointer pipeline (two full grids)
+struct HostFmt {               // how the caller's host arrays are laid out
+    bool elems = false;        // element-major (one G1 / G2 / Fq12 after the other) instead of limb-major planes
+    int out_order = BN254_FQ12_MYFQ12;
+};
 static int run_pipeline(const int* devices, int n_dev, const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_units, size_t k,
-                        int do_final_exp);
+                        int do_final_exp, HostFmt fmt = HostFmt());
 
 int bn254_device_count(void) {
     int cnt = 0;
@@ -404,8 +458,8 @@ int bn254_release_stream(int device, void* stream) {
         sc = it->second;
         c.streams.erase(it);
     }
-    for (Buf* b : {&sc.scratch, &sc.naf, &sc.tmp, &sc.stage[0], &sc.stage[1], &sc.stage[2], &sc.stage[3]})
-        if (b->p) (void)hipFree(b->p);
+    for (Buf* b : {&sc.scratch, &sc.naf, &sc.tmp}) if (b->p) (void)hipFree(b->p);
+    for (Buf& b : sc.stage) if (b.p) (void)hipFree(b.p);
     if (sc.status) (void)hipFree(sc.status);
     return BN254_OK;
 }
@@ -491,6 +545,60 @@ int bn254_pow_batch(const uint64_t* a, const uint64_t* exp, size_t exp_limbs, ui
     return finish_host(out, d3, 384 * n, device, stream);
 }
 
+// ---- element-major data ("elems"): the order the reference's callers hold their values in (&[G1Affine], Vec<MyFq12>, Vec<Fq12>)
+int bn254_soa_from_elems_dev(const uint64_t* elems, uint64_t* soa, size_t words, size_t n, int fq12_order, int device, void* stream) {
+    return launch_layout(true, elems, soa, words, n, words == 48 ? fq12_order : 0, device, stream);
+}
+int bn254_soa_to_elems_dev(const uint64_t* soa, uint64_t* elems, size_t words, size_t n, int fq12_order, int device, void* stream) {
+    return launch_layout(false, soa, elems, words, n, words == 48 ? fq12_order : 0, device, stream);
+}
+int bn254_multi_pairing_batch_elems(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_groups, size_t k, int do_final_exp,
+                                    int out_order, int device, void* stream) {
+    if (n_groups == 0) return BN254_OK;
+    if (!g1 || !g2 || !out || k == 0 || k > MAX_K || (out_order != BN254_FQ12_MYFQ12 && out_order != BN254_FQ12_ARK)) return BN254_ERR_INVALID_ARG;
+    int rc = check_device(device);
+    if (rc) return rc;
+    if (n_groups > PIPE_CHUNK) {
+        if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return BN254_ERR_HIP;
+        HostFmt fmt; fmt.elems = true; fmt.out_order = out_order;
+        return run_pipeline(&device, 1, g1, g2, out, n_groups, k, do_final_exp, fmt);
+    }
+    Stage s; uint64_t *e1, *e2, *e3, *d1, *d2, *d3; size_t np = n_groups * k;
+    if ((rc = s.init(device, stream)) || (rc = s.up(g1, 64 * np, &e1)) || (rc = s.up(g2, 128 * np, &e2)) || (rc = s.up(nullptr, 384 * n_groups, &e3)) ||
+        (rc = s.up(nullptr, 64 * np, &d1)) || (rc = s.up(nullptr, 128 * np, &d2)) || (rc = s.up(nullptr, 384 * n_groups, &d3))) return rc;
+    if ((rc = launch_layout(true, e1, d1, 8, np, 0, device, stream)) || (rc = launch_layout(true, e2, d2, 16, np, 0, device, stream))) return rc;
+    rc = (k == 1 && do_final_exp) ? bn254_pairing_batch_dev(d1, d2, d3, n_groups, device, stream)
+                                  : bn254_multi_pairing_batch_dev(d1, d2, d3, n_groups, k, do_final_exp, device, stream);
+    if (rc || (rc = launch_layout(false, d3, e3, 48, n_groups, out_order, device, stream))) return rc;
+    return finish_host(out, e3, 384 * n_groups, device, stream);
+}
+int bn254_multi_pairing_check_batch_elems(const uint64_t* g1, const uint64_t* g2, uint8_t* verdict, size_t n_groups, size_t k, int device, void* stream) {
+    if (n_groups == 0) return BN254_OK;
+    if (!g1 || !g2 || !verdict || k == 0 || k > MAX_K) return BN254_ERR_INVALID_ARG;
+    Stage s; uint64_t *e1, *e2, *d1, *d2, *d3; int rc; size_t np = n_groups * k;
+    if ((rc = s.init(device, stream)) || (rc = s.up(g1, 64 * np, &e1)) || (rc = s.up(g2, 128 * np, &e2)) || (rc = s.up(nullptr, 64 * np, &d1)) ||
+        (rc = s.up(nullptr, 128 * np, &d2)) || (rc = s.up(nullptr, n_groups, &d3))) return rc;
+    if ((rc = launch_layout(true, e1, d1, 8, np, 0, device, stream)) || (rc = launch_layout(true, e2, d2, 16, np, 0, device, stream)) ||
+        (rc = bn254_multi_pairing_check_batch_dev(d1, d2, (uint8_t*)d3, n_groups, k, device, stream))) return rc;
+    return finish_host(verdict, d3, n_groups, device, stream);
+}
+int bn254_pairing_batch_elems(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n, int out_order, int device, void* stream) {
+    return bn254_multi_pairing_batch_elems(g1, g2, out, n, 1, 1, out_order, device, stream);
+}
+int bn254_miller_loop_batch_elems(const uint64_t* g1, const uint64_t* g2, uint64_t* f_out, size_t n, int device, void* stream) {
+    return bn254_multi_pairing_batch_elems(g1, g2, f_out, n, 1, 0, BN254_FQ12_MYFQ12, device, stream);
+}
+int bn254_final_exp_batch_elems(const uint64_t* f_in, uint64_t* out, size_t n, int in_order, int out_order, int device, void* stream) {
+    if (n == 0) return BN254_OK;
+    if (!f_in || !out) return BN254_ERR_INVALID_ARG;
+    Stage s; uint64_t *e1, *e3, *d1, *d3; int rc;
+    if ((rc = s.init(device, stream)) || (rc = s.up(f_in, 384 * n, &e1)) || (rc = s.up(nullptr, 384 * n, &e3)) || (rc = s.up(nullptr, 384 * n, &d1)) ||
+        (rc = s.up(nullptr, 384 * n, &d3))) return rc;
+    if ((rc = launch_layout(true, e1, d1, 48, n, in_order, device, stream)) || (rc = bn254_final_exp_batch_dev(d1, d3, n, device, stream)) ||
+        (rc = launch_layout(false, d3, e3, 48, n, out_order, device, stream))) return rc;
+    return finish_host(out, e3, 384 * n, device, stream);
+}
+
 // ---- host-pointer pipeline, one or several GPUs of this process: contiguous slices of the batch per device,
 // no exchange step.  A slice is cut into chunks of PIPE_CHUNK lanes (two full grids); a worker thread owns one private
 // stream and device buffers for one chunk and walks every second chunk of its device: it stages its chunk of every limb
@@ -498,24 +606,32 @@ int bn254_pow_batch(const uint64_t* a, const uint64_t* exp, size_t exp_limbs, ui
 // workers per device alternate, so one worker's copies run under the other's kernel (the kernels fill the chip and
 // serialise).  Units are pairings (k = 1) or k-pair groups.
 static int run_chunks(int dev, const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_units, size_t k, int do_final_exp, size_t u0,
-                      size_t cnt, size_t chunk, size_t first, size_t step) {
+                      size_t cnt, size_t chunk, size_t first, size_t step, HostFmt fmt) {
     if (cnt == 0 || first * chunk >= cnt) return BN254_OK;
     if (hipSetDevice(dev) != hipSuccess) return BN254_ERR_INVALID_ARG;
     hipStream_t st;
     if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return BN254_ERR_HIP;
     int rc = BN254_OK;
     {
-        Stage s; uint64_t *d1, *d2, *d3;
+        Stage s; uint64_t *d1, *d2, *d3, *e1 = nullptr, *e2 = nullptr, *e3 = nullptr;
         size_t cap = cnt < chunk ? cnt : chunk, np_all = n_units * k;
         if ((rc = s.init(dev, st)) || (rc = s.up(nullptr, 64 * cap * k, &d1)) || (rc = s.up(nullptr, 128 * cap * k, &d2)) || (rc = s.up(nullptr, 384 * cap, &d3))) goto done;
+        if (fmt.elems && ((rc = s.up(nullptr, 64 * cap * k, &e1)) || (rc = s.up(nullptr, 128 * cap * k, &e2)) || (rc = s.up(nullptr, 384 * cap, &e3)))) goto done;
         for (size_t c0 = first * chunk; c0 < cnt; c0 += step * chunk) {
             size_t m = cnt - c0 < chunk ? cnt - c0 : chunk, np = m * k, base = u0 + c0;
-            if (hipMemcpy2DAsync(d1, np * 8, g1 + base * k, np_all * 8, np * 8, 8, hipMemcpyHostToDevice, st) != hipSuccess ||
-                hipMemcpy2DAsync(d2, np * 8, g2 + base * k, np_all * 8, np * 8, 16, hipMemcpyHostToDevice, st) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
+            if (fmt.elems) {           // a chunk of an element-major array is one contiguous run; the planes are made on the device
+                if (hipMemcpyAsync(e1, g1 + base * k * 8, np * 64, hipMemcpyHostToDevice, st) != hipSuccess ||
+                    hipMemcpyAsync(e2, g2 + base * k * 16, np * 128, hipMemcpyHostToDevice, st) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
+                if ((rc = launch_layout(true, e1, d1, 8, np, 0, dev, st)) || (rc = launch_layout(true, e2, d2, 16, np, 0, dev, st))) goto done;
+            } else if (hipMemcpy2DAsync(d1, np * 8, g1 + base * k, np_all * 8, np * 8, 8, hipMemcpyHostToDevice, st) != hipSuccess ||
+                       hipMemcpy2DAsync(d2, np * 8, g2 + base * k, np_all * 8, np * 8, 16, hipMemcpyHostToDevice, st) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
             rc = (k == 1 && do_final_exp) ? bn254_pairing_batch_dev(d1, d2, d3, m, dev, st)
                                           : bn254_multi_pairing_batch_dev(d1, d2, d3, m, k, do_final_exp, dev, st);
             if (rc) goto done;
-            if (hipMemcpy2DAsync(out + base, n_units * 8, d3, m * 8, m * 8, 48, hipMemcpyDeviceToHost, st) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
+            if (fmt.elems) {
+                if ((rc = launch_layout(false, d3, e3, 48, m, fmt.out_order, dev, st))) goto done;
+                if (hipMemcpyAsync(out + base * 48, e3, m * 384, hipMemcpyDeviceToHost, st) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
+            } else if (hipMemcpy2DAsync(out + base, n_units * 8, d3, m * 8, m * 8, 48, hipMemcpyDeviceToHost, st) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
             if ((rc = bn254_last_status(dev, st))) goto done;        // also: the buffers are free for the next chunk
         }
     done:
@@ -528,7 +644,7 @@ static int run_chunks(int dev, const uint64_t* g1, const uint64_t* g2, uint64_t*
 
 // devices[0..n_dev): the batch is split into n_dev contiguous slices
 static int run_pipeline(const int* devices, int n_dev, const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_units, size_t k,
-                        int do_final_exp) {
+                        int do_final_exp, HostFmt fmt) {
     size_t chunk = PIPE_CHUNK;                        // lanes = units (one unit per lane whatever k is)
     size_t per = (n_units + (size_t)n_dev - 1) / (size_t)n_dev;
     std::vector<int> rcs;
@@ -542,7 +658,7 @@ static int run_pipeline(const int* devices, int n_dev, const uint64_t* g1, const
             rcs.push_back(BN254_OK);
             int* slot = &rcs.back();
             int dev = devices[d];
-            th.emplace_back([=] { *slot = run_chunks(dev, g1, g2, out, n_units, k, do_final_exp, u0, c, chunk, w, workers); });
+            th.emplace_back([=] { *slot = run_chunks(dev, g1, g2, out, n_units, k, do_final_exp, u0, c, chunk, w, workers, fmt); });
         }
     }
     for (auto& t : th) t.join();

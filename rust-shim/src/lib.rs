@@ -23,7 +23,15 @@ extern "C" {
     fn bn254_get_naf(exp: *const u64, exp_limbs: usize, naf: *mut i8) -> c_long;
     fn bn254_frob_coeffs(index: usize, out8: *mut u64) -> c_int;
     fn bn254_myfq12_to_ark_index(j: c_int) -> c_int;
+    // element-major entry points: the order a `&[G1Affine]` / `Vec<Fq12>` is copied out in (fields one after the other)
+    fn bn254_pairing_batch_elems(g1: *const u64, g2: *const u64, out: *mut u64, n: usize, out_order: c_int, device: c_int, stream: *mut c_void) -> c_int;
+    fn bn254_multi_pairing_batch_elems(g1: *const u64, g2: *const u64, out: *mut u64, n_groups: usize, k: usize, do_final_exp: c_int,
+                                       out_order: c_int, device: c_int, stream: *mut c_void) -> c_int;
+    fn bn254_multi_pairing_check_batch_elems(g1: *const u64, g2: *const u64, verdict: *mut u8, n_groups: usize, k: usize, device: c_int,
+                                             stream: *mut c_void) -> c_int;
 }
+const FQ12_MYFQ12: c_int = 0;
+const FQ12_ARK: c_int = 1;
 
 pub const BN_X: u64 = 4965661367192848881;
 pub const SIX_U_PLUS_2_NAF: [i8; 65] = [
@@ -98,12 +106,40 @@ pub fn frob_coeffs(index: usize) -> Fq2 {
 pub fn conjugate_fp2(x: Fq2) -> Fq2 { Fq2::new(x.c0, -x.c1) }
 pub fn neg_conjugate_fp2(x: Fq2) -> Fq2 { Fq2::new(-x.c0, x.c1) }
 
+/// Element-major writers: fields copied out one after the other (no transposition on the host; `repr(Rust)` structs are
+/// still never transmuted).  The engine makes its limb-major planes on the device.
+pub fn elems_g1(ps: &[G1Affine]) -> Vec<u64> { let mut b = Vec::with_capacity(8 * ps.len()); for p in ps { b.extend_from_slice(&limbs(&p.x)); b.extend_from_slice(&limbs(&p.y)); } b }
+pub fn elems_g2(qs: &[G2Affine]) -> Vec<u64> {
+    let mut b = Vec::with_capacity(16 * qs.len());
+    for q in qs { for f in [&q.x.c0, &q.x.c1, &q.y.c0, &q.y.c1] { b.extend_from_slice(&limbs(f)); } }
+    b
+}
+fn fq12_from_ark_words(w: &[u64]) -> Fq12 {
+    let f = |j: usize| from_limbs(&w[4 * j..4 * j + 4]);
+    let f2 = |j: usize| Fq2::new(f(2 * j), f(2 * j + 1));
+    Fq12::new(ark_bn254::Fq6::new(f2(0), f2(1), f2(2)), ark_bn254::Fq6::new(f2(3), f2(4), f2(5)))
+}
 /// New: whole batches in one launch (what the engine is for).  Output: MyFq12 per pairing.
 pub fn pairing_batch(ps: &[G1Affine], qs: &[G2Affine]) -> Vec<MyFq12> {
     assert_eq!(ps.len(), qs.len()); let n = ps.len();
-    let (g1, g2) = (pack_g1(ps), pack_g2(qs)); let mut out = vec![0u64; 48 * n];
-    ok(unsafe { bn254_pairing_batch(g1.as_ptr(), g2.as_ptr(), out.as_mut_ptr(), n, 0, core::ptr::null_mut()) });
-    (0..n).map(|i| { let mut c = [0u64; 48]; for w in 0..48 { c[w] = out[w * n + i]; } unpack_fq12(&c) }).collect()
+    let (g1, g2) = (elems_g1(ps), elems_g2(qs)); let mut out = vec![0u64; 48 * n];
+    ok(unsafe { bn254_pairing_batch_elems(g1.as_ptr(), g2.as_ptr(), out.as_mut_ptr(), n, FQ12_MYFQ12, 0, core::ptr::null_mut()) });
+    out.chunks_exact(48).map(unpack_fq12).collect()
+}
+/// New: n x `pairing(p, q)` as `Fq12`, exactly what src/pairing.rs:20-22 returns (the `.into()` runs on the device).
+pub fn pairing_batch_fq12(ps: &[G1Affine], qs: &[G2Affine]) -> Vec<Fq12> {
+    assert_eq!(ps.len(), qs.len()); let n = ps.len();
+    let (g1, g2) = (elems_g1(ps), elems_g2(qs)); let mut out = vec![0u64; 48 * n];
+    ok(unsafe { bn254_pairing_batch_elems(g1.as_ptr(), g2.as_ptr(), out.as_mut_ptr(), n, FQ12_ARK, 0, core::ptr::null_mut()) });
+    out.chunks_exact(48).map(fq12_from_ark_words).collect()
+}
+/// New: groups of k pairs, `multi_miller_loop_native` per group (+ `final_exp_native` when asked), one launch.
+pub fn multi_pairing_batch(ps: &[G1Affine], qs: &[G2Affine], k: usize, do_final_exp: bool) -> Vec<MyFq12> {
+    assert!(k > 0 && ps.len() == qs.len() && ps.len() % k == 0); let n_groups = ps.len() / k;
+    let (g1, g2) = (elems_g1(ps), elems_g2(qs)); let mut out = vec![0u64; 48 * n_groups];
+    ok(unsafe { bn254_multi_pairing_batch_elems(g1.as_ptr(), g2.as_ptr(), out.as_mut_ptr(), n_groups, k, do_final_exp as c_int, FQ12_MYFQ12, 0,
+                                                core::ptr::null_mut()) });
+    out.chunks_exact(48).map(unpack_fq12).collect()
 }
 /// New: the same batch spread over the first `n_devices` GPUs of this process (contiguous slices, no exchange).
 pub fn pairing_sharded(ps: &[G1Affine], qs: &[G2Affine], n_devices: i32) -> Vec<MyFq12> {
@@ -116,8 +152,8 @@ pub fn pairing_sharded(ps: &[G1Affine], qs: &[G2Affine], n_devices: i32) -> Vec<
 /// (the check of final_exp_native.rs:245-263), one verdict per group instead of 384 bytes.
 pub fn multi_pairing_check_batch(ps: &[G1Affine], qs: &[G2Affine], k: usize) -> Vec<bool> {
     assert!(k > 0 && ps.len() == qs.len() && ps.len() % k == 0); let n_groups = ps.len() / k;
-    let (g1, g2) = (pack_g1(ps), pack_g2(qs)); let mut v = vec![0u8; n_groups];
-    ok(unsafe { bn254_multi_pairing_check_batch(g1.as_ptr(), g2.as_ptr(), v.as_mut_ptr(), n_groups, k, 0, core::ptr::null_mut()) });
+    let (g1, g2) = (elems_g1(ps), elems_g2(qs)); let mut v = vec![0u8; n_groups];
+    ok(unsafe { bn254_multi_pairing_check_batch_elems(g1.as_ptr(), g2.as_ptr(), v.as_mut_ptr(), n_groups, k, 0, core::ptr::null_mut()) });
     v.into_iter().map(|b| b != 0).collect()
 }
 #[allow(dead_code)] fn _ark_index(j: i32) -> i32 { unsafe { bn254_myfq12_to_ark_index(j) } }

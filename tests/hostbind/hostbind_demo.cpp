@@ -7,6 +7,8 @@
 //     pairing  g1[8] g2[16]          miller g1[8] g2[16]        multi k (g1[8] g2[16])*k
 //     fexp a[48]                     frob power a[48]           pow n_limbs exp[n] a[48]
 //     frobc index                    naf n_limbs exp[n]
+//     batch n (g1[8] g2[16])*n       -> pairing_batch_fq12 (ark order) and pairing_batch (MyFq12 order), n lines each
+//     check k n_groups (g1[8] g2[16])*(k*n_groups)  -> multi_pairing_check_batch verdicts
 #include <cinttypes>
 #include <cstdio>
 #include <iostream>
@@ -47,6 +49,20 @@ int main() {
                 std::vector<std::pair<const G1Affine*, const G2Affine*>> pairs;
                 for (size_t j = 0; j < k; j++) pairs.push_back({&ps[j], &qs[j]});
                 pr_fq12("multi", multi_miller_loop_native(pairs));
+            } else if (op == "batch") {
+                size_t n = (size_t)rd(in);
+                std::vector<G1Affine> ps(n); std::vector<G2Affine> qs(n);
+                for (size_t j = 0; j < n; j++) { ps[j] = rd_g1(in); qs[j] = rd_g2(in); }
+                std::vector<Fq12> ark = pairing_batch_fq12(ps, qs);           // Vec<Fq12>, as n calls of pairing() return them
+                std::vector<MyFq12> my = pairing_batch(ps, qs);
+                for (auto& e : ark) { std::printf("bark"); for (auto& c : e.flat) pr_fq(c); std::printf("\n"); }
+                for (auto& e : my) pr_fq12("bmy", e);
+            } else if (op == "check") {
+                size_t k = (size_t)rd(in), n = (size_t)rd(in);
+                std::vector<G1Affine> ps(k * n); std::vector<G2Affine> qs(k * n);
+                for (size_t j = 0; j < k * n; j++) { ps[j] = rd_g1(in); qs[j] = rd_g2(in); }
+                std::vector<uint8_t> v = multi_pairing_check_batch(ps, qs, k);
+                std::printf("check"); for (uint8_t b : v) std::printf(" %d", (int)b); std::printf("\n");
             } else if (op == "fexp") {
                 pr_fq12("fexp", final_exp_native(rd_fq12(in)));
             } else if (op == "frob") {

@@ -80,8 +80,28 @@ def test_host_binding_program_on_golden_inputs(tmp_path):
     want.append(("pow", a))
     lines.append("pow 0 " + _words(a))                        # empty exponent vector: likewise
     want.append(("pow", a))
+    # batch forms: std::vector<G1Affine> / <G2Affine> go to the engine as they are (element-major entry points)
+    idx = list(range(7))
+    lines.append("batch %x " % len(idx) + " ".join(_words(HX(vec["g1"][i])) + " " + _words(HX(vec["g2"][i])) for i in idx))
+    want += [("bark", R.myfq12_to_ark(HX(vec["pairing"][i]))) for i in idx] + [("bmy", HX(vec["pairing"][i])) for i in idx]
     lines.append("fexp " + _words([0] * 12))                  # final_exp_native(0): the reference panics (division by zero)
     out = _run(exe, lines)
     for (tag, w), got in zip(want, out):
         assert got[0] == tag and _ints(got[1:]) == w, tag
     assert out[len(want)] == ["panic", "-4"]
+
+
+@pytest.mark.gpu
+def test_host_binding_product_check(tmp_path):
+    """multi_pairing_check_batch through the binding: e(aP, Q) e(-P, aQ) == 1 (the shape of final_exp_native.rs:245-263) in
+    group 0, an unrelated pair of pairs in group 1."""
+    exe = _build(tmp_path)
+    a = 0x1234567
+    P, Q = R.G1_GEN, R.G2_GEN
+    aP, aQ = R.g1_mul(P, a), R.g2_mul(Q, a)
+    negP = (P[0], (-P[1]) % R.P)
+    pts = [(aP, Q), (negP, aQ), (aP, Q), (P, aQ)]
+    fl = lambda q: [q[0][0], q[0][1], q[1][0], q[1][1]]
+    line = "check 2 2 " + " ".join(_words(list(p)) + " " + _words(fl(q)) for p, q in pts)
+    out = _run(exe, [line])
+    assert out[0] == ["check", "1", "0"]
