@@ -112,6 +112,8 @@ struct DeviceCtx {
     int n_cu = 0;
     int32_t* gen_table = nullptr;
     std::map<hipStream_t, StreamCtx> streams;
+    std::mutex pipe_mu;        // one host-pointer pipeline at a time per device (its two workers fill the chip anyway)
+    hipStream_t pipe_stream[2] = {nullptr, nullptr};   // the workers' private streams: created once, their scratch and staging kept
 };
 DeviceCtx g_ctx[64];
 
@@ -303,7 +305,7 @@ struct Stage {
 // ------------------------------------------------------------------ extern "C"
 extern "C" {
 
-constexpr size_t PIPE_CHUNK = 2 * 65536;      // lanes per chunk of the host-pointer pipeline (two full grids)
+constexpr size_t PIPE_CHUNK = 65536;          // lanes per chunk of the host-pointer pipeline (one full grid: one work item per CU)
 struct HostFmt {               // how the caller's host arrays are laid out
     bool elems = false;        // element-major (one G1 / G2 / Fq12 after the other) instead of limb-major planes
     int out_order = BN254_FQ12_MYFQ12;
@@ -600,17 +602,26 @@ int bn254_final_exp_batch_elems(const uint64_t* f_in, uint64_t* out, size_t n, i
 }
 
 // ---- host-pointer pipeline, one or several GPUs of this process: contiguous slices of the batch per device,
-// no exchange step.  A slice is cut into chunks of PIPE_CHUNK lanes (two full grids); a worker thread owns one private
+// no exchange step.  A slice is cut into chunks of PIPE_CHUNK lanes (one full grid); a worker thread owns one private
 // stream and device buffers for one chunk and walks every second chunk of its device: it stages its chunk of every limb
 // plane (2-D copies straight out of / into the caller's SoA arrays), launches the kernel and copies the result back.  Two
 // workers per device alternate, so one worker's copies run under the other's kernel (the kernels fill the chip and
 // serialise).  Units are pairings (k = 1) or k-pair groups.
-static int run_chunks(int dev, const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_units, size_t k, int do_final_exp, size_t u0,
-                      size_t cnt, size_t chunk, size_t first, size_t step, HostFmt fmt) {
+// contiguous copy between pageable host memory and the device, issued as a 2-D copy of 1 MiB rows: measured 2-3x faster
+// than hipMemcpyAsync on the same (pageable) buffers, whose staging path blocks the issuing thread
+static hipError_t copy_rows(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t st) {
+    const size_t row = 1u << 20;
+    size_t rows = bytes / row, rest = bytes - rows * row;
+    hipError_t e = hipSuccess;
+    if (rows) e = hipMemcpy2DAsync(dst, row, src, row, row, rows, kind, st);
+    if (e == hipSuccess && rest) e = hipMemcpyAsync((char*)dst + rows * row, (const char*)src + rows * row, rest, kind, st);
+    return e;
+}
+
+static int run_chunks(int dev, hipStream_t st, const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_units, size_t k, int do_final_exp,
+                      size_t u0, size_t cnt, size_t chunk, size_t first, size_t step, HostFmt fmt) {
     if (cnt == 0 || first * chunk >= cnt) return BN254_OK;
     if (hipSetDevice(dev) != hipSuccess) return BN254_ERR_INVALID_ARG;
-    hipStream_t st;
-    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return BN254_ERR_HIP;
     int rc = BN254_OK;
     {
         Stage s; uint64_t *d1, *d2, *d3, *e1 = nullptr, *e2 = nullptr, *e3 = nullptr;
@@ -620,8 +631,8 @@ static int run_chunks(int dev, const uint64_t* g1, const uint64_t* g2, uint64_t*
         for (size_t c0 = first * chunk; c0 < cnt; c0 += step * chunk) {
             size_t m = cnt - c0 < chunk ? cnt - c0 : chunk, np = m * k, base = u0 + c0;
             if (fmt.elems) {           // a chunk of an element-major array is one contiguous run; the planes are made on the device
-                if (hipMemcpyAsync(e1, g1 + base * k * 8, np * 64, hipMemcpyHostToDevice, st) != hipSuccess ||
-                    hipMemcpyAsync(e2, g2 + base * k * 16, np * 128, hipMemcpyHostToDevice, st) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
+                if (copy_rows(e1, g1 + base * k * 8, np * 64, hipMemcpyHostToDevice, st) != hipSuccess ||
+                    copy_rows(e2, g2 + base * k * 16, np * 128, hipMemcpyHostToDevice, st) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
                 if ((rc = launch_layout(true, e1, d1, 8, np, 0, dev, st)) || (rc = launch_layout(true, e2, d2, 16, np, 0, dev, st))) goto done;
             } else if (hipMemcpy2DAsync(d1, np * 8, g1 + base * k, np_all * 8, np * 8, 8, hipMemcpyHostToDevice, st) != hipSuccess ||
                        hipMemcpy2DAsync(d2, np * 8, g2 + base * k, np_all * 8, np * 8, 16, hipMemcpyHostToDevice, st) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
@@ -630,15 +641,13 @@ static int run_chunks(int dev, const uint64_t* g1, const uint64_t* g2, uint64_t*
             if (rc) goto done;
             if (fmt.elems) {
                 if ((rc = launch_layout(false, d3, e3, 48, m, fmt.out_order, dev, st))) goto done;
-                if (hipMemcpyAsync(out + base * 48, e3, m * 384, hipMemcpyDeviceToHost, st) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
+                if (copy_rows(out + base * 48, e3, m * 384, hipMemcpyDeviceToHost, st) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
             } else if (hipMemcpy2DAsync(out + base, n_units * 8, d3, m * 8, m * 8, 48, hipMemcpyDeviceToHost, st) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
             if ((rc = bn254_last_status(dev, st))) goto done;        // also: the buffers are free for the next chunk
         }
     done:
         (void)hipStreamSynchronize(st);
     }
-    (void)bn254_release_stream(dev, st);
-    (void)hipStreamDestroy(st);
     return rc;
 }
 
@@ -647,6 +656,18 @@ static int run_pipeline(const int* devices, int n_dev, const uint64_t* g1, const
                         int do_final_exp, HostFmt fmt) {
     size_t chunk = PIPE_CHUNK;                        // lanes = units (one unit per lane whatever k is)
     size_t per = (n_units + (size_t)n_dev - 1) / (size_t)n_dev;
+    // the workers' streams (and with them the scratch and the staging buffers, which are kept per stream) live as long as
+    // the library: a pipeline call costs no allocation after the first.  Devices are locked in ascending order.
+    std::vector<std::unique_lock<std::mutex>> locks;
+    for (int d = 0; d < n_dev; d++) {
+        int rc = check_device(devices[d]);
+        if (rc) return rc;
+        if (d && devices[d] <= devices[d - 1]) return BN254_ERR_INVALID_ARG;
+        DeviceCtx& c = g_ctx[devices[d]];
+        locks.emplace_back(c.pipe_mu);
+        for (hipStream_t& st : c.pipe_stream)
+            if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return BN254_ERR_HIP;
+    }
     std::vector<int> rcs;
     std::vector<std::thread> th;
     rcs.reserve((size_t)n_dev * 2);
@@ -658,7 +679,8 @@ static int run_pipeline(const int* devices, int n_dev, const uint64_t* g1, const
             rcs.push_back(BN254_OK);
             int* slot = &rcs.back();
             int dev = devices[d];
-            th.emplace_back([=] { *slot = run_chunks(dev, g1, g2, out, n_units, k, do_final_exp, u0, c, chunk, w, workers, fmt); });
+            hipStream_t st = g_ctx[dev].pipe_stream[w];
+            th.emplace_back([=] { *slot = run_chunks(dev, st, g1, g2, out, n_units, k, do_final_exp, u0, c, chunk, w, workers, fmt); });
         }
     }
     for (auto& t : th) t.join();

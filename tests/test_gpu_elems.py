@@ -150,7 +150,7 @@ def test_elems_product_check_verdicts():
 
 
 def test_elems_pipeline_large_batch():
-    """Above 2^17 lanes the element-major host entry point runs the chunked two-worker pipeline (contiguous chunk copies,
+    """Above 2^16 lanes the element-major host entry point runs the chunked two-worker pipeline (contiguous chunk copies,
     planes made on the device): same words as one device launch, ragged tail included, ark order on the way out."""
     import torch
     pk = H.pkg()

@@ -249,7 +249,7 @@ def test_empty_and_single_element_batches(vec):
 
 
 def test_host_pipeline_matches_device_path():
-    """Host-pointer calls above 2^17 lanes run chunked on private streams (copies under compute): same limbs as the
+    """Host-pointer calls above 2^16 lanes run chunked on private streams (copies under compute): same limbs as the
     single-launch device path, ragged tail included; also for k-pair groups."""
     import torch
     pk = H.pkg()
@@ -344,13 +344,13 @@ def test_helpers_vs_oracle_multi_limb_exponent():
 
 
 def test_host_pipeline_chunk_edges():
-    """Chunk boundaries of the host-pointer pipeline: one lane more than a chunk (a 1-lane tail chunk for the second worker)
-    and exactly one chunk (single-launch path), against the device path."""
+    """Chunk boundaries of the host-pointer pipeline (chunks of 2^16 lanes): one lane more than a chunk (a 1-lane tail chunk
+    for the second worker), exactly one chunk (single-launch path), two chunks plus one lane, against the device path."""
     import torch
     pk = H.pkg()
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream(dev)
-    for n in ((1 << 17) + 1, 1 << 17):
+    for n in ((1 << 16) + 1, 1 << 16, (1 << 17) + 1):
         g1 = torch.zeros(8 * n, dtype=torch.int64, device=dev)
         g2 = torch.zeros(16 * n, dtype=torch.int64, device=dev)
         out = torch.zeros(48 * n, dtype=torch.int64, device=dev)
