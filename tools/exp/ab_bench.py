@@ -59,7 +59,8 @@ def main():
                 times[p].append(a.elapsed_time(b))
             else:
                 got = out[:48 * groups].view(48, groups)[:, pos].cpu().numpy().view(np.uint64).reshape(-1).copy()
-                assert np.array_equal(pkg.layout.to_aos(got, 48), want), f"{p}: wrong results"
+                if not os.environ.get("AB_NOCHECK"):      # timing-only experiments with deliberately broken variants
+                    assert np.array_equal(pkg.layout.to_aos(got, 48), want), f"{p}: wrong results"
     base = None
     for p in libs:
         t = sorted(times[p])
