@@ -151,6 +151,10 @@ int bn254_miller_loop_batch_elems(const uint64_t* g1, const uint64_t* g2, uint64
 int bn254_multi_pairing_batch_elems(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_groups, size_t k, int do_final_exp,
                                     int out_order, int device, void* stream);
 int bn254_final_exp_batch_elems(const uint64_t* f_in, uint64_t* out, size_t n, int in_order, int out_order, int device, void* stream);
+/* one process, several GPUs (as bn254_pairing_sharded / bn254_multi_pairing_sharded), element-major host arrays */
+int bn254_pairing_sharded_elems(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n, int out_order, int n_devices);
+int bn254_multi_pairing_sharded_elems(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_groups, size_t k, int do_final_exp,
+                                      int out_order, int n_devices);
 /* the product-of-pairings check (final_exp_native.rs:245-263) on element-major pairs: one byte per group */
 int bn254_multi_pairing_check_batch_elems(const uint64_t* g1, const uint64_t* g2, uint8_t* verdict, size_t n_groups, size_t k, int device,
                                           void* stream);

@@ -162,15 +162,12 @@ inline std::vector<MyFq12> multi_pairing_batch(const std::vector<G1Affine>& ps, 
     return r;
 }
 
-// One process, several GPUs: contiguous slices per device (bn254_pairing_sharded; limb-major host arrays).
+// One process, several GPUs: contiguous slices per device, no exchange step (bn254_pairing_sharded_elems).
 inline std::vector<MyFq12> pairing_sharded(const std::vector<G1Affine>& ps, const std::vector<G2Affine>& qs, int n_devices) {
     const size_t n = ps.size();
     if (qs.size() != n) throw Panic(BN254_ERR_INVALID_ARG);
-    std::vector<uint64_t> g1(8 * n), g2(16 * n), out(48 * n);
-    for (size_t i = 0; i < n; i++) { detail::pack_g1(ps[i], g1.data(), n, i); detail::pack_g2(qs[i], g2.data(), n, i); }
-    check(bn254_pairing_sharded(g1.data(), g2.data(), out.data(), n, n_devices));
     std::vector<MyFq12> r(n);
-    for (size_t i = 0; i < n; i++) r[i] = detail::unpack_fq12(out.data(), n, i);
+    check(bn254_pairing_sharded_elems(detail::words(ps.data()), detail::words(qs.data()), detail::words(r.data()), n, BN254_FQ12_MYFQ12, n_devices));
     return r;
 }
 

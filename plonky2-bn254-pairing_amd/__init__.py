@@ -93,6 +93,8 @@ _PROTOS = {
     "bn254_pairing_batch_elems": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "bn254_miller_loop_batch_elems": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "bn254_multi_pairing_batch_elems": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_pairing_sharded_elems": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_int]),
+    "bn254_multi_pairing_sharded_elems": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "bn254_multi_pairing_check_batch_elems": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "bn254_final_exp_batch_elems": (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
 }
@@ -296,6 +298,24 @@ def multi_pairing_batch_elems(g1, g2, n_groups, k, do_final_exp=True, out_order=
     out = np.empty(FQ12_WORDS * n_groups, dtype=np.uint64)
     _check(lib.bn254_multi_pairing_batch_elems(_ptr(g1), _ptr(g2), _ptr(out), n_groups, k, 1 if do_final_exp else 0, out_order, device, None),
            "multi_miller_loop_native")
+    return out
+
+
+def pairing_sharded_elems(g1, g2, n, n_devices, out_order=FQ12_MYFQ12):
+    """pairing_batch_elems over devices 0..n_devices-1 of this process (contiguous slices, no exchange step)."""
+    lib = load_library()
+    g1, g2 = _np_in(g1, G1_WORDS, n), _np_in(g2, G2_WORDS, n)
+    out = np.empty(FQ12_WORDS * n, dtype=np.uint64)
+    _check(lib.bn254_pairing_sharded_elems(_ptr(g1), _ptr(g2), _ptr(out), n, out_order, n_devices), "pairing (sharded)")
+    return out
+
+
+def multi_pairing_sharded_elems(g1, g2, n_groups, k, n_devices, do_final_exp=True, out_order=FQ12_MYFQ12):
+    lib = load_library()
+    g1, g2 = _np_in(g1, G1_WORDS, n_groups * k), _np_in(g2, G2_WORDS, n_groups * k)
+    out = np.empty(FQ12_WORDS * n_groups, dtype=np.uint64)
+    _check(lib.bn254_multi_pairing_sharded_elems(_ptr(g1), _ptr(g2), _ptr(out), n_groups, k, 1 if do_final_exp else 0, out_order, n_devices),
+           "multi_miller_loop_native (sharded)")
     return out
 
 

@@ -688,15 +688,27 @@ static int run_pipeline(const int* devices, int n_dev, const uint64_t* g1, const
     return BN254_OK;
 }
 
-int bn254_multi_pairing_sharded(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_groups, size_t k, int do_final_exp, int n_devices) {
+static int sharded(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_groups, size_t k, int do_final_exp, int n_devices, HostFmt fmt) {
     if (n_groups == 0) return BN254_OK;
-    if (!g1 || !g2 || !out || k == 0 || k > MAX_K || n_devices <= 0) return BN254_ERR_INVALID_ARG;
+    if (!g1 || !g2 || !out || k == 0 || k > MAX_K || n_devices <= 0 || (fmt.out_order != BN254_FQ12_MYFQ12 && fmt.out_order != BN254_FQ12_ARK))
+        return BN254_ERR_INVALID_ARG;
     int cnt = bn254_device_count();
     if (cnt <= 0) return BN254_ERR_NO_DEVICE;
     if (n_devices > cnt) return BN254_ERR_INVALID_ARG;
     std::vector<int> devs((size_t)n_devices);
     for (int d = 0; d < n_devices; d++) devs[(size_t)d] = d;
-    return run_pipeline(devs.data(), n_devices, g1, g2, out, n_groups, k, do_final_exp);
+    return run_pipeline(devs.data(), n_devices, g1, g2, out, n_groups, k, do_final_exp, fmt);
+}
+int bn254_multi_pairing_sharded(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_groups, size_t k, int do_final_exp, int n_devices) {
+    return sharded(g1, g2, out, n_groups, k, do_final_exp, n_devices, HostFmt());
+}
+int bn254_multi_pairing_sharded_elems(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_groups, size_t k, int do_final_exp,
+                                      int out_order, int n_devices) {
+    HostFmt fmt; fmt.elems = true; fmt.out_order = out_order;
+    return sharded(g1, g2, out, n_groups, k, do_final_exp, n_devices, fmt);
+}
+int bn254_pairing_sharded_elems(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n, int out_order, int n_devices) {
+    return bn254_multi_pairing_sharded_elems(g1, g2, out, n, 1, 1, out_order, n_devices);
 }
 
 int bn254_pairing_sharded(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n, int n_devices) {

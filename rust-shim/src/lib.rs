@@ -27,6 +27,7 @@ extern "C" {
     fn bn254_pairing_batch_elems(g1: *const u64, g2: *const u64, out: *mut u64, n: usize, out_order: c_int, device: c_int, stream: *mut c_void) -> c_int;
     fn bn254_multi_pairing_batch_elems(g1: *const u64, g2: *const u64, out: *mut u64, n_groups: usize, k: usize, do_final_exp: c_int,
                                        out_order: c_int, device: c_int, stream: *mut c_void) -> c_int;
+    fn bn254_pairing_sharded_elems(g1: *const u64, g2: *const u64, out: *mut u64, n: usize, out_order: c_int, n_devices: c_int) -> c_int;
     fn bn254_multi_pairing_check_batch_elems(g1: *const u64, g2: *const u64, verdict: *mut u8, n_groups: usize, k: usize, device: c_int,
                                              stream: *mut c_void) -> c_int;
 }
@@ -144,9 +145,9 @@ pub fn multi_pairing_batch(ps: &[G1Affine], qs: &[G2Affine], k: usize, do_final_
 /// New: the same batch spread over the first `n_devices` GPUs of this process (contiguous slices, no exchange).
 pub fn pairing_sharded(ps: &[G1Affine], qs: &[G2Affine], n_devices: i32) -> Vec<MyFq12> {
     assert_eq!(ps.len(), qs.len()); let n = ps.len();
-    let (g1, g2) = (pack_g1(ps), pack_g2(qs)); let mut out = vec![0u64; 48 * n];
-    ok(unsafe { bn254_pairing_sharded(g1.as_ptr(), g2.as_ptr(), out.as_mut_ptr(), n, n_devices) });
-    (0..n).map(|i| { let mut c = [0u64; 48]; for w in 0..48 { c[w] = out[w * n + i]; } unpack_fq12(&c) }).collect()
+    let (g1, g2) = (elems_g1(ps), elems_g2(qs)); let mut out = vec![0u64; 48 * n];
+    ok(unsafe { bn254_pairing_sharded_elems(g1.as_ptr(), g2.as_ptr(), out.as_mut_ptr(), n, FQ12_MYFQ12, n_devices) });
+    out.chunks_exact(48).map(unpack_fq12).collect()
 }
 /// New: `final_exp_native(multi_miller_loop_native(group)) == MyFq12::one` for every group of k pairs
 /// (the check of final_exp_native.rs:245-263), one verdict per group instead of 384 bytes.

@@ -207,6 +207,11 @@ def test_sharded_entry_point_single_process(vec):
     with pytest.raises(pk.Bn254Error) as ei:
         pk.pairing_sharded(g1, g2, n, n_dev + 1)
     assert ei.value.status == pk.ERR_INVALID_ARG
+    # element-major host arrays through the same per-device pipeline
+    e1, e2 = H.g1_aos(P), H.g2_aos(Q)
+    assert np.array_equal(pk.pairing_sharded_elems(e1, e2, n, n_dev), H.to_aos(want, 48))
+    assert np.array_equal(pk.multi_pairing_sharded_elems(e1, e2, n_groups, k, n_dev, do_final_exp=False),
+                          H.to_aos(pk.multi_pairing_batch(g1, g2, n_groups, k, do_final_exp=False), 48))
 
 
 def test_streams_are_independent():
