@@ -61,6 +61,7 @@ def parse(argv=None):
     ap.add_argument("--log2-batch", type=int, default=None,
                     help="pairings per GPU per step = 2^k (default: 20 at N = 1 = configs[2], 21 at N > 1 = configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-power", action="store_true", help="do not sample the package power (rocm-smi) during the timed steps")
     ap.add_argument("--no-extra", action="store_true", help="skip configs[1] and configs[3] (reported under \"extra\" at N = 1)")
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="wall-clock budget of the cpu_baseline legs (single thread + all cores)")
     return ap.parse_args(argv)
@@ -165,6 +166,47 @@ def load_engine():
         return getattr(importlib.import_module(mod), attr)(), True
     import __graft_entry__
     return __graft_entry__.build(), False
+
+
+class PowerSampler:
+    """Package power (rocm-smi) sampled by a host thread while the timed steps run: k_pairing is power-bound (DESIGN.md
+    section 3), so the line carries the watts it ran at.  Pure observation -- no GPU setting is touched."""
+
+    def __init__(self):
+        import threading
+        self.samples, self.stop, self.limit = [], threading.Event(), None
+        self.thread = threading.Thread(target=self._run, daemon=True)
+
+    @staticmethod
+    def _read(flag, key):
+        import re
+        try:
+            txt = subprocess.run(["rocm-smi", flag], capture_output=True, text=True, timeout=5).stdout
+            m = re.search(key + r"[^:]*:\s*([0-9.]+)", txt)
+            return float(m.group(1)) if m else None
+        except Exception:
+            return None
+
+    def _run(self):
+        while not self.stop.is_set():
+            w = self._read("--showpower", r"Power \(W\)")
+            if w is not None:
+                self.samples.append(w)
+
+    def __enter__(self):
+        self.thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop.set()
+        self.thread.join(timeout=10)
+        self.limit = self._read("--showmaxpower", r"Max Graphics Package Power \(W\)")
+
+    def summary(self):
+        s_ = self.samples[1:-1] if len(self.samples) > 4 else self.samples        # drop the ramps
+        if not s_:
+            return None
+        return {"avg_w": sum(s_) / len(s_), "max_w": max(s_), "samples": len(s_), "limit_w": self.limit, "source": "rocm-smi --showpower during the timed steps"}
 
 
 def spot_check(pkg, torch, g1, g2, out, n, positions, threads):
@@ -293,20 +335,25 @@ def run_rank(args):
         dist.barrier()
     sync()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)] if on_gpu else []
-    t0 = time.perf_counter()
-    if on_gpu:
-        for a, b in evs:
-            a.record(stream)
-            step()
-            b.record(stream)
-    else:
-        for _ in range(args.steps):
-            step()
-    sync()
-    if dist:
-        dist.barrier()
-    sync()
-    elapsed = time.perf_counter() - t0
+    import contextlib
+    # (not under a profiler: its preloaded library would ride into the rocm-smi child processes)
+    profiled = any(k.startswith(("ROCP", "ROCPROF")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    power = PowerSampler() if (on_gpu and rank == 0 and not args.no_power and not profiled) else None
+    with (power or contextlib.nullcontext()):
+        t0 = time.perf_counter()
+        if on_gpu:
+            for a, b in evs:
+                a.record(stream)
+                step()
+                b.record(stream)
+        else:
+            for _ in range(args.steps):
+                step()
+        sync()
+        if dist:
+            dist.barrier()
+        sync()
+        elapsed = time.perf_counter() - t0
     pkg.last_status(local_rank, stream)
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if (backend == "nccl" and on_gpu) else "cpu")
@@ -364,6 +411,7 @@ def run_rank(args):
                              "wave_instr_per_s": insts_per_pairing * (n / 64) / (kern_avg_ms * 1e-3), "peak_wave_instr_per_s": 1024 * 2.4e9 / 4,
                              "frac": insts_per_pairing * (n / 64) / (kern_avg_ms * 1e-3) / (1024 * 2.4e9 / 4),
                              "note": "all VALU instructions the kernel issues against 1024 SIMDs x 2.4 GHz (nominal) / 4 cycles"},
+                         "package_power": power.summary() if power else None,
                          "hbm": {"bound": "hbm", "achieved": 576 * n / (kern_avg_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                                  "frac": 576 * n / (kern_avg_ms * 1e-3) / 8e12, "traffic": traffic,
                                  "note": "the schema's HBM view of the same kernel: algorithmic bytes (576 B/pairing) over the launch time "

@@ -6,7 +6,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/icache_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra $*"
+BENCH="python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra --no-power $*"
 timeout 600 rocprofv3 --kernel-trace --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQC_TC_INST_REQ SQ_INSTS_VALU SQ_WAVE_CYCLES --output-format csv -d $OUT -o ic -- $BENCH > $OUT/ic.log 2>&1; echo "rc=$?"
 cd $GRAFT_REPO_ROOT
 python3 - <<PY
