@@ -206,6 +206,12 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None):
                 v[lo + 1] = (r >> 32) & M32
                 m.carry_out(a[1], 0)
                 m.count_valu += 1
+            elif op == "v_lshl_add_u64":
+                r = ((m.vsrc64(a[1]) << (m.vsrc(a[2]) & 7)) + m.vsrc64(a[3])) & ((1 << 64) - 1)
+                lo = int(re.match(r"v\[(\d+):", a[0]).group(1))
+                v[lo] = r & M32
+                v[lo + 1] = (r >> 32) & M32
+                m.count_valu += 1
             elif op == "v_ashrrev_i64":
                 sh = m.vsrc(a[1]) & 63
                 c = m.vsrc64(a[2])
