@@ -175,3 +175,25 @@ def test_sharded_nccl_on_visible_gpus():
     for p in procs:
         p.join(timeout=60)
     assert res == [(r, True) for r in range(world)]
+
+
+def test_bench_power_sampler_reads_rocm_smi(tmp_path, monkeypatch):
+    """bench.py's package-power sampler: parses `rocm-smi --showpower / --showmaxpower` (a stand-in script on PATH here),
+    drops the ramp samples, and reports nothing when the tool is absent."""
+    import time
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    fake = tmp_path / "rocm-smi"
+    fake.write_text("#!/bin/sh\ncase \"$1\" in\n"
+                    "  --showpower) echo 'GPU[0]\t\t: Current Socket Graphics Package Power (W): 1321.0';;\n"
+                    "  --showmaxpower) echo 'GPU[0]\t\t: Max Graphics Package Power (W): 1400.0';;\nesac\n")
+    fake.chmod(0o755)
+    monkeypatch.setenv("PATH", str(tmp_path) + os.pathsep + os.environ["PATH"])
+    with bench.PowerSampler() as ps:
+        time.sleep(0.5)
+    s = ps.summary()
+    assert s and s["avg_w"] == 1321.0 and s["max_w"] == 1321.0 and s["limit_w"] == 1400.0 and s["samples"] >= 1
+    monkeypatch.setenv("PATH", str(tmp_path / "nowhere"))
+    with bench.PowerSampler() as ps:
+        time.sleep(0.1)
+    assert ps.summary() is None
