@@ -145,8 +145,8 @@ def test_l1_routines():
             for j in range(4):
                 assert (val(m, j) - want[j]) % P == 0, (name, t, j)
                 assert _is_norm(m, list(range(NL * j, NL * j + NL))) and abs(val(m, j)) < 0.52 * P, (name, t, j)
-    # mul6 (fused Fq6 multiplication, schoolbook with lazy reduction): a in home blocks 0..2 (also as unnormalised sums of two
-    # normalised values), b normalised in home blocks 3..5
+    # mul6 (fused Fq6 multiplication, schoolbook with lazy reduction, Karatsuba inside the a1 / a2 products): a in home blocks
+    # 0..2 (also as unnormalised sums of two normalised values), b normalised in home blocks 3..5
     for t in range(10):
         a = [(rnd(), rnd()) for _ in range(3)]
         b = [(rnd(), rnd()) for _ in range(3)]
@@ -166,7 +166,7 @@ def test_l1_routines():
         S.run_block(B["mul6"], m)
         v = lambda i, j: f2m(a[i], b[j])
         want = [f2a(v(0, 0), xi(f2a(v(1, 2), v(2, 1)))), f2a(f2a(v(0, 1), v(1, 0)), xi(v(2, 2))), f2a(f2a(v(0, 2), v(1, 1)), v(2, 0))]
-        where = [K4.HOME0 + K4.SLOT_DW, K4.HOME0 + 2 * K4.SLOT_DW, K4.A0]            # c0 -> home 1, c1 -> home 2, c2 -> A
+        where = [K4.HOME0 + 6 * K4.SLOT_DW, K4.HOME0 + 2 * K4.SLOT_DW, K4.A0]        # c0 -> home 6, c1 -> home 2, c2 -> A
         for c in range(3):
             for h in range(2):
                 regs = list(range(where[c] + NL * h, where[c] + NL * h + NL))
@@ -466,3 +466,23 @@ def test_l1_fused_point_steps():
             assert get(m, where[k_]) == w, ("addstep", t, k_)
             assert _is_norm(m, list(range(where[k_], where[k_] + NL))) and _is_norm(m, list(range(where[k_] + NL, where[k_] + 2 * NL)))
         assert m.max_acc < (1 << 63)
+
+
+def test_simulator_accumulator_check_has_teeth():
+    """64-bit column accumulators may wrap transiently (kfips: the difference products come before the terms that cancel them);
+    consuming a wrapped value is what the simulator must catch."""
+    big = (1 << 31) - 1
+    m = S.Machine()
+    m.v[2], m.v[3], m.v[6], m.v[7] = big, big, (-big) & 0xFFFFFFFF, big
+    wrap = [f"v_mad_i64_i32 v[4:5], vcc, v2, v3, {'0' if i == 0 else 'v[4:5]'}" for i in range(3)]          # 3 * 2^62: beyond 2^63
+    back = ["v_mad_i64_i32 v[4:5], vcc, v6, v7, v[4:5]"] * 2                                                 # - 2 * 2^62: back inside
+    S.run_block(wrap + back + ["v_ashrrev_i64 v[4:5], 29, v[4:5]"], m)
+    assert m.transient_wraps >= 1 and (m.v[4] | (m.v[5] << 32)) == ((big * big) >> 29)
+    m = S.Machine()
+    m.v[2], m.v[3] = big, big
+    with pytest.raises(S.SimError, match="wrapped"):
+        S.run_block(wrap + ["v_ashrrev_i64 v[4:5], 29, v[4:5]"], m)
+    m = S.Machine()
+    m.v[2], m.v[3] = big, big
+    with pytest.raises(S.SimError, match="wrapped"):
+        S.run_block(wrap + ["v_mov_b32_e32 v8, v4"], m)

@@ -197,6 +197,90 @@ class L1v4:
             self.e.emit(text, vw=vw)
         self.pool.free(acc, acc + 1, *m)
 
+    def kfips(self, kterms, sterms, out_re, out_im):
+        """(out_re, out_im) <- both components of the sum of the Fq2 products x y over kterms + sterms, divided by R' (one
+        Montgomery reduction per component).  x = (x0, x1), y = (y0, y1): limb lists.
+        kterms use KARATSUBA per limb pair: per column
+            U = sum x0[i] y0[j],   W = sum x1[i] y1[j]          (fresh 64-bit accumulators, each computed ONCE)
+            re += U - W,           im += sum (x1 - x0)[i] (y0 - y1)[j] + U + W
+        three multiply-adds per limb pair instead of four; the 64-bit combinations (five instructions per column) are shared
+        by all the Karatsuba products of the pass.  sterms go the schoolbook way, four multiply-adds per limb pair straight
+        into the two accumulators (they cost no extra registers beyond one negated vector).  x limbs of up to two units
+        (an unnormalised sum), y normalised.
+        Why: the kernels are power-bound and a multiply-add is the dearest instruction (1.84 nJ per wave-instruction against
+        1.0 for a 32-bit add / subtract, profiles/r02_energy_calib.txt); fewer issue slots come on top.
+        Magnitudes per column (units of 2^56; x of mx units, y of one): |U|, |W| <= 9 k mx, re <= 18 (k + s) mx: below 2^63
+        like every column of the schoolbook passes.  The im accumulator takes the schoolbook products, then the DIFFERENCE
+        products (up to 4 mx units each, 36 k mx in all), then U and W, which cancel most of them: with two-unit operands
+        it may pass 2^63 in between.  That is harmless -- 64-bit sums are exact mod 2^64 and the value that is finally
+        shifted out is the true one, <= 18 (k + s) mx -- and it is what the simulator's accumulator check verifies.
+        Result limb j is written after column j + NL (in place over a FIRST operand x is fine; never over a y)."""
+        e = self.e
+        nk = len(kterms)
+        dx = [[self.pool.alloc() for _ in range(NL)] for _ in range(nk)]
+        dy = [[self.pool.alloc() for _ in range(NL)] for _ in range(nk)]
+        for k, (x, y) in enumerate(kterms):
+            self.limbwise("v_sub_u32_e32", dx[k], x[1], x[0])
+            self.limbwise("v_sub_u32_e32", dy[k], y[0], y[1])
+        nx = []
+        for x, y in sterms:
+            n_ = [self.pool.alloc() for _ in range(NL)]
+            self._neg_into(n_, x[1])
+            nx.append(n_)
+        (a0, P0), (a1, P1), (u, PU), (w, PW) = self._acc(), self._acc(), self._acc(), self._acc()
+        m0 = [self.pool.alloc() for _ in range(NL)]
+        m1 = [self.pool.alloc() for _ in range(NL)]
+        for c in range(2 * NL - 1):
+            lo_i, hi_i = max(0, c - (NL - 1)), min(NL - 1, c)
+            rng_i = range(lo_i, hi_i + 1)
+            f0 = f1 = c == 0
+            for (x, y), n_ in zip(sterms, nx):                      # schoolbook terms: straight into the accumulators
+                for i in rng_i:
+                    self._mad(a0, P0, x[0][i], y[0][c - i], f0)
+                    self._mad(a0, P0, n_[i], y[1][c - i], False)
+                    self._mad(a1, P1, x[0][i], y[1][c - i], f1)
+                    self._mad(a1, P1, x[1][i], y[0][c - i], False)
+                    f0 = f1 = False
+            fu = fw = True
+            for x, y in kterms:
+                for i in rng_i:
+                    self._mad(u, PU, x[0][i], y[0][c - i], fu)
+                    fu = False
+            for x, y in kterms:
+                for i in rng_i:
+                    self._mad(w, PW, x[1][i], y[1][c - i], fw)
+                    fw = False
+            for k in range(nk):
+                for i in rng_i:
+                    self._mad(a1, P1, dx[k][i], dy[k][c - i], f1)
+                    f1 = False
+            e.emit(f"v_lshl_add_u64 {P1}, {PU}, 0, {P1}", vw=[a1, a1 + 1])                      # im += U
+            e.emit(f"v_sub_co_u32_e32 v{u}, vcc, v{u}, v{w}", w=["vcc"], vw=[u])                 # U - W (low word) ...
+            e.emit(f"v_lshl_add_u64 {P1}, {PW}, 0, {P1}", vw=[a1, a1 + 1])                      # im += W
+            e.emit(f"v_subb_co_u32_e32 v{u + 1}, vcc, v{u + 1}, v{w + 1}, vcc", r=["vcc"], w=["vcc"], vw=[u + 1])
+            if f0:
+                e.emit(f"v_mov_b32_e32 v{a0}, v{u}", vw=[a0])
+                e.emit(f"v_mov_b32_e32 v{a0 + 1}, v{u + 1}", vw=[a0 + 1])
+            else:
+                e.emit(f"v_lshl_add_u64 {P0}, {PU}, 0, {P0}", vw=[a0, a0 + 1])                  # re += U - W
+            for acc, P, m, out in ((a0, P0, m0, out_re), (a1, P1, m1, out_im)):
+                if c < NL:
+                    for i in range(c):
+                        self._mad(acc, P, m[i], self.p[c - i], False)
+                    e.emit(f"v_mul_lo_u32 v{m[c]}, v{acc}, {self.n0}", vw=[m[c]])
+                    e.emit(f"v_bfe_i32 v{m[c]}, v{m[c]}, 0, {LB}", vw=[m[c]])
+                    self._mad(acc, P, m[c], self.p[0], False)
+                    e.emit(f"v_ashrrev_i64 {P}, {LB}, {P}", vw=[acc, acc + 1])
+                else:
+                    for i in range(c - (NL - 1), NL):
+                        self._mad(acc, P, m[i], self.p[c - i], False)
+                    self._digit(acc, P, out[c - NL])
+        e.emit(f"v_mov_b32_e32 v{out_re[NL - 1]}, v{a0}", vw=[out_re[NL - 1]])
+        e.emit(f"v_mov_b32_e32 v{out_im[NL - 1]}, v{a1}", vw=[out_im[NL - 1]])
+        self.pool.free(a0, a0 + 1, a1, a1 + 1, u, u + 1, w, w + 1, *m0, *m1)
+        for v_ in dx + dy + nx:
+            self.pool.free(*v_)
+
     def lincomb(self, outs, termss, reduce=False):
         """outs[j] <- sum of coef * vec over termss[j] (lists of (inline-constant coefficient, limb list)), NORMALISED
         (balanced limbs; top limb: the rest), on one 64-bit carry chain per output, the chains interleaved limb by limb so
@@ -385,29 +469,38 @@ class L1v4:
             self.pool.free(*n)
 
     def r_mul6(self):
-        """Fq6 multiplication in Fq2[v]/(v^3 - xi), schoolbook with LAZY REDUCTION: nine Fq2 products, but each of the six
-        output components is ONE column pass over six Fq products with one Montgomery reduction (Karatsuba: six Fq2 products
-        = 24 Fq products, but 12 reductions and three recombination chains -- 4 % more instructions):
+        """Fq6 multiplication in Fq2[v]/(v^3 - xi), schoolbook over Fq2 with LAZY REDUCTION: nine Fq2 products, each of the
+        three output coefficients ONE dual column pass (kfips: both components, one Montgomery reduction each):
             c0 = a0 b0 + (xi a1) b2 + (xi a2) b1     c1 = a0 b1 + a1 b0 + (xi a2) b2     c2 = a0 b2 + a1 b1 + a2 b0
-        a = (a0, a1, a2) in home blocks 0..2 (limbs of up to two units: unnormalised sums are fine), b in home blocks 3..5
-        (normalised).  Results (reduction outputs: normalised, values per kgen4_prog.Prog._mul6_regs):
-            c0 -> home block 1,  c1 -> home block 2,  c2 -> block A.
-        Scratch: home blocks 6, 7 (xi a1, xi a2), the pool.  a1, a2 are destroyed; a0 and b survive."""
+        In every pass the a0 product goes the schoolbook way and the other two are Karatsuba products (a: limbs of up to two
+        units -- unnormalised sums are fine --, b normalised).  (Karatsuba over Fq6 -- six Fq2 products -- needs twelve
+        reductions and three recombination chains: 4 % more instructions.)
+        a = (a0, a1, a2) in home blocks 0..2, b in home blocks 3..5.  Results (reduction outputs: normalised, values per
+        kgen4_prog.Prog._mul6_regs):   c0 -> home block 6,  c1 -> home block 2,  c2 -> block A.
+        xi a2 is formed after the c2 pass (home 7), xi a1 after the c1 pass (home 6): every pass finds 71 free registers (two
+        accumulator pairs + two fresh ones, two quotient vectors, four difference vectors, one negation) in the pool, block B
+        and the home blocks that are dead at that point.  a1, a2, block B and home blocks 6, 7 are destroyed; a0 and b survive."""
         H = lambda k: self.fq2(HOME0 + SLOT_DW * k)
+        blk = lambda r0: list(range(r0, r0 + SLOT_DW))
         a, b = [H(0), H(1), H(2)], [H(3), H(4), H(5)]
         xa1, xa2 = H(6), H(7)
         A = self.fq2(A0)
-        for src, dst in ((a[1], xa1), (a[2], xa2)):                      # xi a = (9 a.0 - a.1, 9 a.1 + a.0), normalised
-            self.lincomb([dst[0], dst[1]], [[(9, src[0]), (-1, src[1])], [(9, src[1]), (1, src[0])]])
-        t2 = [(a[0], b[2]), (a[1], b[1]), (a[2], b[0])]
-        self._pass3(A[1], t2, imag=True)                                  # c2 -> block A (the only user of a2 itself)
-        self._pass3(A[0], t2, imag=False)
-        t1 = [(a[0], b[1]), (a[1], b[0]), (xa2, b[2])]
-        self._pass3(a[2][1], t1, imag=True)                               # c1 over a2 (dead by now)
-        self._pass3(a[2][0], t1, imag=False)
-        t0 = [(a[0], b[0]), (xa1, b[2]), (xa2, b[1])]
-        self._pass3(a[1][1], t0, imag=True)                               # c0 over a1 (dead by now)
-        self._pass3(a[1][0], t0, imag=False)
+        xi = lambda src, dst: self.lincomb([dst[0], dst[1]], [[(9, src[0]), (-1, src[1])], [(9, src[1]), (1, src[0])]])      # normalised
+
+        def with_regs(extra, fn):
+            self.pool.free_regs += extra
+            fn()
+            for r in extra:
+                self.pool.free_regs.remove(r)
+
+        with_regs(blk(B0) + blk(HOME0 + 6 * SLOT_DW) + blk(HOME0 + 7 * SLOT_DW),
+                  lambda: self.kfips([(a[1], b[1]), (a[2], b[0])], [(a[0], b[2])], A[0], A[1]))               # c2 -> block A
+        xi(a[2], xa2)
+        with_regs(blk(B0) + blk(HOME0 + 6 * SLOT_DW),
+                  lambda: self.kfips([(a[1], b[0]), (xa2, b[2])], [(a[0], b[1])], a[2][0], a[2][1]))          # c1 -> home 2 (a2 is dead)
+        xi(a[1], xa1)
+        with_regs(blk(B0) + blk(HOME0 + SLOT_DW),
+                  lambda: self.kfips([(xa1, b[2]), (xa2, b[1])], [(a[0], b[0])], xa1[0], xa1[1]))             # c0 in place over xi a1
 
 
     # ------------------------------------------------------------------ fused G2 steps of the Miller loop

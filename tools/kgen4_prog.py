@@ -631,10 +631,11 @@ class Prog:
         return m_, v_
 
     def _mul6_regs(self, a, b, a_plus=None, b_plus=None):
-        """Fused Fq6 multiplication (L1 mul6, schoolbook with one reduction per output component) of (a + a_plus) by
-        (b + b_plus), coefficient-wise sums formed while the operands are loaded into the home blocks: the a side may stay
-        an unnormalised sum (two units), the b side is normalised.  Returns the three result 'slots' [c0, c1, c2]:
-        c0 = HOME(1), c1 = HOME(2), c2 = block A (None), all normalised; home blocks 1, 2, 6, 7 and block A are clobbered."""
+        """Fused Fq6 multiplication (L1 mul6: schoolbook over Fq2, one dual column pass per output coefficient with the a1 / a2
+        products as Karatsuba products) of (a + a_plus) by (b + b_plus), coefficient-wise sums formed while the operands are
+        loaded into the home blocks: the a side may stay an unnormalised sum (two units), the b side is normalised.
+        Returns the three result 'slots' [c0, c1, c2]: c0 = HOME(6), c1 = HOME(2), c2 = block A (None), all normalised; home
+        blocks 1, 2, 6, 7, block A and block B are clobbered."""
         ma = mb = va = vb = 0.0
         for k, s_ in enumerate(b):
             m_, v_ = self._load_sum(HOME0 + SLOT_DW * (3 + k), s_, b_plus[k] if b_plus else None, 1.0)
@@ -642,11 +643,13 @@ class Prog:
         for k, s_ in enumerate(a):
             m_, v_ = self._load_sum(HOME0 + SLOT_DW * k, s_, a_plus[k] if a_plus else None, 2.0)
             ma, va = max(ma, m_), max(va, v_)
-        # worst column: a0 b2 + a1 b1 + a2 b0 (three products of ma x mb); the xi a terms are normalised
+        # worst column: three Fq2 products of ma x mb limbs (54 limb products) + nine reduction products.  (Inside a pass the
+        # Karatsuba difference products may carry the imaginary accumulator beyond 64 bits before U and W cancel them: sums are
+        # exact mod 2^64 and the value that is finally shifted out is the true one -- tools/ksim.py checks exactly that.)
         self._need(2 * NL * 3 * ma * mb <= COL_BUDGET, f"mul6 operand limbs {ma} {mb}")
         self._need(10 * va <= V_CAP and vb <= V_CAP, f"mul6 operand values {va} {vb}")
         self._raw_call("mul6")
-        res = [HOME(1, "mul6.c0"), HOME(2, "mul6.c1"), None]
+        res = [HOME(6, "mul6.c0"), HOME(2, "mul6.c1"), None]
         v0 = 42 * va * vb / K_RP + 0.5            # c0 = a0 b0 + (xi a1) b2 + (xi a2) b1: 2 (1 + 10 + 10) va vb / K + 1/2
         v1 = 24 * va * vb / K_RP + 0.5            # c1 = a0 b1 + a1 b0 + (xi a2) b2
         v2 = 6 * va * vb / K_RP + 0.5             # c2 = a0 b2 + a1 b1 + a2 b0
@@ -657,7 +660,7 @@ class Prog:
             self.max_v = max(self.max_v, v)
         self.vA = v2
         self.rA = self.r_norm()
-        self.tagA = None
+        self.tagA = self.tagB = None
         return res
 
     def fq6_mul(self, a, b, out, a_plus=None, b_plus=None):

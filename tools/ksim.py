@@ -38,7 +38,9 @@ class Machine:
         self.count = 0        # dynamic instruction count
         self.count_valu = 0
         self.count_nop = 0
-        self.max_acc = 0      # largest |column accumulator| seen (v3 kernels)
+        self.max_acc = 0      # largest |column accumulator| that fitted 64 signed bits
+        self.exact = {}       # low register of a 64-bit accumulator pair -> its true integer value
+        self.transient_wraps = 0
         self.l2_stack, self.l2_incl = [], {}     # profile mode: instructions inclusive of callees, per outermost L2 routine
         self.profile = None   # dict: (region label, opcode) -> dynamic count, when set to {} before run()
         self.call_log = None  # list: labels of the L2 routines called, in order (bound certification cross-check)
@@ -84,9 +86,40 @@ class Machine:
             return
         raise SimError("bad sgpr " + name)
 
+    # 64-bit column accumulators may wrap around TRANSIENTLY (two's complement sums are exact mod 2^64: L1v4.kfips adds the
+    # Karatsuba difference products before the terms that cancel them); what must never happen is that a wrapped value is
+    # CONSUMED.  `exact` keeps the true integer of every pair written by v_mad_i64_i32 / v_lshl_add_u64; any other read of a
+    # register of a pair whose true value does not fit 64 signed bits is an error.
+    def exact_of(self, tok):
+        """true value of a 64-bit accumulator operand (falls back to the signed register content)"""
+        m = re.match(r"v\[(\d+):(\d+)\]", tok)
+        c = self.vsrc64(tok, check=False)
+        if m:
+            ex = self.exact.get(int(m.group(1)))
+            if ex is not None and (ex - c) % (1 << 64) == 0:
+                return ex
+        return c - (1 << 64) if c >> 63 else c
+
+    def set_exact(self, lo, val):
+        self.v[lo] = val & M32
+        self.v[lo + 1] = (val >> 32) & M32
+        self.exact[lo] = val
+        if -(1 << 63) <= val < (1 << 63):
+            self.max_acc = max(self.max_acc, abs(val))
+        else:
+            self.transient_wraps += 1
+
+    def _consume(self, r):
+        ex = self.exact.get(r & ~1)
+        if ex is not None and not (-(1 << 63) <= ex < (1 << 63)):
+            cur = (self.v[r & ~1] or 0) | ((self.v[(r & ~1) + 1] or 0) << 32)
+            if (ex - cur) % (1 << 64) == 0:
+                raise SimError(f"a wrapped 64-bit accumulator (v[{r & ~1}:{(r & ~1) + 1}], true value {ex}) is consumed")
+
     def vsrc(self, tok, valu=True):
         """32-bit source operand of a VALU instruction."""
         if tok[0] == "v" and tok[1].isdigit():
+            self._consume(int(tok[1:]))
             x = self.v[int(tok[1:])]
             if x is None:
                 if self.check_uninit:
@@ -101,12 +134,14 @@ class Machine:
             return M32
         return int(tok, 0) & M32
 
-    def vsrc64(self, tok):
+    def vsrc64(self, tok, check=True):
         m = re.match(r"v\[(\d+):(\d+)\]", tok)
         if m:
             lo = int(m.group(1))
             if lo % 2:
                 raise SimError("odd-aligned 64-bit VGPR operand " + tok)
+            if check:
+                self._consume(lo)
             a, b = self.v[lo], self.v[lo + 1]
             if a is None or b is None:
                 if self.check_uninit:
@@ -129,7 +164,9 @@ class Machine:
         self.valu_w[reg] = self.count
 
     def vset(self, tok, val):
-        self.v[int(tok[1:])] = val & M32
+        r = int(tok[1:])
+        self.v[r] = val & M32
+        self.exact.pop(r & ~1, None)
 
 
 def run(lines, m, entry=None, max_steps=200_000_000, trace=None):
@@ -193,24 +230,17 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None):
                 x, y = m.vsrc(a[2]), m.vsrc(a[3])
                 x = x - (1 << 32) if x >> 31 else x
                 y = y - (1 << 32) if y >> 31 else y
-                c = m.vsrc64(a[4])
-                c = c - (1 << 64) if c >> 63 else c
-                r = x * y + c
-                if not (-(1 << 63) <= r < (1 << 63)):
-                    raise SimError("signed 64-bit column accumulator overflow")
-                m.max_acc = max(m.max_acc, abs(r))
+                r = x * y + m.exact_of(a[4])
                 lo = int(re.match(r"v\[(\d+):", a[0]).group(1))
                 if lo % 2:
                     raise SimError("odd-aligned 64-bit VGPR dest")
-                v[lo] = r & M32
-                v[lo + 1] = (r >> 32) & M32
+                m.set_exact(lo, r)
                 m.carry_out(a[1], 0)
                 m.count_valu += 1
             elif op == "v_lshl_add_u64":
-                r = ((m.vsrc64(a[1]) << (m.vsrc(a[2]) & 7)) + m.vsrc64(a[3])) & ((1 << 64) - 1)
+                r = (m.exact_of(a[1]) << (m.vsrc(a[2]) & 7)) + m.exact_of(a[3])
                 lo = int(re.match(r"v\[(\d+):", a[0]).group(1))
-                v[lo] = r & M32
-                v[lo + 1] = (r >> 32) & M32
+                m.set_exact(lo, r)
                 m.count_valu += 1
             elif op == "v_ashrrev_i64":
                 sh = m.vsrc(a[1]) & 63
