@@ -384,26 +384,18 @@ class L1v4:
         self._fq2_mul(self.fq2(A0), self.fq2(B0), self.fq2(A0))
 
     def r_mul3(self):
-        """A <- A*B + H0*H1 + H2*H3 (Fq2 products, H_k = home block k), ONE reduction per output component:
-        two fused six-product column passes.  H0 and H2 are destroyed (their c1 halves get negated).  All six operands
-        normalised (54 products of 2^56 per column)."""
+        """A <- A*B + H0*H1 + H2*H3 (Fq2 products, H_k = home block k), ONE reduction per output component: one dual column
+        pass with three Karatsuba products (kfips), in place over A.  The other five operands survive.  Operand limbs below 3.9
+        units (the limb-wise differences stay within int32); the column budget is the caller's check (Prog.mul3).  Scratch: the
+        pool and home blocks 6, 7, 8 (80 registers)."""
         blocks = [(A0, B0), (HOME0, HOME0 + SLOT_DW), (HOME0 + 2 * SLOT_DW, HOME0 + 3 * SLOT_DW)]
-        xs = [self.fq2(x) for x, _ in blocks]
-        ys = [self.fq2(y) for _, y in blocks]
-        t = [self.pool.alloc() for _ in range(NL)]
-        prods = []
-        for (x0, x1), (y0, y1) in zip(xs, ys):
-            prods += [(x0, y1), (x1, y0)]
-        # x1[i] is dead in pass 1 after column i + NL - 1: its negation (for pass 2) rides in the upper columns
-        neg = [(f"v_sub_u32_e32 v{x1[i]}, 0, v{x1[i]}", [x1[i]], NL + i, 99) for i in range(NL) for (x0, x1) in xs]
-        self.fips(prods, t, fillers=neg, gap=6)                      # c1
-        prods = []
-        for (x0, x1), (y0, y1) in zip(xs, ys):
-            prods += [(x0, y0), (x1, y1)]
-        # c1 (in t) moves into A.c1 as soon as pass 2 has read A.c1[i] for the last time (column i + NL - 1)
-        mov = [(f"v_mov_b32_e32 v{A0 + NL + i}, v{t[i]}", [A0 + NL + i], NL + i, 99) for i in range(NL)]
-        self.fips(prods, self.blk(A0, 0), fillers=mov)               # c0, in place over A.c0
-        self.pool.free(*t)
+        terms = [(self.fq2(x), self.fq2(y)) for x, y in blocks]
+        extra = list(range(HOME0 + 6 * SLOT_DW, HOME0 + 9 * SLOT_DW))
+        self.pool.free_regs += extra
+        a = self.fq2(A0)
+        self.kfips(terms, [], a[0], a[1])
+        for r in extra:
+            self.pool.free_regs.remove(r)
 
     def r_sqr(self):
         """(a0 + a1 u)^2 = (a0+a1)(a0-a1) + 2 a0 a1 u ; both passes write in place.  A normalised."""

@@ -472,7 +472,7 @@ class Prog:
             # 64-bit chains: any int32 limbs in, normalised out; values grow tenfold
             self._need(mag(rA) <= 7.9, f"mulxi {rA}")
             v_out = 10 * vA
-            if v_out > V_CAP / 2:
+            if v_out > V_CAP / 2 or k == "reduce":
                 name = direct = "mulxir"
                 v_out = 0.51
             out = self.r_norm(v_out)
@@ -498,7 +498,7 @@ class Prog:
     def dbl(self): return self.call("dbl")
     def neg(self): return self.call("neg")
     def conj(self): return self.call("negc1")
-    def mulxi(self): return self.call("mulxi")
+    def mulxi(self, reduce=False): return self.call("mulxi", k="reduce" if reduce else None)
     def scale(self, k): return self.call("scale", k=k)
 
     def v_limit(self, dst):
@@ -541,20 +541,26 @@ class Prog:
             self.free_tmp.insert(0, s)
 
     # ---- operand blocks H0..H3 of the three-term multiply (home registers 0..3 used as raw blocks)
-    def reserve_blocks(self, count=4):
+    MUL3_SCRATCH = (6, 7, 8)          # home blocks the three-term multiply (L1 mul3: a Karatsuba pass) uses as scratch
+
+    def reserve_blocks(self, count=4, scratch=()):
+        """home blocks 0..count-1 become raw operand blocks, `scratch` blocks are handed to the L1 routine: neither may hold
+        a temporary of this program until release_blocks()"""
         self._saved_tmp = self.free_tmp
-        self._n_reserved = count
-        self.free_tmp = [t for t in self.free_tmp if not (t.kind == "home" and t.idx < count)]
-        assert len(self._saved_tmp) - len(self.free_tmp) == count, f"home blocks 0..{count - 1} must be free"
+        taken = lambda t: t.kind == "home" and (t.idx < count or t.idx in scratch)
+        self._held = [t for t in self.free_tmp if taken(t)]
+        self.free_tmp = [t for t in self.free_tmp if not taken(t)]
+        assert len(self._held) == count + len(scratch), f"home blocks 0..{count - 1} and {scratch} must be free"
+        self._scratch_reserved = tuple(scratch)
         self.tagH = [None] * 4
         self.eH = [None] * 4
         self.vH = [V_STORE] * 4
         self._blocks_reserved = True
 
     def release_blocks(self):
-        held = [t for t in self._saved_tmp if t.kind == "home" and t.idx < self._n_reserved]
-        self.free_tmp = held + self.free_tmp
+        self.free_tmp = self._held + self.free_tmp
         self._blocks_reserved = False
+        self._scratch_reserved = ()
 
     def ldH(self, k, slot):
         """home block k <- slot (straight ds_read for LDS slots)."""
@@ -575,11 +581,13 @@ class Prog:
         self._need(2 * NL * worst <= COL_BUDGET, f"mul3 {worst}")
         vs = (self.vA, self.v_of(y), *self.vH)
         self._need(max(vs) <= V_CAP, f"mul3 operand value {vs}")
+        # L1v4.kfips forms c1 - c0 / c0 - c1 of every operand limb by limb: below 2^31 as long as the limbs stay under 3.9 units
+        self._need(max(mag(rA), mag(self.r_of(y)), *(mag(h) for h in self.eH)) <= 3.9, "mul3 operand limbs")
+        assert getattr(self, "_scratch_reserved", ()) == self.MUL3_SCRATCH, "mul3 needs home blocks 6, 7, 8 as scratch"
         self.vA = 2 * (self.vA * self.v_of(y) + self.vH[0] * self.vH[1] + self.vH[2] * self.vH[3]) / K_RP + 0.5
         self._raw_call("mul3")
         self.rA = self.r_norm()
-        self.tagH[0] = self.tagH[2] = None          # destroyed
-        return self
+        return self                                  # (all five other operands survive)
 
     # ================================================================ L2 algorithms: Fq6 / Fq12
     def _load_norm_sum(self, blk, s1, s2):
@@ -767,7 +775,7 @@ class Prog:
     # ================================================================ sparse multiplications (miller_loop_native.rs:46-110)
     def mul_by_034(self, F, L0, L3, L4):
         """f *= L0 + L3 w^3 + L4 w^4 with one reduction per output coefficient (xi folded into the line)."""
-        self.reserve_blocks()
+        self.reserve_blocks(scratch=self.MUL3_SCRATCH)
         L3x, L4x = self.tmp(), self.tmp()
         self.A(L3).mulxi().to(L3x)
         self.A(L4).mulxi().to(L4x)
@@ -790,30 +798,32 @@ class Prog:
         self.release_blocks()
 
     def mul_by_235(self, F, L2, L3, L5):
-        """f *= L2 w^2 + L3 w^3 + L5 w^5, same scheme."""
-        self.reserve_blocks()
-        L2x, L3x, L5x = self.tmp(), self.tmp(), self.tmp()
-        self.A(L2).mulxi().to(L2x)
+        """f *= L2 w^2 + L3 w^3 + L5 w^5, same scheme.  Five temporaries (two xi-multiplied line coefficients, three results
+        that wait for their place): the order below frees the places as early as possible, and the two coefficients that are
+        xi times a plain sum take the xi afterwards.
+            c0 = xi (a4 b2 + a3 b3 + a1 b5)   c1 = xi (a5 b2 + a4 b3 + a2 b5)   c2 = a0 b2 + xi (a5 b3 + a3 b5)
+            c3 = a1 b2 + a0 b3 + xi a4 b5     c4 = a2 b2 + a1 b3 + xi a5 b5     c5 = a3 b2 + a2 b3 + a0 b5"""
+        self.reserve_blocks(scratch=self.MUL3_SCRATCH)
+        L3x, L5x = self.tmp(), self.tmp()
         self.A(L3).mulxi().to(L3x)
         self.A(L5).mulxi().to(L5x)
-        c = [self.tmp() for _ in range(4)]
-        # c0 = xi (a4 b2 + a3 b3 + a1 b5) ; c1 = xi (a5 b2 + a4 b3 + a2 b5)
-        for k, (i2, i3, i5) in enumerate(((4, 3, 1), (5, 4, 2))):
-            self.ldH(1, L3x).ldH(3, L5x).ldH(0, F[i3]).ldH(2, F[i5])
-            self.A(F[i2]).mul3(L2x).to(c[k])
-        # c2 = a0 b2 + xi (a5 b3 + a3 b5)
-        self.ldH(1, L3x).ldH(3, L5x).ldH(0, F[5]).ldH(2, F[3])
-        self.A(F[0]).mul3(L2).to(c[2])
-        # c3 = a1 b2 + a0 b3 + xi a4 b5 ; c4 = a2 b2 + a1 b3 + xi a5 b5
-        for k, (i2, i3, i5) in ((3, (1, 0, 4)), (4, (2, 1, 5))):
-            self.ldH(1, L3).ldH(3, L5x).ldH(0, F[i3]).ldH(2, F[i5])
-            self.A(F[i2]).mul3(L2).to(c[k] if k == 3 else F[4])           # a4 is not read after c3
-        # c5 = a3 b2 + a2 b3 + a0 b5
-        self.ldH(1, L3).ldH(3, L5).ldH(0, F[2]).ldH(2, F[0])
+        t0, t1, t2 = self.tmp(), self.tmp(), self.tmp()
+        for dst, (i2, i3, i5) in ((t0, (4, 3, 1)), (t1, (5, 4, 2))):                 # c0, c1 (reduced after the xi: they are stored)
+            self.ldH(1, L3).ldH(3, L5).ldH(0, F[i3]).ldH(2, F[i5])
+            self.A(F[i2]).mul3(L2).mulxi(reduce=True).to(dst)
+        self.ldH(1, L3).ldH(3, L5x).ldH(0, F[0]).ldH(2, F[4])                        # c3: a4 has now been read by c0, c1, c3
+        self.A(F[1]).mul3(L2).to(t2)
+        self.ldH(1, L3).ldH(3, L5x).ldH(0, F[1]).ldH(2, F[5])                        # c4 -> its place; a1 read by c0, c3, c4
+        self.A(F[2]).mul3(L2).to(F[4])
+        self.mov(F[1], t1)
+        self.ldH(1, L3x).ldH(3, L5x).ldH(0, F[5]).ldH(2, F[3])                       # c2 (into the freed temporary); a5 read by c1, c2, c4
+        self.A(F[0]).mul3(L2).to(t1)
+        self.ldH(1, L3).ldH(3, L5).ldH(0, F[2]).ldH(2, F[0])                         # c5 -> its place
         self.A(F[3]).mul3(L2).to(F[5])
-        for k in range(4):
-            self.mov(F[k], c[k])
-        self.rel(L2x, L3x, L5x, *c)
+        self.mov(F[0], t0)
+        self.mov(F[2], t1)
+        self.mov(F[3], t2)
+        self.rel(L3x, L5x, t0, t1, t2)
         self.release_blocks()
 
     # ================================================================ G2 steps (homogeneous projective, no inversions)
