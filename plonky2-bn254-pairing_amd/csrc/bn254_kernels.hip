@@ -26,12 +26,25 @@ constexpr size_t SLOT_BYTES = BN254_SLOT_BYTES;         // one Fq2: 2 x 9 balanc
 constexpr size_t MAX_K = 64;                            // pairs per group of the multi-pairing kernels
 
 // ------------------------------------------------------------------ kernels
+// Where a kernel's code starts matters: the same kernel text ran up to 3 % slower from one library build to the next (the
+// k-pair kernels most: their step loop sits at the edge of the 64 KB instruction cache), depending on where the other kernels
+// had pushed it.  Every kernel therefore starts on a 64 KB boundary, its body BN254_KERNEL_PAD bytes behind it -- the best of 24
+// offsets measured (profiles/r02_ab.txt: +1.0 % on the Groth16 shape, +0.5 % on 2^20 pairings against the best unaligned build,
+// worst offset -3.2 %).  What is left is run-to-run: the physical placement of the code object.
+#ifndef BN254_KERNEL_ALIGN
+#define BN254_KERNEL_ALIGN 65536
+#endif
+#ifndef BN254_KERNEL_PAD
+#define BN254_KERNEL_PAD 13824
+#endif
+#define BN254_STR2(x) #x
+#define BN254_STR(x) BN254_STR2(x)
 #define BN254_ASM_KERNEL(NAME, BLOB)                                                                                       \
-    __global__ void __launch_bounds__(BLOCK, 1)                                                                            \
+    __global__ void __launch_bounds__(BLOCK, 1) __attribute__((aligned(BN254_KERNEL_ALIGN)))                               \
     NAME(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in, uint64_t* out, uint32_t n, uint32_t k, uint4* scratch, \
          uint32_t gslot_stride, int* status) {                                                                             \
         uint32_t tid = threadIdx.x, bid = blockIdx.x, grid = gridDim.x;                                                    \
-        asm volatile(BLOB                                                                                                  \
+        asm volatile("s_branch BN254_PAD_%=\n .fill " BN254_STR(BN254_KERNEL_PAD) ", 1, 0\n BN254_PAD_%=:\n" BLOB                 \
                      :                                                                                                     \
                      : "s"(g1), "s"(g2), "s"(f_in), "s"(out), "s"(n), "s"(k), "s"(scratch), "s"(gslot_stride), "s"(status), \
                        "v"(tid), "s"(bid), "s"(grid)                                                                       \

@@ -153,6 +153,9 @@ def test_l1_routines():
         m = _m4([], rng, 0)
         for r in list(range(K4.HOME0 + 6 * K4.SLOT_DW, K4.HOME0 + 8 * K4.SLOT_DW)) + list(range(0, 2 * K4.SLOT_DW)):
             m.v[r] = rng.getrandbits(32)
+        book = {r: rng.getrandbits(32) for r in (K4.V_IDX8, K4.V_IDX, K4.V_TID, K4.V_FLAG)}     # parked in spare AGPRs meanwhile
+        for r, x in book.items():
+            m.v[r] = x
         for k, el in enumerate(a + b):
             blk = K4.HOME0 + K4.SLOT_DW * k
             if t % 2 and k < 3:                  # a sum of two normalised values, limb by limb
@@ -164,6 +167,7 @@ def test_l1_routines():
             else:
                 put(m, blk, el)
         S.run_block(B["mul6"], m)
+        assert all(m.v[r] == x for r, x in book.items())
         v = lambda i, j: f2m(a[i], b[j])
         want = [f2a(v(0, 0), xi(f2a(v(1, 2), v(2, 1)))), f2a(f2a(v(0, 1), v(1, 0)), xi(v(2, 2))), f2a(f2a(v(0, 2), v(1, 1)), v(2, 0))]
         where = [K4.HOME0 + 6 * K4.SLOT_DW, K4.HOME0 + 2 * K4.SLOT_DW, K4.A0]        # c0 -> home 6, c1 -> home 2, c2 -> A

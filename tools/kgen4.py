@@ -468,15 +468,13 @@ class L1v4:
         """Fq6 multiplication in Fq2[v]/(v^3 - xi), schoolbook over Fq2 with LAZY REDUCTION: nine Fq2 products, each of the
         three output coefficients ONE dual column pass (kfips: both components, one Montgomery reduction each):
             c0 = a0 b0 + (xi a1) b2 + (xi a2) b1     c1 = a0 b1 + a1 b0 + (xi a2) b2     c2 = a0 b2 + a1 b1 + a2 b0
-        The c2 pass runs three Karatsuba products; in the other two the a0 product goes the schoolbook way (registers: see
-        below).  a: limbs of up to two units -- unnormalised sums are fine --, b normalised.  (Karatsuba over Fq6 -- six Fq2 products -- needs twelve
+        All nine are Karatsuba products.  a: limbs of up to two units -- unnormalised sums are fine --, b normalised.  (Karatsuba over Fq6 -- six Fq2 products -- needs twelve
         reductions and three recombination chains: 4 % more instructions.)
         a = (a0, a1, a2) in home blocks 0..2, b in home blocks 3..5.  Results (reduction outputs: normalised, values per
         kgen4_prog.Prog._mul6_regs):   c0 -> home block 6,  c1 -> home block 2,  c2 -> block A.
         xi a2 is formed after the c2 pass (home 7), xi a1 after the c1 pass (home 6), so that every pass finds its registers
-        (two accumulator pairs + two fresh ones, two quotient vectors, two difference vectors per Karatsuba product, one
-        negation per schoolbook product: 80 for the c2 pass, 71 for the others) in the pool, block B and the home blocks that
-        are dead at that point (94 / 76 / 76).  a1, a2, block B and home blocks 6, 7 are destroyed; a0 and b survive."""
+        (two accumulator pairs + two fresh ones, two quotient vectors, six difference vectors: 80) in the pool, block B, the
+        home blocks that are dead at that point and, for the last two passes, four parked bookkeeping registers (94 / 80 / 80).  a1, a2, block B and home blocks 6, 7 are destroyed; a0 and b survive."""
         H = lambda k: self.fq2(HOME0 + SLOT_DW * k)
         blk = lambda r0: list(range(r0, r0 + SLOT_DW))
         a, b = [H(0), H(1), H(2)], [H(3), H(4), H(5)]
@@ -491,13 +489,20 @@ class L1v4:
                 self.pool.free_regs.remove(r)
 
         with_regs(blk(B0) + blk(HOME0 + 6 * SLOT_DW) + blk(HOME0 + 7 * SLOT_DW),
-                  lambda: self.kfips([(a[0], b[2]), (a[1], b[1]), (a[2], b[0])], [], A[0], A[1]))              # c2 -> block A (94 free registers: all three Karatsuba)
+                  lambda: self.kfips([(a[0], b[2]), (a[1], b[1]), (a[2], b[0])], [], A[0], A[1]))              # c2 -> block A
         xi(a[2], xa2)
-        with_regs(blk(B0) + blk(HOME0 + 6 * SLOT_DW),
-                  lambda: self.kfips([(a[1], b[0]), (xa2, b[2])], [(a[0], b[1])], a[2][0], a[2][1]))          # c1 -> home 2 (a2 is dead)
+        # the other two passes find 76 registers where three Karatsuba products need 80: the four bookkeeping registers (batch
+        # index, thread id, flags) wait in the four spare AGPRs meanwhile
+        park = [V_IDX8, V_IDX, V_TID, V_FLAG]
+        for i, r in enumerate(park):
+            self.e.emit(f"v_accvgpr_write_b32 a{SLOT_DW * N_AGPR_SLOTS + i}, v{r}")
+        with_regs(blk(B0) + blk(HOME0 + 6 * SLOT_DW) + park,
+                  lambda: self.kfips([(a[0], b[1]), (a[1], b[0]), (xa2, b[2])], [], a[2][0], a[2][1]))        # c1 -> home 2 (a2 is dead)
         xi(a[1], xa1)
-        with_regs(blk(B0) + blk(HOME0 + SLOT_DW),
-                  lambda: self.kfips([(xa1, b[2]), (xa2, b[1])], [(a[0], b[0])], xa1[0], xa1[1]))             # c0 in place over xi a1
+        with_regs(blk(B0) + blk(HOME0 + SLOT_DW) + park,
+                  lambda: self.kfips([(a[0], b[0]), (xa1, b[2]), (xa2, b[1])], [], xa1[0], xa1[1]))           # c0 in place over xi a1
+        for i, r in enumerate(park):
+            self.e.emit(f"v_accvgpr_read_b32 v{r}, a{SLOT_DW * N_AGPR_SLOTS + i}", vw=[r])
 
 
     # ------------------------------------------------------------------ fused G2 steps of the Miller loop
