@@ -256,17 +256,18 @@ class L1v4:
                     f1 = False
             # re += U - W, im += U + W.  The borrow of the 64-bit subtraction travels through VCC (two wait states between
             # its two halves): the two additions into im fill them.
+            # (the VOP3 encodings: between 8-byte instructions a 4-byte one would cost an alignment s_nop)
             if f0:
-                e.emit(f"v_sub_co_u32_e32 v{a0}, vcc, v{u}, v{w}", w=["vcc"], vw=[a0])
+                e.emit(f"v_sub_co_u32_e64 v{a0}, vcc, v{u}, v{w}", w=["vcc"], vw=[a0])
             else:
                 e.emit(f"v_lshl_add_u64 {P0}, {PU}, 0, {P0}", vw=[a0, a0 + 1])
-                e.emit(f"v_sub_co_u32_e32 v{a0}, vcc, v{a0}, v{w}", w=["vcc"], vw=[a0])
+                e.emit(f"v_sub_co_u32_e64 v{a0}, vcc, v{a0}, v{w}", w=["vcc"], vw=[a0])
             e.emit(f"v_lshl_add_u64 {P1}, {PU}, 0, {P1}", vw=[a1, a1 + 1])
             e.emit(f"v_lshl_add_u64 {P1}, {PW}, 0, {P1}", vw=[a1, a1 + 1])
             if f0:
-                e.emit(f"v_subb_co_u32_e32 v{a0 + 1}, vcc, v{u + 1}, v{w + 1}, vcc", r=["vcc"], w=["vcc"], vw=[a0 + 1])
+                e.emit(f"v_subb_co_u32_e64 v{a0 + 1}, vcc, v{u + 1}, v{w + 1}, vcc", r=["vcc"], w=["vcc"], vw=[a0 + 1])
             else:
-                e.emit(f"v_subb_co_u32_e32 v{a0 + 1}, vcc, v{a0 + 1}, v{w + 1}, vcc", r=["vcc"], w=["vcc"], vw=[a0 + 1])
+                e.emit(f"v_subb_co_u32_e64 v{a0 + 1}, vcc, v{a0 + 1}, v{w + 1}, vcc", r=["vcc"], w=["vcc"], vw=[a0 + 1])
             for acc, P, m, out in ((a0, P0, m0, out_re), (a1, P1, m1, out_im)):
                 if c < NL:
                     for i in range(c):
