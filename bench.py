@@ -50,7 +50,8 @@ PEAK_MUL32_PER_S = 554e9 * 64
 NOMINAL_PEAK_MUL32_PER_S = 9.83e12
 LOG2_SINGLE = 20                         # configs[2]
 LOG2_PER_GPU_MULTI = 21                  # configs[4]: 2^24 over 8 GPUs
-PMC_SUMMARY = os.environ.get("BENCH_PMC_SUMMARY", os.path.join(ROOT, "profiles", "r02_pmc.json"))
+PMC_SUMMARY = os.environ.get("BENCH_PMC_SUMMARY", os.path.join(ROOT, "profiles", "r03_pmc.json"))
+KERNEL_HEADER = os.path.join(ROOT, "plonky2-bn254-pairing_amd", "csrc", "pairing_asm_gen.h")
 
 
 def parse(argv=None):
@@ -145,14 +146,34 @@ def cpu_baseline(pkg, g1_soa, g2_soa, n_avail, seconds):
                       f"step, NAF pow with divisions; constants cached): {done1} on one thread in {dt1:.1f} s, {done} on {cores} pthreads in {dt:.1f} s"}
 
 
-def pmc_summary():
+def kernel_header_sha16():
+    """Identifies the kernel code a PMC summary was collected on (tools/summarize_prof.py records the same digest)."""
+    import hashlib
+    try:
+        with open(KERNEL_HEADER, "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+def pmc_summary(log2, kern_avg_ms):
     """Counter-derived fields come from the committed rocprofv3 --pmc summary of this same command (collected in separate
-    passes as the MI355X guide prescribes), NOT from this run: they are labelled as such."""
+    passes as the MI355X guide prescribes), NOT from this run: they are labelled as such -- and dropped (None, with the reason)
+    when the summary cannot describe this run: another batch size, another generation of the kernel code (digest of
+    pairing_asm_gen.h), or a kernel time more than 5 % away from the one rocprofv3 saw."""
     try:
         with open(PMC_SUMMARY) as f:
-            return json.load(f).get("_notes", {})
+            notes = json.load(f).get("_notes", {})
     except Exception:
-        return {}
+        return {}, "no PMC summary at " + os.path.relpath(PMC_SUMMARY, ROOT)
+    if notes.get("log2_batch") != log2:
+        return {}, f"PMC summary is for 2^{notes.get('log2_batch')} lanes, this run for 2^{log2}"
+    if notes.get("kernel_header_sha16") != kernel_header_sha16():
+        return {}, "PMC summary was collected on other kernel code (pairing_asm_gen.h digest differs)"
+    ref = notes.get("kernel_ms_avg_rocprof")
+    if not ref or abs(kern_avg_ms - ref) > 0.05 * ref:
+        return {}, f"kernel time of this run ({kern_avg_ms:.2f} ms) is more than 5 % from the profiled one ({ref} ms)"
+    return notes, None
 
 
 # ------------------------------------------------------------------------------------------------ one rank
@@ -374,7 +395,8 @@ def run_rank(args):
         exchange["bytes_scattered"] = 192 * (n_total - n)
         exchange["bytes_gathered"] = 384 * (n_total - n)
         exchange["note"] = ("rank 0 -> peers: G1/G2 slices, peers -> rank 0: Fq12 outputs; torch.distributed batch_isend_irecv on device "
-                            "tensors (backend nccl = RCCL over xGMI); wall-clock incl. the staging copies, outside the timed steps")
+                            "tensors (backend nccl = RCCL over xGMI; under gloo the device tensors bounce through pinned host buffers); "
+                            "wall-clock incl. the staging copies, outside the timed steps")
 
     rc = 0
     if rank == 0:
@@ -382,10 +404,9 @@ def run_rank(args):
         value = total / elapsed
         per_gpu_rate = n / (kern_avg_ms * 1e-3)
         achieved = per_gpu_rate * W_MUL32_PER_PAIRING
-        notes = pmc_summary()
-        same_cfg = notes.get("log2_batch") == log2
-        traffic = notes.get("hbm_bytes_per_launch_corrected") if same_cfg else None
-        insts_per_pairing = notes.get("valu_wave_insts_per_pairing")       # wave-instructions per 64-lane work item
+        notes, stale = pmc_summary(log2, kern_avg_ms)
+        traffic = notes.get("hbm_bytes_per_launch_corrected")
+        insts_per_item = notes.get("valu_wave_insts_per_work_item")        # wave-instructions per 64 pairings (one wave's lanes)
         cfg_name = "configs[2]" if (world == 1 and log2 == 20) else ("configs[4]" if (world > 1 and log2 == 21) else "custom size")
         rec = {
             "metric": "BN254 pairings/sec (whole node)", "value": value, "unit": "pairings/s", "n_gpus": world,
@@ -396,21 +417,28 @@ def run_rank(args):
             "config": {"workload": f"2^{log2} independent pairings per GPU per step, {world} GPU(s): BASELINE.json {cfg_name}; "
                                    f"pairing() = final_exp_native(miller_loop_native)",
                        "pairings_per_gpu": n, "pairings_total": n_total, "layout": "SoA limb-major u64 Montgomery, inputs resident in HBM",
+                       "ranks_share_one_gpu": bool(on_gpu and world > 1 and os.environ.get("BENCH_SHARE_GPU")),
                        "sharding": None if world == 1 else "contiguous slices per rank, scattered from / gathered to rank 0 over RCCL outside the timed steps; no data-path collective"},
             "roofline": {"bound": "valu-int32-mul", "achieved": achieved / 1e12, "peak": PEAK_MUL32_PER_S / 1e12, "unit": "T mul32/s",
                          "frac": achieved / PEAK_MUL32_PER_S, "traffic": traffic,
+                         "achieved_note": "work-normalised: SURVEY.md 8(d)'s algorithmic mul32 per pairing x pairings/s (kernel time from HIP events), "
+                                          "not the multiply-adds the kernel executes",
                          "traffic_note": f"HBM bytes per launch from the committed PMC summary {os.path.relpath(PMC_SUMMARY, ROOT)} (separate --pmc passes of this "
-                                         "command; raw and corrected counters there), not measured in this run; algorithmic bytes per launch = 576 B x pairings",
+                                         "command; raw and corrected counters there), not measured in this run; algorithmic bytes per launch = 576 B x pairings"
+                                         + (f"; DROPPED: {stale}" if stale else ""),
+                         "pmc_summary_kernel_ms": notes.get("kernel_ms_avg_rocprof"), "kernel_header_sha16": kernel_header_sha16(),
                          "algorithmic_bytes_per_launch": 576 * n,
                          "kernel": "k_pairing", "kernel_ms_avg": kern_avg_ms, "kernel_ms_min": kern_ms[0],
                          "work_per_unit": f"{W_MUL32_PER_PAIRING} mul32 = {W_FQMUL_PER_PAIRING} fqmul x 136 per pairing (SURVEY.md 8d)",
                          "frac_of_nominal_quarter_rate_peak": achieved / NOMINAL_PEAK_MUL32_PER_S,
-                         "valu_issue": None if not insts_per_pairing else {
-                             "source": "SQ_INSTS_VALU per 64-lane work item from the committed PMC summary x this run's kernel time",
-                             "wave_instr_per_pairing": insts_per_pairing,
-                             "wave_instr_per_s": insts_per_pairing * (n / 64) / (kern_avg_ms * 1e-3), "peak_wave_instr_per_s": 1024 * 2.4e9 / 4,
-                             "frac": insts_per_pairing * (n / 64) / (kern_avg_ms * 1e-3) / (1024 * 2.4e9 / 4),
-                             "note": "all VALU instructions the kernel issues against 1024 SIMDs x 2.4 GHz (nominal) / 4 cycles"},
+                         "valu_issue": None if not insts_per_item else {
+                             "source": "SQ_INSTS_VALU per wave work item (64 pairings) from the committed PMC summary x this run's kernel time",
+                             "wave_instr_per_work_item": insts_per_item,
+                             "wave_instr_per_s": insts_per_item * (n / 64) / (kern_avg_ms * 1e-3), "peak_wave_instr_per_s": 1024 * 2.4e9 / 4,
+                             "frac": insts_per_item * (n / 64) / (kern_avg_ms * 1e-3) / (1024 * 2.4e9 / 4),
+                             "issue_utilisation_at_measured_clock": notes.get("valu_issue_utilisation_at_measured_clock"),
+                             "note": "all VALU instructions the kernel issues against 1024 SIMDs x 2.4 GHz (nominal) / 4 cycles; the profile's own "
+                                     "clock (GRBM_GUI_ACTIVE / kernel time) gives the utilisation at the clock the package actually held"},
                          "package_power": power.summary() if power else None,
                          "hbm": {"bound": "hbm", "achieved": 576 * n / (kern_avg_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                                  "frac": 576 * n / (kern_avg_ms * 1e-3) / 8e12, "traffic": traffic,
@@ -446,9 +474,10 @@ def run_rank(args):
         if rc == 0:
             print(json.dumps(rec), flush=True)
     if dist:
-        if rc:
-            dist.destroy_process_group()
-            sys.exit(rc)
+        # every rank leaves with rank 0's verdict (a failed oracle gate must not leave the peers waiting in a barrier)
+        t = torch.tensor([rc], dtype=torch.int32, device=dev if (backend == "nccl" and on_gpu) else "cpu")
+        dist.broadcast(t, src=0)
+        rc = int(t.item())
         dist.barrier()
         dist.destroy_process_group()
     return rc

@@ -21,15 +21,26 @@
  *            timed path).  The un-suffixed entry points take HOST pointers and stage
  *            through the device (PCIe inclusive).
  * STREAM     `stream` is a hipStream_t (NULL = default stream).  `_dev` calls are enqueued
- *            on it and return after the launch; status words are read with a stream sync
- *            only inside bn254_last_status().  Host-pointer calls synchronise before
- *            returning.
+ *            on it and return after the launch -- none of them waits for the stream
+ *            (bn254_pow_batch_dev copies its digits through pinned staging slots); status
+ *            words are read, on that same stream, only inside bn254_last_status().
+ *            Host-pointer calls synchronise before returning.
  * ERRORS     0 = success, negative = failure (bn254_strerror).  The reference panics on
  *            the same conditions (division by zero in ark's `/`); the Rust shim turns a
  *            negative status back into a panic.  Points at infinity are outside the
  *            reference's contract (it reads raw x/y) and outside this one.
- * THREADING  Re-entrant; no global state except lazily created per-device scratch
- *            buffers guarded by a mutex.
+ * THREADING  Re-entrant.  The only state is what the library keeps per (device, stream):
+ *            scratch, the status word, the staging buffers of the host-pointer calls.  Each
+ *            such context has a mutex: a `_dev` call holds it from the look-up of its
+ *            buffers to the launch, a host-pointer call from staging to the read-back of
+ *            its results, so host threads may share a stream (the scalar Rust / C++
+ *            signatures all use device 0 / the NULL stream: concurrent callers are
+ *            serialised, not corrupted); calls on different streams run independently.
+ * LIFETIME   A stream's context is created by the first call that names the stream and lives
+ *            until bn254_release_stream(device, stream) -- call it before destroying a stream
+ *            you used, otherwise its buffers stay allocated (a later stream that reuses the
+ *            handle value simply inherits them).  The private streams of the host-pointer
+ *            pipeline and of the `_sharded_dev` calls live as long as the library.
  */
 #ifndef BN254_PAIRING_H
 #define BN254_PAIRING_H
@@ -55,7 +66,8 @@ const char* bn254_strerror(int status);
 /* Synchronises `stream` on `device` and returns the sticky status of the device-side
  * checks (zero divisor) accumulated since the last call; clears it. */
 int bn254_last_status(int device, void* stream);
-/* Bytes of device scratch a call over n lanes will use (informational). */
+/* Bytes of device scratch a call over n lanes (k pairs each) will use on the current device (informational;
+ * the persistent grid is min(work items, CUs of that device), 256 CUs assumed when no device is visible). */
 size_t bn254_scratch_bytes(size_t n, size_t k);
 /* Scratch and the status word are kept per (device, stream), so calls on different streams are independent;
  * this frees what the library holds for `stream` (call it before destroying a stream you used). */
@@ -82,7 +94,10 @@ int bn254_final_exp_batch(const uint64_t* f_in, uint64_t* out, size_t n, int dev
  * n_groups independent groups of k pairs (G1 then G2, the reference's argument order);
  * pair j of group g is element g*k + j of the g1/g2 batches (batch length n_groups*k).
  * do_final_exp != 0 applies final_exp_native to each group's shared-f Miller value
- * (the Groth16 shape). */
+ * (the Groth16 shape).  Any k >= 1, as the reference's Vec: one kernel holds up to 64 pairs
+ * per lane; larger groups are walked in sub-groups of 64 whose Miller values are multiplied
+ * (MyFq12 Mul) -- the same field element, limb for limb (the reference's own test asserts
+ * multi == product, :336-348). */
 int bn254_multi_pairing_batch_dev(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_groups, size_t k,
                                   int do_final_exp, int device, void* stream);
 int bn254_multi_pairing_batch(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_groups, size_t k,
@@ -103,6 +118,17 @@ int bn254_multi_pairing_check_batch(const uint64_t* g1, const uint64_t* g2, uint
 int bn254_pairing_sharded(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n, int n_devices);
 int bn254_multi_pairing_sharded(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_groups, size_t k,
                                 int do_final_exp, int n_devices);
+
+/* Device-pointer form of the above: the whole batch (limb-major planes) is resident in HBM of devices[0]
+ * (devices == NULL: devices 0..n_devices-1) and `stream` is a stream of that device behind which the inputs are
+ * valid.  Shard i -- contiguous slice i of the units -- runs on devices[i]; its slices move plane by plane with
+ * hipMemcpyPeerAsync (copy engines over xGMI: no CU on either side, so transfers run under the other shards'
+ * kernels) and the results land in `out` on devices[0].  A device may be named more than once (its shards take
+ * turns).  Returns when all results are in `out` (synchronous), with the first failure of any shard. */
+int bn254_pairing_sharded_dev(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n, const int* devices, int n_devices,
+                              void* stream);
+int bn254_multi_pairing_sharded_dev(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_groups, size_t k, int do_final_exp,
+                                    const int* devices, int n_devices, void* stream);
 
 /* ---- batched public helpers of the reference ------------------------------------------ */
 

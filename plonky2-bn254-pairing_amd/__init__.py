@@ -75,6 +75,9 @@ _PROTOS = {
     "bn254_multi_pairing_check_batch": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "bn254_pairing_sharded": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_int]),
     "bn254_multi_pairing_sharded": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int]),
+    "bn254_pairing_sharded_dev": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_multi_pairing_sharded_dev": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                                       ctypes.c_void_p]),
     "bn254_release_stream": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p]),
     "bn254_fq12_mul_batch_dev": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "bn254_fq12_mul_batch": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
@@ -375,6 +378,23 @@ def multi_pairing_batch_dev(g1, g2, out, n_groups, k, do_final_exp=True, device=
 def multi_pairing_check_batch_dev(g1, g2, verdict, n_groups, k, device=0, stream=None):
     _check(load_library().bn254_multi_pairing_check_batch_dev(_dev(g1), _dev(g2), _dev(verdict), n_groups, k, device, _stream(stream)),
            "multi-pairing check")
+
+
+def _devlist(devices):
+    arr = (ctypes.c_int * len(devices))(*devices)
+    return arr, len(devices)
+
+
+def pairing_sharded_dev(g1, g2, out, n, devices, stream=None):
+    """n pairings resident on devices[0] (device tensors / pointers), slice i computed on devices[i]; synchronous."""
+    arr, nd = _devlist(devices)
+    _check(load_library().bn254_pairing_sharded_dev(_dev(g1), _dev(g2), _dev(out), n, arr, nd, _stream(stream)), "pairing (sharded, device)")
+
+
+def multi_pairing_sharded_dev(g1, g2, out, n_groups, k, devices, do_final_exp=True, stream=None):
+    arr, nd = _devlist(devices)
+    _check(load_library().bn254_multi_pairing_sharded_dev(_dev(g1), _dev(g2), _dev(out), n_groups, k, 1 if do_final_exp else 0, arr, nd,
+                                                          _stream(stream)), "multi_miller_loop_native (sharded, device)")
 
 
 def release_stream(device=0, stream=None):

@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -70,6 +71,18 @@ __global__ void __launch_bounds__(256) k_is_one(const uint64_t* __restrict__ f, 
     }
 }
 
+// Pairs [j0, j0 + ks) of every k-pair group, as a contiguous ks-pair batch (groups of more than MAX_K pairs are walked in
+// sub-groups, launch_pairing): plane w of the source has n*k entries, pair j of group g at g*k + j.  HBM-bound, coalesced
+// on the destination side.
+__global__ void __launch_bounds__(256) k_subgroup(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, size_t n, size_t k, size_t j0,
+                                                  size_t ks, int planes) {
+    size_t per = n * ks;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per * (size_t)planes; i += (size_t)gridDim.x * blockDim.x) {
+        size_t w = i / per, r = i - w * per, g = r / ks, j = r - g * ks;
+        dst[i] = src[w * n * k + g * k + j0 + j];
+    }
+}
+
 enum { OP_MUL = 0, OP_FROB = 1, OP_POW = 2 };
 
 // Element-major <-> limb-major.  The reference's callers hold `&[G1Affine]`, `Vec<(&G1Affine, &G2Affine)>`, `Vec<MyFq12>`,
@@ -109,24 +122,39 @@ __global__ void __launch_bounds__(256) k_layout(const uint64_t* __restrict__ src
 // ------------------------------------------------------------------ host side
 // Scratch, the status word and the staging buffers of the host-pointer entry points are kept per (device, stream): calls on
 // different streams of one device are independent ("library is re-entrant, one HIP stream per call").  Calls on
-// ONE stream are stream-ordered, as with any HIP API: the caller serialises them.
+// ONE stream are stream-ordered on the device; on the host they are serialised by the stream context's mutex: a `_dev` call
+// holds it from the look-up of its buffers to the launch, a host-pointer call from staging to the read-back of its results
+// (two host threads may therefore share a stream -- e.g. the NULL stream behind the scalar Rust / C++ signatures).
 struct Buf {
     void* p = nullptr;
     size_t bytes = 0;
 };
+struct NafSlot {               // pinned host staging of one pow_native call's NAF digits (no stream synchronisation in the call)
+    int8_t* host = nullptr;
+    size_t bytes = 0;
+    hipEvent_t done = nullptr; // recorded behind the copy that reads `host`
+};
 struct StreamCtx {
+    std::recursive_mutex mu;
     Buf scratch, naf, tmp;
+    Buf sub[4];                // groups of more than MAX_K pairs: sub-group inputs (G1, G2) and the two Miller values in flight
     Buf stage[8];              // device staging of the host-pointer entry points (inputs / outputs), grown on demand
+    NafSlot naf_ring[4];
+    unsigned naf_next = 0;
     int* status = nullptr;
+    int* status_host = nullptr;   // pinned: the status word is read back on the caller's stream
 };
 struct DeviceCtx {
-    std::mutex mu;             // guards `streams` and the one-time initialisation only: never held across a blocking HIP call
+    std::mutex mu;             // guards `streams`, `shard_streams` and the one-time initialisation; not held across kernel work
     bool init = false;
     int n_cu = 0;
+    std::mutex table_mu;       // the generator table upload (138 KB, blocking) has its own lock
     int32_t* gen_table = nullptr;
-    std::map<hipStream_t, StreamCtx> streams;
+    std::map<hipStream_t, std::unique_ptr<StreamCtx>> streams;
     std::mutex pipe_mu;        // one host-pointer pipeline at a time per device (its two workers fill the chip anyway)
     hipStream_t pipe_stream[2] = {nullptr, nullptr};   // the workers' private streams: created once, their scratch and staging kept
+    std::mutex shard_mu;       // one device-pointer sharded call at a time per device
+    std::vector<hipStream_t> shard_streams;            // private streams of bn254_*_sharded_dev (one per shard on this device)
 };
 DeviceCtx g_ctx[64];
 
@@ -148,7 +176,16 @@ int ensure(Buf& b, size_t bytes, hipStream_t stream) {
     return BN254_OK;
 }
 
+StreamCtx* stream_ctx(int device, void* stream) {
+    DeviceCtx& c = g_ctx[device];
+    std::lock_guard<std::mutex> lk(c.mu);
+    std::unique_ptr<StreamCtx>& p = c.streams[(hipStream_t)stream];
+    if (!p) p.reset(new StreamCtx());
+    return p.get();
+}
+
 struct LaunchCtx {
+    std::unique_lock<std::recursive_mutex> lock;     // the stream context stays ours until the launch has been issued
     StreamCtx* s;
     int n_cu;
     uint4* scratch;
@@ -162,7 +199,6 @@ int ctx_get(int device, void* stream, size_t k, size_t n_items, LaunchCtx* out, 
     int rc = check_device(device);
     if (rc) return rc;
     DeviceCtx& c = g_ctx[device];
-    StreamCtx* sc;
     {
         std::lock_guard<std::mutex> lk(c.mu);
         if (!c.init) {
@@ -174,12 +210,18 @@ int ctx_get(int device, void* stream, size_t k, size_t n_items, LaunchCtx* out, 
             for (const void* f : kernels) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
             c.init = true;
         }
-        if (want_table && !c.gen_table) {          // 138 KB, once per device
-            if (hipMalloc(&c.gen_table, sizeof(BN254_GEN_TABLE)) != hipSuccess) return BN254_ERR_ALLOC;
-            HIPCHK(hipMemcpy(c.gen_table, BN254_GEN_TABLE, sizeof(BN254_GEN_TABLE), hipMemcpyHostToDevice));
-        }
-        sc = &c.streams[(hipStream_t)stream];      // std::map: the reference stays valid
     }
+    if (want_table) {                              // 138 KB, once per device
+        std::lock_guard<std::mutex> lk(c.table_mu);
+        if (!c.gen_table) {
+            int32_t* t = nullptr;
+            if (hipMalloc(&t, sizeof(BN254_GEN_TABLE)) != hipSuccess) return BN254_ERR_ALLOC;
+            if (hipMemcpy(t, BN254_GEN_TABLE, sizeof(BN254_GEN_TABLE), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(t); return BN254_ERR_HIP; }
+            c.gen_table = t;
+        }
+    }
+    StreamCtx* sc = stream_ctx(device, stream);
+    out->lock = std::unique_lock<std::recursive_mutex>(sc->mu);
     if (!sc->status) {
         HIPCHK(hipMalloc(&sc->status, sizeof(int)));
         HIPCHK(hipMemsetAsync(sc->status, 0, sizeof(int), (hipStream_t)stream));
@@ -198,16 +240,56 @@ int ctx_get(int device, void* stream, size_t k, size_t n_items, LaunchCtx* out, 
     return BN254_OK;
 }
 
+int launch_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, size_t power, const int8_t* naf_host, int naf_len,
+              int device, void* stream);
+
 template <bool M, bool F>
 int launch_pairing(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in, uint64_t* out, size_t n_groups, size_t k, int device, void* stream) {
     if (n_groups == 0) return BN254_OK;
-    if (!out || (M && (!g1 || !g2)) || (!M && !f_in) || k == 0 || k > MAX_K) return BN254_ERR_INVALID_ARG;
-    if (n_groups * k >= (1ull << 29)) return BN254_ERR_INVALID_ARG;   // 32-bit byte offsets of the SoA planes in the kernels
+    if (!out || (M && (!g1 || !g2)) || (!M && !f_in) || k == 0 || (!M && k != 1)) return BN254_ERR_INVALID_ARG;
+    if (n_groups * k >= (1ull << 29) || n_groups * k / k != n_groups) return BN254_ERR_INVALID_ARG;   // 32-bit byte offsets of the SoA planes in the kernels
+    hipStream_t st = (hipStream_t)stream;
+    if (k > MAX_K) {
+        // multi_miller_loop_native takes any Vec (miller_loop_native.rs:192-282, :324-326); the k-pair kernels hold at most MAX_K
+        // pairs' state.  The shared-f Miller value of a group IS the product of the Miller values of any partition of its pairs
+        // -- the same field element, hence the same limbs (the reference's own T1, :336-348, asserts it for singletons): walk
+        // the group in sub-groups of <= MAX_K pairs, multiply the values (MyFq12 Mul), one final exponentiation at the end.
+        StreamCtx* sc;
+        std::unique_lock<std::recursive_mutex> hold;
+        {
+            LaunchCtx c;
+            int rc = ctx_get(device, stream, 1, (n_groups + BLOCK - 1) / BLOCK, &c);
+            if (rc) return rc;
+            sc = c.s;
+            hold = std::move(c.lock);
+        }
+        int rc;
+        if ((rc = ensure(sc->sub[0], 64 * n_groups * MAX_K, st)) || (rc = ensure(sc->sub[1], 128 * n_groups * MAX_K, st)) ||
+            (rc = ensure(sc->sub[2], 384 * n_groups, st)) || (rc = ensure(sc->sub[3], 384 * n_groups, st)))
+            return rc;
+        uint64_t *s1 = (uint64_t*)sc->sub[0].p, *s2 = (uint64_t*)sc->sub[1].p, *acc = (uint64_t*)sc->sub[2].p, *val = (uint64_t*)sc->sub[3].p;
+        size_t n_sub = (k + MAX_K - 1) / MAX_K;
+        for (size_t s = 0; s < n_sub; s++) {
+            size_t j0 = s * MAX_K, ks = k - j0 < MAX_K ? k - j0 : MAX_K;
+            size_t blocks = (n_groups * ks * 16 + 255) / 256;
+            if (blocks > 16384) blocks = 16384;
+            hipLaunchKernelGGL(k_subgroup, dim3((uint32_t)blocks), dim3(256), 0, st, g1, s1, n_groups, k, j0, ks, 8);
+            hipLaunchKernelGGL(k_subgroup, dim3((uint32_t)blocks), dim3(256), 0, st, g2, s2, n_groups, k, j0, ks, 16);
+            HIPCHK(hipGetLastError());
+            bool last = s + 1 == n_sub;
+            uint64_t* dst = s == 0 ? acc : val;
+            if ((rc = launch_pairing<true, false>(s1, s2, nullptr, dst, n_groups, ks, device, stream))) return rc;
+            // acc <- acc * val; the last product lands in `out` when no final exponentiation follows
+            if (s > 0 && (rc = launch_op(OP_MUL, acc, val, (last && !F) ? out : acc, n_groups, 0, nullptr, 0, device, stream))) return rc;
+        }
+        if (F) return launch_pairing<false, true>(nullptr, nullptr, acc, out, n_groups, 1, device, stream);
+        return BN254_OK;
+    }
     LaunchCtx c;
     int rc = ctx_get(device, stream, k, (n_groups + BLOCK - 1) / BLOCK, &c);
     if (rc) return rc;
     auto go = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3(c.grid), dim3(BLOCK), LDS_BYTES, (hipStream_t)stream, g1, g2, f_in, out, (uint32_t)n_groups, (uint32_t)k,
+        hipLaunchKernelGGL(kern, dim3(c.grid), dim3(BLOCK), LDS_BYTES, st, g1, g2, f_in, out, (uint32_t)n_groups, (uint32_t)k,
                            c.scratch, c.stride, c.status);
     };
     if (k == 1) {
@@ -215,7 +297,6 @@ int launch_pairing(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in,
         else if (M) go(k_miller);
         else go(k_fexp);
     } else {
-        if (!M) return BN254_ERR_INVALID_ARG;
         if (F) go(k_mpairing);
         else go(k_mmiller);
     }
@@ -236,8 +317,22 @@ int launch_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_
         while (naf_len > 0 && naf_host[naf_len - 1] == 0) naf_len--;        // the top digit of a NAF is +1
         if (naf_len < 1 || naf_len >= 65536) return BN254_ERR_INVALID_ARG;   // 16-bit length field of the kernel's k argument
         if ((rc = ensure(c.s->naf, (size_t)naf_len + 64, (hipStream_t)stream))) return rc;
-        HIPCHK(hipMemcpyAsync(c.s->naf.p, naf_host, (size_t)naf_len, hipMemcpyHostToDevice, (hipStream_t)stream));
-        HIPCHK(hipStreamSynchronize((hipStream_t)stream));   // naf_host is a caller temporary
+        // naf_host is a caller temporary and the call must not wait for the stream: the digits go through one of four pinned
+        // staging slots; a slot is reused once the copy that read it has completed (its event), i.e. only the fifth call in
+        // flight on one stream ever waits.  The device-side buffer is shared: copies and kernels are ordered by the stream.
+        NafSlot& slot = c.s->naf_ring[c.s->naf_next++ % 4];
+        if (slot.done) HIPCHK(hipEventSynchronize(slot.done));
+        else HIPCHK(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+        if (slot.bytes < (size_t)naf_len) {
+            if (slot.host) HIPCHK(hipHostFree(slot.host));
+            slot.host = nullptr; slot.bytes = 0;
+            size_t cap = ((size_t)naf_len + 4095) & ~(size_t)4095;
+            if (hipHostMalloc((void**)&slot.host, cap, hipHostMallocDefault) != hipSuccess) return BN254_ERR_ALLOC;
+            slot.bytes = cap;
+        }
+        memcpy(slot.host, naf_host, (size_t)naf_len);
+        HIPCHK(hipMemcpyAsync(c.s->naf.p, slot.host, (size_t)naf_len, hipMemcpyHostToDevice, (hipStream_t)stream));
+        HIPCHK(hipEventRecord(slot.done, (hipStream_t)stream));
         naf_dev = (const int8_t*)c.s->naf.p;
         kk = 2u | ((uint32_t)naf_len << 16);
         for (int t = 0; t < naf_len; t++) if (naf_host[t] < 0) { kk |= 1u << 8; break; }   // 1/a is needed
@@ -288,17 +383,19 @@ long get_naf_host(const uint64_t* exp_in, size_t n, int8_t* naf) {
     return (long)k;
 }
 
-// host-pointer entry points: inputs are staged through per-stream device buffers that are kept (and grown) across calls
+// host-pointer entry points: inputs are staged through per-stream device buffers that are kept (and grown) across calls.
+// A Stage owns the stream context from the first staged byte to the end of the call (the read-back in finish_host): a second
+// host thread on the same (device, stream) waits instead of overwriting staged inputs or freeing a buffer under the kernel.
 struct Stage {
     StreamCtx* sc = nullptr;
+    std::unique_lock<std::recursive_mutex> lock;
     hipStream_t st;
     int used = 0;
     int init(int device, void* stream) {
         int rc = check_device(device);
         if (rc) return rc;
-        DeviceCtx& c = g_ctx[device];
-        std::lock_guard<std::mutex> lk(c.mu);
-        sc = &c.streams[(hipStream_t)stream];
+        sc = stream_ctx(device, stream);
+        lock = std::unique_lock<std::recursive_mutex>(sc->mu);
         st = (hipStream_t)stream;
         return BN254_OK;
     }
@@ -348,18 +445,26 @@ const char* bn254_strerror(int status) {
 int bn254_last_status(int device, void* stream) {
     int rc = check_device(device);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-    int* status = nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    StreamCtx* sc = nullptr;
     {
         DeviceCtx& c = g_ctx[device];
         std::lock_guard<std::mutex> lk(c.mu);
-        auto it = c.streams.find((hipStream_t)stream);
-        if (it == c.streams.end() || !it->second.status) return BN254_OK;
-        status = it->second.status;
+        auto it = c.streams.find(st);
+        if (it != c.streams.end()) sc = it->second.get();
     }
-    int h = 0;
-    HIPCHK(hipMemcpy(&h, status, sizeof(int), hipMemcpyDeviceToHost));
-    if (h) { HIPCHK(hipMemset(status, 0, sizeof(int))); return BN254_ERR_ZERO_DIVISOR; }
+    if (!sc) { HIPCHK(hipStreamSynchronize(st)); return BN254_OK; }
+    std::lock_guard<std::recursive_mutex> lk(sc->mu);
+    if (!sc->status) { HIPCHK(hipStreamSynchronize(st)); return BN254_OK; }
+    // the read-back (and the clearing store) are enqueued on the caller's stream: other streams are not touched
+    if (!sc->status_host && hipHostMalloc((void**)&sc->status_host, sizeof(int), hipHostMallocDefault) != hipSuccess) return BN254_ERR_ALLOC;
+    HIPCHK(hipMemcpyAsync(sc->status_host, sc->status, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (*sc->status_host) {
+        HIPCHK(hipMemsetAsync(sc->status, 0, sizeof(int), st));
+        HIPCHK(hipStreamSynchronize(st));
+        return BN254_ERR_ZERO_DIVISOR;
+    }
     return BN254_OK;
 }
 
@@ -369,9 +474,12 @@ static int finish_host(void* h_out, const void* d_out, size_t bytes, int device,
 }
 
 size_t bn254_scratch_bytes(size_t n, size_t k) {
-    size_t items = (n + BLOCK - 1) / BLOCK;
-    size_t grid = items < 256 ? (items ? items : 1) : 256;          // MI355X: 256 CUs
-    return (size_t)(BN254_GSLOTS + BN254_GSLOTS_PER_PAIR * (k > 1 ? k : 0)) * SLOT_BYTES * grid * BLOCK;
+    size_t items = (n + BLOCK - 1) / BLOCK, cus = 256;              // MI355X: 256 CUs when no device can be asked
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = (size_t)v;
+    size_t grid = items < cus ? (items ? items : 1) : cus;           // persistent kernels: the grid never exceeds the CU count
+    size_t kk = k > MAX_K ? MAX_K : k;                                // larger groups are walked in sub-groups of MAX_K pairs
+    return (size_t)(BN254_GSLOTS + BN254_GSLOTS_PER_PAIR * (kk > 1 ? kk : 0)) * SLOT_BYTES * grid * BLOCK;
 }
 
 int bn254_pairing_batch_dev(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n, int device, void* stream) {
@@ -447,9 +555,9 @@ int bn254_generate_pairs_dev(uint64_t seed, uint64_t* g1_out, uint64_t* g2_out, 
 int bn254_multi_pairing_check_batch_dev(const uint64_t* g1, const uint64_t* g2, uint8_t* verdict, size_t n_groups, size_t k, int device,
                                         void* stream) {
     if (n_groups == 0) return BN254_OK;
-    if (!g1 || !g2 || !verdict || k == 0 || k > MAX_K) return BN254_ERR_INVALID_ARG;
+    if (!g1 || !g2 || !verdict || k == 0) return BN254_ERR_INVALID_ARG;
     LaunchCtx c;
-    int rc = ctx_get(device, stream, k, (n_groups + BLOCK - 1) / BLOCK, &c);
+    int rc = ctx_get(device, stream, k > MAX_K ? 1 : k, (n_groups + BLOCK - 1) / BLOCK, &c);
     if (rc) return rc;
     if ((rc = ensure(c.s->tmp, 384 * n_groups, (hipStream_t)stream))) return rc;
     if ((rc = launch_pairing<true, true>(g1, g2, nullptr, (uint64_t*)c.s->tmp.p, n_groups, k, device, stream))) return rc;
@@ -464,18 +572,22 @@ int bn254_release_stream(int device, void* stream) {
     int rc = check_device(device);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-    StreamCtx sc;
+    std::unique_ptr<StreamCtx> sc;
     {
         DeviceCtx& c = g_ctx[device];
         std::lock_guard<std::mutex> lk(c.mu);
         auto it = c.streams.find((hipStream_t)stream);
         if (it == c.streams.end()) return BN254_OK;
-        sc = it->second;
+        sc = std::move(it->second);
         c.streams.erase(it);
     }
-    for (Buf* b : {&sc.scratch, &sc.naf, &sc.tmp}) if (b->p) (void)hipFree(b->p);
-    for (Buf& b : sc.stage) if (b.p) (void)hipFree(b.p);
-    if (sc.status) (void)hipFree(sc.status);
+    { std::lock_guard<std::recursive_mutex> lk(sc->mu); }      // a call that was still inside the library has left it
+    for (Buf* b : {&sc->scratch, &sc->naf, &sc->tmp}) if (b->p) (void)hipFree(b->p);
+    for (Buf& b : sc->stage) if (b.p) (void)hipFree(b.p);
+    for (Buf& b : sc->sub) if (b.p) (void)hipFree(b.p);
+    for (NafSlot& n : sc->naf_ring) { if (n.host) (void)hipHostFree(n.host); if (n.done) (void)hipEventDestroy(n.done); }
+    if (sc->status) (void)hipFree(sc->status);
+    if (sc->status_host) (void)hipHostFree(sc->status_host);
     return BN254_OK;
 }
 
@@ -526,7 +638,7 @@ int bn254_multi_pairing_batch(const uint64_t* g1, const uint64_t* g2, uint64_t* 
     if (!g1 || !g2 || !out || k == 0) return BN254_ERR_INVALID_ARG;
     int rc = check_device(device);
     if (rc) return rc;
-    if (n_groups > PIPE_CHUNK && k <= MAX_K) {
+    if (n_groups > PIPE_CHUNK) {
         if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return BN254_ERR_HIP;
         return run_pipeline(&device, 1, g1, g2, out, n_groups, k, do_final_exp);
     }
@@ -570,7 +682,7 @@ int bn254_soa_to_elems_dev(const uint64_t* soa, uint64_t* elems, size_t words, s
 int bn254_multi_pairing_batch_elems(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_groups, size_t k, int do_final_exp,
                                     int out_order, int device, void* stream) {
     if (n_groups == 0) return BN254_OK;
-    if (!g1 || !g2 || !out || k == 0 || k > MAX_K || (out_order != BN254_FQ12_MYFQ12 && out_order != BN254_FQ12_ARK)) return BN254_ERR_INVALID_ARG;
+    if (!g1 || !g2 || !out || k == 0 || (out_order != BN254_FQ12_MYFQ12 && out_order != BN254_FQ12_ARK)) return BN254_ERR_INVALID_ARG;
     int rc = check_device(device);
     if (rc) return rc;
     if (n_groups > PIPE_CHUNK) {
@@ -589,7 +701,7 @@ int bn254_multi_pairing_batch_elems(const uint64_t* g1, const uint64_t* g2, uint
 }
 int bn254_multi_pairing_check_batch_elems(const uint64_t* g1, const uint64_t* g2, uint8_t* verdict, size_t n_groups, size_t k, int device, void* stream) {
     if (n_groups == 0) return BN254_OK;
-    if (!g1 || !g2 || !verdict || k == 0 || k > MAX_K) return BN254_ERR_INVALID_ARG;
+    if (!g1 || !g2 || !verdict || k == 0) return BN254_ERR_INVALID_ARG;
     Stage s; uint64_t *e1, *e2, *d1, *d2, *d3; int rc; size_t np = n_groups * k;
     if ((rc = s.init(device, stream)) || (rc = s.up(g1, 64 * np, &e1)) || (rc = s.up(g2, 128 * np, &e2)) || (rc = s.up(nullptr, 64 * np, &d1)) ||
         (rc = s.up(nullptr, 128 * np, &d2)) || (rc = s.up(nullptr, n_groups, &d3))) return rc;
@@ -703,7 +815,7 @@ static int run_pipeline(const int* devices, int n_dev, const uint64_t* g1, const
 
 static int sharded(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_groups, size_t k, int do_final_exp, int n_devices, HostFmt fmt) {
     if (n_groups == 0) return BN254_OK;
-    if (!g1 || !g2 || !out || k == 0 || k > MAX_K || n_devices <= 0 || (fmt.out_order != BN254_FQ12_MYFQ12 && fmt.out_order != BN254_FQ12_ARK))
+    if (!g1 || !g2 || !out || k == 0 || n_devices <= 0 || (fmt.out_order != BN254_FQ12_MYFQ12 && fmt.out_order != BN254_FQ12_ARK))
         return BN254_ERR_INVALID_ARG;
     int cnt = bn254_device_count();
     if (cnt <= 0) return BN254_ERR_NO_DEVICE;
@@ -726,6 +838,90 @@ int bn254_pairing_sharded_elems(const uint64_t* g1, const uint64_t* g2, uint64_t
 
 int bn254_pairing_sharded(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n, int n_devices) {
     return bn254_multi_pairing_sharded(g1, g2, out, n, 1, 1, n_devices);
+}
+
+// ---- device-pointer multi-GPU entry (one process): the batch lives in HBM of devices[0] (limb-major planes),
+// shard i = contiguous slice i of the units runs on devices[i] on a private stream of that device.  The slices travel as
+// plane-by-plane 1-D copies -- hipMemcpyPeerAsync between devices: copy engines over xGMI, no CU on either side, so they run
+// under the other shards' kernels (which fill their chips: profiles/r03_coresidency.txt) -- ordered behind `stream` by an
+// event.  A device may appear several times (two shards on one GPU take turns on it): that is how the path is tested on a
+// one-GPU box.  Synchronous: returns when every shard's results are in `out` and its status word has been read.
+static int sharded_dev(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_units, size_t k, int do_final_exp, const int* devices,
+                       int n_dev, void* stream) {
+    if (n_units == 0) return BN254_OK;
+    if (!g1 || !g2 || !out || k == 0 || n_dev <= 0 || n_dev > 64 || n_units * k >= (1ull << 29)) return BN254_ERR_INVALID_ARG;
+    int cnt = bn254_device_count();
+    if (cnt <= 0) return BN254_ERR_NO_DEVICE;
+    std::vector<int> devs((size_t)n_dev);
+    for (int i = 0; i < n_dev; i++) {
+        devs[(size_t)i] = devices ? devices[i] : i;
+        if (devs[(size_t)i] < 0 || devs[(size_t)i] >= cnt || devs[(size_t)i] >= 64) return BN254_ERR_INVALID_ARG;
+    }
+    const int root = devs[0];
+    std::vector<std::unique_lock<std::mutex>> locks;          // distinct devices, ascending: no lock-order inversion between calls
+    for (int d = 0; d < 64; d++)
+        for (int x : devs) if (x == d) { locks.emplace_back(g_ctx[d].shard_mu); break; }
+    std::vector<hipStream_t> sts((size_t)n_dev);
+    for (int i = 0; i < n_dev; i++) {
+        int d = devs[(size_t)i];
+        size_t j = 0;
+        for (int e = 0; e < i; e++) j += devs[(size_t)e] == d;
+        if (hipSetDevice(d) != hipSuccess) return BN254_ERR_HIP;
+        if (d != root) {                                       // direct xGMI access both ways (already enabled: fine)
+            (void)hipDeviceEnablePeerAccess(root, 0);
+            (void)hipGetLastError();
+        }
+        DeviceCtx& c = g_ctx[d];
+        std::lock_guard<std::mutex> lk(c.mu);
+        while (c.shard_streams.size() <= j) {
+            hipStream_t st = nullptr;
+            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return BN254_ERR_HIP;
+            c.shard_streams.push_back(st);
+        }
+        sts[(size_t)i] = c.shard_streams[j];
+    }
+    if (hipSetDevice(root) != hipSuccess) return BN254_ERR_HIP;
+    for (int d : devs) if (d != root) { (void)hipDeviceEnablePeerAccess(d, 0); (void)hipGetLastError(); }
+    hipEvent_t ready = nullptr;
+    HIPCHK(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+    int rc = BN254_OK;
+    if (hipEventRecord(ready, (hipStream_t)stream) != hipSuccess) rc = BN254_ERR_HIP;
+    const size_t np_all = n_units * k;
+    std::vector<Stage> stages((size_t)n_dev);
+    for (int i = 0; i < n_dev && !rc; i++) {
+        size_t lo = n_units * (size_t)i / (size_t)n_dev, hi = n_units * (size_t)(i + 1) / (size_t)n_dev, m = hi - lo, np = m * k;
+        if (m == 0) continue;
+        int d = devs[(size_t)i];
+        hipStream_t st = sts[(size_t)i];
+        Stage& s = stages[(size_t)i];
+        uint64_t *d1, *d2, *d3;
+        if ((rc = s.init(d, st)) || (rc = s.up(nullptr, 64 * np, &d1)) || (rc = s.up(nullptr, 128 * np, &d2)) || (rc = s.up(nullptr, 384 * m, &d3))) break;
+        if (hipStreamWaitEvent(st, ready, 0) != hipSuccess) { rc = BN254_ERR_HIP; break; }
+        auto plane = [&](void* dst, int dst_dev, const void* src, int src_dev, size_t bytes) {
+            return dst_dev == src_dev ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st)
+                                      : hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, st);
+        };
+        for (size_t w = 0; w < 8 && !rc; w++) if (plane(d1 + w * np, d, g1 + w * np_all + lo * k, root, np * 8) != hipSuccess) rc = BN254_ERR_HIP;
+        for (size_t w = 0; w < 16 && !rc; w++) if (plane(d2 + w * np, d, g2 + w * np_all + lo * k, root, np * 8) != hipSuccess) rc = BN254_ERR_HIP;
+        if (rc) break;
+        rc = (k == 1 && do_final_exp) ? bn254_pairing_batch_dev(d1, d2, d3, m, d, st) : bn254_multi_pairing_batch_dev(d1, d2, d3, m, k, do_final_exp, d, st);
+        for (size_t w = 0; w < 48 && !rc; w++) if (plane(out + w * n_units + lo, root, d3 + w * m, d, m * 8) != hipSuccess) rc = BN254_ERR_HIP;
+    }
+    for (int i = 0; i < n_dev; i++) {                          // always drain what was issued, then report the first failure
+        if (!stages[(size_t)i].sc) continue;
+        int r = bn254_last_status(devs[(size_t)i], sts[(size_t)i]);
+        if (!rc) rc = r;
+    }
+    (void)hipSetDevice(root);
+    (void)hipEventDestroy(ready);
+    return rc;
+}
+int bn254_multi_pairing_sharded_dev(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_groups, size_t k, int do_final_exp,
+                                    const int* devices, int n_devices, void* stream) {
+    return sharded_dev(g1, g2, out, n_groups, k, do_final_exp, devices, n_devices, stream);
+}
+int bn254_pairing_sharded_dev(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n, const int* devices, int n_devices, void* stream) {
+    return sharded_dev(g1, g2, out, n, 1, 1, devices, n_devices, stream);
 }
 
 }  // extern "C"

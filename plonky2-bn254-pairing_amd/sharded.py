@@ -2,10 +2,18 @@
 SoA batch per rank, NO data-path collective -- the units (`pairing(p, q)`, /root/reference/src/pairing.rs:20-22)
 are independent.  The only exchanges are the north star's scatter of the G1/G2 inputs from rank 0 and the gather
 of the Fq12 outputs to rank 0, as grouped point-to-point operations (`torch.distributed.batch_isend_irecv`:
-one grouped RCCL launch per direction under backend "nccl", the same code over CPU tensors under "gloo").
+one grouped RCCL launch per direction under backend "nccl", the same code under "gloo").
 
-All buffers are torch tensors of int64 words (the u64 Montgomery limbs, SoA limb-major) that live where the
-process group can move them: device tensors under nccl (xGMI, no host bounce), CPU tensors under gloo.
+All buffers are torch tensors of int64 words (the u64 Montgomery limbs, SoA limb-major).  Under nccl they are device
+tensors and travel over xGMI with no host bounce.  gloo moves host memory only: device tensors then go through a pinned
+host buffer on either side (`_P2P`) -- that is how the configs[4] flow runs with two ranks on ONE GPU (RCCL refuses two
+ranks on a device), HIP engine and device-resident shards included.
+
+Transfers never run under the pairing kernel: it is persistent and holds every register of every SIMD and 144 KiB of each
+CU's LDS for the whole launch, so a communication kernel cannot co-reside (measured: profiles/r03_coresidency.txt -- a
+kernel enqueued behind it starts when the launch ends, one that is resident first delays a whole workgroup's chain).  The
+exchange steps therefore sit between launches: scatter, compute, gather.  (Copy-engine transfers do overlap; the
+single-process `bn254_pairing_sharded_dev` uses them.)
 
 `compute(g1, g2, m) -> out` is the per-rank hot path on one contiguous chunk of m pairings: the HIP engine on the
 rank's own device and current stream by default (`hip_compute`), anything with the same signature in the CPU tests.
@@ -26,10 +34,32 @@ def _cols(t, words, n, lo, hi):
     return t.view(words, n)[:, lo:hi].contiguous().view(-1)
 
 
-def _run(dist, ops):
-    if ops:
-        for w in dist.batch_isend_irecv(ops):
+class _P2P:
+    """One point-to-point transfer of a flat int64 tensor.  Device tensors under a backend that moves host memory only
+    (gloo) are bounced through a pinned host buffer: filled before the send, copied to the device after the receive."""
+
+    def __init__(self, dist, kind, tensor, peer):
+        self.kind, self.tensor, self.bounce = kind, tensor, None
+        wire = tensor
+        if tensor.is_cuda and dist.get_backend() != "nccl":
+            import torch
+            self.bounce = torch.empty(tensor.shape, dtype=tensor.dtype, device="cpu", pin_memory=True)
+            if kind == "send":
+                self.bounce.copy_(tensor)                # synchronous on the current stream: the data is in host memory now
+            wire = self.bounce
+        self.op = dist.P2POp(dist.isend if kind == "send" else dist.irecv, wire, peer)
+
+    def finish(self):
+        if self.bounce is not None and self.kind == "recv":
+            self.tensor.copy_(self.bounce)
+
+
+def _run(dist, xfers):
+    if xfers:
+        for w in dist.batch_isend_irecv([x.op for x in xfers]):
             w.wait()
+        for x in xfers:
+            x.finish()
 
 
 def hip_compute(device_index=None):
@@ -62,12 +92,12 @@ def scatter_inputs(full_g1, full_g2, n, g1_local, g2_local, dist):
             for full, words in ((full_g1, 8), (full_g2, 16)):
                 s = _cols(full, words, n, rlo, rhi)
                 keep.append(s)
-                ops.append(dist.P2POp(dist.isend, s, r))
+                ops.append(_P2P(dist, "send", s, r))
         if hi > lo:
             g1_local.view(8, hi - lo).copy_(full_g1.view(8, n)[:, lo:hi])
             g2_local.view(16, hi - lo).copy_(full_g2.view(16, n)[:, lo:hi])
     elif hi > lo:
-        ops = [dist.P2POp(dist.irecv, g1_local, 0), dist.P2POp(dist.irecv, g2_local, 0)]
+        ops = [_P2P(dist, "recv", g1_local, 0), _P2P(dist, "recv", g2_local, 0)]
     _run(dist, ops)
 
 
@@ -79,7 +109,7 @@ def gather_outputs(out_local, n, dist, device=None):
     lo, hi = shard_bounds(n, world, rank)
     if rank != 0:
         if hi > lo:
-            _run(dist, [dist.P2POp(dist.isend, out_local, 0)])
+            _run(dist, [_P2P(dist, "send", out_local, 0)])
         return None
     full = torch.empty(48 * n, dtype=torch.int64, device=device if device is not None else out_local.device)
     ops, parts = [], []
@@ -89,7 +119,7 @@ def gather_outputs(out_local, n, dist, device=None):
             continue
         t = torch.empty(48 * (rhi - rlo), dtype=torch.int64, device=full.device)
         parts.append((rlo, rhi, t))
-        ops.append(dist.P2POp(dist.irecv, t, r))
+        ops.append(_P2P(dist, "recv", t, r))
     if hi > lo:
         full.view(48, n)[:, lo:hi].copy_(out_local.view(48, hi - lo))
     _run(dist, ops)
@@ -98,12 +128,21 @@ def gather_outputs(out_local, n, dist, device=None):
     return full
 
 
+def _default_device(dist, like):
+    import torch
+    if like is not None:
+        return like.device
+    if dist.get_backend() == "nccl":                       # RCCL moves device memory: this rank's GPU
+        return torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
+    return torch.device("cpu")
+
+
 def pairing_sharded(g1, g2, n, dist=None, compute=None, scatter_from_root=False, gather_to_root=True, chunk=1 << 19, device=None):
     """n independent pairings over the ranks of `dist`.  Returns (local SoA result, gathered SoA result on rank 0 or None).
 
     g1 / g2: SoA tensors of the WHOLE batch -- valid on every rank, or on rank 0 only with scatter_from_root (other ranks
-    may pass None).  Each rank walks its slice in chunks of `chunk` lanes; with gather_to_root a finished chunk is sent to
-    rank 0 while the next chunk computes (rank 0 posts all its receives up front as one grouped operation)."""
+    may pass None).  Each rank walks its slice in launches of `chunk` lanes; the exchange steps sit between launches
+    (scatter, then all of the rank's compute, then the gather): nothing is posted while a pairing kernel runs."""
     import torch
     compute = compute or hip_compute()
     if dist is None or not dist.is_initialized():
@@ -113,46 +152,17 @@ def pairing_sharded(g1, g2, n, dist=None, compute=None, scatter_from_root=False,
     lo, hi = shard_bounds(n, world, rank)
     n_local = hi - lo
     if device is None:
-        device = g1.device if g1 is not None else torch.device("cpu")
+        device = _default_device(dist, g1)
     if scatter_from_root:
         l1 = torch.empty(8 * n_local, dtype=torch.int64, device=device)
         l2 = torch.empty(16 * n_local, dtype=torch.int64, device=device)
         scatter_inputs(g1, g2, n, l1, l2, dist)
     else:
         l1, l2 = _cols(g1, 8, n, lo, hi), _cols(g2, 16, n, lo, hi)
-
-    def chunks(a, b):
-        return [(c, min(c + chunk, b)) for c in range(a, b, chunk)]
-
-    # rank 0: one grouped launch of every receive (rank r's chunk c arrives in posting order on the (r, 0) pair)
-    pending, recv_parts = [], []
-    if gather_to_root and rank == 0:
-        full = torch.empty(48 * n, dtype=torch.int64, device=device)
-        ops = []
-        for r in range(1, world):
-            rlo, rhi = shard_bounds(n, world, r)
-            for a, b in chunks(rlo, rhi):
-                t = torch.empty(48 * (b - a), dtype=torch.int64, device=device)
-                recv_parts.append((a, b, t))
-                ops.append(dist.P2POp(dist.irecv, t, r))
-        pending = dist.batch_isend_irecv(ops) if ops else []
     local = torch.empty(48 * n_local, dtype=torch.int64, device=device)
-    sends = []
-    for a, b in chunks(0, n_local):
-        m = b - a
-        o = compute(_cols(l1, 8, n_local, a, b), _cols(l2, 16, n_local, a, b), m)
-        local.view(48, n_local)[:, a:b].copy_(o.view(48, m))
-        if gather_to_root and rank != 0:
-            sends.append((o, dist.batch_isend_irecv([dist.P2POp(dist.isend, o, 0)])))      # travels while the next chunk computes
-    for _, ws in sends:
-        for w in ws:
-            w.wait()
-    gathered = None
-    if gather_to_root and rank == 0:
-        for w in pending:
-            w.wait()
-        full.view(48, n)[:, lo:hi].copy_(local.view(48, n_local))
-        for a, b, t in recv_parts:
-            full.view(48, n)[:, a:b].copy_(t.view(48, b - a))
-        gathered = full
+    for a in range(0, n_local, chunk):
+        b = min(a + chunk, n_local)
+        o = compute(_cols(l1, 8, n_local, a, b), _cols(l2, 16, n_local, a, b), b - a)
+        local.view(48, n_local)[:, a:b].copy_(o.view(48, b - a))
+    gathered = gather_outputs(local, n, dist, device=device) if gather_to_root else None
     return local, gathered

@@ -1,0 +1,197 @@
+"""GPU tests of the host side of the C ABI added in round 3:
+
+  * groups of more than 64 pairs (`multi_miller_loop_native` takes any Vec, /root/reference/src/miller_loop_native.rs:324-326):
+    sub-group composition against the oracle at k = 65, 130, 200, shared-f Miller value, final value and the `== 1` verdict;
+  * `bn254_pairing_sharded_dev` / `bn254_multi_pairing_sharded_dev`: device-resident batch, one shard per entry of the device
+    list -- a device named twice / three times runs the whole slice / copy / gather path on a one-GPU box;
+  * host threads: two threads on the SAME (device, stream) through the host-pointer entry points (the scalar Rust / C++
+    signatures all use device 0 and the NULL stream), and two threads on two streams through the `_dev` entry points
+    (`pow_native`, `frobenius_map_native`, `pairing`), none of which waits for its stream."""
+import threading
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _pairs(n, mul=5, seed=8):
+    base_P, base_Q = H.subgroup_points(seed)
+    P = [base_P[(i * mul + 1) % seed] for i in range(n)]
+    Q = [base_Q[(i * 3 + i // seed) % seed] for i in range(n)]
+    return H.g1_aos(P), H.g2_aos(Q)
+
+
+@pytest.mark.parametrize("k,n_groups", [(65, 3), (130, 2), (200, 1)])
+def test_groups_of_more_than_64_pairs(k, n_groups):
+    pk = H.pkg()
+    g1a, g2a = _pairs(n_groups * k)
+    g1, g2 = H.to_soa(g1a, 8), H.to_soa(g2a, 16)
+    want_m = H.oracle_multi_miller(g1a, g2a, n_groups, k)
+    got_m = H.to_aos(pk.multi_pairing_batch(g1, g2, n_groups, k, do_final_exp=False), 48)
+    assert np.array_equal(got_m, want_m), f"multi_miller_loop_native k={k}"
+    want = H.oracle_multi_pairing(g1a, g2a, n_groups, k)
+    got = H.to_aos(pk.multi_pairing_batch(g1, g2, n_groups, k, do_final_exp=True), 48)
+    assert np.array_equal(got, want), f"multi pairing k={k}"
+    # element-major entry point, ark order out
+    got_e = pk.multi_pairing_batch_elems(g1a, g2a, n_groups, k, do_final_exp=True, out_order=pk.FQ12_MYFQ12)
+    assert np.array_equal(got_e, want)
+
+
+def test_product_check_on_a_long_group():
+    """66 pairs whose product is one: 33 x [e(aP, bQ) e(abP, -Q)] (the T3 pattern, final_exp_native.rs:245-263), next to a
+    group with one pair exchanged."""
+    pk = H.pkg()
+    t3 = H.load_golden("bn254_vectors.json")["t3"]
+    P3 = [tuple(int(x, 16) for x in p) for p in t3["g1"]]
+    Q3 = [((int(q[0], 16), int(q[1], 16)), (int(q[2], 16), int(q[3], 16))) for q in t3["g2"]]
+    good_p, good_q = P3 * 33, Q3 * 33
+    bad_p, bad_q = list(good_p), list(good_q)
+    bad_p[65] = P3[0]                                         # the pair in the second sub-group (64 + 2)
+    g1 = H.to_soa(H.g1_aos(good_p + bad_p + good_p), 8)
+    g2 = H.to_soa(H.g2_aos(good_q + bad_q + good_q), 16)
+    assert pk.multi_pairing_check_batch(g1, g2, 3, 66).tolist() == [1, 0, 1]
+
+
+def test_sharded_dev_one_gpu_device_list():
+    import torch
+    pk = H.pkg()
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev)
+    n = 5 * 256 + 77
+    g1 = torch.zeros(8 * n, dtype=torch.int64, device=dev)
+    g2 = torch.zeros(16 * n, dtype=torch.int64, device=dev)
+    pk.generate_pairs_dev(0xB2540009, g1, g2, n, 0, st)
+    ref = torch.zeros(48 * n, dtype=torch.int64, device=dev)
+    pk.pairing_batch_dev(g1, g2, ref, n, 0, st)
+    pk.last_status(0, st)
+    for devices in ([0], [0, 0], [0, 0, 0]):
+        out = torch.zeros(48 * n, dtype=torch.int64, device=dev)
+        pk.pairing_sharded_dev(g1, g2, out, n, devices, st)
+        assert torch.equal(out, ref), f"devices={devices}"
+    # k-pair groups stay whole; ragged split (7 groups over 3 shards), Miller value only
+    k, groups = 4, 7
+    ref = torch.zeros(48 * groups, dtype=torch.int64, device=dev)
+    m1, m2 = g1.view(8, n)[:, : groups * k].contiguous().view(-1), g2.view(16, n)[:, : groups * k].contiguous().view(-1)
+    pk.multi_pairing_batch_dev(m1, m2, ref, groups, k, False, 0, st)
+    pk.last_status(0, st)
+    out = torch.zeros(48 * groups, dtype=torch.int64, device=dev)
+    pk.multi_pairing_sharded_dev(m1, m2, out, groups, k, [0, 0, 0], do_final_exp=False, stream=st)
+    assert torch.equal(out, ref)
+    # more shards than units: empty slices are skipped
+    out = torch.zeros(48 * 2, dtype=torch.int64, device=dev)
+    pk.multi_pairing_sharded_dev(m1, m2, out, 2, k, [0, 0, 0], do_final_exp=False, stream=st)
+    assert torch.equal(out.view(48, 2), ref.view(48, groups)[:, :2])
+    with pytest.raises(pk.Bn254Error) as ei:
+        pk.pairing_sharded_dev(g1, g2, out, n, [0, pk.device_count()], st)
+    assert ei.value.status == pk.ERR_INVALID_ARG
+    # spot check against the oracle through the sharded path
+    pos = [0, n // 3, n - 1]
+    out = torch.zeros(48 * n, dtype=torch.int64, device=dev)
+    pk.pairing_sharded_dev(g1, g2, out, n, [0, 0], st)
+    g1h = g1.view(8, n)[:, pos].cpu().numpy().view(np.uint64).reshape(-1).copy()
+    g2h = g2.view(16, n)[:, pos].cpu().numpy().view(np.uint64).reshape(-1).copy()
+    got = out.view(48, n)[:, pos].cpu().numpy().view(np.uint64).reshape(-1).copy()
+    assert np.array_equal(pk.layout.to_aos(got, 48), H.oracle_pairing(pk.layout.to_aos(g1h, 8), pk.layout.to_aos(g2h, 16), len(pos), threads=3))
+
+
+def test_two_host_threads_share_the_null_stream():
+    """The reference's functions are pure and `Send + Sync`: two threads calling the host-pointer entry points
+    on device 0 / the NULL stream with different batch sizes (the staging buffers are per stream and grow) get their own
+    results."""
+    pk = H.pkg()
+    sizes = (300, 2100)
+    inputs, want = [], []
+    for n in sizes:
+        g1a, g2a = _pairs(n, mul=3 + n % 4)
+        g1, g2 = H.to_soa(g1a, 8), H.to_soa(g2a, 16)
+        inputs.append((g1, g2, n))
+        want.append(pk.pairing_batch(g1, g2, n))
+    assert np.array_equal(H.to_aos(want[0], 48)[: 48 * 40], H.oracle_pairing(*_pairs(40, mul=3 + sizes[0] % 4), 40, threads=4))
+    errors = []
+
+    def work(t):
+        try:
+            g1, g2, n = inputs[t]
+            for rep in range(6):
+                got = pk.pairing_batch(g1, g2, n)
+                if not np.array_equal(got, want[t]):
+                    errors.append((t, rep))
+                f = pk.final_exp_batch(pk.miller_loop_batch(g1[: 8 * n], g2[: 16 * n], n), n) if rep == 0 else None
+                if f is not None and not np.array_equal(f, want[t]):
+                    errors.append((t, "split"))
+        except Exception as e:      # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+
+
+def test_two_host_threads_two_streams_dev_calls():
+    """pow_native / frobenius_map_native / pairing through the `_dev` entry points from two host threads, each on its own
+    stream; pow's digits travel through pinned slots, so neither thread waits for its stream inside the call (more calls are
+    queued than there are slots)."""
+    import torch
+    pk = H.pkg()
+    lib = pk.load_library()
+    dev = torch.device("cuda:0")
+    n = 1 << 12
+    xs = H.rand_fq12(6, seed=5)
+    a_host = H.to_soa(H.fq12_aos([xs[i % 6] for i in range(n)]), 48)
+    a = torch.from_numpy(a_host.view(np.int64).copy()).to(dev)
+    exps = [[pk.BN_X], [0xFFFFFFFFFFFFFFF1, 0x3], [0x8000000000000001]]
+    want_pow = [H.oracle_pow_native(H.fq12_aos(xs), e, 6)[1] for e in exps]
+    want_frob = H.oracle_frobenius(H.fq12_aos(xs), 5, 6)
+    g1 = torch.zeros(8 * n, dtype=torch.int64, device=dev)
+    g2 = torch.zeros(16 * n, dtype=torch.int64, device=dev)
+    pk.generate_pairs_dev(0xB254000A, g1, g2, n, 0, torch.cuda.current_stream(dev))
+    ref_pair = torch.zeros(48 * n, dtype=torch.int64, device=dev)
+    pk.pairing_batch_dev(g1, g2, ref_pair, n, 0, torch.cuda.current_stream(dev))
+    pk.last_status(0, torch.cuda.current_stream(dev))
+    errors = []
+
+    def head(t, m=6):
+        return pk.layout.to_aos(t.view(48, n)[:, :m].cpu().numpy().view(np.uint64).reshape(-1).copy(), 48)
+
+    def work(t):
+        try:
+            st = torch.cuda.Stream(dev)
+            import ctypes
+            S = ctypes.c_void_p(st.cuda_stream)
+            outs = []
+            for rep in range(3):                                   # 9 pow calls in flight on one stream: the 4-slot ring wraps
+                for e in exps:
+                    o = torch.zeros(48 * n, dtype=torch.int64, device=dev)
+                    ev = np.array(e, dtype=np.uint64)
+                    rc = lib.bn254_pow_batch_dev(ctypes.c_void_p(a.data_ptr()), ev.ctypes.data_as(ctypes.c_void_p), ev.size,
+                                                 ctypes.c_void_p(o.data_ptr()), n, 0, S)
+                    assert rc == 0
+                    outs.append(o)
+            fr = torch.zeros(48 * n, dtype=torch.int64, device=dev)
+            assert lib.bn254_frobenius_map_batch_dev(ctypes.c_void_p(a.data_ptr()), 5, ctypes.c_void_p(fr.data_ptr()), n, 0, S) == 0
+            pr = torch.zeros(48 * n, dtype=torch.int64, device=dev)
+            pk.pairing_batch_dev(g1, g2, pr, n, 0, st)
+            pk.last_status(0, st)
+            for i, o in enumerate(outs):
+                if not np.array_equal(head(o), want_pow[i % 3]):
+                    errors.append((t, "pow", i))
+            if not np.array_equal(head(fr), want_frob):
+                errors.append((t, "frob"))
+            if not torch.equal(pr, ref_pair):
+                errors.append((t, "pairing"))
+            pk.release_stream(0, st)
+        except Exception as e:      # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors

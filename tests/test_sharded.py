@@ -1,10 +1,14 @@
-"""Multi-rank sharding: slices, scatter from rank 0, chunked compute with the gather of chunk i
-travelling under chunk i + 1, gather to rank 0.
+"""Multi-rank sharding: slices, scatter from rank 0, compute on the shards, gather to rank 0 -- the exchange
+steps sit between launches (the pairing kernel fills the chip: profiles/r03_coresidency.txt).
 
   * world_size-2 / 3 `gloo` runs on CPU tensors with an injected per-rank compute (the CPU oracle) -- the sharding logic is
     what is under test here;
-  * `-m gpu`: the SAME function body under backend "nccl" (RCCL) on device tensors with the HIP engine as the compute, one
-    rank per visible GPU (world size 1 on a one-GPU box: every code path except the peer transfers);
+  * `-m gpu`, two ranks on ONE GPU: the same function bodies with the HIP engine on device-resident shards; gloo carries the
+    slices (device tensors bounce through pinned host buffers -- RCCL refuses two ranks on one device): `pairing_sharded`
+    directly, and bench.py's whole configs[4] flow (`--gpus 2`: generate on rank 0, scatter, timed HIP compute per rank,
+    gather, oracle gate on the peer's slice);
+  * `-m gpu`, backend "nccl" (RCCL) on device tensors, one rank per visible GPU -- skipped on a one-GPU box, where it would
+    move nothing;
   * bench.py's own launcher (`--gpus 2` with no WORLD_SIZE in the environment) on CPU with a stand-in engine."""
 import importlib
 import json
@@ -163,7 +167,8 @@ def _nccl_worker(rank, world, port, n, chunk, q):
 def test_sharded_nccl_on_visible_gpus():
     """backend nccl (RCCL), device tensors, the HIP engine on each rank's own device and stream: one rank per visible GPU."""
     world = torch.cuda.device_count()
-    assert world >= 1
+    if world < 2:
+        pytest.skip("one visible GPU: RCCL would move nothing (the two-rank flow runs over gloo on the shared GPU instead)")
     n = 3 * 4096 + 77
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -175,6 +180,79 @@ def test_sharded_nccl_on_visible_gpus():
     for p in procs:
         p.join(timeout=60)
     assert res == [(r, True) for r in range(world)]
+
+
+def _shared_gpu_worker(rank, world, port, n, chunk, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sh = _sh()
+    pk = H.pkg()
+    st = torch.cuda.current_stream(dev)
+    g1 = g2 = None
+    if rank == 0:
+        g1 = torch.zeros(8 * n, dtype=torch.int64, device=dev)
+        g2 = torch.zeros(16 * n, dtype=torch.int64, device=dev)
+        pk.generate_pairs_dev(0xB2540007, g1, g2, n, 0, st)
+        pk.last_status(0, st)
+    local, gathered = sh.pairing_sharded(g1, g2, n, dist=dist, compute=sh.hip_compute(0), scatter_from_root=True, chunk=chunk, device=dev)
+    pk.last_status(0, st)
+    lo, hi = sh.shard_bounds(n, world, rank)
+    ok = local.is_cuda and local.numel() == 48 * (hi - lo)
+    if rank == 0:
+        ref = torch.empty(48 * n, dtype=torch.int64, device=dev)
+        pk.pairing_batch_dev(g1, g2, ref, n, 0, st)
+        pk.last_status(0, st)
+        ok = ok and gathered.is_cuda and torch.equal(gathered, ref)
+        pos = [0, n // 2 + 3, n - 1]                      # the last two lie in rank 1's slice
+        g1h = g1.view(8, n)[:, pos].cpu().numpy().view(np.uint64).reshape(-1).copy()
+        g2h = g2.view(16, n)[:, pos].cpu().numpy().view(np.uint64).reshape(-1).copy()
+        want = H.oracle_pairing(pk.layout.to_aos(g1h, 8), pk.layout.to_aos(g2h, 16), len(pos), threads=3)
+        got = gathered.view(48, n)[:, pos].cpu().numpy().view(np.uint64).reshape(-1).copy()
+        ok = ok and np.array_equal(pk.layout.to_aos(got, 48), want)
+    else:
+        ok = ok and gathered is None
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_pairing_sharded_two_ranks_on_one_gpu():
+    """Two ranks, HIP engine, device-resident shards on the one visible GPU; gloo carries the slices through pinned host
+    buffers.  Ragged: 3 launches of <= 1024 lanes per rank."""
+    n = 2 * 2500 + 1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33000 + os.getpid() % 2000
+    procs = [ctx.Process(target=_shared_gpu_worker, args=(r, 2, port, n, 1024, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
+
+
+@pytest.mark.gpu
+def test_bench_configs4_flow_two_ranks_on_one_gpu():
+    """bench.py --gpus 2 on the HIP engine (BASELINE.json configs[4] at 2^14 per rank): rank 0 generates 2 x 2^14 pairs on
+    the device, scatters, both ranks time their device-resident shard, outputs are gathered and the oracle gate checks
+    positions of rank 1's slice.  BENCH_SHARE_GPU maps both ranks to the one GPU; gloo carries the slices."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(BENCH_SHARE_GPU="1", BENCH_DIST_BACKEND="gloo", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--log2-batch", "14",
+                        "--no-power"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-1000:], p.stderr[-3000:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["dist_backend"] == "gloo" and rec["verified_vs_oracle"] is True
+    assert rec["config"]["pairings_per_gpu"] == 1 << 14 and rec["config"]["pairings_total"] == 1 << 15
+    assert rec["exchange"]["bytes_scattered"] == 192 << 14 and rec["exchange"]["bytes_gathered"] == 384 << 14
+    assert "TEST ENGINE" not in rec["data"] and rec["value"] > 0
+    assert rec["config"]["ranks_share_one_gpu"] is True
 
 
 def test_bench_power_sampler_reads_rocm_smi(tmp_path, monkeypatch):

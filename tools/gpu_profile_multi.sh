@@ -14,4 +14,4 @@ for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES S
   timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT -o pmc_$i -- $BENCH > $OUT/pmc_$i.log 2>&1; echo "pmc $i rc=$?"
 done
 cd $GRAFT_REPO_ROOT
-PROF_KERNEL="::k_mpairing(" PROF_LOG2_BATCH=18 python3 tools/summarize_prof.py $OUT $TAG
+PROF_KERNEL="::k_mpairing(" PROF_LOG2_BATCH=18 PROF_K=4 python3 tools/summarize_prof.py $OUT $TAG
