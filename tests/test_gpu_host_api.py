@@ -82,7 +82,8 @@ def test_sharded_dev_one_gpu_device_list():
     assert torch.equal(out, ref)
     # more shards than units: empty slices are skipped
     out = torch.zeros(48 * 2, dtype=torch.int64, device=dev)
-    pk.multi_pairing_sharded_dev(m1, m2, out, 2, k, [0, 0, 0], do_final_exp=False, stream=st)
+    s1, s2 = g1.view(8, n)[:, : 2 * k].contiguous().view(-1), g2.view(16, n)[:, : 2 * k].contiguous().view(-1)
+    pk.multi_pairing_sharded_dev(s1, s2, out, 2, k, [0, 0, 0], do_final_exp=False, stream=st)
     assert torch.equal(out.view(48, 2), ref.view(48, groups)[:, :2])
     with pytest.raises(pk.Bn254Error) as ei:
         pk.pairing_sharded_dev(g1, g2, out, n, [0, pk.device_count()], st)
