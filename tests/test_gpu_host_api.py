@@ -166,17 +166,22 @@ def test_two_host_threads_two_streams_dev_calls():
             import ctypes
             S = ctypes.c_void_p(st.cuda_stream)
             outs = []
+            # result buffers first, on this thread's stream: torch.zeros fills on the CURRENT stream, and a fill on the default
+            # stream would race the engine's writes on `st`
+            with torch.cuda.stream(st):
+                bufs = [torch.zeros(48 * n, dtype=torch.int64, device=dev) for _ in range(11)]
+            st.synchronize()
             for rep in range(3):                                   # 9 pow calls in flight on one stream: the 4-slot ring wraps
                 for e in exps:
-                    o = torch.zeros(48 * n, dtype=torch.int64, device=dev)
+                    o = bufs[len(outs)]
                     ev = np.array(e, dtype=np.uint64)
                     rc = lib.bn254_pow_batch_dev(ctypes.c_void_p(a.data_ptr()), ev.ctypes.data_as(ctypes.c_void_p), ev.size,
                                                  ctypes.c_void_p(o.data_ptr()), n, 0, S)
                     assert rc == 0
                     outs.append(o)
-            fr = torch.zeros(48 * n, dtype=torch.int64, device=dev)
+            fr = bufs[9]
             assert lib.bn254_frobenius_map_batch_dev(ctypes.c_void_p(a.data_ptr()), 5, ctypes.c_void_p(fr.data_ptr()), n, 0, S) == 0
-            pr = torch.zeros(48 * n, dtype=torch.int64, device=dev)
+            pr = bufs[10]
             pk.pairing_batch_dev(g1, g2, pr, n, 0, st)
             pk.last_status(0, st)
             for i, o in enumerate(outs):

@@ -160,6 +160,8 @@ GLOB_TMP0 = 6 * N_GREG           # eight overflow temporaries: slots 72..79
 N_GSLOTS = GLOB_TMP0 + 8         # scratch slots of the single-pairing kernels; pair j of a multi kernel: N_GSLOTS + 7 j + ...
 GCHUNK0 = 512                    # byte offset of the first 16-byte chunk plane inside a wave's part of a scratch slot (after the tails)
 
+MARKERS = bool(int(os.environ.get("KGEN_MARKERS", "0")))      # tools/instr_histogram.py: LM_* labels at the phase changes inside routines
+_marker_n = [0]
 ALIGN_CODE = bool(int(os.environ.get("KGEN_ALIGN", "1")))     # keep 8-byte instructions 8-byte aligned (asmcore.align_code)
 
 # ---- static bound tracking -------------------------------------------------------------------------------------------
@@ -265,6 +267,13 @@ class Prog:
 
     def _count(self, k):
         self.stats[k] = self.stats.get(k, 0) + 1
+
+    def marker(self, name):
+        """profiling builds only (KGEN_MARKERS=1): a label the simulator's region map picks up; the shipped code has none"""
+        if MARKERS:
+            self.wait()
+            _marker_n[0] += 1
+            self.e.label(f"LM_{name}_{_marker_n[0]}_%=")
 
     # ---------------------------------------------------------------- data movement (18-dword slots)
     N_B128 = SLOT_DW // 4          # four 16-byte chunks ...
@@ -775,6 +784,7 @@ class Prog:
     # ================================================================ sparse multiplications (miller_loop_native.rs:46-110)
     def mul_by_034(self, F, L0, L3, L4):
         """f *= L0 + L3 w^3 + L4 w^4 with one reduction per output coefficient (xi folded into the line)."""
+        self.marker("mul034")
         self.reserve_blocks(scratch=self.MUL3_SCRATCH)
         L3x, L4x = self.tmp(), self.tmp()
         self.A(L3).mulxi().to(L3x)
@@ -803,6 +813,7 @@ class Prog:
         xi times a plain sum take the xi afterwards.
             c0 = xi (a4 b2 + a3 b3 + a1 b5)   c1 = xi (a5 b2 + a4 b3 + a2 b5)   c2 = a0 b2 + xi (a5 b3 + a3 b5)
             c3 = a1 b2 + a0 b3 + xi a4 b5     c4 = a2 b2 + a1 b3 + xi a5 b5     c5 = a3 b2 + a2 b3 + a0 b5"""
+        self.marker("mul235")
         self.reserve_blocks(scratch=self.MUL3_SCRATCH)
         L3x, L5x = self.tmp(), self.tmp()
         self.A(L3).mulxi().to(L3x)
@@ -874,7 +885,9 @@ class Prog:
             self.wait()
             after_load()
         R = out or R
+        self.marker("dblstep")
         self._raw_call("dblstep")
+        self.marker("stepout")
         sq = lambda x: 4 * x * x / K_RP + 0.5
         ml = lambda x, y: 2 * x * y / K_RP + 0.5
         bq = c = sq(v)
@@ -897,7 +910,9 @@ class Prog:
             self.wait()
             after_load()
         R = out or R
+        self.marker("addstep")
         self._raw_call("addstep")
+        self.marker("stepout")
         sq = lambda x: 4 * x * x / K_RP + 0.5
         ml = lambda x, y: 2 * x * y / K_RP + 0.5
         th = mu = v + ml(v, v)

@@ -43,6 +43,8 @@ class Machine:
         self.transient_wraps = 0
         self.l2_stack, self.l2_incl = [], {}     # profile mode: instructions inclusive of callees, per outermost L2 routine
         self.profile = None   # dict: (region label, opcode) -> dynamic count, when set to {} before run()
+        self.hook = None      # profile mode: hook(opcode, args, region label, call stack) per executed instruction
+        self.stack = []       # profile mode: [(return register, callee label)] of the s_call_b64 frames that are open
         self.call_log = None  # list: labels of the L2 routines called, in order (bound certification cross-check)
         self.max_stored = 0   # largest |signed dword| written to LDS (v3: limb magnitudes of stored values)
 
@@ -212,6 +214,15 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None):
                 m.l2_stack.pop()
             top = m.l2_stack[0] if m.l2_stack else "(main)"
             m.l2_incl[top] = m.l2_incl.get(top, 0) + 1
+            if m.hook is not None:
+                m.hook(op, a, region[pc], m.stack)
+            if op == "s_call_b64":
+                tgt = a[1]
+                while prog[labels[tgt]][0] == "s_branch" and tgt.startswith("L_hop"):
+                    tgt = prog[labels[tgt]][1][0]
+                m.stack.append((a[0], tgt))
+            elif op == "s_setpc_b64" and m.stack and m.stack[-1][0] == a[0]:
+                m.stack.pop()
         pc += 1
         steps += 1
         if steps > max_steps:
