@@ -184,6 +184,16 @@ StreamCtx* stream_ctx(int device, void* stream) {
     return p.get();
 }
 
+// Scratch layout (pairing_asm_gen.h: BN254_SCRATCH_WG_CONTIGUOUS).  Contiguous per workgroup: [workgroup][slot][wave][...], the
+// workgroup pitch rounded up to 2 MiB so that a CU's 80+ slots share one or two pages (the slot-major layout put every slot of
+// a workgroup on a different 2 MiB page: 4.7 MB apart at a full grid); the kernels take the pitch as their stride argument.
+size_t scratch_slots(size_t k) { return (size_t)BN254_GSLOTS + BN254_GSLOTS_PER_PAIR * (k > 1 ? k : 0); }
+size_t scratch_pitch(size_t k, size_t grid) {
+    if (!BN254_SCRATCH_WG_CONTIGUOUS) return grid * BLOCK * SLOT_BYTES;                 // bytes between slots
+    size_t wg = scratch_slots(k) * BLOCK * SLOT_BYTES, page = (size_t)2 << 20;
+    return (wg + page - 1) / page * page;                                              // bytes between workgroups
+}
+
 struct LaunchCtx {
     std::unique_lock<std::recursive_mutex> lock;     // the stream context stays ours until the launch has been issued
     StreamCtx* s;
@@ -228,15 +238,15 @@ int ctx_get(int device, void* stream, size_t k, size_t n_items, LaunchCtx* out, 
     }
     uint32_t grid = (uint32_t)(n_items < (size_t)c.n_cu ? n_items : (size_t)c.n_cu);
     if (grid == 0) grid = 1;
-    size_t slots = BN254_GSLOTS + BN254_GSLOTS_PER_PAIR * (k > 1 ? k : 0);
-    if ((rc = ensure(sc->scratch, slots * SLOT_BYTES * (size_t)grid * BLOCK, (hipStream_t)stream))) return rc;
+    size_t pitch = scratch_pitch(k, grid);
+    if ((rc = ensure(sc->scratch, BN254_SCRATCH_WG_CONTIGUOUS ? pitch * grid : pitch * scratch_slots(k), (hipStream_t)stream))) return rc;
     out->s = sc;
     out->n_cu = c.n_cu;
     out->scratch = (uint4*)sc->scratch.p;
     out->status = sc->status;
     out->gen_table = c.gen_table;
     out->grid = grid;
-    out->stride = grid * BLOCK * (uint32_t)SLOT_BYTES;      // bytes between scratch slots
+    out->stride = (uint32_t)pitch;
     return BN254_OK;
 }
 
@@ -479,7 +489,7 @@ size_t bn254_scratch_bytes(size_t n, size_t k) {
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = (size_t)v;
     size_t grid = items < cus ? (items ? items : 1) : cus;           // persistent kernels: the grid never exceeds the CU count
     size_t kk = k > MAX_K ? MAX_K : k;                                // larger groups are walked in sub-groups of MAX_K pairs
-    return (size_t)(BN254_GSLOTS + BN254_GSLOTS_PER_PAIR * (kk > 1 ? kk : 0)) * SLOT_BYTES * grid * BLOCK;
+    return BN254_SCRATCH_WG_CONTIGUOUS ? scratch_pitch(kk, grid) * grid : scratch_pitch(kk, grid) * scratch_slots(kk);
 }
 
 int bn254_pairing_batch_dev(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n, int device, void* stream) {

@@ -55,6 +55,15 @@ def dbl_step(Rp, Pt):
     BF = add(B, F)
     Y3 = sub(sqr(BF), small(sqr(E), 12))
     Z3 = small(mul(B, H), 4)
+    # The kernels return this point scaled by xi^2 and never form E = 3 b' Z^2 (a multiplication by a full-size constant):
+    # with N = 9 Z^2, T = xi B - 3 N, S = xi B + 3 N:  xi^2 (X3, Y3, Z3) = (2 xi X Y T, S^2 - 12 N^2, 4 (xi B)(xi H))
+    # (tools/kgen4.py: L1v4.r_dblstep).  Any representative of the projective point serves the following steps.
+    N = small(C, 9)
+    xB = mul_xi(B)
+    T, S = sub(xB, small(N, 3)), add(xB, small(N, 3))
+    scaled = (small(mul_xi(mul(mul(X, Y), T)), 2), sub(sqr(S), small(sqr(N), 12)), small(mul(xB, mul_xi(H)), 4))
+    assert scaled == tuple(mul_xi(mul_xi(c)) for c in (X3, Y3, Z3))
+    X3, Y3, Z3 = scaled
     L0 = sub(mul_xi(B), small(C, 9))     # (B - E) * xi = xi*B - 9*C
     L3 = mul_fq(H, Pt[1])
     L4 = neg(mul_fq(small(XX, 3), Pt[0]))

@@ -316,23 +316,37 @@ def test_pairing_kernel_generators(vec):
     assert out == HX(vec["pairing"][0])
 
 
-def test_multi_pairing_kernel(vec):
-    """k = 2 shared-f kernel: exact multi_miller_loop_native value (tracked scale)."""
-    g = vec["groups"][0]
+def _soa(rows):
+    n = len(rows)
+    out = [0] * (len(rows[0]) * 4 * n)
+    for i, el in enumerate(rows):
+        for c, x in enumerate(el):
+            for l, w in enumerate(R.limbs4(R.to_mont(x))):
+                out[(c * 4 + l) * n + i] = w
+    return out
+
+
+def test_multi_pairing_kernel_resident_points(vec):
+    """k = 4 (the Groth16 shape) shared-f kernel, exact multi_miller_loop_native value (tracked scale).  k <= 4: the pairs'
+    evaluation points stay packed in LDS slots 0, 1, 6, 7, the stream carries R only and prefetches Q for the addition steps."""
+    g = vec["groups"][3]
     k, idx = g["k"], g["idx"]
-
-    def soa(rows):
-        n = len(rows)
-        out = [0] * (len(rows[0]) * 4 * n)
-        for i, el in enumerate(rows):
-            for c, x in enumerate(el):
-                for l, w in enumerate(R.limbs4(R.to_mont(x))):
-                    out[(c * 4 + l) * n + i] = w
-        return out
-
-    g1, g2 = soa([HX(vec["g1"][i]) for i in idx]), soa([HX(vec["g2"][i]) for i in idx])
+    assert k == 4
+    g1, g2 = _soa([HX(vec["g1"][i]) for i in idx]), _soa([HX(vec["g2"][i]) for i in idx])
     out, m = run_kernel(K4P.KernelBuilder(do_miller=True, do_fexp=False, track=True, multi=True), g1, g2, k=k)
     assert out == HX(g["miller"])
+
+
+def test_multi_pairing_kernel_streamed_points(vec):
+    """k = 5: more pairs than stay on chip -- P travels with R through the prefetch buffer, Q is fetched in the addition steps.
+    Expected value: the product of the single Miller values (the reference's own T1, miller_loop_native.rs:336-348)."""
+    idx = [1, 2, 5, 8, 11]
+    g1, g2 = _soa([HX(vec["g1"][i]) for i in idx]), _soa([HX(vec["g2"][i]) for i in idx])
+    out, m = run_kernel(K4P.KernelBuilder(do_miller=True, do_fexp=False, track=True, multi=True), g1, g2, k=len(idx))
+    want = HX(vec["miller"][idx[0]])
+    for i in idx[1:]:
+        want = R.fq12_mul(want, HX(vec["miller"][i]))
+    assert out == want
 
 
 def test_helper_kernel(vec):
@@ -440,12 +454,17 @@ def test_l1_fused_point_steps():
         E = f2m(C, three_b)
         Fv = f2k(E, 3)
         Hh = f2k(f2m(Y, Z), 2)
-        want = {"X3": f2m(f2k(f2m(X, Y), 2), f2s(Bq, Fv)), "Y3": f2s(f2m(f2a(Bq, Fv), f2a(Bq, Fv)), f2k(f2m(E, E), 12)),
-                "Z3": f2k(f2m(Bq, Hh), 4), "L0": f2s(xi(Bq), f2k(C, 9)), "L3": f2k(Hh, py), "L4": f2k(f2m(X, X), (-3 * px) % P)}
+        # the routine returns the new point scaled by xi^2 (no multiplication by the curve constant 3 b' = 9 / xi)
+        xi2 = lambda x: xi(xi(x))
+        want = {"X3": xi2(f2m(f2k(f2m(X, Y), 2), f2s(Bq, Fv))), "Y3": xi2(f2s(f2m(f2a(Bq, Fv), f2a(Bq, Fv)), f2k(f2m(E, E), 12))),
+                "Z3": xi2(f2k(f2m(Bq, Hh), 4)), "L0": f2s(xi(Bq), f2k(C, 9)), "L3": f2k(Hh, py), "L4": f2k(f2m(X, X), (-3 * px) % P)}
         where = {"X3": H_(0), "Y3": H_(1), "Z3": H_(2), "L0": H_(7), "L3": H_(4), "L4": H_(5)}
         for k_, w in want.items():
             assert get(m, where[k_]) == w, ("dblstep", t, k_)
-            assert _is_norm(m, list(range(where[k_], where[k_] + NL))) and _is_norm(m, list(range(where[k_] + NL, where[k_] + 2 * NL)))
+            if k_ != "L0":                       # L0 = xi B - N leaves as a limb-wise difference (two units)
+                assert _is_norm(m, list(range(where[k_], where[k_] + NL))) and _is_norm(m, list(range(where[k_] + NL, where[k_] + 2 * NL)))
+            if k_ in ("X3", "Y3", "Z3"):
+                assert all(abs(_sval([m.v[where[k_] + NL * h + i] for i in range(NL)])) < 0.52 * P for h in range(2)), k_
         assert m.max_acc < (1 << 63)
     for t in range(6):
         X, Y, Z, x2, y2 = [(rng.randrange(P), rng.randrange(P)) for _ in range(5)]

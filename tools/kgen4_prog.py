@@ -160,8 +160,27 @@ GLOB_TMP0 = 6 * N_GREG           # eight overflow temporaries: slots 72..79
 N_GSLOTS = GLOB_TMP0 + 8         # scratch slots of the single-pairing kernels; pair j of a multi kernel: N_GSLOTS + 7 j + ...
 GCHUNK0 = 512                    # byte offset of the first 16-byte chunk plane inside a wave's part of a scratch slot (after the tails)
 
+# timing experiments only (tools/exp/build_variant.sh; results are WRONG with any of these set): drop the streamed R stores /
+# the pair-state prefetch loads of the multi-pairing loop, to see what the memory side of the stream costs
+EXP_NO_RSTORE = bool(int(os.environ.get("KGEN_EXP_NO_RSTORE", "0")))
+EXP_NO_PREFETCH = bool(int(os.environ.get("KGEN_EXP_NO_PREFETCH", "0")))
+# Cache-policy bits of the scratch loads / stores.  Measured on the Groth16 shape (same-box A/B, profiles/r03_ab.txt): stores
+# with system scope (sc0 sc1: written through, nothing lingers in L2 for data that is re-read 100 us later) +2.4 %, "nt" +1.7 %,
+# sc0 / sc1 alone or nt + sc1 worse; any bit on the loads costs 0.3 .. 0.6 %.  Neutral on k_pairing (+0.1 %).
+SCRATCH_LD_MOD = os.environ.get("KGEN_SCRATCH_LD_MOD", "")
+SCRATCH_ST_MOD = os.environ.get("KGEN_SCRATCH_ST_MOD", "sc0 sc1")
+EXP_NO_SWAIT = bool(int(os.environ.get("KGEN_EXP_NO_SWAIT", "0")))          # no s_waitcnt at the start of a streamed step
+# The next pair's prefetch is issued slot by slot behind the first four passes of the current pair's sparse multiplication instead
+# of as one burst of 25 loads in front of the step: +1.9 % on the Groth16 shape (the four waves of a CU run in step: a burst is
+# 100 KiB-lines at once into one L1)
+SPREAD_PREFETCH = int(os.environ.get("KGEN_SPREAD_PF", "1"))
 MARKERS = bool(int(os.environ.get("KGEN_MARKERS", "0")))      # tools/instr_histogram.py: LM_* labels at the phase changes inside routines
 _marker_n = [0]
+# Scratch layout.  "slot": [slot][workgroup][wave][...] -- a workgroup's 80+ slots lie a whole grid's worth apart (4.7 MB at a
+# full grid: every slot access of a CU touches a different 2 MiB page).  "wg": [workgroup][slot][wave][...] -- all the slots
+# of a workgroup are contiguous (kernel argument %7 is then the workgroup pitch, the slot pitch a constant).
+SCRATCH_WG = os.environ.get("KGEN_SCRATCH", "wg") == "wg"
+WG_SLOT_PITCH = BLOCK_LANES_SLOT = 256 * SLOT_BYTES            # bytes of one slot of one workgroup (4 waves x 4608 B)
 ALIGN_CODE = bool(int(os.environ.get("KGEN_ALIGN", "1")))     # keep 8-byte instructions 8-byte aligned (asmcore.align_code)
 
 # ---- static bound tracking -------------------------------------------------------------------------------------------
@@ -180,6 +199,14 @@ V_REDN_AT = 4.0             # a store that has to normalise anyway reduces as we
 STORE_MAG = 2.05            # stored values may keep limbs of up to two units (sums / differences of two normalised values)
 LIMB_MAG = 6.9              # int32 limbs that `norm` may meet: |limb| + 2^28 < 2^31
 R_NORM = (-1.0, 1.0)
+
+
+def _ldm():
+    return (" " + SCRATCH_LD_MOD) if SCRATCH_LD_MOD else ""
+
+
+def _stm():
+    return (" " + SCRATCH_ST_MOD) if SCRATCH_ST_MOD else ""
 
 
 def mag(r):
@@ -319,9 +346,9 @@ class Prog:
         elif slot.kind in ("glob", "globdyn"):
             self._glob_base(slot)
             for c in range(self.N_B128):
-                e.emit(f"global_load_dwordx4 v[{blk + 4 * c}:{blk + 4 * c + 3}], v{V_GOFF}, {S_GADDR} offset:{GCHUNK0 + 1024 * c}", kind="vmem",
+                e.emit(f"global_load_dwordx4 v[{blk + 4 * c}:{blk + 4 * c + 3}], v{V_GOFF}, {S_GADDR} offset:{GCHUNK0 + 1024 * c}" + _ldm(), kind="vmem",
                        vw=range(blk + 4 * c, blk + 4 * c + 4))
-            e.emit(f"global_load_dwordx2 v[{blk + 16}:{blk + 17}], v{V_GOFF8}, {S_GADDR} offset:0", kind="vmem", vw=[blk + 16, blk + 17])
+            e.emit(f"global_load_dwordx2 v[{blk + 16}:{blk + 17}], v{V_GOFF8}, {S_GADDR} offset:0" + _ldm(), kind="vmem", vw=[blk + 16, blk + 17])
             self.vm_pending = True
         else:
             raise ValueError(slot.kind)
@@ -345,9 +372,9 @@ class Prog:
         elif slot.kind in ("glob", "globdyn"):
             self._glob_base(slot)
             for c in range(self.N_B128):
-                e.emit(f"global_store_dwordx4 v{V_GOFF}, v[{blk + 4 * c}:{blk + 4 * c + 3}], {S_GADDR} offset:{GCHUNK0 + 1024 * c}", kind="vmem",
+                e.emit(f"global_store_dwordx4 v{V_GOFF}, v[{blk + 4 * c}:{blk + 4 * c + 3}], {S_GADDR} offset:{GCHUNK0 + 1024 * c}" + _stm(), kind="vmem",
                        store=range(blk + 4 * c, blk + 4 * c + 4))
-            e.emit(f"global_store_dwordx2 v{V_GOFF8}, v[{blk + 16}:{blk + 17}], {S_GADDR} offset:0", kind="vmem", store=[blk + 16, blk + 17])
+            e.emit(f"global_store_dwordx2 v{V_GOFF8}, v[{blk + 16}:{blk + 17}], {S_GADDR} offset:0" + _stm(), kind="vmem", store=[blk + 16, blk + 17])
             e.raw("s_nop 1")        # wide-store data hazard: the next VALU write of the block may sit behind a call
         else:
             raise ValueError(slot.kind)
@@ -782,8 +809,10 @@ class Prog:
         self.release_blocks()
 
     # ================================================================ sparse multiplications (miller_loop_native.rs:46-110)
-    def mul_by_034(self, F, L0, L3, L4):
-        """f *= L0 + L3 w^3 + L4 w^4 with one reduction per output coefficient (xi folded into the line)."""
+    def mul_by_034(self, F, L0, L3, L4, between=None):
+        """f *= L0 + L3 w^3 + L4 w^4 with one reduction per output coefficient (xi folded into the line).
+        between(i): the caller's code behind pass i (the multi-pairing kernels spread their prefetch loads there)."""
+        between = between or (lambda i: None)
         self.marker("mul034")
         self.reserve_blocks(scratch=self.MUL3_SCRATCH)
         L3x, L4x = self.tmp(), self.tmp()
@@ -794,12 +823,15 @@ class Prog:
         for k, (i0, i3, i4) in enumerate(((0, 3, 2), (1, 4, 3), (2, 5, 4))):
             self.ldH(1, L3x).ldH(3, L4x).ldH(0, F[i3]).ldH(2, F[i4])
             self.A(F[i0]).mul3(L0).to(c[k])
+            between(k)
         # c3 = a3 L0 + a0 L3 + a5 xiL4   (a3 is not read again: the result goes straight to its place)
         self.ldH(1, L3).ldH(3, L4x).ldH(0, F[0]).ldH(2, F[5])
         self.A(F[3]).mul3(L0).to(F[3])
+        between(3)
         # c4 = a4 L0 + a1 L3 + a0 L4 ; c5 = a5 L0 + a2 L3 + a1 L4
         self.ldH(1, L3).ldH(3, L4).ldH(0, F[1]).ldH(2, F[0])
         self.A(F[4]).mul3(L0).to(F[4])
+        between(4)
         self.ldH(0, F[2]).ldH(2, F[1])
         self.A(F[5]).mul3(L0).to(F[5])
         for k in range(3):
@@ -807,12 +839,13 @@ class Prog:
         self.rel(L3x, L4x, *c)
         self.release_blocks()
 
-    def mul_by_235(self, F, L2, L3, L5):
+    def mul_by_235(self, F, L2, L3, L5, between=None):
         """f *= L2 w^2 + L3 w^3 + L5 w^5, same scheme.  Five temporaries (two xi-multiplied line coefficients, three results
         that wait for their place): the order below frees the places as early as possible, and the two coefficients that are
         xi times a plain sum take the xi afterwards.
             c0 = xi (a4 b2 + a3 b3 + a1 b5)   c1 = xi (a5 b2 + a4 b3 + a2 b5)   c2 = a0 b2 + xi (a5 b3 + a3 b5)
             c3 = a1 b2 + a0 b3 + xi a4 b5     c4 = a2 b2 + a1 b3 + xi a5 b5     c5 = a3 b2 + a2 b3 + a0 b5"""
+        between = between or (lambda i: None)
         self.marker("mul235")
         self.reserve_blocks(scratch=self.MUL3_SCRATCH)
         L3x, L5x = self.tmp(), self.tmp()
@@ -822,13 +855,17 @@ class Prog:
         for dst, (i2, i3, i5) in ((t0, (4, 3, 1)), (t1, (5, 4, 2))):                 # c0, c1 (reduced after the xi: they are stored)
             self.ldH(1, L3).ldH(3, L5).ldH(0, F[i3]).ldH(2, F[i5])
             self.A(F[i2]).mul3(L2).mulxi(reduce=True).to(dst)
+            between(0 if dst is t0 else 1)
         self.ldH(1, L3).ldH(3, L5x).ldH(0, F[0]).ldH(2, F[4])                        # c3: a4 has now been read by c0, c1, c3
         self.A(F[1]).mul3(L2).to(t2)
+        between(2)
         self.ldH(1, L3).ldH(3, L5x).ldH(0, F[1]).ldH(2, F[5])                        # c4 -> its place; a1 read by c0, c3, c4
         self.A(F[2]).mul3(L2).to(F[4])
+        between(3)
         self.mov(F[1], t1)
         self.ldH(1, L3x).ldH(3, L5x).ldH(0, F[5]).ldH(2, F[3])                       # c2 (into the freed temporary); a5 read by c1, c2, c4
         self.A(F[0]).mul3(L2).to(t1)
+        between(4)
         self.ldH(1, L3).ldH(3, L5).ldH(0, F[2]).ldH(2, F[0])                         # c5 -> its place
         self.A(F[3]).mul3(L2).to(F[5])
         self.mov(F[0], t0)
@@ -869,17 +906,28 @@ class Prog:
             vs.append(self.v_of(s_))
         return max(vs)
 
-    def _step_out(self, k, dst, v):
-        """dst <- home block k (a normalised result of value bound v)"""
+    def _step_out(self, k, dst, v, limbs=1.0):
+        """dst <- home block k (a result of value bound v; normalised, or with limbs of up to `limbs` units)"""
         self._need(v <= self.v_limit(dst) and v <= V_CAP, f"fused step result {dst}: {v} p")
-        self.store(HOME0 + SLOT_DW * k, dst)
-        self.slot_r[self.key(dst)] = self.r_norm(v)
+        self._need(limbs <= (1.0 if self.key(dst) in self.norm_keys else STORE_MAG), f"fused step result {dst}: limbs of {limbs} units")
+        if not (EXP_NO_RSTORE and dst.kind == "globdyn"):
+            self.store(HOME0 + SLOT_DW * k, dst)
+        self.slot_r[self.key(dst)] = self.r_norm(v) if limbs <= 1.0 else (-max(limbs, v / K_TOP), max(limbs, v / K_TOP))
         self.slot_v[self.key(dst)] = v
         self.max_v = max(self.max_v, v)
 
-    def _dbl_step_fused(self, R, Pt, line, out=None, after_load=None):
+    def _load_point_p(self, Pt, load_p):
+        """block B <- (Px limbs, Py limbs) of the evaluation point; load_p: the caller's own code for it (multi-pairing kernels)"""
+        if load_p is None:
+            return max(self._load_fq(B0, Pt[0]), self._load_fq(B0 + NL, Pt[1]))
+        for s_ in Pt:
+            self._need(mag(self.r_of(s_)) <= 1.0, f"{s_} is not normalised")
+        load_p(self)
+        return max(self.v_of(Pt[0]), self.v_of(Pt[1]))
+
+    def _dbl_step_fused(self, R, Pt, line, out=None, after_load=None, load_p=None):
         v = self._step_in(R)
-        vp = max(self._load_fq(B0, Pt[0]), self._load_fq(B0 + NL, Pt[1]))
+        vp = self._load_point_p(Pt, load_p)
         self.tagA = self.tagB = None
         if after_load:
             self.wait()
@@ -888,23 +936,33 @@ class Prog:
         self.marker("dblstep")
         self._raw_call("dblstep")
         self.marker("stepout")
+        # transfer function of L1v4.r_dblstep (the xi^2-scaled doubling): B = Y^2, N = 9 Z^2, H = 2 Y Z, T / S = xi B -+ 3 N
         sq = lambda x: 4 * x * x / K_RP + 0.5
         ml = lambda x, y: 2 * x * y / K_RP + 0.5
         bq = c = sq(v)
         hh = sq(2 * v) + bq + c
-        e_ = ml(c, 1.0)
-        fv = 3 * e_
-        self._step_out(0, R[0], ml(2 * ml(v, v), bq + fv))
+        xb, xh, n = 10 * bq, 10 * hh, 9 * c
+        t_ = xb + 3 * n
+        self._need(max(xb, xh, t_) <= V_CAP, f"dblstep operand values {xb} {xh} {t_}")
+        self._need(max(4 * ml(xb, xh), 20 * ml(ml(v, v), t_), sq(t_) + 12 * sq(n)) <= 8 * V_CAP, "dblstep: values in front of the reducing chains")
+        self._step_out(0, R[0], 0.51)
         self._step_out(1, R[1], 0.51)
-        self._step_out(2, R[2], 4 * ml(bq, hh))
-        self._step_out(7, line[0], 10 * bq + 9 * c)
+        self._step_out(2, R[2], 0.51)
+        self._step_out(7, line[0], xb + n, limbs=2.0)
         self._step_out(4, line[1], hh * vp / K_RP + 0.5)
         self._step_out(5, line[2], 3 * sq(v) * vp / K_RP + 0.5)
         self.wait()
 
-    def _add_step_fused(self, R, Q, Pt, line, out=None, after_load=None):
-        v = self._step_in(list(R) + list(Q))
-        vp = max(self._load_fq(B0, Pt[0]), self._load_fq(B0 + NL, Pt[1]))
+    def _add_step_fused(self, R, Q, Pt, line, out=None, after_load=None, load_p=None, load_q=None):
+        if load_q is None:
+            v = self._step_in(list(R) + list(Q))
+        else:                       # home blocks 3, 4 <- (x2, y2) by the caller's own code
+            v = self._step_in(list(R))
+            for s_ in Q:
+                self._need(mag(self.r_of(s_)) <= 1.0, f"fused step operand {s_} is not normalised")
+                v = max(v, self.v_of(s_))
+            load_q(self)
+        vp = self._load_point_p(Pt, load_p)
         self.tagA = self.tagB = None
         if after_load:
             self.wait()
@@ -929,7 +987,7 @@ class Prog:
         self._step_out(8, line[1], th * vp / K_RP + 0.5)
         self.wait()
 
-    def dbl_step(self, R, Pt, line, scale=None, out=None, after_load=None):
+    def dbl_step(self, R, Pt, line, scale=None, out=None, after_load=None, load_p=None):
         """R=(X,Y,Z) <- 2R ; line = (L0, L3, L4) of the tangent at the old R evaluated at P (Pt = (PX, PY) slots, scalar in c0).
         scale: slot of the running line scale s <- s * Z^2 (the caller squares it with f)."""
         X, Y, Z = R
@@ -937,8 +995,8 @@ class Prog:
         if self._fused_ok():
             if scale is not None:
                 self.A(Z).sqr().mul(scale).to(scale)
-            return self._dbl_step_fused(R, Pt, line, out, after_load)
-        assert out is None and after_load is None
+            return self._dbl_step_fused(R, Pt, line, out, after_load, load_p)
+        assert out is None and after_load is None and load_p is None
         Bq, C, E, Fv, H, T = [self.tmp() for _ in range(6)]
         self.A(Y).sqr().to(Bq)
         self.A(Z).sqr().to(C)
@@ -962,7 +1020,7 @@ class Prog:
         self.A(Bq).mul(H).scale(4).to(Z)
         self.rel(Bq, C, E, Fv, H, T)
 
-    def add_step(self, R, Q, Pt, line, scale=None, update=True, out=None, after_load=None):
+    def add_step(self, R, Q, Pt, line, scale=None, update=True, out=None, after_load=None, load_p=None, load_q=None):
         """R <- R + Q (Q = (x2, y2) affine slots); line = (L2, L3, L5) of the chord through old R and Q at P."""
         X, Y, Z = R
         x2, y2 = Q
@@ -970,8 +1028,8 @@ class Prog:
         if update and self._fused_ok():
             if scale is not None:
                 self.A(scale).mul(Z).to(scale)
-            return self._add_step_fused(R, Q, Pt, line, out, after_load)
-        assert out is None and after_load is None
+            return self._add_step_fused(R, Q, Pt, line, out, after_load, load_p, load_q)
+        assert out is None and after_load is None and load_p is None and load_q is None
         th, mu, T, U = [self.tmp() for _ in range(4)]
         if scale is not None:
             self.A(scale).mul(Z).to(scale)
@@ -1035,7 +1093,7 @@ class _PhaseList(list):
 class KernelBuilder:
     """Assembles one kernel blob.  Operand order of the asm statement (all inputs):
        %0 g1 (s64)  %1 g2 (s64)  %2 f_in (s64)  %3 out (s64)  %4 n (s32)  %5 k (s32)  %6 scratch (s64)
-       %7 scratch slot stride in bytes (s32)  %8 status (s64)  %9 tid (v32)  %10 block id (s32)  %11 grid size (s32)"""
+       %7 scratch pitch in bytes (s32): between the workgroups' blocks (layout "wg") / between slots (layout "slot")  %8 status (s64)  %9 tid (v32)  %10 block id (s32)  %11 grid size (s32)"""
 
     # slot map -------------------------------------------------------------------------------------
     # The Miller loop touches the Fq12 accumulator f in every routine (18 + 6 slot accesses per sparse multiplication): there
@@ -1436,9 +1494,9 @@ class KernelBuilder:
             e.salu("s_addc_u32 s63, s65, 0")
             for c in range(Prog.N_B128):
                 r = land[n] + 4 * c
-                e.emit(f"global_load_dwordx4 v[{r}:{r + 3}], v{V_GOFF}, {S_GADDR} offset:{GCHUNK0 + 1024 * c}", kind="vmem", vw=range(r, r + 4))
+                e.emit(f"global_load_dwordx4 v[{r}:{r + 3}], v{V_GOFF}, {S_GADDR} offset:{GCHUNK0 + 1024 * c}" + _ldm(), kind="vmem", vw=range(r, r + 4))
             r = land[n] + 16
-            e.emit(f"global_load_dwordx2 v[{r}:{r + 1}], v{V_GOFF8}, {S_GADDR} offset:0", kind="vmem", vw=[r, r + 1])
+            e.emit(f"global_load_dwordx2 v[{r}:{r + 1}], v{V_GOFF8}, {S_GADDR} offset:0" + _ldm(), kind="vmem", vw=[r, r + 1])
         e.raw("s_waitcnt vmcnt(0)")
         for n, d in enumerate(dests):
             p.store(land[n], d) if d.kind != "home" or HOME0 + SLOT_DW * d.idx != land[n] else None
@@ -1458,8 +1516,8 @@ class KernelBuilder:
             e.salu(f"s_add_u32 s62, s64, s{S_TMP0}")
             e.salu("s_addc_u32 s63, s65, 0")
             for c in range(Prog.N_B128):
-                e.emit(f"global_load_dwordx4 a[{a0 + 4 * c}:{a0 + 4 * c + 3}], v{V_GOFF}, {S_GADDR} offset:{GCHUNK0 + 1024 * c}", kind="vmem")
-            e.emit(f"global_load_dwordx2 a[{a0 + 16}:{a0 + 17}], v{V_GOFF8}, {S_GADDR} offset:0", kind="vmem")
+                e.emit(f"global_load_dwordx4 a[{a0 + 4 * c}:{a0 + 4 * c + 3}], v{V_GOFF}, {S_GADDR} offset:{GCHUNK0 + 1024 * c}" + _ldm(), kind="vmem")
+            e.emit(f"global_load_dwordx2 a[{a0 + 16}:{a0 + 17}], v{V_GOFF8}, {S_GADDR} offset:0" + _ldm(), kind="vmem")
             p.slot_r.pop(p.key(dst), None)
             p.slot_v.pop(p.key(dst), None)
 
@@ -1507,12 +1565,12 @@ class KernelBuilder:
         e.salu(f"s_mov_b64 {S_OUT}, %3")
         e.salu(f"s_mov_b32 s{S_N}, %4")
         e.salu(f"s_mov_b32 s{S_K}, %5")
-        e.salu(f"s_mov_b32 s{S_GSTRIDE}, %7")
+        e.salu(f"s_mov_b32 s{S_GSTRIDE}, " + (f"{WG_SLOT_PITCH}" if SCRATCH_WG else "%7"))
         e.salu(f"s_mov_b64 {S_STATUS}, %8")
         e.salu(f"s_mov_b32 s{S_ITEM}, %10")
         e.salu(f"s_mov_b32 s{S_GRID}, %11")
         # scratch base of this workgroup: scratch + block * 256 * 72 ; lane offset = tid * 72
-        e.salu(f"s_mul_i32 s{S_TMP0}, %10, {BLOCK * SLOT_BYTES}")
+        e.salu(f"s_mul_i32 s{S_TMP0}, %10, " + ("%7" if SCRATCH_WG else f"{BLOCK * SLOT_BYTES}"))
         e.salu(f"s_mov_b64 {S_SCRATCH}, %6")
         e.salu(f"s_add_u32 s64, s64, s{S_TMP0}")
         e.salu("s_addc_u32 s65, s65, 0")
@@ -2057,6 +2115,11 @@ class KernelBuilder:
             self.pair_out(e, p)
 
         self.pair_loop(e, "first", first_step)
+        # resident-P mode: the evaluation points move into the LDS slots the one-pair routines above no longer need
+        e.salu(f"s_cmp_le_u32 s{S_K}, {self.RES_K}")
+        e.salu(f"s_cbranch_scc0 {L('L_mf_nopack')}")
+        self.pair_loop(e, "pack", lambda: self._emit_pack_p(e, p))
+        e.label(L("L_mf_nopack"))
         e.salu(f"s_mul_i32 s{self.S_GNEXT}, s{S_GSTRIDE}, {self.PAIR_SLOT0}")      # prime the stream: pair 0
         self.call2(e, "L2_prefetch")
         e.salu(f"s_mov_b32 s{S_I}, 63")
@@ -2253,27 +2316,106 @@ class KernelBuilder:
     # ---------------------------------------------------------------------------------------------
     # multi-pairing main loop: STREAMED pair state.  The k pairs of a group share f, so their points take turns; their
     # state (P, Q, R) lives in scratch.  Swapping it through resident slots (load, wait, compute, store) leaves the global
-    # latency exposed twice per pair and step -- 14 % of the Groth16-shape kernel's time.  Instead the NEXT pair's P and R are
+    # latency exposed twice per pair and step -- 14 % of the Groth16-shape kernel's time.  Instead the NEXT pair's state is
     # fetched straight into five AGPR slots (global loads can target AGPRs, no VGPR is needed) while the current pair's step
     # and its sparse multiplication run; the fused step reads its operands from that buffer and writes the new R from its
-    # register blocks straight back to scratch.  (Q is only needed by the 27 addition steps: fetched synchronously there.)
+    # register blocks straight back to scratch.
+    #   * k > RES_K: the buffer takes P and R of the next pair; Q (needed by the 27 addition steps only) is fetched
+    #     synchronously there.
+    #   * k <= RES_K (the Groth16 shape, k = 4): P never changes, so every pair's (Px, Py) sits packed in ONE slot of the four
+    #     LDS slots that are idle during the loop (the resident Q and R slots of the one-pair routines): the stream carries R only
+    #     (3 slots in, 3 out per step instead of 5 + 3), and the two freed buffer slots take the next pair's Q whenever the next
+    #     step is an addition -- nothing is fetched synchronously any more.
     S_GNEXT = 49               # byte offset of the NEXT pair's scratch block
+    RES_K = 4                  # largest k whose evaluation points stay on chip
+    RES_P_LDS = (0, 1, 6, 7)   # LDS slot of pair j's packed (Px, Py)
 
     @property
     def BUF(self):
         return {"PX": AGPR(10, "bPX"), "PY": AGPR(11, "bPY"), "RX": AGPR(12, "bRX"), "RY": AGPR(13, "bRY"), "RZ": AGPR(9, "bRZ")}
 
-    def _emit_prefetch(self, e):
-        """buffer <- {PX, PY, RX, RY, RZ} of the pair whose scratch block starts at S_GNEXT; nobody waits here"""
-        for name, k in (("PX", 0), ("PY", 1), ("RX", 4), ("RY", 5), ("RZ", 6)):
+    def _emit_buf_loads(self, e, pairs):
+        """buffer slot <- scratch slot k of the pair whose block starts at S_GNEXT, for (buffer name, k) in pairs; nobody waits"""
+        for name, k in pairs:
+            if EXP_NO_PREFETCH:
+                break
             a0 = SLOT_DW * self.BUF[name].idx
             e.salu(f"s_mul_i32 s{S_TMP0}, s{S_GSTRIDE}, {k}")
             e.salu(f"s_add_u32 s{S_TMP0}, s{S_TMP0}, s{self.S_GNEXT}")
             e.salu(f"s_add_u32 s62, s64, s{S_TMP0}")
             e.salu("s_addc_u32 s63, s65, 0")
             for c in range(Prog.N_B128):
-                e.emit(f"global_load_dwordx4 a[{a0 + 4 * c}:{a0 + 4 * c + 3}], v{V_GOFF}, {S_GADDR} offset:{GCHUNK0 + 1024 * c}", kind="vmem")
-            e.emit(f"global_load_dwordx2 a[{a0 + 16}:{a0 + 17}], v{V_GOFF8}, {S_GADDR} offset:0", kind="vmem")
+                e.emit(f"global_load_dwordx4 a[{a0 + 4 * c}:{a0 + 4 * c + 3}], v{V_GOFF}, {S_GADDR} offset:{GCHUNK0 + 1024 * c}" + _ldm(), kind="vmem")
+            e.emit(f"global_load_dwordx2 a[{a0 + 16}:{a0 + 17}], v{V_GOFF8}, {S_GADDR} offset:0" + _ldm(), kind="vmem")
+
+    def _emit_prefetch_part(self, e, part, q):
+        """the prefetch, slot group by slot group (KGEN_SPREAD_PF): part 0..2 = RX, RY, RZ; part 3 = P or Q (as _emit_prefetch)"""
+        L = self.lab
+        if part < 3:
+            self._emit_buf_loads(e, ((("RX", 4), ("RY", 5), ("RZ", 6))[part],))
+            return
+        u = self.uid()
+        e.salu(f"s_cmp_le_u32 s{S_K}, {self.RES_K}")
+        e.salu(f"s_cbranch_scc1 {L(f'L_pf_res_{u}')}")
+        self._emit_buf_loads(e, (("PX", 0), ("PY", 1)))
+        e.salu(f"s_branch {L(f'L_pf_done_{u}')}")
+        e.label(L(f"L_pf_res_{u}"))
+        if q == "last":
+            e.salu(f"s_add_u32 s{S_TMP0}, s{S_JP}, 1")
+            e.salu(f"s_cmp_lt_u32 s{S_TMP0}, s{S_K}")
+            e.salu(f"s_cbranch_scc1 {L(f'L_pf_done_{u}')}")
+            e.salu(f"s_bitcmp1_b64 {S_NAF_NZ}, s{S_I}")
+            e.salu(f"s_cbranch_scc0 {L(f'L_pf_done_{u}')}")
+        self._emit_buf_loads(e, (("PX", 2), ("PY", 3)))
+        e.label(L(f"L_pf_done_{u}"))
+
+    def _emit_prefetch(self, e, q="always"):
+        """buffer <- state of the pair whose scratch block starts at S_GNEXT (R; P or -- resident-P mode -- Q); nobody waits here.
+        q: when the resident-P mode also fetches Q: "always", or "last" = only behind the LAST pair's doubling step of an iteration
+        whose digit is non-zero (the next step is then pair 0's addition step)."""
+        L = self.lab
+        u = self.uid()
+        self._emit_buf_loads(e, (("RX", 4), ("RY", 5), ("RZ", 6)))
+        e.salu(f"s_cmp_le_u32 s{S_K}, {self.RES_K}")
+        e.salu(f"s_cbranch_scc1 {L(f'L_pf_res_{u}')}")
+        self._emit_buf_loads(e, (("PX", 0), ("PY", 1)))
+        e.salu(f"s_branch {L(f'L_pf_done_{u}')}")
+        e.label(L(f"L_pf_res_{u}"))
+        if q == "last":
+            e.salu(f"s_add_u32 s{S_TMP0}, s{S_JP}, 1")
+            e.salu(f"s_cmp_lt_u32 s{S_TMP0}, s{S_K}")
+            e.salu(f"s_cbranch_scc1 {L(f'L_pf_done_{u}')}")           # not the last pair: a doubling step follows
+            e.salu(f"s_bitcmp1_b64 {S_NAF_NZ}, s{S_I}")
+            e.salu(f"s_cbranch_scc0 {L(f'L_pf_done_{u}')}")           # zero digit: a doubling step follows
+        self._emit_buf_loads(e, (("PX", 2), ("PY", 3)))               # the freed P slots take (x2, y2)
+        e.label(L(f"L_pf_done_{u}"))
+
+    def _res_p_addr(self, e, v_chunks, v_tail):
+        """v_chunks / v_tail <- LDS byte addresses (16-byte chunk plane 0, tail plane) of the packed P of pair S_JP"""
+        a, b, c, d = self.RES_P_LDS
+        assert (a, b) == (0, 1) and d == c + 1, "slot(j) = j for j < 2, j + c - 2 above"
+        e.salu(f"s_cmp_ge_u32 s{S_JP}, 2")
+        e.salu(f"s_cselect_b32 s{S_TMP0}, {c - 2}, 0")
+        e.salu(f"s_add_u32 s{S_TMP0}, s{S_TMP0}, s{S_JP}")
+        e.salu(f"s_lshl_b32 s{S_TMP1}, s{S_TMP0}, {(Prog.N_B128 * 4096).bit_length() - 1}")       # [slot][chunk][lane] uint4: 16 KiB per slot
+        e.emit(f"v_add_u32_e32 v{v_chunks}, s{S_TMP1}, v{V_LDS}", vw=[v_chunks])
+        e.salu(f"s_lshl_b32 s{S_TMP1}, s{S_TMP0}, 11")                                            # tails: 2 KiB per slot
+        e.emit(f"v_add_u32_e32 v{v_tail}, s{S_TMP1}, v{V_LTAIL}", vw=[v_tail])
+
+    def _emit_pack_p(self, e, p):
+        """resident-P mode: LDS slot of pair S_JP <- (Px, Py) packed into one slot (S_GBASE = the pair's scratch block)"""
+        p.reset_tags()
+        p.load(A0, GlobDyn(0))
+        p.load(B0, GlobDyn(1))
+        p.wait()
+        for i in range(NL):
+            e.emit(f"v_mov_b32_e32 v{A0 + NL + i}, v{B0 + i}", vw=[A0 + NL + i])
+        va, vt = B0, B0 + 1                                   # (block B is dead now)
+        self._res_p_addr(e, va, vt)
+        for c in range(Prog.N_B128):
+            e.emit(f"ds_write_b128 v{va}, v[{A0 + 4 * c}:{A0 + 4 * c + 3}] offset:{4096 * c}", kind="lds")
+        e.emit(f"ds_write_b64 v{vt}, v[{A0 + 16}:{A0 + 17}]", kind="lds")
+        p.reset_tags()
 
     def _stream_routines(self, sc):
         buf = self.BUF
@@ -2282,14 +2424,56 @@ class KernelBuilder:
         temps = [HOME(i) for i in range(N_HOME)] + self.MILLER_FREE[1] + [GLOB(GLOB_TMP0 + i) for i in range(8)]
         L = self.lab
 
+        def load_p(p):
+            """block B <- (Px, Py): from the buffer, or -- resident-P mode -- from the pair's packed LDS slot"""
+            e = p.e
+            u = self.uid()
+            e.salu(f"s_cmp_le_u32 s{S_K}, {self.RES_K}")
+            e.salu(f"s_cbranch_scc1 {L(f'L_lp_res_{u}')}")
+            p._load_fq(B0, Pb[0])
+            p._load_fq(B0 + NL, Pb[1])
+            e.salu(f"s_branch {L(f'L_lp_done_{u}')}")
+            e.label(L(f"L_lp_res_{u}"))
+            va, vt = A0, A0 + 1                               # block A is free until the step itself
+            self._res_p_addr(e, va, vt)
+            for c in range(Prog.N_B128):
+                e.emit(f"ds_read_b128 v[{B0 + 4 * c}:{B0 + 4 * c + 3}], v{va} offset:{4096 * c}", kind="lds", vw=range(B0 + 4 * c, B0 + 4 * c + 4))
+            e.emit(f"ds_read_b64 v[{B0 + 16}:{B0 + 17}], v{vt}", kind="lds", vw=[B0 + 16, B0 + 17])
+            e.raw("s_waitcnt lgkmcnt(0)")
+            e.label(L(f"L_lp_done_{u}"))
+
+        def load_q(p):
+            """home blocks 3, 4 <- (x2, y2): the prefetched copy (resident-P mode) or synchronously from the pair's scratch block"""
+            e = p.e
+            u = self.uid()
+            e.salu(f"s_cmp_le_u32 s{S_K}, {self.RES_K}")
+            e.salu(f"s_cbranch_scc1 {L(f'L_lq_res_{u}')}")
+            p.load(HOME0 + SLOT_DW * 3, GlobDyn(2))
+            p.load(HOME0 + SLOT_DW * 4, GlobDyn(3))
+            p.wait()
+            e.salu(f"s_branch {L(f'L_lq_done_{u}')}")
+            e.label(L(f"L_lq_res_{u}"))
+            p.load(HOME0 + SLOT_DW * 3, Pb[0])
+            p.load(HOME0 + SLOT_DW * 4, Pb[1])
+            e.label(L(f"L_lq_done_{u}"))
+
+        def spread(p, q):
+            def between(i):
+                if i < 4:
+                    p.wait()
+                    self._emit_prefetch_part(p.e, i, q)
+            return between if SPREAD_PREFETCH else None
+
         def dbl_s(p):
-            p.e.raw("s_waitcnt vmcnt(0)")                       # the prefetch of this pair has landed
-            p.dbl_step(Rb, Pb, self.LINE, scale=sc, out=Rout, after_load=lambda: self._emit_prefetch(p.e))
-            p.mul_by_034(self.F, *self.LINE)
+            if not EXP_NO_SWAIT:
+                p.e.raw("s_waitcnt vmcnt(0)")                   # the prefetch of this pair has landed
+            p.dbl_step(Rb, Pb, self.LINE, scale=sc, out=Rout, after_load=(None if SPREAD_PREFETCH else lambda: self._emit_prefetch(p.e, q="last")), load_p=load_p)
+            p.mul_by_034(self.F, *self.LINE, between=spread(p, "last"))
 
         def add_s(p):
             e = p.e
-            e.raw("s_waitcnt vmcnt(0)")
+            if not EXP_NO_SWAIT:
+                e.raw("s_waitcnt vmcnt(0)")
 
             def after():
                 # S = +-Q by the sign of the current digit: y2 sits in home block 4
@@ -2299,13 +2483,14 @@ class KernelBuilder:
                     r = HOME0 + SLOT_DW * 4 + i
                     e.emit(f"v_sub_u32_e32 v{r}, 0, v{r}", vw=[r])
                 e.label(L("L_as_pos"))
-                self._emit_prefetch(e)
-            p.add_step(Rb, (GlobDyn(2), GlobDyn(3)), Pb, self.LINE, scale=sc, out=Rout, after_load=after)
-            p.mul_by_235(self.F, *self.LINE)
+                if not SPREAD_PREFETCH:
+                    self._emit_prefetch(e, q="always")
+            p.add_step(Rb, (GlobDyn(2), GlobDyn(3)), Pb, self.LINE, scale=sc, out=Rout, after_load=after, load_p=load_p, load_q=load_q)
+            p.mul_by_235(self.F, *self.LINE, between=spread(p, "always"))
 
         self.l2_routine("L2_dblmul_s", dbl_s, temps, local=self.LINE)
         self.l2_routine("L2_addmul_s", add_s, temps, local=self.LINE)
-        self.l2_routine("L2_prefetch", lambda p: self._emit_prefetch(p.e), temps)
+        self.l2_routine("L2_prefetch", lambda p: self._emit_prefetch(p.e, q="always"), temps)
 
     def pair_select_next(self, e):
         """S_GNEXT <- byte offset of the scratch block of pair (S_JP + 1) mod k"""
