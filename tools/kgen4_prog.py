@@ -169,6 +169,7 @@ EXP_NO_PREFETCH = bool(int(os.environ.get("KGEN_EXP_NO_PREFETCH", "0")))
 # sc0 / sc1 alone or nt + sc1 worse; any bit on the loads costs 0.3 .. 0.6 %.  Neutral on k_pairing (+0.1 %).
 SCRATCH_LD_MOD = os.environ.get("KGEN_SCRATCH_LD_MOD", "")
 SCRATCH_ST_MOD = os.environ.get("KGEN_SCRATCH_ST_MOD", "sc0 sc1")
+EXP_NO_SCRATCH = bool(int(os.environ.get("KGEN_EXP_NO_SCRATCH", "0")))      # TIMING ONLY: no scratch load / store is emitted at all
 EXP_NO_SWAIT = bool(int(os.environ.get("KGEN_EXP_NO_SWAIT", "0")))          # no s_waitcnt at the start of a streamed step
 # The next pair's prefetch is issued slot by slot behind the first four passes of the current pair's sparse multiplication instead
 # of as one burst of 25 loads in front of the step: +1.9 % on the Groth16 shape (the four waves of a CU run in step: a burst is
@@ -343,6 +344,8 @@ class Prog:
             w = bal_limbs(mont4(slot.c0)) + bal_limbs(mont4(slot.c1))
             for i in range(SLOT_DW):
                 e.emit(f"v_mov_b32_e32 v{blk + i}, {hx(w[i])}", vw=[blk + i])
+        elif slot.kind in ("glob", "globdyn") and EXP_NO_SCRATCH:
+            pass
         elif slot.kind in ("glob", "globdyn"):
             self._glob_base(slot)
             for c in range(self.N_B128):
@@ -369,6 +372,8 @@ class Prog:
         elif slot.kind == "agpr":
             for i in range(SLOT_DW):
                 e.emit(f"v_accvgpr_write_b32 a{SLOT_DW * slot.idx + i}, v{blk + i}")
+        elif slot.kind in ("glob", "globdyn") and EXP_NO_SCRATCH:
+            pass
         elif slot.kind in ("glob", "globdyn"):
             self._glob_base(slot)
             for c in range(self.N_B128):
@@ -733,28 +738,38 @@ class Prog:
         self.rel(V0, V1, V2, S)
 
     def fq12_mul(self, F, Bs, conj_b=False):
-        """F <- F * B (Karatsuba over Fq6) on the fused Fq6 multiplication: the sums of the third product are formed while
-        its operands are loaded and its results are combined straight from the registers (B is not modified)."""
+        """F <- F * B (Karatsuba over Fq6: T0 = A0 B0, T1 = A1 B1, M = (A0 + A1)(B0 + B1)) on the fused Fq6 multiplication; B is
+        not modified.  THREE temporaries: M is formed first (its sums while the operands are loaded); T0 then goes straight to
+        the places of A0 -- dead from there on -- and leaves M; T1 completes both halves from the registers:
+            F0 = T0.0 + xi T1.2   F2 = T0.1 + T1.0   F4 = T0.2 + T1.1        F1, F3, F5 = M - T0 - T1
+        (Six temporaries -- T0 and T1 held until the end -- cost the final exponentiation its last free on-chip slots: with three,
+        the eight LDS slots hold a whole Fq12 register next to f and the multiplication operand.)"""
         if conj_b:
             for k in (1, 3, 5):
                 self.A(Bs[k]).neg().to(Bs[k])
         A_0, A_1 = [F[0], F[2], F[4]], [F[1], F[3], F[5]]
         B_0, B_1 = [Bs[0], Bs[2], Bs[4]], [Bs[1], Bs[3], Bs[5]]
-        T0 = [self.tmp() for _ in range(3)]
-        T1 = [self.tmp() for _ in range(3)]
+        M = [self.tmp() for _ in range(3)]
         assert self.homes_free, "fq12_mul runs on the fused Fq6 multiplication (home blocks 0..7 must be free)"
-        if True:
-            self.fq6_mul(A_0, B_0, T0)
-            self.fq6_mul(A_1, B_1, T1)
-            M = self._mul6_regs(A_0, B_0, A_1, B_1)               # (A0 + A1)(B0 + B1)
-            self.sub(T0[2]).sub(T1[2]).to(F[5])                   # c2 is in block A
-            self.A(M[0]).sub(T0[0]).sub(T1[0]).to(F[1])
-            self.A(M[1]).sub(T0[1]).sub(T1[1]).to(F[3])
-        self.A(T1[2]).mulxi().add(T0[0]).to(F[0])
-        self.A(T0[1]).add(T1[0]).to(F[2])
-        self.A(T0[2]).add(T1[1]).to(F[4])
-        self.rel(*T0)
-        self.rel(*T1)
+        res = self._mul6_regs(A_0, B_0, A_1, B_1)                 # (A0 + A1)(B0 + B1): c2 in block A
+        self.to(M[2])
+        self.A(res[0]).to(M[0])
+        self.A(res[1]).to(M[1])
+        res = self._mul6_regs(A_0, B_0)                           # T0; A0 = F0, F2, F4 is dead now
+        self.to(F[4]).rsub(M[2]).to(M[2])                         # F4 <- T0.2 ; M.2 -= T0.2
+        self.A(res[0]).to(F[0])
+        self.A(M[0]).sub(res[0]).to(M[0])
+        self.A(res[1]).to(F[2])
+        self.A(M[1]).sub(res[1]).to(M[1])
+        res = self._mul6_regs(A_1, B_1)                           # T1; A1 = F1, F3, F5 is dead now
+        self.to(F[5])                                             # T1.2 parked in the place it finally leaves through
+        self.mulxi().add(F[0]).to(F[0])
+        self.A(M[2]).sub(F[5]).to(F[5])
+        self.A(res[0]).add(F[2]).to(F[2])
+        self.A(M[0]).sub(res[0]).to(F[1])
+        self.A(res[1]).add(F[4]).to(F[4])
+        self.A(M[1]).sub(res[1]).to(F[3])
+        self.rel(*M)
 
     def fq12_sqr(self, F):
         """F <- F^2 (complex squaring over Fq6: t = A0 A1, u = (A0 + A1)(A0 + v A1))."""
@@ -1167,7 +1182,7 @@ class KernelBuilder:
         """Slots that hold normalised values on every routine boundary of `phase` (Prog.norm_keys)."""
         keys = [Prog.key(s_) for s_ in self.F]
         if phase == "fexp":
-            keys += [Prog.key(s_) for s_ in self.BOP] + [("globdyn", i) for i in range(6)]
+            keys += [Prog.key(s_) for s_ in self.BOP] + [Prog.key(s_) for s_ in self.LREG] + [("globdyn", i) for i in range(6)]
         else:       # the point state of the Miller loop (and its per-pair copies in scratch): operands of the fused steps
             keys += [Prog.key(s_) for s_ in (*self.R, self.QX, self.QY, self.PX, self.PY, self.SX, self.SY)]
             keys += [("globdyn", i) for i in range(7)]
@@ -1214,11 +1229,18 @@ class KernelBuilder:
         return (homes + fa + ([] if self.track else ([self.SCALE] if self.SCALE.kind == "agpr" else [])) + list(extra) + fl
                 + ([] if self.track or self.SCALE.kind == "agpr" else [self.SCALE]) + [GLOB(GLOB_TMP0 + i) for i in range(8)])
 
-    def fexp_temps(self, no_homes=False):
+    # An on-chip Fq12 register of the final exponentiation: six of the eight LDS slots (free there since fq12_mul works with three
+    # temporaries -- home block 8, AGPR 13 and, outside the inversion, AGPR 9).  It holds conj(b^13) during an x-power (half of the
+    # twelve digit multiplications use it: no operand fetch) and T0 during the y-chain.
+    LREG = [LDS(i, f"L{i - 2}") for i in range(2, 8)]
+
+    def fexp_temps(self, no_homes=False, lds=False):
+        """lds: the LDS slots as temporaries -- only for the routines of the easy part (inversion), which run before the on-chip
+        register LREG is live."""
         # fastest first: home registers, then AGPR slots (72 cycles either way), then LDS (a slot store costs 130-270 cycles)
         homes = [HOME(8)] if no_homes else [HOME(i) for i in range(N_HOME)]
         if self.F_IN_AGPR and self.F_AGPR_FEXP:      # f: AGPR 0..5, the multiplication operand: AGPR 6..8, 10..12 (9: the Fq-inversion base)
-            return homes + [AGPR(13)] + [LDS(i) for i in range(N_LDS_SLOTS)] + [GLOB(GLOB_TMP0 + i) for i in range(8)]
+            return homes + [AGPR(13)] + ([LDS(i) for i in range(N_LDS_SLOTS)] if lds else []) + [GLOB(GLOB_TMP0 + i) for i in range(8)]
         return homes + [AGPR(i) for i in (6, 7, 8, 10, 11, 12, 13)] + [LDS(6), LDS(7)] + [GLOB(GLOB_TMP0 + i) for i in range(8)]
 
     # ---------------------------------------------------------------------------------------------
@@ -1275,13 +1297,15 @@ class KernelBuilder:
         self._phase = "fexp"
         if self.do_fexp:
             if not (self.do_miller and self.track):
-                self.l2_routine("L2_fqinv", self._fq_inv, self.fexp_temps())
+                self.l2_routine("L2_fqinv", self._fq_inv, self.fexp_temps(lds=True))
             self.l2_routine("L2_cyc", lambda p: p.fq12_cyc_sqr(self.F), self.fexp_temps())
             self.l2_routine("L2_redF", self._reduce_f, self.fexp_temps())
             self._mulG_routines()
             for k in (1, 2, 3):
                 self.l2_routine(f"L2_frob{k}", lambda p, k=k: self._frobenius(p, k), self.fexp_temps())
-            self.l2_routine("L2_inv", self._fq12_inv, self.fexp_temps())
+            self.l2_routine("L2_inv", self._fq12_inv, self.fexp_temps(lds=True))
+            self.l2_routine("L2_stL", lambda p: [p.A(self.F[i]).to(self.LREG[i]) for i in range(6)], self.fexp_temps())
+            self.l2_routine("L2_ldL", lambda p: [p.A(self.LREG[i]).to(self.F[i]) for i in range(6)], self.fexp_temps())
             self.l2_routine("L2_stG", lambda p: [p.A(self.F[i]).to(GlobDyn(i)) for i in range(6)], self.fexp_temps())
             self.l2_routine("L2_ldG", lambda p: self.batch_load_globdyn(p.e, p, range(6), self.F), self.fexp_temps())
             self.l2_routine("L2_ldGc", lambda p: (self.batch_load_globdyn(p.e, p, range(6), self.F),
@@ -1291,7 +1315,7 @@ class KernelBuilder:
             if self.helper:
                 for k in range(4, 12):
                     self.l2_routine(f"L2_frob{k}", lambda p, k=k: self._frobenius(p, k), self.fexp_temps())
-                self.l2_routine("L2_sqrF", lambda p: p.fq12_sqr(self.F), self.fexp_temps(no_homes=True))
+                self.l2_routine("L2_sqrF", lambda p: p.fq12_sqr(self.F), self.fexp_temps(no_homes=True, lds=True))
         self._phase = "miller"              # the main program only touches F
         self.main_body(main)
         # Layout: s_call_b64 / s_branch reach +-128 KB.  The leaf routines (called from everywhere) and the main control
@@ -1387,20 +1411,18 @@ class KernelBuilder:
                 elif op[0] == "mul":
                     mul_by(op[2])
                 elif op[0] == "powx":
-                    seq.append("L2_stG")
-                    run("L2_cyc"); run("L2_cyc"); seq.append("L2_stG")
-                    for _ in range(3):
-                        mul_by()
-                        seq.append("L2_stG")
-                    if X_DIGITS[-1] != 13:
-                        seq.append("L2_ldG")
-                    xd = X_DIGITS[:-1]
-                    for d in range(len(xd) - 1, -1, -1):
-                        if xd[d] != 0:
-                            seq.append("L2_pfB")
-                        run("L2_cyc")
-                        if xd[d] != 0:
-                            run("L2_mul_body", label="L2_mulGc_w" if xd[d] < 0 else "L2_mulG_w")
+                    for o, a in self.powx_ops(store_base=op[2]):
+                        if o == "call":
+                            if a in ("L2_mulL", "L2_mulLc"):
+                                run("L2_mul_body", label=a)
+                            else:
+                                run(a)
+                        elif o in ("st", "ld", "pf"):
+                            seq.append({"st": "L2_stG", "ld": "L2_ldG", "pf": "L2_pfB"}[o])
+                        else:
+                            run("L2_mul_body", label={"mul": "L2_mulG", "mulc": "L2_mulGc", "mul_w": "L2_mulG_w", "mulc_w": "L2_mulGc_w"}[o])
+                elif op[1] in ("L2_mulL", "L2_mulLc"):
+                    run("L2_mul_body", label=op[1])
                 else:
                     run(op[1])
         return {"max_stored": worst, "calls": calls, "sequence": seq}
@@ -1418,64 +1440,54 @@ class KernelBuilder:
         for k in range(6):
             p.A(self.F[k]).redn().to(self.F[k])
 
+    def powx_ops(self, store_base):
+        """The x-power F <- F^BN_X as a straight list of steps (emitted by _powx_routine, replayed by certify_values):
+        ("st" | "ld" | "mul" | "mulc" | "pf", register) with register = an Fq12 scratch register number or "base" (the caller's),
+        ("call", L2 routine).  b^13 -- half of the digit multiplications -- never goes to scratch: conj(b^13) sits in the on-chip
+        register LREG (the first digit that uses it is -13; the one +13 conjugates f around the multiplication instead)."""
+        ops = [("st", "base")] if store_base else []
+        ops += [("call", "L2_cyc"), ("call", "L2_cyc"), ("st", G_B4),                  # b^4
+                ("mul", "base"), ("st", G_POW[5]),                                     # b^5 = b^4 b
+                ("mul", G_B4), ("st", G_POW[9]),                                       # b^9 = b^5 b^4
+                ("mul", G_B4), ("call", "L2_conjF"), ("call", "L2_stL")]               # conj(b^13) = conj(b^9 b^4) -> LREG
+        top = X_DIGITS[-1]
+        ops.append(("ld", "base" if top == 1 else G_POW[top]) if top != 13 else ("call", "L2_ldLc"))
+        for d in reversed(X_DIGITS[:-1]):
+            if d == 0:
+                ops.append(("call", "L2_cyc"))
+            elif abs(d) == 13:
+                ops.append(("call", "L2_cyc"))
+                ops += [("call", "L2_mulL")] if d < 0 else [("call", "L2_conjF"), ("call", "L2_mulL"), ("call", "L2_conjF")]
+            else:
+                reg = "base" if abs(d) == 1 else G_POW[abs(d)]
+                ops += [("pf", reg), ("call", "L2_cyc"), ("mulc_w" if d < 0 else "mul_w", reg)]      # the fetch runs under the squaring
+        return ops
+
     def _powx_routine(self):
-        """F <- F^BN_X for cyclotomic F (base b = F on entry, S_GBASE = its scratch register): the X_DIGITS schedule.
-        Same value as pow_native(a, [BN_X]) (final_exp_native.rs:56-84) for unitary a."""
+        """F <- F^BN_X for cyclotomic F (base b = F on entry, S_GBASE = its scratch register): the X_DIGITS schedule, unrolled
+        (control code only: every step is a call).  Same value as pow_native(a, [BN_X]) (final_exp_native.rs:56-84) for unitary a.
+        Entry L3_powx stores b into its register first, L3_powx_ns finds it there already."""
+        assert X_DIGITS[-1] != 13
         e = Emitter()
         L = self.lab
-
-        def c2(name):
-            e.salu(f"s_call_b64 {S_RET2}, {L(name)}")
-
-        def greg(j):
-            e.salu(f"s_mul_i32 s{S_GBASE}, s{S_GSTRIDE}, {6 * j}")
-
+        name = {"st": "L2_stG", "ld": "L2_ldG", "mul": "L2_mulG", "mulc": "L2_mulGc", "pf": "L2_pfB", "mul_w": "L2_mulG_w", "mulc_w": "L2_mulGc_w"}
         e.label(L("L3_powx"))
         e.salu(f"s_mov_b32 s{S_PB}, s{S_GBASE}")
-        c2("L2_stG")                                                  # G[base] = b
-        c2("L2_cyc"); c2("L2_cyc"); greg(G_B4); c2("L2_stG")          # b^4
-        e.salu(f"s_mov_b32 s{S_GBASE}, s{S_PB}")
-        c2("L2_mulG"); greg(G_POW[5]); c2("L2_stG")                   # b^5 = b^4 b
-        greg(G_B4); c2("L2_mulG"); greg(G_POW[9]); c2("L2_stG")       # b^9 = b^5 b^4
-        greg(G_B4); c2("L2_mulG"); greg(G_POW[13]); c2("L2_stG")      # b^13 = b^9 b^4
-        top = X_DIGITS[-1]
-        if top == 1:
-            e.salu(f"s_mov_b32 s{S_GBASE}, s{S_PB}")
-        else:
-            greg(G_POW[top])
-        if top != 13:
-            c2("L2_ldG")
-        e.salu(f"s_mov_b32 s{S_J}, {self.x_top - 1}")
-        e.label(L("L3_powx_loop"))
-        e.salu(f"s_bitcmp1_b64 {S_XNAF_NZ}, s{S_J}")
-        e.salu(f"s_cbranch_scc1 {L('L3_powx_nz')}")
-        c2("L2_cyc")
-        e.salu(f"s_branch {L('L3_powx_next')}")
-        e.label(L("L3_powx_nz"))
-        # select the power: S_GBASE <- register of b^(X_POWERS[idx]); fetch it under the squaring
-        e.salu(f"s_mov_b32 s{S_GBASE}, s{S_PB}")
-        for bit, mask in ((0, S_XIDX0), (1, S_XIDX1)):
-            e.salu(f"s_bitcmp1_b64 {mask}, s{S_J}")
-            e.salu(f"s_cselect_b32 s{S_TMP0}, {1 << bit}, 0")
-            e.salu(f"s_{'mov' if bit == 0 else 'or'}_b32 s{S_TMP1}, s{S_TMP0}" + (f", s{S_TMP1}" if bit else ""))
-        e.salu(f"s_cmp_eq_u32 s{S_TMP1}, 0")
-        e.salu(f"s_cbranch_scc1 {L('L3_powx_sel')}")
-        # registers of b^5, b^9, b^13 are consecutive: G_POW[5] + (idx - 1)
-        e.salu(f"s_add_u32 s{S_TMP1}, s{S_TMP1}, {G_POW[5] - 1}")
-        e.salu(f"s_mul_i32 s{S_TMP1}, s{S_TMP1}, 6")
-        e.salu(f"s_mul_i32 s{S_GBASE}, s{S_GSTRIDE}, s{S_TMP1}")
-        e.label(L("L3_powx_sel"))
-        c2("L2_pfB")
-        c2("L2_cyc")
-        e.salu(f"s_bitcmp1_b64 {S_XNAF_NEG}, s{S_J}")
-        e.salu(f"s_cbranch_scc1 {L('L3_powx_neg')}")
-        c2("L2_mulG_w")
-        e.salu(f"s_branch {L('L3_powx_next')}")
-        e.label(L("L3_powx_neg"))
-        c2("L2_mulGc_w")
-        e.label(L("L3_powx_next"))
-        e.salu(f"s_sub_u32 s{S_J}, s{S_J}, 1")
-        e.salu(f"s_cbranch_scc0 {L('L3_powx_loop')}")
+        e.salu(f"s_call_b64 {S_RET2}, {L('L2_stG')}")
+        e.salu(f"s_branch {L('L3_powx_go')}")
+        e.label(L("L3_powx_ns"))
+        e.salu(f"s_mov_b32 s{S_PB}, s{S_GBASE}")
+        e.label(L("L3_powx_go"))
+        for op, arg in self.powx_ops(store_base=False):
+            if op == "call":
+                e.salu(f"s_call_b64 {S_RET2}, {L(arg)}")
+                continue
+            if op not in ("mul_w", "mulc_w"):                       # (the waiting entries find the operand fetched by "pf")
+                if arg == "base":
+                    e.salu(f"s_mov_b32 s{S_GBASE}, s{S_PB}")
+                else:
+                    e.salu(f"s_mul_i32 s{S_GBASE}, s{S_GSTRIDE}, {6 * arg}")
+            e.salu(f"s_call_b64 {S_RET2}, {L(name[op])}")
         e.salu(f"s_setpc_b64 {S_RET3}")
         self.control_sections.append(e)           # control code: placed next to the main program (it calls L2 routines of both halves)
 
@@ -1488,6 +1500,8 @@ class KernelBuilder:
         p.reset_tags()
         p.wait()
         for n, k in enumerate(ks):
+            if EXP_NO_SCRATCH:
+                break
             e.salu(f"s_mul_i32 s{S_TMP0}, s{S_GSTRIDE}, {k}")
             e.salu(f"s_add_u32 s{S_TMP0}, s{S_TMP0}, s{S_GBASE}")
             e.salu(f"s_add_u32 s62, s64, s{S_TMP0}")
@@ -1511,6 +1525,10 @@ class KernelBuilder:
         p.wait()
         for k, dst in enumerate(self.BOP):
             a0 = SLOT_DW * dst.idx
+            p.slot_r.pop(p.key(dst), None)
+            p.slot_v.pop(p.key(dst), None)
+            if EXP_NO_SCRATCH:
+                continue
             e.salu(f"s_mul_i32 s{S_TMP0}, s{S_GSTRIDE}, {k}")
             e.salu(f"s_add_u32 s{S_TMP0}, s{S_TMP0}, s{S_GBASE}")
             e.salu(f"s_add_u32 s62, s64, s{S_TMP0}")
@@ -1526,10 +1544,23 @@ class KernelBuilder:
         L2_pfB issues the operand loads and returns (the x-power loop calls it BEFORE the cyclotomic squaring that precedes
         the multiplication: the ~3 us of a 27 KB-per-wave fetch that every wave of the chip issues at about the same time
         run under the squaring); L2_mulG_w / L2_mulGc_w wait for them and multiply; L2_mulG / L2_mulGc do both."""
-        e, p = self.new_prog(self.fexp_temps(no_homes=True))
+        # three temporaries: home block 8 and the two AGPR slots that are free here (9 is the Fq inversion's base: not running)
+        e, p = self.new_prog([HOME(8), AGPR(13), self.FQINV_BASE] + [GLOB(GLOB_TMP0 + i) for i in range(8)])
         e.label(self.lab("L2_pfB"))
         self._emit_load_bop(e, p)
         e.salu(f"s_setpc_b64 {S_RET2}")
+        # operand = the on-chip register: copied into the operand slots (138 instructions, no memory wait to speak of);
+        # L2_mulLc multiplies by its conjugate
+        for name, conj in (("L2_mulL", False), ("L2_mulLc", True)):
+            e.label(self.lab(name))
+            p.reset_tags()
+            for i in range(6):
+                p.A(self.LREG[i])
+                if conj and i % 2:
+                    p.neg()
+                p.to(self.BOP[i])
+            p.wait()
+            e.salu(f"s_branch {self.lab('L2_mul_body')}")
         e.label(self.lab("L2_mulGc"))
         self._emit_load_bop(e, p)
         e.label(self.lab("L2_mulGc_w"))
@@ -2337,7 +2368,7 @@ class KernelBuilder:
     def _emit_buf_loads(self, e, pairs):
         """buffer slot <- scratch slot k of the pair whose block starts at S_GNEXT, for (buffer name, k) in pairs; nobody waits"""
         for name, k in pairs:
-            if EXP_NO_PREFETCH:
+            if EXP_NO_PREFETCH or EXP_NO_SCRATCH:
                 break
             a0 = SLOT_DW * self.BUF[name].idx
             e.salu(f"s_mul_i32 s{S_TMP0}, s{S_GSTRIDE}, {k}")
@@ -2522,10 +2553,11 @@ class KernelBuilder:
             self.gsel(e, j)
             self.call2(e, "L2_mulGc" if conj else "L2_mulG")
 
-        def powx(j):
-            tr.append(("powx", j))
+        def powx(j, stored):
+            """F <- F^x with register j as the base's scratch register; stored: it already holds F"""
+            tr.append(("powx", j, not stored))
             self.gsel(e, j)
-            e.salu(f"s_call_b64 {S_RET3}, {self.lab('L3_powx')}")
+            e.salu(f"s_call_b64 {S_RET3}, {self.lab('L3_powx_ns' if stored else 'L3_powx')}")
 
         def c2(n):
             tr.append(("call", n))
@@ -2537,9 +2569,9 @@ class KernelBuilder:
         c2("L2_frob1"); st(G2)
         ld(GM); c2("L2_frob2"); st(G3)
         ld(GM); c2("L2_frob3"); mul(G3); mul(G2); st(G2)              # y0
-        ld(GM); powx(GM); st(G3)                                      # mx
-        powx(G3); st(G4)                                              # mx2
-        powx(G4); st(G5)                                              # mx3
+        ld(GM); powx(GM, True)                                        # mx   (the x-power stores its base itself: the next one's
+        powx(G3, False)                                               # mx2   base register IS the result register)
+        powx(G4, False); st(G5)                                       # mx3
         ld(G3); c2("L2_frob1"); st(G6)                                # mxp
         ld(G4); c2("L2_frob1"); mul(G3); st(G7)                       # mx * mx2p
         ld(G4); c2("L2_frob2"); st(G3)                                # y2
@@ -2547,14 +2579,14 @@ class KernelBuilder:
         c2("L2_cyc")                                                  # T0 = y6^2
         mul(G7, conj=True)                                            # * y4
         mul(G4, conj=True)                                            # * y5
-        st(G0)
+        c2("L2_stL")                                                  # T0 lives in the on-chip register from here on
         ld(G6, conj=True); mul(G4, conj=True)                         # T1 = y3 * y5
-        mul(G0); st(G5)                                               # T1 *= T0
-        ld(G0); mul(G3); st(G0)                                       # T0 = y2 * T0
-        ld(G5); c2("L2_cyc"); mul(G0); c2("L2_cyc"); st(G5)           # T1 = (T1^2 * T0)^2
-        mul(GM, conj=True); st(G0)                                    # T0 = T1 * y1
+        c2("L2_mulL"); st(G5)                                         # T1 *= T0
+        c2("L2_ldL"); mul(G3); c2("L2_stL")                           # T0 = y2 * T0
+        ld(G5); c2("L2_cyc"); c2("L2_mulL"); c2("L2_cyc"); st(G5)     # T1 = (T1^2 * T0)^2
+        mul(GM, conj=True); c2("L2_stL")                              # T0 = T1 * y1
         ld(G5); mul(G2); st(G5)                                       # T1 = T1 * y0
-        ld(G0); c2("L2_cyc"); mul(G5)                                 # T0 = T0^2 * T1
+        c2("L2_ldL"); c2("L2_cyc"); mul(G5)                           # T0 = T0^2 * T1
 
     def store_out(self, e, p):
         p.reset_tags()
