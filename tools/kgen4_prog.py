@@ -1304,6 +1304,7 @@ class KernelBuilder:
             for k in (1, 2, 3):
                 self.l2_routine(f"L2_frob{k}", lambda p, k=k: self._frobenius(p, k), self.fexp_temps())
             self.l2_routine("L2_inv", self._fq12_inv, self.fexp_temps(lds=True))
+            self.l2_routine("L2_cpB", lambda p: [p.A(self.F[i]).to(self.BOP[i]) for i in range(6)], self.fexp_temps())
             self.l2_routine("L2_stL", lambda p: [p.A(self.F[i]).to(self.LREG[i]) for i in range(6)], self.fexp_temps())
             self.l2_routine("L2_ldL", lambda p: [p.A(self.LREG[i]).to(self.F[i]) for i in range(6)], self.fexp_temps())
             self.l2_routine("L2_stG", lambda p: [p.A(self.F[i]).to(GlobDyn(i)) for i in range(6)], self.fexp_temps())
@@ -1410,10 +1411,14 @@ class KernelBuilder:
                     seq.append("L2_ldGc" if op[2] else "L2_ldG")
                 elif op[0] == "mul":
                     mul_by(op[2])
+                elif op[0] == "pf":
+                    seq.append("L2_pfB")
+                elif op[0] == "mulw":
+                    run("L2_mul_body", label="L2_mulGc_w" if op[1] else "L2_mulG_w")
                 elif op[0] == "powx":
                     for o, a in self.powx_ops(store_base=op[2]):
                         if o == "call":
-                            if a in ("L2_mulL", "L2_mulLc"):
+                            if a in ("L2_mulL", "L2_mulLc", "L2_mul_body"):
                                 run("L2_mul_body", label=a)
                             else:
                                 run(a)
@@ -1421,7 +1426,7 @@ class KernelBuilder:
                             seq.append({"st": "L2_stG", "ld": "L2_ldG", "pf": "L2_pfB"}[o])
                         else:
                             run("L2_mul_body", label={"mul": "L2_mulG", "mulc": "L2_mulGc", "mul_w": "L2_mulG_w", "mulc_w": "L2_mulGc_w"}[o])
-                elif op[1] in ("L2_mulL", "L2_mulLc"):
+                elif op[1] in ("L2_mulL", "L2_mulLc", "L2_mul_body"):
                     run("L2_mul_body", label=op[1])
                 else:
                     run(op[1])
@@ -1446,10 +1451,10 @@ class KernelBuilder:
         ("call", L2 routine).  b^13 -- half of the digit multiplications -- never goes to scratch: conj(b^13) sits in the on-chip
         register LREG (the first digit that uses it is -13; the one +13 conjugates f around the multiplication instead)."""
         ops = [("st", "base")] if store_base else []
-        ops += [("call", "L2_cyc"), ("call", "L2_cyc"), ("st", G_B4),                  # b^4
-                ("mul", "base"), ("st", G_POW[5]),                                     # b^5 = b^4 b
-                ("mul", G_B4), ("st", G_POW[9]),                                       # b^9 = b^5 b^4
-                ("mul", G_B4), ("call", "L2_conjF"), ("call", "L2_stL")]               # conj(b^13) = conj(b^9 b^4) -> LREG
+        ops += [("pf", "base"), ("call", "L2_cyc"), ("call", "L2_cyc"), ("st", G_B4),  # b^4 (the operand b is fetched under the squarings)
+                ("mul_w", "base"), ("pf", G_B4), ("st", G_POW[5]),                     # b^5 = b^4 b
+                ("mul_w", G_B4), ("st", G_POW[9]),                                     # b^9 = b^5 b^4
+                ("call", "L2_mul_body"), ("call", "L2_conjF"), ("call", "L2_stL")]     # conj(b^13) = conj(b^9 b^4) -> LREG (b^4 is still in the operand slots)
         top = X_DIGITS[-1]
         ops.append(("ld", "base" if top == 1 else G_POW[top]) if top != 13 else ("call", "L2_ldLc"))
         for d in reversed(X_DIGITS[:-1]):
@@ -2553,6 +2558,16 @@ class KernelBuilder:
             self.gsel(e, j)
             self.call2(e, "L2_mulGc" if conj else "L2_mulG")
 
+        def pf(j):
+            """the operand of the NEXT multiplication is fetched under whatever runs in between (nothing there touches the operand slots)"""
+            tr.append(("pf", j))
+            self.gsel(e, j)
+            self.call2(e, "L2_pfB")
+
+        def mulw(conj=False):
+            tr.append(("mulw", conj))
+            self.call2(e, "L2_mulGc_w" if conj else "L2_mulG_w")
+
         def powx(j, stored):
             """F <- F^x with register j as the base's scratch register; stored: it already holds F"""
             tr.append(("powx", j, not stored))
@@ -2562,31 +2577,36 @@ class KernelBuilder:
         def c2(n):
             tr.append(("call", n))
             self.call2(e, n)
-        # easy part (:195-206)
-        st(G0); c2("L2_inv"); mul(G0, conj=True); st(G0); c2("L2_frob2"); mul(G0)
-        # hard part (:130-169)
-        st(GM)
-        c2("L2_frob1"); st(G2)
-        ld(GM); c2("L2_frob2"); st(G3)
-        ld(GM); c2("L2_frob3"); mul(G3); mul(G2); st(G2)              # y0
-        ld(GM); powx(GM, True)                                        # mx   (the x-power stores its base itself: the next one's
+        # Scratch is touched only where a value has to outlive the three on-chip Fq12 places (f, the multiplication operand, the
+        # LDS register): an operand that IS the current f is copied on chip (cpB), one that has work in front of it is fetched under
+        # that work (pf ... mulw); only the second of two back-to-back multiplications waits for its operand.
+        cpB = lambda: c2("L2_cpB")                    # operand slots <- f
+        mulB = lambda: c2("L2_mul_body")              # f *= the operand slots as they are
+        # easy part (:195-206): f2 = conj(a) / a ; f = frob(f2, 2) * f2 -- no scratch at all
+        cpB(); c2("L2_inv"); mulw(conj=True); cpB(); c2("L2_frob2"); mulB()
+        # hard part (:130-169); m stays in the on-chip register while its three Frobenius images are multiplied together
+        st(GM); c2("L2_stL")
+        c2("L2_frob1"); cpB()
+        c2("L2_ldL"); c2("L2_frob2"); mulB(); cpB()
+        c2("L2_ldL"); c2("L2_frob3"); mulB(); st(G2)                  # y0
+        c2("L2_ldL"); powx(GM, True)                                  # mx   (the x-power stores its base itself: the next one's
         powx(G3, False)                                               # mx2   base register IS the result register)
         powx(G4, False); st(G5)                                       # mx3
         ld(G3); c2("L2_frob1"); st(G6)                                # mxp
-        ld(G4); c2("L2_frob1"); mul(G3); st(G7)                       # mx * mx2p
+        ld(G4); pf(G3); c2("L2_frob1"); mulw(); st(G7)                # mx * mx2p
         ld(G4); c2("L2_frob2"); st(G3)                                # y2
-        ld(G5); c2("L2_frob1"); mul(G5); c2("L2_conjF")               # y6
-        c2("L2_cyc")                                                  # T0 = y6^2
-        mul(G7, conj=True)                                            # * y4
+        ld(G5); cpB(); c2("L2_frob1"); mulB(); c2("L2_conjF")         # y6
+        pf(G7); c2("L2_cyc")                                          # T0 = y6^2
+        mulw(conj=True)                                               # * y4
         mul(G4, conj=True)                                            # * y5
         c2("L2_stL")                                                  # T0 lives in the on-chip register from here on
-        ld(G6, conj=True); mul(G4, conj=True)                         # T1 = y3 * y5
+        pf(G4); ld(G6, conj=True); mulw(conj=True)                    # T1 = y3 * y5
         c2("L2_mulL"); st(G5)                                         # T1 *= T0
-        c2("L2_ldL"); mul(G3); c2("L2_stL")                           # T0 = y2 * T0
-        ld(G5); c2("L2_cyc"); c2("L2_mulL"); c2("L2_cyc"); st(G5)     # T1 = (T1^2 * T0)^2
-        mul(GM, conj=True); c2("L2_stL")                              # T0 = T1 * y1
-        ld(G5); mul(G2); st(G5)                                       # T1 = T1 * y0
-        c2("L2_ldL"); c2("L2_cyc"); mul(G5)                           # T0 = T0^2 * T1
+        pf(G3); c2("L2_ldL"); mulw(); c2("L2_stL")                    # T0 = y2 * T0
+        ld(G5); c2("L2_cyc"); c2("L2_mulL"); pf(GM); c2("L2_cyc"); st(G5)     # T1 = (T1^2 * T0)^2
+        mulw(conj=True); c2("L2_stL")                                 # T0 = T1 * y1
+        pf(G2); ld(G5); mulw(); cpB()                                 # T1 = T1 * y0 (-> the operand slots)
+        c2("L2_ldL"); c2("L2_cyc"); mulB()                            # T0 = T0^2 * T1
 
     def store_out(self, e, p):
         p.reset_tags()
