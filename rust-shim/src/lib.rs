@@ -18,6 +18,10 @@ extern "C" {
     fn bn254_multi_pairing_check_batch(g1: *const u64, g2: *const u64, verdict: *mut u8, n_groups: usize, k: usize, device: c_int,
                                        stream: *mut c_void) -> c_int;
     fn bn254_pairing_sharded(g1: *const u64, g2: *const u64, out: *mut u64, n: usize, n_devices: c_int) -> c_int;
+    // device pointers on devices[0] (NULL: devices 0..n_devices-1); shard i runs on devices[i]; synchronous
+    #[allow(dead_code)]
+    fn bn254_pairing_sharded_dev(g1: *const u64, g2: *const u64, out: *mut u64, n: usize, devices: *const c_int, n_devices: c_int,
+                                 stream: *mut c_void) -> c_int;
     fn bn254_frobenius_map_batch(a: *const u64, power: usize, out: *mut u64, n: usize, device: c_int, stream: *mut c_void) -> c_int;
     fn bn254_pow_batch(a: *const u64, exp: *const u64, exp_limbs: usize, out: *mut u64, n: usize, device: c_int, stream: *mut c_void) -> c_int;
     fn bn254_get_naf(exp: *const u64, exp_limbs: usize, naf: *mut i8) -> c_long;

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Full GPU round (run through gpurun): parity tests, smoke, bench (2^20 headline + extra configs), rocprofv3 profile.
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
-TAG=${1:-r02}
+TAG=${1:-r03}
 timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -5
 timeout 300 python -c "import __graft_entry__ as g; g.build(); g.smoke(); print('smoke ok')" 2>&1 | tail -2
 timeout 900 python bench.py --steps 5 --warmup 1 > gpurun_out/bench_$TAG.log 2>&1; echo "bench rc=$?"; grep '^{"metric' gpurun_out/bench_$TAG.log > gpurun_out/bench_$TAG.json; python - <<PY

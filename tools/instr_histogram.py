@@ -107,10 +107,10 @@ class Phases:
             return "Frobenius maps (final_exp_native.rs:17-54)"
         if name == "L2_cyc":
             return ("x-powers: cyclotomic squarings (pow_native, :56-84)" if in_powx else "y-chain: cyclotomic squarings (:153-166)")
-        if name in ("L2_mul_body", "L2_mulG", "L2_mulGc", "L2_mulG_w", "L2_mulGc_w", "L2_pfB"):
+        if name in ("L2_mul_body", "L2_mulG", "L2_mulGc", "L2_mulG_w", "L2_mulGc_w", "L2_pfB", "L2_mulL", "L2_mulLc"):
             return ("x-powers: fq12_mul (table b^5 b^9 b^13 + digits)" if in_powx else "easy part + y-chain: fq12_mul (:135-166, :198-205)")
-        if name in ("L2_stG", "L2_ldG", "L2_ldGc", "L2_conjF", "L2_redF"):
-            return "Fq12 register moves to / from scratch (stG / ldG / conj)"
+        if name in ("L2_stG", "L2_ldG", "L2_ldGc", "L2_conjF", "L2_redF", "L2_stL", "L2_ldL", "L2_cpB"):
+            return "Fq12 register moves: scratch (stG / ldG), on-chip register (stL / ldL), operand copy (cpB), conj"
         if name in ("L2_descale", "L2_sqscale"):
             return "line-scale tracking (exact miller_loop_native value)"
         return name
