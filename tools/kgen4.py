@@ -197,6 +197,38 @@ class L1v4:
             self.e.emit(text, vw=vw)
         self.pool.free(acc, acc + 1, *m)
 
+    def fips_sq(self, a, out):
+        """out <- a^2 / R' mod p for ONE Fq value (normalised limbs): the symmetric products once -- column k takes a_i (2 a_j) for
+        i < j, i + j = k and a_(k/2)^2: 45 limb products instead of 81.  Same column sweep, reduction and result rules as fips
+        (in place over a is fine).  Used by the Fermat inversion (254 squarings per pairing)."""
+        acc, P = self._acc()
+        m = [self.pool.alloc() for _ in range(NL)]
+        d = [self.pool.alloc() for _ in range(NL)]
+        for i in range(NL):
+            self.e.emit(f"v_lshlrev_b32_e32 v{d[i]}, 1, v{a[i]}", vw=[d[i]])
+        first = True
+        for k in range(2 * NL - 1):
+            for i in range(max(0, k - (NL - 1)), (k + 1) // 2):          # i < k - i
+                self._mad(acc, P, a[i], d[k - i], first)
+                first = False
+            if k % 2 == 0:
+                self._mad(acc, P, a[k // 2], a[k // 2], first)
+                first = False
+            if k < NL:
+                for i in range(k):
+                    self._mad(acc, P, m[i], self.p[k - i], False)
+                self.e.emit(f"v_mul_lo_u32 v{m[k]}, v{acc}, {self.n0}", vw=[m[k]])
+                self.e.emit(f"v_bfe_i32 v{m[k]}, v{m[k]}, 0, {LB}", vw=[m[k]])
+                self._mad(acc, P, m[k], self.p[0], False)
+                self.e.emit(f"v_ashrrev_i64 {P}, {LB}, {P}", vw=[acc, acc + 1])
+            else:
+                for i in range(k - (NL - 1), NL):
+                    self._mad(acc, P, m[i], self.p[k - i], False)
+                self._digit(acc, P, out[k - NL])
+        self.e.emit(f"v_mov_b32_e32 v{out[NL - 1]}, v{acc}", vw=[out[NL - 1]])
+        self.pool.free(acc, acc + 1, *m)
+        self.pool.free(*d)
+
     def kfips(self, kterms, sterms, out_re, out_im):
         """(out_re, out_im) <- both components of the sum of the Fq2 products x y over kterms + sterms, divided by R' (one
         Montgomery reduction per component).  x = (x0, x1), y = (y0, y1): limb lists.
@@ -677,7 +709,7 @@ class L1v4:
 
     def r_fqsqr(self):
         a0 = self.blk(A0, 0)
-        self.fips([(a0, a0)], a0)            # result limb j lands after column j + NL, when a0[j] is dead
+        self.fips_sq(a0, a0)                 # result limb j lands after column j + NL, when a0[j] (and its doubled copy's use) is dead
 
     def r_add(self):
         self._lw("v_add_u32_e32", self.fq2(A0), self.fq2(A0), self.fq2(B0))

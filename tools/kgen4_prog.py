@@ -1719,32 +1719,95 @@ class KernelBuilder:
         for k in (1, 2, 5):
             p.to(self.F[k])
 
+    FQINV_WINDOW = 3
+
+    @staticmethod
+    def fqinv_schedule(w):
+        """Sliding-window schedule of a^(p-2): (first odd value, [(squarings, odd multiplier)] from the top bit down)."""
+        bits = bin(P_INT - 2)[2:]
+        n, i, out, first = len(bits), 0, [], None
+        while i < n:
+            if bits[i] == "0":
+                j = i
+                while j < n and bits[j] == "0":
+                    j += 1
+                zeros, i = j - i, j
+            else:
+                zeros = 0
+            if i >= n:
+                out.append((zeros, 0))                    # trailing zeros (none for p - 2, which is odd)
+                break
+            j = min(i + w, n)
+            while bits[j - 1] == "0":
+                j -= 1
+            val = int(bits[i:j], 2)
+            if first is None:
+                first = val
+            else:
+                out.append((zeros + (j - i), val))
+            i = j
+        return first, out
+
     def _fq_inv(self, p):
         """A.c0 <- A.c0^(p-2) (Fermat; fixed exponent, uniform control flow).  Input / output normalised.
-        Called with S_RET2; uses S_RET1 for the multiplies and s[60:61] as scratch."""
+        Sliding window of three bits over the odd powers a, a^3, a^5, a^7 (a, a^3 in the AGPR slot FQINV_BASE, a^5, a^7 in the top
+        eighteen pool registers): 253 squarings -- each 45 limb products, L1v4.fips_sq -- and 56 + 4 multiplications instead of
+        253 and 109 full products.  Called with S_RET2; uses S_RET1 for its own two subroutines and s[60:61] as scratch."""
         e = p.e
-        base = self.FQINV_BASE
-        p.wait()
-        p.store(A0, base)
-        p.load(B0, base)
-        p.tagA = p.tagB = None
-        ex = P_INT - 2
-        words = [(ex >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
+        L = self.lab
         uid = self.uid()
-        for limb in range(7, -1, -1):
-            top = 28 if limb == 7 else 31              # p < 2^254: bit 253 (= bit 29 of limb 7) is consumed by r = a
-            lbl = self.lab(f"L_fqinv_{limb}_{uid}")
-            skip = self.lab(f"L_fqinv_skip_{limb}_{uid}")
-            e.salu(f"s_mov_b32 s{S_TMP1}, 0x{words[limb]:x}")
-            e.salu(f"s_mov_b32 s{S_TMP0}, {top}")
-            e.label(lbl)
-            L1v4(e).r_fqsqr()                      # inlined: 381 call / return pairs were a fifth of the kernel's taken branches
-            e.salu(f"s_bitcmp1_b32 s{S_TMP1}, s{S_TMP0}")
-            e.salu(f"s_cbranch_scc0 {skip}")
-            L1v4(e).r_fqmul()
-            e.label(skip)
-            e.salu(f"s_sub_u32 s{S_TMP0}, s{S_TMP0}, 1")
-            e.salu(f"s_cbranch_scc0 {lbl}")
+        base = self.FQINV_BASE
+        first, sched = self.fqinv_schedule(self.FQINV_WINDOW)
+        assert self.FQINV_WINDOW == 3 and all(v in (1, 3, 5, 7) for _, v in sched) and first in (1, 3, 5, 7)
+        RA, X2, RB = L1v4.blk(A0, 0), L1v4.blk(A0, 1), L1v4.blk(B0, 0)
+        T5, T7 = list(range(58, 67)), list(range(67, 76))          # the top of the pool: kept out of the leaf routines' hands below
+        a9 = SLOT_DW * base.idx
+
+        def l1():
+            g = L1v4(e)
+            g.pool.free_regs = [r for r in g.pool.free_regs if r < 58]
+            return g
+
+        p.wait()
+        p.tagA = p.tagB = None
+        for i in range(NL):
+            e.emit(f"v_accvgpr_write_b32 a{a9 + i}, v{RA[i]}")                       # a
+        l1().fips_sq(RA, X2)                                                        # a^2
+        l1().fips([(RA, X2)], RB)                                                   # a^3
+        for i in range(NL):
+            e.emit(f"v_accvgpr_write_b32 a{a9 + NL + i}, v{RB[i]}")
+        l1().fips([(RB, X2)], T5)                                                   # a^5
+        l1().fips([(T5, X2)], T7)                                                   # a^7
+        src = {1: None, 3: RB, 5: T5, 7: T7}[first]                                # the top window
+        if src is not None:
+            for i in range(NL):
+                e.emit(f"v_mov_b32_e32 v{RA[i]}, v{src[i]}", vw=[RA[i]])
+        sq_l = L(f"L_fqinv_sq_{uid}")
+        mul_l = {v: L(f"L_fqinv_m{v}_{uid}") for v in (1, 3, 5, 7)}
+        for nsq, val in sched:
+            e.salu(f"s_mov_b32 s{S_TMP0}, {nsq - 1}")
+            e.salu(f"s_call_b64 {S_RET1}, {sq_l}")
+            if val:
+                e.salu(f"s_call_b64 {S_RET1}, {mul_l[val]}")
+        e.salu(f"s_branch {L(f'L_fqinv_done_{uid}')}")
+        # subroutine: S_TMP0 + 1 squarings of RA
+        e.label(sq_l)
+        l1().fips_sq(RA, RA)
+        e.salu(f"s_sub_u32 s{S_TMP0}, s{S_TMP0}, 1")
+        e.salu(f"s_cbranch_scc0 {sq_l}")
+        e.salu(f"s_setpc_b64 {S_RET1}")
+        # subroutines: RA *= a^v
+        for v in (1, 3, 5, 7):
+            e.label(mul_l[v])
+            if v in (1, 3):
+                off = a9 + (NL if v == 3 else 0)
+                for i in range(NL):
+                    e.emit(f"v_accvgpr_read_b32 v{RB[i]}, a{off + i}", vw=[RB[i]])
+                l1().fips([(RA, RB)], RA)
+            else:
+                l1().fips([(RA, T5 if v == 5 else T7)], RA)
+            e.salu(f"s_setpc_b64 {S_RET1}")
+        e.label(L(f"L_fqinv_done_{uid}"))
         p.set_A_fresh()
 
     def _fq2_inv_inline(self, p, src, dst):
