@@ -170,6 +170,10 @@ EXP_NO_PREFETCH = bool(int(os.environ.get("KGEN_EXP_NO_PREFETCH", "0")))
 SCRATCH_LD_MOD = os.environ.get("KGEN_SCRATCH_LD_MOD", "")
 SCRATCH_ST_MOD = os.environ.get("KGEN_SCRATCH_ST_MOD", "sc0 sc1")
 EXP_NO_SCRATCH = bool(int(os.environ.get("KGEN_EXP_NO_SCRATCH", "0")))      # TIMING ONLY: no scratch load / store is emitted at all
+# The line coefficients go from the fused point step to the sparse multiplication in registers (home blocks 7, 4, 5; the xi-multiplied
+# copies are formed straight in the operand blocks) instead of through three AGPR slots and two temporaries: -180 moves per sparse
+# multiplication, no LDS temporary left in it, and the freed slots take the result temporaries.
+LINE_IN_REGS = bool(int(os.environ.get("KGEN_LINE_REGS", "1")))
 EXP_NO_SWAIT = bool(int(os.environ.get("KGEN_EXP_NO_SWAIT", "0")))          # no s_waitcnt at the start of a streamed step
 # The next pair's prefetch is issued slot by slot behind the first four passes of the current pair's sparse multiplication instead
 # of as one burst of 25 loads in front of the step: +1.9 % on the Groth16 shape (the four waves of a CU run in step: a burst is
@@ -829,6 +833,8 @@ class Prog:
         between(i): the caller's code behind pass i (the multi-pairing kernels spread their prefetch loads there)."""
         between = between or (lambda i: None)
         self.marker("mul034")
+        if L3.kind == "home":
+            return self._mul_by_034_regs(F, L0, L3, L4, between)
         self.reserve_blocks(scratch=self.MUL3_SCRATCH)
         L3x, L4x = self.tmp(), self.tmp()
         self.A(L3).mulxi().to(L3x)
@@ -854,6 +860,87 @@ class Prog:
         self.rel(L3x, L4x, *c)
         self.release_blocks()
 
+    # ---- the same two multiplications with the line where the fused point step left it: La in home block 7, Lb in home block 4,
+    # Lc in home block 5 (LINE_REGS).  La goes to block B once (all six passes use it), Lb / Lc stay parked in home blocks 4 / 5 --
+    # the three-term multiply does not touch them -- and are copied, or multiplied by xi on the way, straight into the operand
+    # blocks 1 / 3 as the passes need them.  No slot is written for the line; the three result temporaries are the only ones.
+    LINE_REGS = (HOME(7, "La"), HOME(4, "Lb"), HOME(5, "Lc"))
+
+    def _hold_line(self, La, Lb, Lc):
+        assert (La.idx, Lb.idx, Lc.idx) == (7, 4, 5)
+        self._B(La)                                               # block B <- La (home block 7 becomes scratch of the multiply)
+        self.wait()
+        held = [t for t in self.free_tmp if t.kind == "home" and t.idx in (4, 5)]
+        assert len(held) == 2, "home blocks 4, 5 must be free temporaries of the routine"
+        self.free_tmp = [t for t in self.free_tmp if t not in held]
+        self.reserve_blocks(scratch=self.MUL3_SCRATCH)
+        return held
+
+    def _xi_into(self, k, src, tag):
+        """home block k <- xi * src (src: a parked home slot), normalised, on the 64-bit chains; no slot is touched"""
+        self._need(mag(self.r_of(src)) <= 7.9, f"xi of {src}")
+        v = 10 * self.v_of(src)
+        self._need(v <= V_CAP, f"xi {src}: value {v}")
+        self.wait()
+        g = L1v4(self.e)
+        d, s_ = g.fq2(HOME0 + SLOT_DW * k), g.fq2(HOME0 + SLOT_DW * src.idx)
+        g.lincomb([d[0], d[1]], [[(9, s_[0]), (-1, s_[1])], [(9, s_[1]), (1, s_[0])]])
+        self.tagH[k], self.eH[k], self.vH[k] = tag, self.r_norm(v), v
+        self._count("xi_into")
+
+    def _mul_by_034_regs(self, F, L0, L3, L4, between):
+        held = self._hold_line(L0, L3, L4)
+        L3x, L4x = Slot("regs", 1, "xiLb"), Slot("regs", 3, "xiLc")
+        self._xi_into(1, L3, L3x)
+        self._xi_into(3, L4, L4x)
+        c = [self.tmp() for _ in range(3)]
+        for k, (i0, i3, i4) in enumerate(((0, 3, 2), (1, 4, 3), (2, 5, 4))):
+            self.ldH(0, F[i3]).ldH(2, F[i4])
+            self.A(F[i0]).mul3(L0).to(c[k])
+            between(k)
+        self.ldH(1, L3).ldH(0, F[0]).ldH(2, F[5])                   # c3 = a3 L0 + a0 L3 + a5 xiL4
+        self.A(F[3]).mul3(L0).to(F[3])
+        between(3)
+        self.ldH(3, L4).ldH(0, F[1]).ldH(2, F[0])                   # c4 = a4 L0 + a1 L3 + a0 L4
+        self.A(F[4]).mul3(L0).to(F[4])
+        between(4)
+        self.ldH(0, F[2]).ldH(2, F[1])                              # c5 = a5 L0 + a2 L3 + a1 L4
+        self.A(F[5]).mul3(L0).to(F[5])
+        for k in range(3):
+            self.mov(F[k], c[k])
+        self.rel(*c)
+        self.release_blocks()
+        self.free_tmp = held + self.free_tmp
+
+    def _mul_by_235_regs(self, F, L2, L3, L5, between):
+        held = self._hold_line(L2, L3, L5)
+        L3x, L5x = Slot("regs", 1, "xiLb"), Slot("regs", 3, "xiLc")
+        t0, t1, t2 = self.tmp(), self.tmp(), self.tmp()
+        for dst, (i2, i3, i5) in ((t0, (4, 3, 1)), (t1, (5, 4, 2))):                 # c0, c1 = xi (a b2 + a' b3 + a'' b5)
+            self.ldH(1, L3).ldH(3, L5).ldH(0, F[i3]).ldH(2, F[i5])
+            self.A(F[i2]).mul3(L2).mulxi(reduce=True).to(dst)
+            between(0 if dst is t0 else 1)
+        self._xi_into(3, L5, L5x)
+        self.ldH(0, F[0]).ldH(2, F[4])                                               # c3 = a1 b2 + a0 b3 + xi a4 b5
+        self.A(F[1]).mul3(L2).to(t2)
+        between(2)
+        self.ldH(0, F[1]).ldH(2, F[5])                                               # c4 -> its place
+        self.A(F[2]).mul3(L2).to(F[4])
+        between(3)
+        self.mov(F[1], t1)
+        self._xi_into(1, L3, L3x)
+        self.ldH(0, F[5]).ldH(2, F[3])                                               # c2 = a0 b2 + xi (a5 b3 + a3 b5), into the freed temporary
+        self.A(F[0]).mul3(L2).to(t1)
+        between(4)
+        self.ldH(1, L3).ldH(3, L5).ldH(0, F[2]).ldH(2, F[0])                         # c5 -> its place
+        self.A(F[3]).mul3(L2).to(F[5])
+        self.mov(F[0], t0)
+        self.mov(F[2], t1)
+        self.mov(F[3], t2)
+        self.rel(t0, t1, t2)
+        self.release_blocks()
+        self.free_tmp = held + self.free_tmp
+
     def mul_by_235(self, F, L2, L3, L5, between=None):
         """f *= L2 w^2 + L3 w^3 + L5 w^5, same scheme.  Five temporaries (two xi-multiplied line coefficients, three results
         that wait for their place): the order below frees the places as early as possible, and the two coefficients that are
@@ -862,6 +949,8 @@ class Prog:
             c3 = a1 b2 + a0 b3 + xi a4 b5     c4 = a2 b2 + a1 b3 + xi a5 b5     c5 = a3 b2 + a2 b3 + a0 b5"""
         between = between or (lambda i: None)
         self.marker("mul235")
+        if L3.kind == "home":
+            return self._mul_by_235_regs(F, L2, L3, L5, between)
         self.reserve_blocks(scratch=self.MUL3_SCRATCH)
         L3x, L5x = self.tmp(), self.tmp()
         self.A(L3).mulxi().to(L3x)
@@ -925,7 +1014,9 @@ class Prog:
         """dst <- home block k (a result of value bound v; normalised, or with limbs of up to `limbs` units)"""
         self._need(v <= self.v_limit(dst) and v <= V_CAP, f"fused step result {dst}: {v} p")
         self._need(limbs <= (1.0 if self.key(dst) in self.norm_keys else STORE_MAG), f"fused step result {dst}: limbs of {limbs} units")
-        if not (EXP_NO_RSTORE and dst.kind == "globdyn"):
+        if dst.kind == "home" and dst.idx == k:
+            pass                                       # the result stays where the routine left it
+        elif not (EXP_NO_RSTORE and dst.kind == "globdyn"):
             self.store(HOME0 + SLOT_DW * k, dst)
         self.slot_r[self.key(dst)] = self.r_norm(v) if limbs <= 1.0 else (-max(limbs, v / K_TOP), max(limbs, v / K_TOP))
         self.slot_v[self.key(dst)] = v
@@ -992,14 +1083,31 @@ class Prog:
         cc = d = sq(th)
         e_, fz, g = ml(mu, d), ml(v, cc), ml(v, d)
         hh = e_ + fz + 2 * g
-        self.vA, self.rA, self.tagA = 2 * ml(v, v) - 0.5, None, None          # L5 = X y2 - x2 Y (one reduction): block A
-        self.rA = self.r_norm()
-        self.to(line[2])
+        v5 = 2 * ml(v, v) - 0.5                                                # L5 = X y2 - x2 Y (one reduction): block A
+        in_regs = line[1].kind == "home" and line[1].idx == 4
+        if not in_regs:
+            self.vA, self.rA, self.tagA = v5, None, None
+            self.rA = self.r_norm()
+            self.to(line[2])
         self._step_out(6, R[0], ml(mu, hh))
         self._step_out(4, R[1], 2 * (th * (g + hh) + e_ * v) / K_RP + 0.5)
         self._step_out(2, R[2], ml(v, e_))
         self._step_out(7, line[0], mu * vp / K_RP + 0.5)
-        self._step_out(8, line[1], th * vp / K_RP + 0.5)
+        if in_regs:                     # home 4 (Y3) has left: L3 parks there, L5 in home 5 (blocks 8 and A belong to the sparse multiplication)
+            assert (line[0].kind, line[0].idx, line[2].kind, line[2].idx) == ("home", 7, "home", 5)
+            self.wait()
+            for i in range(SLOT_DW):
+                self.e.emit(f"v_mov_b32_e32 v{HOME0 + SLOT_DW * 4 + i}, v{HOME0 + SLOT_DW * 8 + i}", vw=[HOME0 + SLOT_DW * 4 + i])
+            for i in range(SLOT_DW):
+                self.e.emit(f"v_mov_b32_e32 v{HOME0 + SLOT_DW * 5 + i}, v{A0 + i}", vw=[HOME0 + SLOT_DW * 5 + i])
+            for dst, vv in ((line[1], th * vp / K_RP + 0.5), (line[2], v5)):
+                self._need(vv <= self.v_limit(dst) and vv <= V_CAP, f"fused step result {dst}: {vv} p")
+                self.slot_r[self.key(dst)] = self.r_norm(vv)
+                self.slot_v[self.key(dst)] = vv
+                self.max_v = max(self.max_v, vv)
+            self.tagA = None
+        else:
+            self._step_out(8, line[1], th * vp / K_RP + 0.5)
         self.wait()
 
     def dbl_step(self, R, Pt, line, scale=None, out=None, after_load=None, load_p=None):
@@ -1010,7 +1118,10 @@ class Prog:
         if self._fused_ok():
             if scale is not None:
                 self.A(Z).sqr().mul(scale).to(scale)
-            return self._dbl_step_fused(R, Pt, line, out, after_load, load_p)
+            if LINE_IN_REGS:
+                line = self.LINE_REGS
+            self._dbl_step_fused(R, Pt, line, out, after_load, load_p)
+            return line
         assert out is None and after_load is None and load_p is None
         Bq, C, E, Fv, H, T = [self.tmp() for _ in range(6)]
         self.A(Y).sqr().to(Bq)
@@ -1034,6 +1145,7 @@ class Prog:
         self.A(Bq).add(Fv).sqr().sub(T).to(Y)
         self.A(Bq).mul(H).scale(4).to(Z)
         self.rel(Bq, C, E, Fv, H, T)
+        return line
 
     def add_step(self, R, Q, Pt, line, scale=None, update=True, out=None, after_load=None, load_p=None, load_q=None):
         """R <- R + Q (Q = (x2, y2) affine slots); line = (L2, L3, L5) of the chord through old R and Q at P."""
@@ -1043,7 +1155,10 @@ class Prog:
         if update and self._fused_ok():
             if scale is not None:
                 self.A(scale).mul(Z).to(scale)
-            return self._add_step_fused(R, Q, Pt, line, out, after_load, load_p, load_q)
+            if LINE_IN_REGS:
+                line = self.LINE_REGS
+            self._add_step_fused(R, Q, Pt, line, out, after_load, load_p, load_q)
+            return line
         assert out is None and after_load is None and load_p is None and load_q is None
         th, mu, T, U = [self.tmp() for _ in range(4)]
         if scale is not None:
@@ -1069,6 +1184,7 @@ class Prog:
             self.A(Z).mul(E).to(Z)                            # Z3 = Z E
             self.rel(Cc, D, E)
         self.rel(th, mu, T, U)
+        return line
 
 
     def pt_add(self, R, Q):
@@ -1270,18 +1386,21 @@ class KernelBuilder:
             # during f^2 the line and the addition point are dead (in the multi kernels the S slots hold the prefetched pair)
             self.l2_routine("L2_sqr", lambda p: p.fq12_sqr(self.F),
                             self.miller_temps(extra=(tuple(self.LINE) if self.multi else (self.SX, self.SY, *self.LINE)), no_homes=True))
-            self.l2_routine("L2_dblmul", lambda p: (p.dbl_step(self.R, (self.PX, self.PY), self.LINE, scale=sc),
-                                                    p.mul_by_034(self.F, *self.LINE)), self.miller_temps(extra=(self.SX, self.SY)), local=self.LINE)
+            # (routines that run the fused steps hand the line over in registers: the LINE slots are then ordinary temporaries)
+            hot = lambda name: LINE_IN_REGS and Prog.FUSED_STEPS and name not in self.COLD
+            line_tmp = lambda name: tuple(self.LINE) if hot(name) else ()
+            self.l2_routine("L2_dblmul", lambda p: p.mul_by_034(self.F, *p.dbl_step(self.R, (self.PX, self.PY), self.LINE, scale=sc)),
+                            self.miller_temps(extra=(*line_tmp("L2_dblmul"), self.SX, self.SY)), local=self.LINE)
             self.l2_routine("L2_dblfirst", lambda p: self._dbl_first(p), self.miller_temps(), local=self.LINE)
 
             def addmul(p, update):
-                p.add_step(self.R, (self.SX, self.SY), (self.PX, self.PY), self.LINE, scale=sc, update=update)
+                line = p.add_step(self.R, (self.SX, self.SY), (self.PX, self.PY), self.LINE, scale=sc, update=update)
                 glob = [t for t in p.free_tmp if t.kind == "glob"]
                 p.free_tmp = [t for t in p.free_tmp if t.kind != "glob"] + [self.SX, self.SY] + glob    # S is dead now
                 p.temp_keys = p.temp_keys | {Prog.key(self.SX), Prog.key(self.SY)}
-                p.mul_by_235(self.F, *self.LINE)
+                p.mul_by_235(self.F, *line)
 
-            self.l2_routine("L2_addmul", lambda p: addmul(p, True), self.miller_temps(), local=self.LINE)
+            self.l2_routine("L2_addmul", lambda p: addmul(p, True), self.miller_temps(extra=line_tmp("L2_addmul")), local=self.LINE)
             self.l2_routine("L2_addmul_last", lambda p: addmul(p, False), self.miller_temps(), local=self.LINE)
             if self.multi:
                 self._stream_routines(sc)
@@ -2520,7 +2639,8 @@ class KernelBuilder:
         buf = self.BUF
         Rb, Pb = [buf["RX"], buf["RY"], buf["RZ"]], (buf["PX"], buf["PY"])
         Rout = [GlobDyn(4), GlobDyn(5), GlobDyn(6)]
-        temps = [HOME(i) for i in range(N_HOME)] + self.MILLER_FREE[1] + [GLOB(GLOB_TMP0 + i) for i in range(8)]
+        temps = ([HOME(i) for i in range(N_HOME)] + (list(self.LINE) if LINE_IN_REGS and Prog.FUSED_STEPS else []) + self.MILLER_FREE[1]
+                 + [GLOB(GLOB_TMP0 + i) for i in range(8)])
         L = self.lab
 
         def load_p(p):
@@ -2566,8 +2686,8 @@ class KernelBuilder:
         def dbl_s(p):
             if not EXP_NO_SWAIT:
                 p.e.raw("s_waitcnt vmcnt(0)")                   # the prefetch of this pair has landed
-            p.dbl_step(Rb, Pb, self.LINE, scale=sc, out=Rout, after_load=(None if SPREAD_PREFETCH else lambda: self._emit_prefetch(p.e, q="last")), load_p=load_p)
-            p.mul_by_034(self.F, *self.LINE, between=spread(p, "last"))
+            line = p.dbl_step(Rb, Pb, self.LINE, scale=sc, out=Rout, after_load=(None if SPREAD_PREFETCH else lambda: self._emit_prefetch(p.e, q="last")), load_p=load_p)
+            p.mul_by_034(self.F, *line, between=spread(p, "last"))
 
         def add_s(p):
             e = p.e
@@ -2584,8 +2704,8 @@ class KernelBuilder:
                 e.label(L("L_as_pos"))
                 if not SPREAD_PREFETCH:
                     self._emit_prefetch(e, q="always")
-            p.add_step(Rb, (GlobDyn(2), GlobDyn(3)), Pb, self.LINE, scale=sc, out=Rout, after_load=after, load_p=load_p, load_q=load_q)
-            p.mul_by_235(self.F, *self.LINE, between=spread(p, "always"))
+            line = p.add_step(Rb, (GlobDyn(2), GlobDyn(3)), Pb, self.LINE, scale=sc, out=Rout, after_load=after, load_p=load_p, load_q=load_q)
+            p.mul_by_235(self.F, *line, between=spread(p, "always"))
 
         self.l2_routine("L2_dblmul_s", dbl_s, temps, local=self.LINE)
         self.l2_routine("L2_addmul_s", add_s, temps, local=self.LINE)
