@@ -1002,13 +1002,59 @@ class Prog:
                 raise ValueError(slot.kind)
         return self.v_of(slot)
 
-    def _step_in(self, slots):
+    def _step_in(self, slots, alt=None):
+        """home block k <- slots[k].  alt = (condition emitter, other slots for the first three, label maker): the R operands
+        come from `alt` slots when the run-time condition holds (SCC set by the emitter) -- pair 0 of a multi-pairing group keeps
+        its R in LDS."""
         vs = []
+        if alt is not None:
+            cond, other, lab = alt
+            l_alt, l_done = lab("L_si_alt"), lab("L_si_done")
+            for s_ in list(slots[:3]) + list(other):
+                self._need(mag(self.r_of(s_)) <= 1.0, f"fused step operand {s_} is not normalised")
+                vs.append(self.v_of(s_))
+            self.wait()
+            cond(self.e)
+            self.e.salu(f"s_cbranch_scc1 {l_alt}")
+            for k in range(3):
+                self.load(HOME0 + SLOT_DW * k, slots[k])
+            self.wait()
+            self.e.salu(f"s_branch {l_done}")
+            self.e.label(l_alt)
+            for k in range(3):
+                self.load(HOME0 + SLOT_DW * k, other[k])
+            self.wait()
+            self.e.label(l_done)
+            slots = slots[3:]
+            base = 3
+        else:
+            base = 0
         for k, s_ in enumerate(slots):
             self._need(mag(self.r_of(s_)) <= 1.0, f"fused step operand {s_} is not normalised")
-            self.load(HOME0 + SLOT_DW * k, s_)
+            self.load(HOME0 + SLOT_DW * (base + k), s_)
             vs.append(self.v_of(s_))
         return max(vs)
+
+    def _step_out_r(self, blocks, R, vs, alt):
+        """the three coordinates of the new R: home blocks -> R slots, or -> the `alt` slots when the run-time condition holds"""
+        if alt is None:
+            for k, dst, v in zip(blocks, R, vs):
+                self._step_out(k, dst, v)
+            return
+        cond, other, lab = alt
+        l_alt, l_done = lab("L_so_alt"), lab("L_so_done")
+        self.wait()
+        cond(self.e)
+        self.e.salu(f"s_cbranch_scc1 {l_alt}")
+        for k, dst, v in zip(blocks, R, vs):
+            self._step_out(k, dst, v)
+        self.wait()
+        self.e.salu(f"s_branch {l_done}")
+        self.e.label(l_alt)
+        for k, dst, v in zip(blocks, other, vs):
+            self._step_out(k, dst, v)
+        self.wait()
+        self.e.label(l_done)
 
     def _step_out(self, k, dst, v, limbs=1.0):
         """dst <- home block k (a result of value bound v; normalised, or with limbs of up to `limbs` units)"""
@@ -1031,8 +1077,22 @@ class Prog:
         load_p(self)
         return max(self.v_of(Pt[0]), self.v_of(Pt[1]))
 
-    def _dbl_step_fused(self, R, Pt, line, out=None, after_load=None, load_p=None):
-        v = self._step_in(R)
+    def _scale_from_z(self, scale, square):
+        """scale *= Z (or Z^2) with Z where the step has just put it (home block 2): the R slots differ from pair to pair"""
+        z = HOME(2, "Z")
+        self.slot_r[self.key(z)], self.slot_v[self.key(z)] = R_NORM, V_STORE
+        self.tagA = None
+        self.A(z)
+        if square:
+            self.sqr()
+        self.mul(scale).to(scale)
+        self.wait()
+        self.tagA = self.tagB = None
+
+    def _dbl_step_fused(self, R, Pt, line, out=None, after_load=None, load_p=None, alt_r=None, scale_in=None):
+        v = self._step_in(R, alt_r)
+        if scale_in is not None:
+            self._scale_from_z(scale_in, square=True)
         vp = self._load_point_p(Pt, load_p)
         self.tagA = self.tagB = None
         if after_load:
@@ -1051,19 +1111,20 @@ class Prog:
         t_ = xb + 3 * n
         self._need(max(xb, xh, t_) <= V_CAP, f"dblstep operand values {xb} {xh} {t_}")
         self._need(max(4 * ml(xb, xh), 20 * ml(ml(v, v), t_), sq(t_) + 12 * sq(n)) <= 8 * V_CAP, "dblstep: values in front of the reducing chains")
-        self._step_out(0, R[0], 0.51)
-        self._step_out(1, R[1], 0.51)
-        self._step_out(2, R[2], 0.51)
+        self._step_out_r((0, 1, 2), R, (0.51, 0.51, 0.51), alt_r)
         self._step_out(7, line[0], xb + n, limbs=2.0)
         self._step_out(4, line[1], hh * vp / K_RP + 0.5)
         self._step_out(5, line[2], 3 * sq(v) * vp / K_RP + 0.5)
         self.wait()
 
-    def _add_step_fused(self, R, Q, Pt, line, out=None, after_load=None, load_p=None, load_q=None):
+    def _add_step_fused(self, R, Q, Pt, line, out=None, after_load=None, load_p=None, load_q=None, alt_r=None, scale_in=None):
         if load_q is None:
-            v = self._step_in(list(R) + list(Q))
+            v = self._step_in(list(R) + list(Q), alt_r)
         else:                       # home blocks 3, 4 <- (x2, y2) by the caller's own code
-            v = self._step_in(list(R))
+            v = self._step_in(list(R), alt_r)
+        if scale_in is not None:
+            self._scale_from_z(scale_in, square=False)
+        if load_q is not None:
             for s_ in Q:
                 self._need(mag(self.r_of(s_)) <= 1.0, f"fused step operand {s_} is not normalised")
                 v = max(v, self.v_of(s_))
@@ -1089,9 +1150,7 @@ class Prog:
             self.vA, self.rA, self.tagA = v5, None, None
             self.rA = self.r_norm()
             self.to(line[2])
-        self._step_out(6, R[0], ml(mu, hh))
-        self._step_out(4, R[1], 2 * (th * (g + hh) + e_ * v) / K_RP + 0.5)
-        self._step_out(2, R[2], ml(v, e_))
+        self._step_out_r((6, 4, 2), R, (ml(mu, hh), 2 * (th * (g + hh) + e_ * v) / K_RP + 0.5, ml(v, e_)), alt_r)
         self._step_out(7, line[0], mu * vp / K_RP + 0.5)
         if in_regs:                     # home 4 (Y3) has left: L3 parks there, L5 in home 5 (blocks 8 and A belong to the sparse multiplication)
             assert (line[0].kind, line[0].idx, line[2].kind, line[2].idx) == ("home", 7, "home", 5)
@@ -1110,19 +1169,19 @@ class Prog:
             self._step_out(8, line[1], th * vp / K_RP + 0.5)
         self.wait()
 
-    def dbl_step(self, R, Pt, line, scale=None, out=None, after_load=None, load_p=None):
+    def dbl_step(self, R, Pt, line, scale=None, out=None, after_load=None, load_p=None, alt_r=None):
         """R=(X,Y,Z) <- 2R ; line = (L0, L3, L4) of the tangent at the old R evaluated at P (Pt = (PX, PY) slots, scalar in c0).
         scale: slot of the running line scale s <- s * Z^2 (the caller squares it with f)."""
         X, Y, Z = R
         L0, L3, L4 = line
         if self._fused_ok():
-            if scale is not None:
+            if scale is not None and alt_r is None:
                 self.A(Z).sqr().mul(scale).to(scale)
             if LINE_IN_REGS:
                 line = self.LINE_REGS
-            self._dbl_step_fused(R, Pt, line, out, after_load, load_p)
+            self._dbl_step_fused(R, Pt, line, out, after_load, load_p, alt_r, scale_in=(scale if alt_r is not None else None))
             return line
-        assert out is None and after_load is None and load_p is None
+        assert out is None and after_load is None and load_p is None and alt_r is None
         Bq, C, E, Fv, H, T = [self.tmp() for _ in range(6)]
         self.A(Y).sqr().to(Bq)
         self.A(Z).sqr().to(C)
@@ -1147,19 +1206,19 @@ class Prog:
         self.rel(Bq, C, E, Fv, H, T)
         return line
 
-    def add_step(self, R, Q, Pt, line, scale=None, update=True, out=None, after_load=None, load_p=None, load_q=None):
+    def add_step(self, R, Q, Pt, line, scale=None, update=True, out=None, after_load=None, load_p=None, load_q=None, alt_r=None):
         """R <- R + Q (Q = (x2, y2) affine slots); line = (L2, L3, L5) of the chord through old R and Q at P."""
         X, Y, Z = R
         x2, y2 = Q
         L2, L3, L5 = line
         if update and self._fused_ok():
-            if scale is not None:
+            if scale is not None and alt_r is None:
                 self.A(scale).mul(Z).to(scale)
             if LINE_IN_REGS:
                 line = self.LINE_REGS
-            self._add_step_fused(R, Q, Pt, line, out, after_load, load_p, load_q)
+            self._add_step_fused(R, Q, Pt, line, out, after_load, load_p, load_q, alt_r, scale_in=(scale if alt_r is not None else None))
             return line
-        assert out is None and after_load is None and load_p is None and load_q is None
+        assert out is None and after_load is None and load_p is None and load_q is None and alt_r is None
         th, mu, T, U = [self.tmp() for _ in range(4)]
         if scale is not None:
             self.A(scale).mul(Z).to(scale)
@@ -1302,6 +1361,8 @@ class KernelBuilder:
         else:       # the point state of the Miller loop (and its per-pair copies in scratch): operands of the fused steps
             keys += [Prog.key(s_) for s_ in (*self.R, self.QX, self.QY, self.PX, self.PY, self.SX, self.SY)]
             keys += [("globdyn", i) for i in range(7)]
+            if self.multi and self.r0_resident():
+                keys += [Prog.key(s_) for s_ in self.R0_LDS]
         return frozenset(keys)
 
     def new_prog(self, temps, phase=None):
@@ -2338,6 +2399,15 @@ class KernelBuilder:
         e.salu(f"s_cbranch_scc0 {L('L_mf_nopack')}")
         self.pair_loop(e, "pack", lambda: self._emit_pack_p(e, p))
         e.label(L("L_mf_nopack"))
+        if self.r0_resident():                                        # pair 0's R moves on chip for the whole loop
+            e.salu(f"s_mov_b32 s{S_JP}, 0")
+            self.pair_select(e)
+            p.reset_tags()
+            e.raw("s_waitcnt vmcnt(0)")                               # (the stores of the first steps have been acknowledged)
+            for k_, dst in zip((4, 5, 6), self.R0_LDS):
+                p.A(GlobDyn(k_)).to(dst)
+            p.wait()
+            p.reset_tags()
         e.salu(f"s_mul_i32 s{self.S_GNEXT}, s{S_GSTRIDE}, {self.PAIR_SLOT0}")      # prime the stream: pair 0
         self.call2(e, "L2_prefetch")
         e.salu(f"s_mov_b32 s{S_I}, 63")
@@ -2365,6 +2435,16 @@ class KernelBuilder:
         e.label(L("L_mnoadd"))
         e.salu(f"s_sub_u32 s{S_I}, s{S_I}, 1")
         e.salu(f"s_cbranch_scc0 {L('L_mloop')}")
+
+        if self.r0_resident():                                        # ... and back to its scratch block for the end steps
+            e.salu(f"s_mov_b32 s{S_JP}, 0")
+            self.pair_select(e)
+            p.reset_tags()
+            for k_, src in zip((4, 5, 6), self.R0_LDS):
+                p.A(src).to(GlobDyn(k_))
+            p.wait()
+            e.raw("s_waitcnt vmcnt(0)")                               # acknowledged before the end steps read the block back
+            p.reset_tags()
 
         def end_pair():
             self.pair_in(e, p, with_q=True)
@@ -2544,6 +2624,11 @@ class KernelBuilder:
     #     LDS slots that are idle during the loop (the resident Q and R slots of the one-pair routines): the stream carries R only
     #     (3 slots in, 3 out per step instead of 5 + 3), and the two freed buffer slots take the next pair's Q whenever the next
     #     step is an addition -- nothing is fetched synchronously any more.
+    R0_LDS = [LDS(3, "R0X"), LDS(4, "R0Y"), LDS(5, "R0Z")]    # pair 0's R during the streamed loop
+
+    def r0_resident(self):
+        return bool(int(os.environ.get("KGEN_R0_LDS", "1"))) and LINE_IN_REGS and Prog.FUSED_STEPS and SPREAD_PREFETCH
+
     S_GNEXT = 49               # byte offset of the NEXT pair's scratch block
     RES_K = 4                  # largest k whose evaluation points stay on chip
     RES_P_LDS = (0, 1, 6, 7)   # LDS slot of pair j's packed (Px, Py)
@@ -2570,7 +2655,14 @@ class KernelBuilder:
         """the prefetch, slot group by slot group (KGEN_SPREAD_PF): part 0..2 = RX, RY, RZ; part 3 = P or Q (as _emit_prefetch)"""
         L = self.lab
         if part < 3:
+            if self.r0_resident():                        # the next pair is pair 0 (the index wraps): its R is on chip
+                u = self.uid()
+                e.salu(f"s_add_u32 s{S_TMP0}, s{S_JP}, 1")
+                e.salu(f"s_cmp_lt_u32 s{S_TMP0}, s{S_K}")
+                e.salu(f"s_cbranch_scc0 {L(f'L_pf_r0_{u}')}")
             self._emit_buf_loads(e, ((("RX", 4), ("RY", 5), ("RZ", 6))[part],))
+            if self.r0_resident():
+                e.label(L(f"L_pf_r0_{u}"))
             return
         u = self.uid()
         e.salu(f"s_cmp_le_u32 s{S_K}, {self.RES_K}")
@@ -2639,9 +2731,13 @@ class KernelBuilder:
         buf = self.BUF
         Rb, Pb = [buf["RX"], buf["RY"], buf["RZ"]], (buf["PX"], buf["PY"])
         Rout = [GlobDyn(4), GlobDyn(5), GlobDyn(6)]
-        temps = ([HOME(i) for i in range(N_HOME)] + (list(self.LINE) if LINE_IN_REGS and Prog.FUSED_STEPS else []) + self.MILLER_FREE[1]
-                 + [GLOB(GLOB_TMP0 + i) for i in range(8)])
+        res0 = self.r0_resident()
+        temps = ([HOME(i) for i in range(N_HOME)] + (list(self.LINE) if LINE_IN_REGS and Prog.FUSED_STEPS else [])
+                 + ([] if res0 else self.MILLER_FREE[1]) + [GLOB(GLOB_TMP0 + i) for i in range(8)])
         L = self.lab
+        # pair 0's R never leaves the chip: it lives in the three LDS slots the sparse multiplications no longer need (R0_LDS); the
+        # steps pick their R source / destination by the pair index
+        alt = (lambda e_: e_.salu(f"s_cmp_eq_u32 s{S_JP}, 0"), self.R0_LDS, lambda n: L(f"{n}_{self.uid()}")) if res0 else None
 
         def load_p(p):
             """block B <- (Px, Py): from the buffer, or -- resident-P mode -- from the pair's packed LDS slot"""
@@ -2686,7 +2782,8 @@ class KernelBuilder:
         def dbl_s(p):
             if not EXP_NO_SWAIT:
                 p.e.raw("s_waitcnt vmcnt(0)")                   # the prefetch of this pair has landed
-            line = p.dbl_step(Rb, Pb, self.LINE, scale=sc, out=Rout, after_load=(None if SPREAD_PREFETCH else lambda: self._emit_prefetch(p.e, q="last")), load_p=load_p)
+            line = p.dbl_step(Rb, Pb, self.LINE, scale=sc, out=Rout, after_load=(None if SPREAD_PREFETCH else lambda: self._emit_prefetch(p.e, q="last")), load_p=load_p,
+                              alt_r=alt)
             p.mul_by_034(self.F, *line, between=spread(p, "last"))
 
         def add_s(p):
@@ -2704,12 +2801,12 @@ class KernelBuilder:
                 e.label(L("L_as_pos"))
                 if not SPREAD_PREFETCH:
                     self._emit_prefetch(e, q="always")
-            line = p.add_step(Rb, (GlobDyn(2), GlobDyn(3)), Pb, self.LINE, scale=sc, out=Rout, after_load=after, load_p=load_p, load_q=load_q)
+            line = p.add_step(Rb, (GlobDyn(2), GlobDyn(3)), Pb, self.LINE, scale=sc, out=Rout, after_load=after, load_p=load_p, load_q=load_q, alt_r=alt)
             p.mul_by_235(self.F, *line, between=spread(p, "always"))
 
         self.l2_routine("L2_dblmul_s", dbl_s, temps, local=self.LINE)
         self.l2_routine("L2_addmul_s", add_s, temps, local=self.LINE)
-        self.l2_routine("L2_prefetch", lambda p: self._emit_prefetch(p.e, q="always"), temps)
+        self.l2_routine("L2_prefetch", lambda p: (self._emit_prefetch_part(p.e, 3, "always") if res0 else self._emit_prefetch(p.e, q="always")), temps)
 
     def pair_select_next(self, e):
         """S_GNEXT <- byte offset of the scratch block of pair (S_JP + 1) mod k"""
