@@ -243,7 +243,7 @@ def spot_check(pkg, torch, g1, g2, out, n, positions, threads):
     return bool(np.array_equal(pkg.layout.to_aos(got, 48), want))
 
 
-def extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n):
+def extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n, sample_power=False):
     """BASELINE.json configs[1] and configs[3] on one GPU (not the headline `value`); inputs: the resident 2^20 batch."""
     out = {}
 
@@ -269,9 +269,15 @@ def extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n):
     assert groups * k <= n
     o2 = torch.zeros(48 * groups, dtype=torch.int64, device=dev)
     ms = timed(lambda: pkg.multi_pairing_batch_dev(g1, g2, o2, groups, k, True, device=local_rank, stream=stream), 2)
-    out["configs[3]: Groth16 shape, 2^18 groups x 4 pairs, shared final exp"] = {
-        "ms": ms, "groups_per_s": groups / (ms * 1e-3), "pairs_per_s": groups * k / (ms * 1e-3),
-        "roofline_frac": groups / (ms * 1e-3) * W_MUL32_PER_GROTH16_GROUP / PEAK_MUL32_PER_S}
+    g16 = {"ms": ms, "groups_per_s": groups / (ms * 1e-3), "pairs_per_s": groups * k / (ms * 1e-3),
+           "roofline_frac": groups / (ms * 1e-3) * W_MUL32_PER_GROTH16_GROUP / PEAK_MUL32_PER_S, "kernel": "k_mpairing"}
+    if sample_power:                # ~1.5 s of back-to-back launches: long enough for rocm-smi to see what this kernel draws
+        with PowerSampler() as ps:
+            for _ in range(24):
+                pkg.multi_pairing_batch_dev(g1, g2, o2, groups, k, True, device=local_rank, stream=stream)
+            torch.cuda.synchronize(dev)
+        g16["package_power"] = ps.summary()
+    out["configs[3]: Groth16 shape, 2^18 groups x 4 pairs, shared final exp"] = g16
     # data formats either side of the path: element-major <-> limb-major on the device (HBM-bound: every word read once, written once)
     HBM_PEAK = 8.0e12
     lay = {}
@@ -465,7 +471,7 @@ def run_rank(args):
                 print("bench.py: GPU results differ from the oracle -- no measurement reported", file=sys.stderr)
                 rc = 3
         if rc == 0 and on_gpu and world == 1 and not args.no_extra and log2 == LOG2_SINGLE:
-            rec["extra"] = extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n)
+            rec["extra"] = extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n, sample_power=power is not None)
         if rc == 0 and on_gpu and world == 1 and not args.no_cpu_baseline:
             m = min(n, 1 << 15)
             g1h = g1.view(8, n)[:, :m].cpu().numpy().view(np.uint64).reshape(-1).copy()
