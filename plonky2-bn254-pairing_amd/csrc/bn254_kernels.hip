@@ -31,7 +31,8 @@ constexpr size_t MAX_K = 64;                            // pairs per group of th
 // k-pair kernels most: their step loop sits at the edge of the 64 KB instruction cache), depending on where the other kernels
 // had pushed it.  Every kernel therefore starts on a 64 KB boundary, its body BN254_KERNEL_PAD bytes behind it -- the best of 24
 // offsets measured (profiles/r02_ab.txt: +1.0 % on the Groth16 shape, +0.5 % on 2^20 pairings against the best unaligned build,
-// worst offset -3.2 %).  What is left is run-to-run: the physical placement of the code object.
+// worst offset -3.2 %).  What is left is run-to-run: the physical placement of the code object.  (Re-scanned on round 3's kernels:
+// ten offsets within +-0.8 %, inside the noise -- profiles/r03_ab.txt.)
 #ifndef BN254_KERNEL_ALIGN
 #define BN254_KERNEL_ALIGN 65536
 #endif
