@@ -38,9 +38,7 @@ S_GSTRIDE = 66            # bytes between consecutive global slots
 S_I = 67                  # Miller-loop digit index
 S_NAF_NZ = "s[68:69]"     # 6u+2 NAF: non-zero mask, negative mask (digits 0..63)
 S_NAF_NEG = "s[70:71]"
-S_XNAF_NZ = "s[72:73]"    # x-power digit masks
-S_XNAF_NEG = "s[74:75]"
-S_XIDX0, S_XIDX1 = "s[50:51]", "s[52:53]"      # which power a non-zero digit selects (index into X_POWERS)
+# (s50..s53, s72..s75: free -- the x-power schedule is unrolled control code, its digit masks are gone)
 S_J = 76                  # pow_x digit index
 S_GBASE = 77              # global Fq12 register operand of fq12_mul (slot number * stride, low 32 bits)
 S_ITEM = 78
@@ -1814,14 +1812,6 @@ class KernelBuilder:
         e.salu(f"s_mov_b32 s69, 0x{nz >> 32:x}")
         e.salu(f"s_mov_b32 s70, 0x{neg & 0xFFFFFFFF:x}")
         e.salu(f"s_mov_b32 s71, 0x{neg >> 32:x}")
-        xd = list(X_DIGITS[:-1])                       # the top digit is the initial value of the accumulator
-        nz, neg = naf_masks([(d > 0) - (d < 0) for d in xd])
-        self.x_top = len(xd)
-        idx = [X_POWERS.index(abs(d)) if d else 0 for d in xd]
-        for reg, val in ((72, nz), (74, neg), (50, sum((i & 1) << j for j, i in enumerate(idx))),
-                         (52, sum((i >> 1) << j for j, i in enumerate(idx)))):
-            e.salu(f"s_mov_b32 s{reg}, 0x{val & 0xFFFFFFFF:x}")
-            e.salu(f"s_mov_b32 s{reg + 1}, 0x{val >> 32:x}")
         e.salu(f"s_lshl_b32 s{S_NSTRIDE}, s{S_N}, 3")
         e.salu(f"s_add_u32 s{S_NITEMS}, s{S_N}, 255")
         e.salu(f"s_lshr_b32 s{S_NITEMS}, s{S_NITEMS}, 8")
