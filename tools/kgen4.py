@@ -448,31 +448,51 @@ class L1v4:
         self.pool.free(*t)
         self.pool.free(*u)
 
-    def r_sqr4c(self, xi=False):
-        """One Fq4 squaring of the Granger-Scott cyclotomic squaring WITH its recombination, all in registers:
-        (a + b y)^2, y^2 = xi, a in block A, b in block B, zc in home block 3, zd in home block 4 (all normalised):
-            A <- 3 (a^2 + xi b^2) - 2 zc        B <- 3 (2 a b) + 2 zd      (xi variant: B <- 3 xi (2 a b) + 2 zd)
-        both NORMALISED AND REDUCED (values in (-0.51 p, 0.51 p)).
+    def sqr4c_core(self, a, b, zc, zd, oa, ob, t, u, s, xi=False):
+        """One Fq4 squaring of the Granger-Scott cyclotomic squaring WITH its recombination, on explicit register blocks:
+        (a + b y)^2, y^2 = xi (a, b, zc, zd normalised Fq2 blocks):
+            oa <- 3 (a^2 + xi b^2) - 2 zc        ob <- 3 (2 a b) + 2 zd      (xi variant: ob <- 3 xi (2 a b) + 2 zd)
+        both NORMALISED AND REDUCED (values in (-0.51 p, 0.51 p)).  oa / ob may be zc / zd or a / b themselves (a, b are dead
+        once the second product is formed; the chains write limb i of both outputs after reading limb i of every input).
         t = a b ; S = xi b + a (normalised on a 64-bit chain) ; P = (a + b) S ; a^2 + xi b^2 = P - t - xi t.
-        Scratch: home blocks 0..2, the pool."""
-        a, b = self.fq2(A0), self.fq2(B0)
-        t = self.fq2(HOME0)
-        u = self.fq2(HOME0 + SLOT_DW)
-        s = self.fq2(HOME0 + 2 * SLOT_DW)
-        zc = self.fq2(HOME0 + 3 * SLOT_DW)
-        zd = self.fq2(HOME0 + 4 * SLOT_DW)
+        t, u, s: three scratch blocks; the pool."""
         self._fq2_mul(a, b, t, balanced=False)                          # t = a b (a, b stay intact); t and P only feed the chains
         # S = xi b + a = (9 b0 - b1 + a0, 9 b1 + b0 + a1), normalised
         self.lincomb([s[0], s[1]], [[(9, b[0]), (-1, b[1]), (1, a[0])], [(9, b[1]), (1, b[0]), (1, a[1])]])
         self._lw("v_add_u32_e32", u, a, b)                              # u = a + b (two units)
         self._fq2_mul(u, s, u, balanced=False)                          # P = u S, in place
-        # A <- 3 (P - t - xi t) - 2 zc = 3 P - 30 t0 + 3 t1 - 2 zc | 3 P1 - 30 t1 - 3 t0 - 2 zc1
-        self.lincomb([a[0], a[1]], [[(3, u[0]), (-30, t[0]), (3, t[1]), (-2, zc[0])],
-                                    [(3, u[1]), (-30, t[1]), (-3, t[0]), (-2, zc[1])]], reduce=True)
-        if not xi:                                                      # B <- 6 t + 2 zd
-            self.lincomb([b[0], b[1]], [[(6, t[0]), (2, zd[0])], [(6, t[1]), (2, zd[1])]], reduce=True)
-        else:                                                           # B <- 6 xi t + 2 zd = (54 t0 - 6 t1, 54 t1 + 6 t0) + 2 zd
-            self.lincomb([b[0], b[1]], [[(54, t[0]), (-6, t[1]), (2, zd[0])], [(54, t[1]), (6, t[0]), (2, zd[1])]], reduce=True)
+        # oa <- 3 (P - t - xi t) - 2 zc = 3 P - 30 t0 + 3 t1 - 2 zc | 3 P1 - 30 t1 - 3 t0 - 2 zc1
+        self.lincomb([oa[0], oa[1]], [[(3, u[0]), (-30, t[0]), (3, t[1]), (-2, zc[0])],
+                                      [(3, u[1]), (-30, t[1]), (-3, t[0]), (-2, zc[1])]], reduce=True)
+        if not xi:                                                      # ob <- 6 t + 2 zd
+            self.lincomb([ob[0], ob[1]], [[(6, t[0]), (2, zd[0])], [(6, t[1]), (2, zd[1])]], reduce=True)
+        else:                                                           # ob <- 6 xi t + 2 zd = (54 t0 - 6 t1, 54 t1 + 6 t0) + 2 zd
+            self.lincomb([ob[0], ob[1]], [[(54, t[0]), (-6, t[1]), (2, zd[0])], [(54, t[1]), (6, t[0]), (2, zd[1])]], reduce=True)
+
+    def r_sqr4c(self, xi=False):
+        """sqr4c_core on the accumulator-machine blocks: a in block A, b in block B, zc in home block 3, zd in home block 4;
+        A <- out_a, B <- out_b.  Scratch: home blocks 0..2, the pool."""
+        a, b = self.fq2(A0), self.fq2(B0)
+        H = lambda k: self.fq2(HOME0 + SLOT_DW * k)
+        self.sqr4c_core(a, b, H(3), H(4), a, b, H(0), H(1), H(2), xi=xi)
+
+    def cyc3(self):
+        """F <- F^2 for F in the cyclotomic subgroup (Granger-Scott), F0..F5 RESIDENT in home blocks 3..8 -- three Fq4 squarings
+        with their recombination, results in place.  A run of squarings (the x-powers have runs of up to eight) then moves F between
+        its slots and the registers once per run instead of eighteen slot accesses per squaring.
+        The three squarings read each other's inputs in a cycle: (F1, F4) are copied to blocks A, B first.  Scratch: home blocks
+        0..2, blocks A, B, the pool."""
+        H = lambda k: self.fq2(HOME0 + SLOT_DW * k)
+        F = [H(3 + i) for i in range(6)]
+        t, u, s = H(0), H(1), H(2)
+        A, B = self.fq2(A0), self.fq2(B0)
+        for dst, src in ((A, F[1]), (B, F[4])):
+            for h in range(2):
+                for i in range(NL):
+                    self.e.emit(f"v_mov_b32_e32 v{dst[h][i]}, v{src[h][i]}", vw=[dst[h][i]])
+        self.sqr4c_core(F[2], F[5], F[4], F[1], F[4], F[1], t, u, s, xi=True)      # F4' = 3 t4 - 2 F4 ; F1' = 3 xi t5 + 2 F1
+        self.sqr4c_core(A, B, F[2], F[5], F[2], F[5], t, u, s)                     # F2' = 3 t2 - 2 F2 ; F5' = 3 t3 + 2 F5  (a, b = old F1, F4)
+        self.sqr4c_core(F[0], F[3], F[0], F[3], F[0], F[3], t, u, s)               # F0' = 3 t0 - 2 F0 ; F3' = 3 t1 + 2 F3
 
     def r_sqr4cx(self):
         self.r_sqr4c(xi=True)

@@ -1476,7 +1476,7 @@ class KernelBuilder:
         if self.do_fexp:
             if not (self.do_miller and self.track):
                 self.l2_routine("L2_fqinv", self._fq_inv, self.fexp_temps(lds=True))
-            self.l2_routine("L2_cyc", lambda p: p.fq12_cyc_sqr(self.F), self.fexp_temps())
+            self.l2_routine("L2_cyc", self._cyc_run, self.fexp_temps())
             self.l2_routine("L2_redF", self._reduce_f, self.fexp_temps())
             self._mulG_routines()
             for k in (1, 2, 3):
@@ -1595,7 +1595,9 @@ class KernelBuilder:
                     run("L2_mul_body", label="L2_mulGc_w" if op[1] else "L2_mulG_w")
                 elif op[0] == "powx":
                     for o, a in self.powx_ops(store_base=op[2]):
-                        if o == "call":
+                        if o == "cyc":
+                            run("L2_cyc", label="L2_cycN" if a > 1 else "L2_cyc")
+                        elif o == "call":
                             if a in ("L2_mulL", "L2_mulLc", "L2_mul_body"):
                                 run("L2_mul_body", label=a)
                             else:
@@ -1618,6 +1620,31 @@ class KernelBuilder:
             worst = max(worst, self._check_routine(name))
         return {"fixed_point": V_STORE, "max_stored": worst}
 
+    def _cyc_run(self, p):
+        """F <- F^(2^n), n cyclotomic squarings with F resident in home blocks 3..8 for the whole run (L1v4.cyc3): entry L2_cyc does
+        one, entry L2_cycN S_J + 1 (the x-powers have runs of up to eight squarings between two multiplications)."""
+        e = p.e
+        e.salu(f"s_mov_b32 s{S_J}, 0")
+        e.label(self.lab("L2_cycN"))
+        p.reset_tags()
+        for i in range(6):
+            p._need(mag(p.r_of(self.F[i])) <= 1.0, f"cyclotomic squaring: {self.F[i]} is not normalised")
+            p._need(p.v_of(self.F[i]) <= V_CAP / 12, "cyclotomic squaring operand value")       # S = xi b + a enters a product
+            p.load(HOME0 + SLOT_DW * (3 + i), self.F[i])
+        p.wait()
+        loop = self.lab(f"L_cyc_loop_{self.uid()}")
+        e.label(loop)
+        L1v4(e).cyc3()
+        p._count("cyc3")
+        e.salu(f"s_sub_u32 s{S_J}, s{S_J}, 1")
+        e.salu(f"s_cbranch_scc0 {loop}")
+        for i in range(6):
+            p.store(HOME0 + SLOT_DW * (3 + i), self.F[i])
+            k_ = p.key(self.F[i])
+            p.slot_r[k_], p.slot_v[k_] = R_NORM, 0.51
+        p.max_v = max(p.max_v, 0.51)
+        p.reset_tags()
+
     def _reduce_f(self, p):
         """F <- the same residues with representatives back in (-0.51 p, 0.51 p) (L1 redn)."""
         for k in range(6):
@@ -1629,21 +1656,26 @@ class KernelBuilder:
         ("call", L2 routine).  b^13 -- half of the digit multiplications -- never goes to scratch: conj(b^13) sits in the on-chip
         register LREG (the first digit that uses it is -13; the one +13 conjugates f around the multiplication instead)."""
         ops = [("st", "base")] if store_base else []
-        ops += [("pf", "base"), ("call", "L2_cyc"), ("call", "L2_cyc"), ("st", G_B4),  # b^4 (the operand b is fetched under the squarings)
+        ops += [("pf", "base"), ("cyc", 2), ("st", G_B4),                              # b^4 (the operand b is fetched under the squarings)
                 ("mul_w", "base"), ("pf", G_B4), ("st", G_POW[5]),                     # b^5 = b^4 b
                 ("mul_w", G_B4), ("st", G_POW[9]),                                     # b^9 = b^5 b^4
                 ("call", "L2_mul_body"), ("call", "L2_conjF"), ("call", "L2_stL")]     # conj(b^13) = conj(b^9 b^4) -> LREG (b^4 is still in the operand slots)
         top = X_DIGITS[-1]
         ops.append(("ld", "base" if top == 1 else G_POW[top]) if top != 13 else ("call", "L2_ldLc"))
+        run = 0                                                                        # squarings since the last multiplication: ONE resident run
         for d in reversed(X_DIGITS[:-1]):
+            run += 1
             if d == 0:
-                ops.append(("call", "L2_cyc"))
-            elif abs(d) == 13:
-                ops.append(("call", "L2_cyc"))
+                continue
+            if abs(d) == 13:
+                ops.append(("cyc", run))
                 ops += [("call", "L2_mulL")] if d < 0 else [("call", "L2_conjF"), ("call", "L2_mulL"), ("call", "L2_conjF")]
             else:
                 reg = "base" if abs(d) == 1 else G_POW[abs(d)]
-                ops += [("pf", reg), ("call", "L2_cyc"), ("mulc_w" if d < 0 else "mul_w", reg)]      # the fetch runs under the squaring
+                ops += [("pf", reg), ("cyc", run), ("mulc_w" if d < 0 else "mul_w", reg)]      # the fetch runs under the squarings
+            run = 0
+        if run:
+            ops.append(("cyc", run))
         return ops
 
     def _powx_routine(self):
@@ -1664,6 +1696,11 @@ class KernelBuilder:
         for op, arg in self.powx_ops(store_base=False):
             if op == "call":
                 e.salu(f"s_call_b64 {S_RET2}, {L(arg)}")
+                continue
+            if op == "cyc":                                         # a run of `arg` squarings
+                if arg > 1:
+                    e.salu(f"s_mov_b32 s{S_J}, {arg - 1}")
+                e.salu(f"s_call_b64 {S_RET2}, {L('L2_cycN' if arg > 1 else 'L2_cyc')}")
                 continue
             if op not in ("mul_w", "mulc_w"):                       # (the waiting entries find the operand fetched by "pf")
                 if arg == "base":
