@@ -105,7 +105,7 @@ class Phases:
             return "easy part: Fq12 inversion (final_exp_native.rs:200)"
         if name.startswith("L2_frob"):
             return "Frobenius maps (final_exp_native.rs:17-54)"
-        if name == "L2_cyc":
+        if name in ("L2_cyc", "L2_cycN"):
             return ("x-powers: cyclotomic squarings (pow_native, :56-84)" if in_powx else "y-chain: cyclotomic squarings (:153-166)")
         if name in ("L2_mul_body", "L2_mulG", "L2_mulGc", "L2_mulG_w", "L2_mulGc_w", "L2_pfB", "L2_mulL", "L2_mulLc"):
             return ("x-powers: fq12_mul (table b^5 b^9 b^13 + digits)" if in_powx else "easy part + y-chain: fq12_mul (:135-166, :198-205)")

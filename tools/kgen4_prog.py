@@ -773,8 +773,132 @@ class Prog:
         self.A(M[1]).sub(res[1]).to(F[3])
         self.rel(*M)
 
+    # ---- register-level glue around the fused Fq6 multiplication (FUSED_GLUE): the operands of the second product are built
+    # from what the first one left in the home blocks (a0 and b survive mul6), sums that must be normalised come out of ONE 64-bit
+    # chain each, the recombination runs on registers and every result is stored once.
+    def _mul6_call(self, ma, mb, va, vb):
+        """the fused Fq6 multiplication on operands that are already in home blocks 0..2 (limbs of ma units, value va) and 3..5
+        (mb, vb); returns the value bounds of c0 (home 6), c1 (home 2), c2 (block A), all normalised"""
+        self._need(2 * NL * 3 * ma * mb <= COL_BUDGET, f"mul6 operand limbs {ma} {mb}")
+        self._need(10 * va <= V_CAP and vb <= V_CAP, f"mul6 operand values {va} {vb}")
+        self.wait()
+        self._raw_call("mul6")
+        vs = (42 * va * vb / K_RP + 0.5, 24 * va * vb / K_RP + 0.5, 6 * va * vb / K_RP + 0.5)
+        for v in vs:
+            self._need(v <= V_CAP, f"mul6 result value {v}")
+            self.max_v = max(self.max_v, v)
+        self.tagA = self.tagB = None
+        return vs
+
+    def _blk_sum(self, dst, terms, v):
+        """register block dst <- sum of coef * (register block) over terms, NORMALISED on one 64-bit chain per component; reduced as
+        well when the value bound v exceeds what a normalising store would keep (cf. norm()).  Returns the value bound left."""
+        g = L1v4(self.e)
+        d = g.fq2(dst)
+        red = v > V_REDN_AT
+        self._need(v <= 8 * V_CAP, f"chain on a value of {v} p")
+        g.lincomb([d[0], d[1]], [[(c, g.fq2(b)[0]) for c, b in terms], [(c, g.fq2(b)[1]) for c, b in terms]], reduce=red)
+        return 0.51 if red else v
+
+    def _blk_store(self, blk, dst, limbs, v):
+        """dst <- register block blk (limbs of `limbs` units, value bound v): normalised / reduced first exactly where to() would"""
+        g = L1v4(self.e)
+        b = g.fq2(blk)
+        lim = 1.0 if self.key(dst) in self.norm_keys else STORE_MAG
+        need_norm = limbs > max(lim, v / K_TOP)
+        if v > self.v_limit(dst) or (need_norm and (v > V_REDN_AT or limbs > LIMB_MAG)):
+            self._need(v <= 8 * V_CAP and limbs <= 7.9, f"redn of {v} p, limbs {limbs}")
+            g.lincomb([b[0], b[1]], [[(1, b[0])], [(1, b[1])]], reduce=True)
+            limbs, v = 1.0, 0.51
+            self._count("redn")
+        elif need_norm:
+            self._need(limbs <= LIMB_MAG, f"norm of limbs {limbs}")
+            g.norm_limbs(b[0])
+            g.norm_limbs(b[1])
+            limbs = 1.0
+            self._count("norm")
+        self.wait()
+        self.store(blk, dst)
+        self._need(v <= V_CAP, f"value bound {v} p at store")
+        self.slot_r[self.key(dst)] = self.r_norm(v) if limbs <= 1.0 else (-limbs, limbs)
+        self.slot_v[self.key(dst)] = v
+        self.max_v = max(self.max_v, v)
+        if self.tagA is dst:
+            self.tagA = None
+        if self.tagB is dst:
+            self.tagB = None
+
+    def _lw_blocks(self, op, dst, a, b):
+        for i in range(SLOT_DW):
+            self.e.emit(f"{op} v{dst + i}, v{a + i}, v{b + i}", vw=[dst + i])
+
+    def _fq12_sqr_fused(self, F):
+        Hb = lambda k: HOME0 + SLOT_DW * k
+        for s_ in F:
+            self._need(mag(self.r_of(s_)) <= 1.0, f"fq12_sqr: {s_} is not normalised")
+        v = max(self.v_of(s_) for s_ in F)
+        T = [self.tmp() for _ in range(3)]
+        self.tagA = self.tagB = None
+        # t = A0 A1
+        for k, i in enumerate((0, 2, 4)):
+            self.load(Hb(k), F[i])
+        for k, i in enumerate((1, 3, 5)):
+            self.load(Hb(3 + k), F[i])
+        t0, t1, t2 = self._mul6_call(1.0, 1.0, v, v)              # t0 home 6, t1 home 2, t2 block A; home 0 = F0, homes 3..5 = F1, F3, F5 survive
+        for blk, dst, tv in ((Hb(6), T[0], t0), (Hb(2), T[1], t1), (A0, T[2], t2)):
+            self._blk_store(blk, dst, 1.0, tv)
+        # u = (A0 + A1)(A0 + v A1): a' = (F0 + F1, F2 + F3, F4 + F5) raw sums, b' = (F0 + xi F5, F2 + F1, F4 + F3) off the chains
+        self.load(Hb(1), F[2])
+        self.load(Hb(2), F[4])
+        self.wait()
+        g = L1v4(self.e)
+        h0, h5 = g.fq2(Hb(0)), g.fq2(Hb(5))
+        a_ = g.fq2(A0)
+        v_s0 = 11 * v                                             # F0 + xi F5 = (F0.0 + 9 F5.0 - F5.1, F0.1 + 9 F5.1 + F5.0)
+        red0 = v_s0 > V_REDN_AT
+        g.lincomb([a_[0], a_[1]], [[(1, h0[0]), (9, h5[0]), (-1, h5[1])], [(1, h0[1]), (9, h5[1]), (1, h5[0])]], reduce=red0)
+        vb0 = 0.51 if red0 else v_s0
+        vb1 = self._blk_sum(Hb(6), [(1, Hb(1)), (1, Hb(3))], 2 * v)       # F2 + F1
+        vb2 = self._blk_sum(B0, [(1, Hb(2)), (1, Hb(4))], 2 * v)          # F4 + F3
+        for k in range(3):
+            self._lw_blocks("v_add_u32_e32", Hb(k), Hb(k), Hb(3 + k))     # a' (two units)
+        for dst, src in ((Hb(3), A0), (Hb(4), Hb(6)), (Hb(5), B0)):
+            for i in range(SLOT_DW):
+                self.e.emit(f"v_mov_b32_e32 v{dst + i}, v{src + i}", vw=[dst + i])
+        u0, u1, u2 = self._mul6_call(2.0, 1.0, 2 * v, max(vb0, vb1, vb2))
+        # recombination on registers: t0, t1, t2 -> home blocks 3, 4, 5
+        for k in range(3):
+            self.load(Hb(3 + k), T[k])
+        self.wait()
+        self._lw_blocks("v_sub_u32_e32", A0, A0, Hb(5))
+        self._lw_blocks("v_sub_u32_e32", A0, A0, Hb(4))
+        self._blk_store(A0, F[4], 3.0, u2 + t2 + t1)                      # F4 = u2 - t2 - t1
+        h7 = g.fq2(Hb(7))
+        vx = 10 * t2                                                      # X = xi t2 -> home 7 (normalised; reduced when large)
+        redx = vx > V_REDN_AT
+        g2 = L1v4(self.e)
+        g2.lincomb([h7[0], h7[1]], [[(9, h5[0]), (-1, h5[1])], [(9, h5[1]), (1, h5[0])]], reduce=redx)
+        vx = 0.51 if redx else vx
+        self._lw_blocks("v_sub_u32_e32", Hb(6), Hb(6), Hb(3))
+        self._lw_blocks("v_sub_u32_e32", Hb(6), Hb(6), Hb(7))
+        self._blk_store(Hb(6), F[0], 3.0, u0 + t0 + vx)                   # F0 = u0 - t0 - xi t2
+        self._lw_blocks("v_sub_u32_e32", Hb(2), Hb(2), Hb(4))
+        self._lw_blocks("v_sub_u32_e32", Hb(2), Hb(2), Hb(3))
+        self._blk_store(Hb(2), F[2], 3.0, u1 + t1 + t0)                   # F2 = u1 - t1 - t0
+        for k, (dst, tv) in enumerate(((F[1], t0), (F[3], t1), (F[5], t2))):
+            for i in range(SLOT_DW):
+                r = Hb(3 + k) + i
+                self.e.emit(f"v_lshlrev_b32_e32 v{r}, 1, v{r}", vw=[r])
+            self._blk_store(Hb(3 + k), dst, 2.0, 2 * tv)                  # F1, F3, F5 = 2 t
+        self.rel(*T)
+        self.tagA = self.tagB = None
+
+    FUSED_GLUE = bool(int(os.environ.get("KGEN_FUSED_GLUE", "1")))
+
     def fq12_sqr(self, F):
         """F <- F^2 (complex squaring over Fq6: t = A0 A1, u = (A0 + A1)(A0 + v A1))."""
+        if self.FUSED_GLUE and self.homes_free and all(s_.kind != "home" for s_ in F):
+            return self._fq12_sqr_fused(F)
         A_0, A_1 = [F[0], F[2], F[4]], [F[1], F[3], F[5]]
         T = [self.tmp() for _ in range(3)]
         S0 = self.tmp()
@@ -792,38 +916,6 @@ class Prog:
         self.A(T[1]).dbl().to(F[3])
         self.A(T[2]).dbl().to(F[5])
         self.rel(S0, *T)
-
-    def _sqr4c(self, a, b, zc, zd, out_a, out_b, xi=False):
-        """out_a <- 3 (a^2 + xi b^2) - 2 zc ; out_b <- 3 (2 a b) + 2 zd  (xi: 3 xi (2 a b) + 2 zd): one Fq4 squaring of the
-        Granger-Scott cyclotomic squaring with its recombination, in ONE L1 routine.  All four operands normalised;
-        both results normalised and reduced."""
-        vs = []
-        for blk, s_ in ((HOME0 + 3 * SLOT_DW, zc), (HOME0 + 4 * SLOT_DW, zd), (A0, a), (B0, b)):
-            self._need(mag(self.r_of(s_)) <= 1.0, f"sqr4c operand {s_} is not normalised")
-            vs.append(self._load_norm_sum(blk, s_, None))
-        self._need(max(vs) <= V_CAP / 12, f"sqr4c operand values {vs}")      # S = xi b + a enters a product
-        self._raw_call("sqr4cx" if xi else "sqr4c")
-        self.tagH = [None] * 4
-        self.set_A_fresh()
-        self.to(out_a)
-        self.wait()
-        self.store(B0, out_b)
-        k1 = self.key(out_b)
-        self.slot_v[k1] = 0.51
-        self.slot_r[k1] = R_NORM
-        self.tagB = out_b
-
-    def fq12_cyc_sqr(self, F):
-        """Granger-Scott squaring (F in the cyclotomic subgroup), in place: three fused Fq4 squarings with recombination."""
-        self.reserve_blocks(5)
-        t2, t5 = self.tmp(), self.tmp()
-        self._sqr4c(F[1], F[4], F[2], F[5], t2, t5)            # F2' = 3 t2 - 2 F2 ; F5' = 3 t3 + 2 F5  (kept aside: F2, F5 are read below)
-        self._sqr4c(F[0], F[3], F[0], F[3], F[0], F[3])        # F0' = 3 t0 - 2 F0 ; F3' = 3 t1 + 2 F3
-        self._sqr4c(F[2], F[5], F[4], F[1], F[4], F[1], xi=True)   # F4' = 3 t4 - 2 F4 ; F1' = 3 xi t5 + 2 F1
-        self.mov(F[2], t2)
-        self.mov(F[5], t5)
-        self.rel(t2, t5)
-        self.release_blocks()
 
     # ================================================================ sparse multiplications (miller_loop_native.rs:46-110)
     def mul_by_034(self, F, L0, L3, L4, between=None):
