@@ -749,10 +749,12 @@ class Prog:
         if conj_b:
             for k in (1, 3, 5):
                 self.A(Bs[k]).neg().to(Bs[k])
+        assert self.homes_free, "fq12_mul runs on the fused Fq6 multiplication (home blocks 0..7 must be free)"
+        if self.FUSED_GLUE and all(s_.kind != "home" for s_ in list(F) + list(Bs)):
+            return self._fq12_mul_fused(F, Bs)
         A_0, A_1 = [F[0], F[2], F[4]], [F[1], F[3], F[5]]
         B_0, B_1 = [Bs[0], Bs[2], Bs[4]], [Bs[1], Bs[3], Bs[5]]
         M = [self.tmp() for _ in range(3)]
-        assert self.homes_free, "fq12_mul runs on the fused Fq6 multiplication (home blocks 0..7 must be free)"
         res = self._mul6_regs(A_0, B_0, A_1, B_1)                 # (A0 + A1)(B0 + B1): c2 in block A
         self.to(M[2])
         self.A(res[0]).to(M[0])
@@ -891,6 +893,80 @@ class Prog:
                 self.e.emit(f"v_lshlrev_b32_e32 v{r}, 1, v{r}", vw=[r])
             self._blk_store(Hb(3 + k), dst, 2.0, 2 * tv)                  # F1, F3, F5 = 2 t
         self.rel(*T)
+        self.tagA = self.tagB = None
+
+    def _fq12_mul_fused(self, F, Bs):
+        """fq12_mul with register-level glue: operands go straight into the home blocks of the fused Fq6 multiplication (sums formed
+        there), results leave straight from the blocks it fills, the last recombination runs on registers."""
+        Hb = lambda k: HOME0 + SLOT_DW * k
+        for s_ in list(F) + list(Bs):
+            self._need(mag(self.r_of(s_)) <= 1.0, f"fq12_mul: {s_} is not normalised")
+        va = max(self.v_of(s_) for s_ in F)
+        vb = max(self.v_of(s_) for s_ in Bs)
+        M = [self.tmp() for _ in range(3)]
+        self.tagA = self.tagB = None
+        g = L1v4(self.e)
+        # M = (A0 + A1)(B0 + B1): a' raw sums (two units), b' normalised (reduced when the bound asks for it)
+        for k in range(3):
+            self.load(Hb(k), F[2 * k])
+            self.load(Hb(3 + k), Bs[2 * k])
+        vbs = []
+        for k in range(3):
+            self.load(A0, F[2 * k + 1])
+            self.load(B0, Bs[2 * k + 1])
+            self.wait()
+            self._lw_blocks("v_add_u32_e32", Hb(k), Hb(k), A0)
+            self._lw_blocks("v_add_u32_e32", Hb(3 + k), Hb(3 + k), B0)
+            b = g.fq2(Hb(3 + k))
+            if 2 * vb > V_REDN_AT:
+                g.lincomb([b[0], b[1]], [[(1, b[0])], [(1, b[1])]], reduce=True)
+                vbs.append(0.51)
+            else:
+                g.norm_limbs(b[0])
+                g.norm_limbs(b[1])
+                vbs.append(2 * vb)
+        m0, m1, m2 = self._mul6_call(2.0, 1.0, 2 * va, max(vbs))
+        for blk, dst, mv in ((Hb(6), M[0], m0), (Hb(2), M[1], m1), (A0, M[2], m2)):
+            self._blk_store(blk, dst, 1.0, mv)
+        # T0 = A0 B0 -> straight into the places of A0 (dead from here on)
+        for k in range(3):
+            self.load(Hb(k), F[2 * k])
+            self.load(Hb(3 + k), Bs[2 * k])
+        t0 = self._mul6_call(1.0, 1.0, va, vb)
+        for blk, dst, tv in ((Hb(6), F[0], t0[0]), (Hb(2), F[2], t0[1]), (A0, F[4], t0[2])):
+            self._blk_store(blk, dst, 1.0, tv)
+        t0 = [self.slot_v[self.key(F[i])] for i in (0, 2, 4)]         # (a store may have reduced its value)
+        # T1 = A1 B1, then everything else on registers: T1 in home 6, home 2, block A
+        for k in range(3):
+            self.load(Hb(k), F[2 * k + 1])
+            self.load(Hb(3 + k), Bs[2 * k + 1])
+        t1 = self._mul6_call(1.0, 1.0, va, vb)
+        for k in range(3):
+            self.load(Hb(3 + k), F[2 * k])                            # T0.0, T0.1, T0.2
+        for blk, src in ((Hb(0), M[0]), (Hb(1), M[1]), (Hb(7), M[2])):
+            self.load(blk, src)
+        self.wait()
+        mv = [self.slot_v[self.key(m_)] for m_ in M]
+        # F0 = T0.0 + xi T1.2 (one chain, into block B)
+        h3, a_, bb = g.fq2(Hb(3)), g.fq2(A0), g.fq2(B0)
+        v0 = t0[0] + 10 * t1[2]
+        red = v0 > V_REDN_AT
+        g.lincomb([bb[0], bb[1]], [[(1, h3[0]), (9, a_[0]), (-1, a_[1])], [(1, h3[1]), (9, a_[1]), (1, a_[0])]], reduce=red)
+        self._blk_store(B0, F[0], 1.0, 0.51 if red else v0)
+        self._lw_blocks("v_sub_u32_e32", Hb(0), Hb(0), Hb(3))
+        self._lw_blocks("v_sub_u32_e32", Hb(0), Hb(0), Hb(6))
+        self._blk_store(Hb(0), F[1], 3.0, mv[0] + t0[0] + t1[0])      # F1 = M0 - T0.0 - T1.0
+        self._lw_blocks("v_add_u32_e32", Hb(6), Hb(6), Hb(4))
+        self._blk_store(Hb(6), F[2], 2.0, t0[1] + t1[0])              # F2 = T0.1 + T1.0
+        self._lw_blocks("v_sub_u32_e32", Hb(1), Hb(1), Hb(4))
+        self._lw_blocks("v_sub_u32_e32", Hb(1), Hb(1), Hb(2))
+        self._blk_store(Hb(1), F[3], 3.0, mv[1] + t0[1] + t1[1])      # F3 = M1 - T0.1 - T1.1
+        self._lw_blocks("v_add_u32_e32", Hb(2), Hb(2), Hb(5))
+        self._blk_store(Hb(2), F[4], 2.0, t0[2] + t1[1])              # F4 = T0.2 + T1.1
+        self._lw_blocks("v_sub_u32_e32", Hb(7), Hb(7), Hb(5))
+        self._lw_blocks("v_sub_u32_e32", Hb(7), Hb(7), A0)
+        self._blk_store(Hb(7), F[5], 3.0, mv[2] + t0[2] + t1[2])      # F5 = M2 - T0.2 - T1.2
+        self.rel(*M)
         self.tagA = self.tagB = None
 
     FUSED_GLUE = bool(int(os.environ.get("KGEN_FUSED_GLUE", "1")))
