@@ -380,6 +380,23 @@ def multi_pairing_check_batch_dev(g1, g2, verdict, n_groups, k, device=0, stream
            "multi-pairing check")
 
 
+def fq12_mul_batch_dev(a, b, out, n, device=0, stream=None):
+    """MyFq12 `Mul` on device-resident SoA batches (call sites miller_loop_native.rs:153,239,345)."""
+    _check(load_library().bn254_fq12_mul_batch_dev(_dev(a), _dev(b), _dev(out), n, device, _stream(stream)), "MyFq12 mul")
+
+
+def frobenius_map_batch_dev(a, power, out, n, device=0, stream=None):
+    """frobenius_map_native(a, power) on a device-resident SoA batch (src/final_exp_native.rs:17-54)."""
+    _check(load_library().bn254_frobenius_map_batch_dev(_dev(a), power, _dev(out), n, device, _stream(stream)), "frobenius_map_native")
+
+
+def pow_batch_dev(a, exp, out, n, device=0, stream=None):
+    """pow_native(a, exp) on a device-resident SoA batch; exp = u64 limbs, least significant first, shared by the batch
+    (src/final_exp_native.rs:56-84)."""
+    e = np.ascontiguousarray(exp, dtype=np.uint64)
+    _check(load_library().bn254_pow_batch_dev(_dev(a), _ptr(e), e.size, _dev(out), n, device, _stream(stream)), "pow_native")
+
+
 def _devlist(devices):
     arr = (ctypes.c_int * len(devices))(*devices)
     return arr, len(devices)
