@@ -48,9 +48,14 @@ W_MUL32_PER_GROTH16_GROUP = 4_572_184    # 33,619 fqmul x 136 mu
 # assumption was 9.83 T mul32/s; the measured rate is 3.6x that.)
 PEAK_MUL32_PER_S = 554e9 * 64
 NOMINAL_PEAK_MUL32_PER_S = 9.83e12
+# The nominal issue peak: one VALU instruction per SIMD per 4 cycles at the 2.4 GHz boost clock, 1024 SIMDs x 64 lanes =
+# 39.3 T mul32/s.  The calibrated figure above is what a pure multiply-add stream reaches at the clock the package holds at its
+# power limit (the MI355X guide has no integer-VALU peak); both fractions are reported.
+NOMINAL_ISSUE_PEAK_MUL32_PER_S = 1024 * 2.4e9 / 4 * 64
 LOG2_SINGLE = 20                         # configs[2]
 LOG2_PER_GPU_MULTI = 21                  # configs[4]: 2^24 over 8 GPUs
-PMC_SUMMARY = os.environ.get("BENCH_PMC_SUMMARY", os.path.join(ROOT, "profiles", "r03_pmc.json"))
+PMC_SUMMARY = os.environ.get("BENCH_PMC_SUMMARY", os.path.join(ROOT, "profiles", "r04_pmc.json"))
+PMC_SUMMARY_GROTH16 = os.environ.get("BENCH_PMC_SUMMARY_GROTH16", os.path.join(ROOT, "profiles", "r04_groth16_pmc.json"))
 KERNEL_HEADER = os.path.join(ROOT, "plonky2-bn254-pairing_amd", "csrc", "pairing_asm_gen.h")
 
 
@@ -156,16 +161,17 @@ def kernel_header_sha16():
         return None
 
 
-def pmc_summary(log2, kern_avg_ms):
+def pmc_summary(log2, kern_avg_ms, path=None):
     """Counter-derived fields come from the committed rocprofv3 --pmc summary of this same command (collected in separate
     passes as the MI355X guide prescribes), NOT from this run: they are labelled as such -- and dropped (None, with the reason)
     when the summary cannot describe this run: another batch size, another generation of the kernel code (digest of
     pairing_asm_gen.h), or a kernel time more than 5 % away from the one rocprofv3 saw."""
+    path = path or PMC_SUMMARY
     try:
-        with open(PMC_SUMMARY) as f:
+        with open(path) as f:
             notes = json.load(f).get("_notes", {})
     except Exception:
-        return {}, "no PMC summary at " + os.path.relpath(PMC_SUMMARY, ROOT)
+        return {}, "no PMC summary at " + os.path.relpath(path, ROOT)
     if notes.get("log2_batch") != log2:
         return {}, f"PMC summary is for 2^{notes.get('log2_batch')} lanes, this run for 2^{log2}"
     if notes.get("kernel_header_sha16") != kernel_header_sha16():
@@ -178,8 +184,12 @@ def pmc_summary(log2, kern_avg_ms):
 
 # ------------------------------------------------------------------------------------------------ one rank
 def load_engine():
-    """The HIP engine, or -- for the CPU launcher test only -- an injected stand-in (BENCH_TEST_ENGINE=module:attr under tests/)."""
+    """The HIP engine, or -- for the CPU launcher tests only -- an injected stand-in (BENCH_TEST_ENGINE=module:attr under tests/).
+    The hook is honoured only inside a pytest run (PYTEST_CURRENT_TEST, which pytest sets and the launcher's children inherit):
+    anywhere else it is an error, so no environment can make this script print a `value` that is not a measurement."""
     hook = os.environ.get("BENCH_TEST_ENGINE")
+    if hook and not os.environ.get("PYTEST_CURRENT_TEST"):
+        raise SystemExit("bench.py: BENCH_TEST_ENGINE is a test hook and is refused outside pytest (PYTEST_CURRENT_TEST is not set)")
     if hook:
         import importlib
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -264,13 +274,27 @@ def extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n, sample_power=F
     o = torch.zeros(48 * m, dtype=torch.int64, device=dev)
     ms = timed(lambda: pkg.pairing_batch_dev(s1, s2, o, m, device=local_rank, stream=stream), 10)
     out["configs[1]: 2^16 independent pairings"] = {"ms": ms, "pairings_per_s": m / (ms * 1e-3),
-                                                    "roofline_frac": m / (ms * 1e-3) * W_MUL32_PER_PAIRING / PEAK_MUL32_PER_S}
+                                                    "roofline_frac": m / (ms * 1e-3) * W_MUL32_PER_PAIRING / PEAK_MUL32_PER_S,
+                                                    "roofline_frac_of_nominal_issue_peak": m / (ms * 1e-3) * W_MUL32_PER_PAIRING / NOMINAL_ISSUE_PEAK_MUL32_PER_S}
     groups, k = 1 << 18, 4
     assert groups * k <= n
     o2 = torch.zeros(48 * groups, dtype=torch.int64, device=dev)
     ms = timed(lambda: pkg.multi_pairing_batch_dev(g1, g2, o2, groups, k, True, device=local_rank, stream=stream), 2)
+    ach = groups / (ms * 1e-3) * W_MUL32_PER_GROTH16_GROUP
+    notes, stale = pmc_summary(18, ms, PMC_SUMMARY_GROTH16)
+    ipi = notes.get("valu_wave_insts_per_work_item")
     g16 = {"ms": ms, "groups_per_s": groups / (ms * 1e-3), "pairs_per_s": groups * k / (ms * 1e-3),
-           "roofline_frac": groups / (ms * 1e-3) * W_MUL32_PER_GROTH16_GROUP / PEAK_MUL32_PER_S, "kernel": "k_mpairing"}
+           "roofline_frac": ach / PEAK_MUL32_PER_S, "kernel": "k_mpairing",
+           "roofline": {"bound": "valu-int32-mul", "achieved": ach / 1e12, "peak": PEAK_MUL32_PER_S / 1e12, "unit": "T mul32/s", "frac": ach / PEAK_MUL32_PER_S,
+                        "frac_of_nominal_issue_peak": ach / NOMINAL_ISSUE_PEAK_MUL32_PER_S, "nominal_issue_peak": NOMINAL_ISSUE_PEAK_MUL32_PER_S / 1e12,
+                        "traffic": notes.get("hbm_bytes_per_launch_corrected"), "algorithmic_bytes_per_launch": (192 * k + 384) * groups,
+                        "work_per_unit": f"{W_MUL32_PER_GROTH16_GROUP} mul32 per 4-pair group (SURVEY.md 8d)", "kernel": "k_mpairing", "kernel_ms_avg": ms,
+                        "pmc_summary": os.path.relpath(PMC_SUMMARY_GROTH16, ROOT), "pmc_summary_kernel_ms": notes.get("kernel_ms_avg_rocprof"),
+                        "pmc_dropped": stale,
+                        "valu_issue": None if not ipi else {
+                            "wave_instr_per_work_item": ipi, "wave_instr_per_s": ipi * (groups / 64) / (ms * 1e-3),
+                            "frac": ipi * (groups / 64) / (ms * 1e-3) / (1024 * 2.4e9 / 4),
+                            "issue_utilisation_at_measured_clock": notes.get("valu_issue_utilisation_at_measured_clock")}}}
     if sample_power:                # ~1.5 s of back-to-back launches: long enough for rocm-smi to see what this kernel draws
         with PowerSampler() as ps:
             for _ in range(24):
@@ -388,6 +412,15 @@ def run_rank(args):
         elapsed = float(t.item())
     kern_ms = sorted(a.elapsed_time(b) for a, b in evs) if on_gpu else [elapsed / args.steps * 1e3]
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
+    per_rank = None
+    if dist:
+        # every rank's own kernel times and peak memory travel to rank 0: a straggler or a rank close to its memory limit is
+        # visible in the N > 1 line (the timed region itself is the max over ranks, as the contract says)
+        mem = float(torch.cuda.max_memory_allocated(dev)) if on_gpu else 0.0
+        mine = torch.tensor([kern_avg_ms, kern_ms[0], kern_ms[-1], mem], dtype=torch.float64, device=dev if (backend == "nccl" and on_gpu) else "cpu")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [[float(x) for x in t.tolist()] for t in allr]
 
     gathered = None
     if world > 1:
@@ -398,6 +431,8 @@ def run_rank(args):
         sync()
         dist.barrier()
         exchange["gather_ms"] = (time.perf_counter() - t0) * 1e3
+        if on_gpu and rank == 0:
+            exchange["rank0_peak_device_bytes_after_gather"] = int(torch.cuda.max_memory_allocated(dev))
         exchange["bytes_scattered"] = 192 * (n_total - n)
         exchange["bytes_gathered"] = 384 * (n_total - n)
         exchange["note"] = ("rank 0 -> peers: G1/G2 slices, peers -> rank 0: Fq12 outputs; torch.distributed batch_isend_irecv on device "
@@ -437,6 +472,11 @@ def run_rank(args):
                          "kernel": "k_pairing", "kernel_ms_avg": kern_avg_ms, "kernel_ms_min": kern_ms[0],
                          "work_per_unit": f"{W_MUL32_PER_PAIRING} mul32 = {W_FQMUL_PER_PAIRING} fqmul x 136 per pairing (SURVEY.md 8d)",
                          "frac_of_nominal_quarter_rate_peak": achieved / NOMINAL_PEAK_MUL32_PER_S,
+                         "frac_of_nominal_issue_peak": achieved / NOMINAL_ISSUE_PEAK_MUL32_PER_S,
+                         "peaks": {"calibrated": {"value": PEAK_MUL32_PER_S / 1e12, "frac": achieved / PEAK_MUL32_PER_S,
+                                                  "what": "measured v_mad_u64_u32 issue rate, 8 waves/SIMD, at the clock the package holds under that load (profiles/valu_calib_r01.txt)"},
+                                   "nominal_issue": {"value": NOMINAL_ISSUE_PEAK_MUL32_PER_S / 1e12, "frac": achieved / NOMINAL_ISSUE_PEAK_MUL32_PER_S,
+                                                     "what": "1024 SIMDs x 2.4 GHz / 4 cycles x 64 lanes"}, "unit": "T mul32/s"},
                          "valu_issue": None if not insts_per_item else {
                              "source": "SQ_INSTS_VALU per wave work item (64 pairings) from the committed PMC summary x this run's kernel time",
                              "wave_instr_per_work_item": insts_per_item,
@@ -453,6 +493,10 @@ def run_rank(args):
         }
         if world > 1:
             rec["rccl_ranks"] = dist.get_world_size()
+            rec["per_rank"] = {"kernel_ms_avg": [r[0] for r in per_rank], "kernel_ms_min": [r[1] for r in per_rank],
+                               "kernel_ms_max": [r[2] for r in per_rank], "peak_device_bytes": [r[3] for r in per_rank],
+                               "note": "HIP-event time of each rank's own k_pairing launches over the timed steps; torch.cuda.max_memory_allocated per rank "
+                                       "(rank 0 also holds the whole batch and, after the timed steps, the gathered outputs)"}
             rec["dist_backend"] = backend
             rec["exchange"] = exchange
             step_ms = elapsed / args.steps * 1e3
@@ -463,12 +507,23 @@ def run_rank(args):
             pos = sorted({0, 1, 255, 256, n // 2 + 77, n - 257, n - 1, 65535 % n, 65536 % n})
             ok = spot_check(pkg, torch, g1, g2, out, n, pos, threads)
             if world > 1:
-                gp = sorted({n, n + 1, n_total // 2 + 5, n_total - 1})
+                # every peer's slice: its first lane, one in the middle, its last lane -- against the oracle on rank 0's copy of the inputs
+                gp = sorted({r * n + off for r in range(1, world) for off in (0, n // 2 + 5, n - 1)})
                 ok = ok and spot_check(pkg, torch, full[0], full[1], gathered, n_total, gp, threads)
                 ok = ok and bool(torch.equal(gathered.view(48, n_total)[:, :n], out.view(48, n)))
+                rec["verified_positions_in_peer_slices"] = len(gp)
             rec["verified_vs_oracle"] = ok
             if not ok:
                 print("bench.py: GPU results differ from the oracle -- no measurement reported", file=sys.stderr)
+                rc = 3
+        if not on_gpu and world > 1:
+            # launcher tests (stand-in engine): the gathered batch must be what the engine makes of the WHOLE input on rank 0 --
+            # every peer's slice, every lane (shard bounds, scatter and gather all have to be right for that)
+            ref = torch.zeros(48 * n_total, dtype=torch.int64)
+            pkg.pairing_batch_dev(full[0], full[1], ref, n_total)
+            rec["gathered_equals_whole_batch_recomputation"] = bool(torch.equal(ref, gathered))
+            if not rec["gathered_equals_whole_batch_recomputation"]:
+                print("bench.py: gathered outputs differ from the whole-batch recomputation", file=sys.stderr)
                 rc = 3
         if rc == 0 and on_gpu and world == 1 and not args.no_extra and log2 == LOG2_SINGLE:
             rec["extra"] = extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n, sample_power=power is not None)

@@ -20,11 +20,16 @@
  * POINTERS   `*_dev` entry points take DEVICE pointers (HBM-resident inputs/outputs; the
  *            timed path).  The un-suffixed entry points take HOST pointers and stage
  *            through the device (PCIe inclusive).
- * STREAM     `stream` is a hipStream_t (NULL = default stream).  `_dev` calls are enqueued
- *            on it and return after the launch -- none of them waits for the stream
- *            (bn254_pow_batch_dev copies its digits through pinned staging slots); status
- *            words are read, on that same stream, only inside bn254_last_status().
- *            Host-pointer calls synchronise before returning.
+ * STREAM     `stream` is a hipStream_t (NULL = default stream).  `_dev` calls are enqueued on it and return after the
+ *            launch: none of them waits for the stream.  What a `_dev` call may do on the calling thread is ALLOCATE: the
+ *            library keeps scratch, a status word and a few work buffers per (device, stream) and grows them when a call
+ *            needs more (larger n or k, the first group of more than 64 pairs, the first `== one` verdict, the first
+ *            pow_native); an outgrown buffer is retired -- work queued on the stream may still use it -- and freed inside the
+ *            next bn254_last_status / bn254_release_stream.  bn254_reserve(device, stream, n, k) sizes everything for calls of
+ *            up to n lanes x k pairs up front: after it no `_dev` call of that size or smaller allocates.  bn254_pow_batch_dev
+ *            copies its digits through pinned staging slots (four after bn254_reserve, more are added while all are in
+ *            flight; with 64 pow calls queued on one stream the next one waits for the oldest copy).  Status words are read,
+ *            on that same stream, only inside bn254_last_status().  Host-pointer calls synchronise before returning.
  * ERRORS     0 = success, negative = failure (bn254_strerror).  The reference panics on
  *            the same conditions (division by zero in ark's `/`); the Rust shim turns a
  *            negative status back into a panic.  Points at infinity are outside the
@@ -39,8 +44,13 @@
  * LIFETIME   A stream's context is created by the first call that names the stream and lives
  *            until bn254_release_stream(device, stream) -- call it before destroying a stream
  *            you used, otherwise its buffers stay allocated (a later stream that reuses the
- *            handle value simply inherits them).  The private streams of the host-pointer
- *            pipeline and of the `_sharded_dev` calls live as long as the library.
+ *            handle value simply inherits them).  A call that races a release on the same
+ *            (device, stream) keeps the context alive until it returns (the context is
+ *            reference-counted); its buffers are freed by whichever of the two finishes last.
+ *            The private streams of the host-pointer pipeline and of the `_sharded_dev` calls
+ *            live as long as the library, with their buffers: per stream one scratch area of
+ *            grid x pitch bytes (bn254_scratch_bytes: 0.5 GiB for single pairings at a full
+ *            grid, 2.5 GiB for 64 pairs per lane) plus the staging buffers of the largest chunk.
  */
 #ifndef BN254_PAIRING_H
 #define BN254_PAIRING_H
@@ -66,9 +76,14 @@ const char* bn254_strerror(int status);
 /* Synchronises `stream` on `device` and returns the sticky status of the device-side
  * checks (zero divisor) accumulated since the last call; clears it. */
 int bn254_last_status(int device, void* stream);
-/* Bytes of device scratch a call over n lanes (k pairs each) will use on the current device (informational;
- * the persistent grid is min(work items, CUs of that device), 256 CUs assumed when no device is visible). */
+/* Bytes of device scratch a call over n lanes (k pairs each) will use (informational; never touches the HIP runtime:
+ * the persistent grid is min(work items, CUs), CUs = those of a device the library already runs on, else 256). */
 size_t bn254_scratch_bytes(size_t n, size_t k);
+/* Sizes everything the library keeps for (device, stream) -- scratch for k pairs per lane, the status word, the verdict's
+ * Fq12 buffer, the sub-group buffers of groups of more than 64 pairs, the pow_native digit buffer and four pinned staging
+ * slots -- for calls of up to n lanes (units) x k pairs.  Afterwards `_dev` calls of that size or smaller neither allocate
+ * nor wait.  Does not wait for the stream either (buffers that must grow are retired, see STREAM). */
+int bn254_reserve(int device, void* stream, size_t n, size_t k);
 /* Scratch and the status word are kept per (device, stream), so calls on different streams are independent;
  * this frees what the library holds for `stream` (call it before destroying a stream you used). */
 int bn254_release_stream(int device, void* stream);

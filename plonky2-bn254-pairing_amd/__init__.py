@@ -79,6 +79,7 @@ _PROTOS = {
     "bn254_multi_pairing_sharded_dev": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                                                        ctypes.c_void_p]),
     "bn254_release_stream": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p]),
+    "bn254_reserve": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t]),
     "bn254_fq12_mul_batch_dev": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "bn254_fq12_mul_batch": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "bn254_frobenius_map_batch_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
@@ -416,6 +417,11 @@ def multi_pairing_sharded_dev(g1, g2, out, n_groups, k, devices, do_final_exp=Tr
 
 def release_stream(device=0, stream=None):
     _check(load_library().bn254_release_stream(device, _stream(stream)), "release_stream")
+
+
+def reserve(n, k=1, device=0, stream=None):
+    """Sizes the per-(device, stream) buffers for `_dev` calls of up to n lanes x k pairs: no later call of that size allocates."""
+    _check(load_library().bn254_reserve(device, _stream(stream), n, k), "reserve")
 
 
 def generate_pairs_dev(seed, g1_out, g2_out, n, device=0, stream=None):

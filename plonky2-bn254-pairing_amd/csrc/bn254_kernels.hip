@@ -134,16 +134,28 @@ struct NafSlot {               // pinned host staging of one pow_native call's N
     int8_t* host = nullptr;
     size_t bytes = 0;
     hipEvent_t done = nullptr; // recorded behind the copy that reads `host`
+    bool used = false;         // `done` has been recorded at least once
 };
+constexpr size_t NAF_RING_MAX = 64;
 struct StreamCtx {
     std::recursive_mutex mu;
     Buf scratch, naf, tmp;
     Buf sub[4];                // groups of more than MAX_K pairs: sub-group inputs (G1, G2) and the two Miller values in flight
     Buf stage[8];              // device staging of the host-pointer entry points (inputs / outputs), grown on demand
-    NafSlot naf_ring[4];
-    unsigned naf_next = 0;
+    std::vector<void*> retired;   // buffers that were outgrown while work on them may still be queued: freed once the stream has been
+                                  // synchronised (bn254_last_status, bn254_release_stream) -- growing never waits for the stream
+    std::vector<NafSlot> naf_ring;
     int* status = nullptr;
     int* status_host = nullptr;   // pinned: the status word is read back on the caller's stream
+    ~StreamCtx() {                // the last holder (bn254_release_stream, after the stream has been synchronised) frees everything
+        for (Buf* b : {&scratch, &naf, &tmp}) if (b->p) (void)hipFree(b->p);
+        for (Buf& b : stage) if (b.p) (void)hipFree(b.p);
+        for (Buf& b : sub) if (b.p) (void)hipFree(b.p);
+        for (void* q : retired) (void)hipFree(q);
+        for (NafSlot& n : naf_ring) { if (n.host) (void)hipHostFree(n.host); if (n.done) (void)hipEventDestroy(n.done); }
+        if (status) (void)hipFree(status);
+        if (status_host) (void)hipHostFree(status_host);
+    }
 };
 struct DeviceCtx {
     std::mutex mu;             // guards `streams`, `shard_streams` and the one-time initialisation; not held across kernel work
@@ -151,7 +163,7 @@ struct DeviceCtx {
     int n_cu = 0;
     std::mutex table_mu;       // the generator table upload (138 KB, blocking) has its own lock
     int32_t* gen_table = nullptr;
-    std::map<hipStream_t, std::unique_ptr<StreamCtx>> streams;
+    std::map<hipStream_t, std::shared_ptr<StreamCtx>> streams;   // shared: a call keeps its context alive across a concurrent release
     std::mutex pipe_mu;        // one host-pointer pipeline at a time per device (its two workers fill the chip anyway)
     hipStream_t pipe_stream[2] = {nullptr, nullptr};   // the workers' private streams: created once, their scratch and staging kept
     std::mutex shard_mu;       // one device-pointer sharded call at a time per device
@@ -168,21 +180,30 @@ int check_device(int device) {
     return hipSetDevice(device) == hipSuccess ? BN254_OK : BN254_ERR_HIP;
 }
 
-// (re)allocates a per-stream buffer; the old buffer may still be in use by work queued on the stream
-int ensure(Buf& b, size_t bytes, hipStream_t stream) {
+// Grows a per-stream buffer WITHOUT waiting for the stream: work queued on the stream may still use the old buffer, so it is
+// retired (kept until the next synchronisation point of the context) and a new one is allocated.  bn254_reserve sizes every
+// buffer up front, after which no `_dev` call allocates at all.
+int ensure(StreamCtx* sc, Buf& b, size_t bytes) {
     if (bytes <= b.bytes) return BN254_OK;
-    if (b.p) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
-    if (hipMalloc(&b.p, bytes) != hipSuccess) return BN254_ERR_ALLOC;
+    void* q = nullptr;
+    if (hipMalloc(&q, bytes) != hipSuccess) { (void)hipGetLastError(); return BN254_ERR_ALLOC; }
+    if (b.p) sc->retired.push_back(b.p);
+    b.p = q;
     b.bytes = bytes;
     return BN254_OK;
 }
+// the stream has just been synchronised (context mutex held): nothing can still be using the outgrown buffers
+void free_retired(StreamCtx* sc) {
+    for (void* q : sc->retired) (void)hipFree(q);
+    sc->retired.clear();
+}
 
-StreamCtx* stream_ctx(int device, void* stream) {
+std::shared_ptr<StreamCtx> stream_ctx(int device, void* stream) {
     DeviceCtx& c = g_ctx[device];
     std::lock_guard<std::mutex> lk(c.mu);
-    std::unique_ptr<StreamCtx>& p = c.streams[(hipStream_t)stream];
-    if (!p) p.reset(new StreamCtx());
-    return p.get();
+    std::shared_ptr<StreamCtx>& p = c.streams[(hipStream_t)stream];
+    if (!p) p = std::make_shared<StreamCtx>();
+    return p;
 }
 
 // Scratch layout (pairing_asm_gen.h: BN254_SCRATCH_WG_CONTIGUOUS).  Contiguous per workgroup: [workgroup][slot][wave][...], the
@@ -196,8 +217,8 @@ size_t scratch_pitch(size_t k, size_t grid) {
 }
 
 struct LaunchCtx {
+    std::shared_ptr<StreamCtx> s;                    // (declared first: the lock below is released before the context can go)
     std::unique_lock<std::recursive_mutex> lock;     // the stream context stays ours until the launch has been issued
-    StreamCtx* s;
     int n_cu;
     uint4* scratch;
     int* status;
@@ -231,16 +252,18 @@ int ctx_get(int device, void* stream, size_t k, size_t n_items, LaunchCtx* out, 
             c.gen_table = t;
         }
     }
-    StreamCtx* sc = stream_ctx(device, stream);
+    std::shared_ptr<StreamCtx> sc = stream_ctx(device, stream);
     out->lock = std::unique_lock<std::recursive_mutex>(sc->mu);
     if (!sc->status) {
-        HIPCHK(hipMalloc(&sc->status, sizeof(int)));
+        if (hipMalloc(&sc->status, sizeof(int)) != hipSuccess) { sc->status = nullptr; return BN254_ERR_ALLOC; }
         HIPCHK(hipMemsetAsync(sc->status, 0, sizeof(int), (hipStream_t)stream));
     }
     uint32_t grid = (uint32_t)(n_items < (size_t)c.n_cu ? n_items : (size_t)c.n_cu);
     if (grid == 0) grid = 1;
     size_t pitch = scratch_pitch(k, grid);
-    if ((rc = ensure(sc->scratch, BN254_SCRATCH_WG_CONTIGUOUS ? pitch * grid : pitch * scratch_slots(k), (hipStream_t)stream))) return rc;
+    // the kernels form a workgroup's scratch base as blockIdx * pitch in 32 bits (s_mul_i32)
+    if (BN254_SCRATCH_WG_CONTIGUOUS && pitch * grid >= (1ull << 32)) return BN254_ERR_INVALID_ARG;
+    if ((rc = ensure(sc.get(), sc->scratch, BN254_SCRATCH_WG_CONTIGUOUS ? pitch * grid : pitch * scratch_slots(k)))) return rc;
     out->s = sc;
     out->n_cu = c.n_cu;
     out->scratch = (uint4*)sc->scratch.p;
@@ -265,18 +288,12 @@ int launch_pairing(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in,
         // pairs' state.  The shared-f Miller value of a group IS the product of the Miller values of any partition of its pairs
         // -- the same field element, hence the same limbs (the reference's own T1, :336-348, asserts it for singletons): walk
         // the group in sub-groups of <= MAX_K pairs, multiply the values (MyFq12 Mul), one final exponentiation at the end.
-        StreamCtx* sc;
-        std::unique_lock<std::recursive_mutex> hold;
-        {
-            LaunchCtx c;
-            int rc = ctx_get(device, stream, 1, (n_groups + BLOCK - 1) / BLOCK, &c);
-            if (rc) return rc;
-            sc = c.s;
-            hold = std::move(c.lock);
-        }
-        int rc;
-        if ((rc = ensure(sc->sub[0], 64 * n_groups * MAX_K, st)) || (rc = ensure(sc->sub[1], 128 * n_groups * MAX_K, st)) ||
-            (rc = ensure(sc->sub[2], 384 * n_groups, st)) || (rc = ensure(sc->sub[3], 384 * n_groups, st)))
+        LaunchCtx hold;                                 // keeps the context and its (recursive) lock for the whole walk
+        int rc = ctx_get(device, stream, 1, (n_groups + BLOCK - 1) / BLOCK, &hold);
+        if (rc) return rc;
+        StreamCtx* sc = hold.s.get();
+        if ((rc = ensure(sc, sc->sub[0], 64 * n_groups * MAX_K)) || (rc = ensure(sc, sc->sub[1], 128 * n_groups * MAX_K)) ||
+            (rc = ensure(sc, sc->sub[2], 384 * n_groups)) || (rc = ensure(sc, sc->sub[3], 384 * n_groups)))
             return rc;
         uint64_t *s1 = (uint64_t*)sc->sub[0].p, *s2 = (uint64_t*)sc->sub[1].p, *acc = (uint64_t*)sc->sub[2].p, *val = (uint64_t*)sc->sub[3].p;
         size_t n_sub = (k + MAX_K - 1) / MAX_K;
@@ -327,13 +344,22 @@ int launch_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_
     if (op == OP_POW) {
         while (naf_len > 0 && naf_host[naf_len - 1] == 0) naf_len--;        // the top digit of a NAF is +1
         if (naf_len < 1 || naf_len >= 65536) return BN254_ERR_INVALID_ARG;   // 16-bit length field of the kernel's k argument
-        if ((rc = ensure(c.s->naf, (size_t)naf_len + 64, (hipStream_t)stream))) return rc;
-        // naf_host is a caller temporary and the call must not wait for the stream: the digits go through one of four pinned
-        // staging slots; a slot is reused once the copy that read it has completed (its event), i.e. only the fifth call in
-        // flight on one stream ever waits.  The device-side buffer is shared: copies and kernels are ordered by the stream.
-        NafSlot& slot = c.s->naf_ring[c.s->naf_next++ % 4];
-        if (slot.done) HIPCHK(hipEventSynchronize(slot.done));
-        else HIPCHK(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+        if ((rc = ensure(c.s.get(), c.s->naf, (size_t)naf_len + 64))) return rc;
+        // naf_host is a caller temporary and the call must not wait for the stream: the digits go through a pinned staging
+        // slot, which is reused once the copy that read it has completed (its event).  The ring takes a new slot while all
+        // are in flight (bn254_reserve creates four): only with NAF_RING_MAX pow calls queued on one stream does a call wait.
+        // The device-side buffer is shared: copies and kernels are ordered by the stream.
+        NafSlot* free_slot = nullptr;
+        for (NafSlot& ns : c.s->naf_ring)
+            if (ns.done && (!ns.used || hipEventQuery(ns.done) == hipSuccess)) { free_slot = &ns; break; }
+        (void)hipGetLastError();                                                   // hipErrorNotReady of the queries
+        if (!free_slot && c.s->naf_ring.size() < NAF_RING_MAX) {
+            c.s->naf_ring.emplace_back();
+            free_slot = &c.s->naf_ring.back();
+            if (hipEventCreateWithFlags(&free_slot->done, hipEventDisableTiming) != hipSuccess) { c.s->naf_ring.pop_back(); return BN254_ERR_HIP; }
+        }
+        if (!free_slot) { free_slot = &c.s->naf_ring[0]; HIPCHK(hipEventSynchronize(free_slot->done)); }
+        NafSlot& slot = *free_slot;
         if (slot.bytes < (size_t)naf_len) {
             if (slot.host) HIPCHK(hipHostFree(slot.host));
             slot.host = nullptr; slot.bytes = 0;
@@ -344,6 +370,7 @@ int launch_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_
         memcpy(slot.host, naf_host, (size_t)naf_len);
         HIPCHK(hipMemcpyAsync(c.s->naf.p, slot.host, (size_t)naf_len, hipMemcpyHostToDevice, (hipStream_t)stream));
         HIPCHK(hipEventRecord(slot.done, (hipStream_t)stream));
+        slot.used = true;
         naf_dev = (const int8_t*)c.s->naf.p;
         kk = 2u | ((uint32_t)naf_len << 16);
         for (int t = 0; t < naf_len; t++) if (naf_host[t] < 0) { kk |= 1u << 8; break; }   // 1/a is needed
@@ -398,7 +425,7 @@ long get_naf_host(const uint64_t* exp_in, size_t n, int8_t* naf) {
 // A Stage owns the stream context from the first staged byte to the end of the call (the read-back in finish_host): a second
 // host thread on the same (device, stream) waits instead of overwriting staged inputs or freeing a buffer under the kernel.
 struct Stage {
-    StreamCtx* sc = nullptr;
+    std::shared_ptr<StreamCtx> sc;
     std::unique_lock<std::recursive_mutex> lock;
     hipStream_t st;
     int used = 0;
@@ -413,7 +440,7 @@ struct Stage {
     int up(const void* h, size_t bytes, uint64_t** d) {
         if (used >= 8) return BN254_ERR_INVALID_ARG;
         Buf& b = sc->stage[used++];
-        int rc = ensure(b, bytes ? bytes : 8, st);
+        int rc = ensure(sc.get(), b, bytes ? bytes : 8);
         if (rc) return rc;
         *d = (uint64_t*)b.p;
         if (h && bytes && hipMemcpyAsync(b.p, h, bytes, hipMemcpyHostToDevice, st) != hipSuccess) return BN254_ERR_HIP;
@@ -457,20 +484,21 @@ int bn254_last_status(int device, void* stream) {
     int rc = check_device(device);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    StreamCtx* sc = nullptr;
+    std::shared_ptr<StreamCtx> sc;
     {
         DeviceCtx& c = g_ctx[device];
         std::lock_guard<std::mutex> lk(c.mu);
         auto it = c.streams.find(st);
-        if (it != c.streams.end()) sc = it->second.get();
+        if (it != c.streams.end()) sc = it->second;
     }
     if (!sc) { HIPCHK(hipStreamSynchronize(st)); return BN254_OK; }
     std::lock_guard<std::recursive_mutex> lk(sc->mu);
-    if (!sc->status) { HIPCHK(hipStreamSynchronize(st)); return BN254_OK; }
+    if (!sc->status) { HIPCHK(hipStreamSynchronize(st)); free_retired(sc.get()); return BN254_OK; }
     // the read-back (and the clearing store) are enqueued on the caller's stream: other streams are not touched
     if (!sc->status_host && hipHostMalloc((void**)&sc->status_host, sizeof(int), hipHostMallocDefault) != hipSuccess) return BN254_ERR_ALLOC;
     HIPCHK(hipMemcpyAsync(sc->status_host, sc->status, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    free_retired(sc.get());
     if (*sc->status_host) {
         HIPCHK(hipMemsetAsync(sc->status, 0, sizeof(int), st));
         HIPCHK(hipStreamSynchronize(st));
@@ -485,9 +513,11 @@ static int finish_host(void* h_out, const void* d_out, size_t bytes, int device,
 }
 
 size_t bn254_scratch_bytes(size_t n, size_t k) {
-    size_t items = (n + BLOCK - 1) / BLOCK, cus = 256;              // MI355X: 256 CUs when no device can be asked
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = (size_t)v;
+    size_t items = (n + BLOCK - 1) / BLOCK, cus = 256;              // MI355X: 256 CUs unless a device this library already uses says otherwise
+    for (DeviceCtx& c : g_ctx) {                                     // informational: never initialises the HIP runtime itself
+        std::lock_guard<std::mutex> lk(c.mu);
+        if (c.init && c.n_cu > 0) { cus = (size_t)c.n_cu; break; }
+    }
     size_t grid = items < cus ? (items ? items : 1) : cus;           // persistent kernels: the grid never exceeds the CU count
     size_t kk = k > MAX_K ? MAX_K : k;                                // larger groups are walked in sub-groups of MAX_K pairs
     return BN254_SCRATCH_WG_CONTIGUOUS ? scratch_pitch(kk, grid) * grid : scratch_pitch(kk, grid) * scratch_slots(kk);
@@ -570,7 +600,7 @@ int bn254_multi_pairing_check_batch_dev(const uint64_t* g1, const uint64_t* g2, 
     LaunchCtx c;
     int rc = ctx_get(device, stream, k > MAX_K ? 1 : k, (n_groups + BLOCK - 1) / BLOCK, &c);
     if (rc) return rc;
-    if ((rc = ensure(c.s->tmp, 384 * n_groups, (hipStream_t)stream))) return rc;
+    if ((rc = ensure(c.s.get(), c.s->tmp, 384 * n_groups))) return rc;
     if ((rc = launch_pairing<true, true>(g1, g2, nullptr, (uint64_t*)c.s->tmp.p, n_groups, k, device, stream))) return rc;
     size_t blocks = (n_groups + 255) / 256;
     if (blocks > 4096) blocks = 4096;
@@ -583,7 +613,7 @@ int bn254_release_stream(int device, void* stream) {
     int rc = check_device(device);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-    std::unique_ptr<StreamCtx> sc;
+    std::shared_ptr<StreamCtx> sc;
     {
         DeviceCtx& c = g_ctx[device];
         std::lock_guard<std::mutex> lk(c.mu);
@@ -592,13 +622,32 @@ int bn254_release_stream(int device, void* stream) {
         sc = std::move(it->second);
         c.streams.erase(it);
     }
-    { std::lock_guard<std::recursive_mutex> lk(sc->mu); }      // a call that was still inside the library has left it
-    for (Buf* b : {&sc->scratch, &sc->naf, &sc->tmp}) if (b->p) (void)hipFree(b->p);
-    for (Buf& b : sc->stage) if (b.p) (void)hipFree(b.p);
-    for (Buf& b : sc->sub) if (b.p) (void)hipFree(b.p);
-    for (NafSlot& n : sc->naf_ring) { if (n.host) (void)hipHostFree(n.host); if (n.done) (void)hipEventDestroy(n.done); }
-    if (sc->status) (void)hipFree(sc->status);
-    if (sc->status_host) (void)hipHostFree(sc->status_host);
+    // A call that looked the context up before the erase still holds a reference: the context (and its buffers) go when the
+    // last holder lets go.  Such a call may have launched after the synchronisation above: wait for that work too.
+    { std::lock_guard<std::recursive_mutex> lk(sc->mu); }
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return BN254_OK;
+}
+
+int bn254_reserve(int device, void* stream, size_t n, size_t k) {
+    if (k == 0 || n * k >= (1ull << 29) || (n && n * k / n != k)) return BN254_ERR_INVALID_ARG;
+    LaunchCtx c;                                       // scratch for k pairs per lane (sub-groups of MAX_K above that) + the status word
+    int rc = ctx_get(device, stream, k > MAX_K ? MAX_K : k, (n + BLOCK - 1) / BLOCK, &c);
+    if (rc) return rc;
+    StreamCtx* sc = c.s.get();
+    if ((rc = ensure(sc, sc->tmp, 384 * (n ? n : 1)))) return rc;                                   // the `== one` verdict's Fq12 values
+    if ((rc = ensure(sc, sc->naf, 65536 + 64))) return rc;                                          // pow_native digits (16-bit length field)
+    if (k > MAX_K && ((rc = ensure(sc, sc->sub[0], 64 * n * MAX_K)) || (rc = ensure(sc, sc->sub[1], 128 * n * MAX_K)) ||
+                      (rc = ensure(sc, sc->sub[2], 384 * n)) || (rc = ensure(sc, sc->sub[3], 384 * n))))
+        return rc;
+    while (sc->naf_ring.size() < 4) {
+        NafSlot ns;
+        if (hipHostMalloc((void**)&ns.host, 65536, hipHostMallocDefault) != hipSuccess) return BN254_ERR_ALLOC;
+        ns.bytes = 65536;
+        if (hipEventCreateWithFlags(&ns.done, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(ns.host); return BN254_ERR_HIP; }
+        sc->naf_ring.push_back(ns);
+    }
+    if (!sc->status_host && hipHostMalloc((void**)&sc->status_host, sizeof(int), hipHostMallocDefault) != hipSuccess) return BN254_ERR_ALLOC;
     return BN254_OK;
 }
 

@@ -2,7 +2,9 @@
 SoA batch per rank, NO data-path collective -- the units (`pairing(p, q)`, /root/reference/src/pairing.rs:20-22)
 are independent.  The only exchanges are the north star's scatter of the G1/G2 inputs from rank 0 and the gather
 of the Fq12 outputs to rank 0, as grouped point-to-point operations (`torch.distributed.batch_isend_irecv`:
-one grouped RCCL launch per direction under backend "nccl", the same code under "gloo").
+one grouped RCCL launch per direction under backend "nccl", the same code under "gloo").  A slice of a limb-major batch is
+one contiguous run per limb plane, so the transfers go plane by plane straight out of / into the whole-batch tensors on
+rank 0: no temporaries and no second copy on either side (round 4).
 
 All buffers are torch tensors of int64 words (the u64 Montgomery limbs, SoA limb-major).  Under nccl they are device
 tensors and travel over xGMI with no host bounce.  gloo moves host memory only: device tensors then go through a pinned
@@ -34,14 +36,32 @@ def _cols(t, words, n, lo, hi):
     return t.view(words, n)[:, lo:hi].contiguous().view(-1)
 
 
+def _moves_device_memory(dist):
+    """True when the process group carries device tensors itself (RCCL).  `dist.get_backend()` of a default-initialised
+    group may read "undefined" or "cpu:gloo,cuda:nccl": any backend string that names nccl qualifies."""
+    try:
+        name = str(dist.get_backend())
+    except Exception:      # noqa: BLE001
+        return False
+    return "nccl" in name.lower()
+
+
+def _planes(t, words, n, lo, hi):
+    """Plane w of columns [lo, hi) of an SoA batch of n elements: `words` CONTIGUOUS 1-D views (no copy) -- what a
+    point-to-point transfer can send from / receive into directly."""
+    v = t.view(words, n)
+    return [v[w, lo:hi] for w in range(words)]
+
+
 class _P2P:
-    """One point-to-point transfer of a flat int64 tensor.  Device tensors under a backend that moves host memory only
-    (gloo) are bounced through a pinned host buffer: filled before the send, copied to the device after the receive."""
+    """One point-to-point transfer of a contiguous int64 tensor (or view).  Device tensors under a backend that moves host
+    memory only (gloo) are bounced through a pinned host buffer: filled before the send, copied to the device after the
+    receive."""
 
     def __init__(self, dist, kind, tensor, peer):
         self.kind, self.tensor, self.bounce = kind, tensor, None
         wire = tensor
-        if tensor.is_cuda and dist.get_backend() != "nccl":
+        if tensor.is_cuda and not _moves_device_memory(dist):
             import torch
             self.bounce = torch.empty(tensor.shape, dtype=tensor.dtype, device="cpu", pin_memory=True)
             if kind == "send":
@@ -80,59 +100,61 @@ def hip_compute(device_index=None):
 
 def scatter_inputs(full_g1, full_g2, n, g1_local, g2_local, dist):
     """Rank 0 holds the whole SoA batch (8n / 16n words); every rank receives its slice into g1_local / g2_local
-    (8 n_local / 16 n_local words).  Empty slices are skipped on both sides."""
+    (8 n_local / 16 n_local words).  Empty slices are skipped on both sides.  A slice of an SoA batch is one contiguous run
+    per limb plane: rank 0 sends the 8 + 16 plane runs of a peer's slice straight out of the whole-batch tensors (no
+    temporaries), the peer receives them into the planes of its local tensors; all transfers of the step form ONE group."""
     world, rank = dist.get_world_size(), dist.get_rank()
     lo, hi = shard_bounds(n, world, rank)
-    ops, keep = [], []
+    ops = []
     if rank == 0:
         for r in range(1, world):
             rlo, rhi = shard_bounds(n, world, r)
             if rhi == rlo:
                 continue
             for full, words in ((full_g1, 8), (full_g2, 16)):
-                s = _cols(full, words, n, rlo, rhi)
-                keep.append(s)
-                ops.append(_P2P(dist, "send", s, r))
+                ops += [_P2P(dist, "send", v, r) for v in _planes(full, words, n, rlo, rhi)]
         if hi > lo:
             g1_local.view(8, hi - lo).copy_(full_g1.view(8, n)[:, lo:hi])
             g2_local.view(16, hi - lo).copy_(full_g2.view(16, n)[:, lo:hi])
     elif hi > lo:
-        ops = [_P2P(dist, "recv", g1_local, 0), _P2P(dist, "recv", g2_local, 0)]
+        m = hi - lo
+        ops = [_P2P(dist, "recv", v, 0) for v in _planes(g1_local, 8, m, 0, m) + _planes(g2_local, 16, m, 0, m)]
     _run(dist, ops)
 
 
 def gather_outputs(out_local, n, dist, device=None):
     """Every rank's 48 n_local output words travel to rank 0, which returns the whole SoA batch (48 n words); other
-    ranks return None."""
+    ranks return None.  Rank 0 receives each peer's 48 plane runs STRAIGHT into the whole-batch tensor (contiguous views:
+    no temporaries, no second copy); one group of transfers."""
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
     lo, hi = shard_bounds(n, world, rank)
     if rank != 0:
         if hi > lo:
-            _run(dist, [_P2P(dist, "send", out_local, 0)])
+            m = hi - lo
+            _run(dist, [_P2P(dist, "send", v, 0) for v in _planes(out_local, 48, m, 0, m)])
         return None
     full = torch.empty(48 * n, dtype=torch.int64, device=device if device is not None else out_local.device)
-    ops, parts = [], []
+    ops = []
     for r in range(1, world):
         rlo, rhi = shard_bounds(n, world, r)
         if rhi == rlo:
             continue
-        t = torch.empty(48 * (rhi - rlo), dtype=torch.int64, device=full.device)
-        parts.append((rlo, rhi, t))
-        ops.append(_P2P(dist, "recv", t, r))
+        ops += [_P2P(dist, "recv", v, r) for v in _planes(full, 48, n, rlo, rhi)]
     if hi > lo:
         full.view(48, n)[:, lo:hi].copy_(out_local.view(48, hi - lo))
     _run(dist, ops)
-    for rlo, rhi, t in parts:
-        full.view(48, n)[:, rlo:rhi].copy_(t.view(48, rhi - rlo))
     return full
 
 
-def _default_device(dist, like):
+def _default_device(dist, like, compute_is_hip=False):
+    """Where a rank's shard lives when the caller did not say: next to the inputs it was handed; else -- a non-root rank
+    of a scattered run has none -- this rank's GPU whenever the data must be there (RCCL moves device memory; the HIP
+    engine computes on device memory whatever carries the slices), else the host."""
     import torch
     if like is not None:
         return like.device
-    if dist.get_backend() == "nccl":                       # RCCL moves device memory: this rank's GPU
+    if _moves_device_memory(dist) or compute_is_hip:
         return torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
     return torch.device("cpu")
 
@@ -144,6 +166,7 @@ def pairing_sharded(g1, g2, n, dist=None, compute=None, scatter_from_root=False,
     may pass None).  Each rank walks its slice in launches of `chunk` lanes; the exchange steps sit between launches
     (scatter, then all of the rank's compute, then the gather): nothing is posted while a pairing kernel runs."""
     import torch
+    compute_is_hip = compute is None
     compute = compute or hip_compute()
     if dist is None or not dist.is_initialized():
         out = compute(g1, g2, n) if n else torch.empty(0, dtype=torch.int64, device=g1.device)
@@ -152,7 +175,7 @@ def pairing_sharded(g1, g2, n, dist=None, compute=None, scatter_from_root=False,
     lo, hi = shard_bounds(n, world, rank)
     n_local = hi - lo
     if device is None:
-        device = _default_device(dist, g1)
+        device = _default_device(dist, g1, compute_is_hip)
     if scatter_from_root:
         l1 = torch.empty(8 * n_local, dtype=torch.int64, device=device)
         l2 = torch.empty(16 * n_local, dtype=torch.int64, device=device)

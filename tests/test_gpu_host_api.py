@@ -201,3 +201,129 @@ def test_two_host_threads_two_streams_dev_calls():
     for t in th:
         t.join()
     assert not errors, errors
+
+
+def _busy_stream(pk, torch, dev, st, n=1 << 20):
+    """Inputs for a 2^20-lane launch (~110 ms of k_pairing) on stream `st`, generated and synchronised."""
+    with torch.cuda.stream(st):
+        g1 = torch.zeros(8 * n, dtype=torch.int64, device=dev)
+        g2 = torch.zeros(16 * n, dtype=torch.int64, device=dev)
+        out = torch.zeros(48 * n, dtype=torch.int64, device=dev)
+    pk.generate_pairs_dev(0xB254000B, g1, g2, n, 0, st)
+    pk.last_status(0, st)
+    return g1, g2, out, n
+
+
+def test_dev_calls_after_reserve_neither_allocate_nor_wait():
+    """include/bn254_pairing.h, STREAM: after bn254_reserve(device, stream, n, k) a `_dev` call of that size returns while a
+    2^20-lane launch is still running on the same stream -- including the calls that need more than the pairing did (k = 4
+    scratch, the verdict's Fq12 buffer, pow_native's digit buffer and staging slot)."""
+    import time
+    import torch
+    pk = H.pkg()
+    dev = torch.device("cuda:0")
+    st = torch.cuda.Stream(dev)
+    g1, g2, out, n = _busy_stream(pk, torch, dev, st)
+    groups, k = n // 4, 4
+    pk.reserve(n, k, 0, st)
+    with torch.cuda.stream(st):
+        verdict = torch.zeros(groups, dtype=torch.uint8, device=dev)
+        x = torch.zeros(48 * 256, dtype=torch.int64, device=dev)
+        x.view(48, 256)[0] = 7
+        y = torch.zeros(48 * 256, dtype=torch.int64, device=dev)
+    st.synchronize()
+    done = torch.cuda.Event()
+    pk.pairing_batch_dev(g1, g2, out, n, 0, st)                # ~110 ms
+    done.record(st)
+    t0 = time.perf_counter()
+    pk.multi_pairing_check_batch_dev(g1, g2, verdict, groups, k, 0, st)
+    pk.pow_batch_dev(x, [pk.BN_X], y, 256, 0, st)
+    pk.fq12_mul_batch_dev(x, x, y, 256, 0, st)
+    dt = time.perf_counter() - t0
+    still_running = not done.query()
+    pk.last_status(0, st)
+    assert still_running, "a `_dev` call waited for the stream"
+    assert dt < 0.05, f"three `_dev` calls took {dt * 1e3:.1f} ms on the host"
+    assert not bool(verdict.any())                              # generic groups: no product is one
+    pk.release_stream(0, st)
+
+
+def test_unreserved_growth_does_not_wait_for_the_stream():
+    """Without bn254_reserve a call that needs a larger buffer allocates it on the calling thread and RETIRES the old one (freed
+    in the next bn254_last_status): it still does not wait for the work queued on the stream, and the queued launch, which
+    uses the old scratch, finishes with the right result."""
+    import torch
+    pk = H.pkg()
+    dev = torch.device("cuda:0")
+    st = torch.cuda.Stream(dev)
+    g1, g2, out, n = _busy_stream(pk, torch, dev, st)
+    ref = torch.zeros(48 * 4096, dtype=torch.int64, device=dev)
+    cur = torch.cuda.current_stream(dev)
+    h1, h2 = g1.view(8, n)[:, :4096].contiguous().view(-1), g2.view(16, n)[:, :4096].contiguous().view(-1)
+    pk.pairing_batch_dev(h1, h2, ref, 4096, 0, cur)
+    pk.last_status(0, cur)
+    with torch.cuda.stream(st):
+        o4 = torch.zeros(48 * 1024, dtype=torch.int64, device=dev)
+    st.synchronize()
+    done = torch.cuda.Event()
+    pk.pairing_batch_dev(g1, g2, out, n, 0, st)                # scratch for k = 1 at a full grid
+    done.record(st)
+    pk.multi_pairing_batch_dev(g1, g2, o4, 1024, 4, True, 0, st)      # k = 4: the scratch must grow while the launch runs
+    still_running = not done.query()
+    pk.last_status(0, st)
+    assert still_running, "growing a buffer waited for the stream"
+    assert torch.equal(out.view(48, n)[:, :4096], ref.view(48, 4096))
+    pk.release_stream(0, st)
+
+
+def test_release_stream_races_calls_on_the_same_stream():
+    """bn254_release_stream from one thread while another keeps calling on the same (device, stream): the context is
+    reference-counted, the caller either keeps the old context until it returns or creates a fresh one -- results stay right."""
+    import torch
+    pk = H.pkg()
+    dev = torch.device("cuda:0")
+    st = torch.cuda.Stream(dev)
+    n = 2048
+    with torch.cuda.stream(st):
+        g1 = torch.zeros(8 * n, dtype=torch.int64, device=dev)
+        g2 = torch.zeros(16 * n, dtype=torch.int64, device=dev)
+        outs = [torch.zeros(48 * n, dtype=torch.int64, device=dev) for _ in range(2)]
+    pk.generate_pairs_dev(0xB254000C, g1, g2, n, 0, st)
+    pk.pairing_batch_dev(g1, g2, outs[0], n, 0, st)
+    pk.last_status(0, st)
+    errors, stop = [], threading.Event()
+
+    def caller():
+        try:
+            for _ in range(40):
+                pk.pairing_batch_dev(g1, g2, outs[1], n, 0, st)
+                pk.last_status(0, st)
+                if not torch.equal(outs[0], outs[1]):
+                    errors.append("mismatch")
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+        finally:
+            stop.set()
+
+    def releaser():
+        try:
+            while not stop.is_set():
+                pk.release_stream(0, st)
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=caller), threading.Thread(target=releaser)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors[:3]
+    pk.release_stream(0, st)
+
+
+def test_scratch_pitch_overflow_is_rejected():
+    """The kernels form a workgroup's scratch base as blockIdx * pitch in 32 bits: a (grid, k) whose scratch would reach 4 GiB is
+    refused up front.  At 256 CUs the largest k the kernels take (64) needs 2.5 GiB, so every supported call passes."""
+    pk = H.pkg()
+    assert pk.load_library().bn254_scratch_bytes(1 << 20, 64) < (1 << 32)
+    assert pk.load_library().bn254_scratch_bytes(1 << 20, 1) == 512 << 20

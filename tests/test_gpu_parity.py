@@ -579,3 +579,40 @@ def test_fused_and_split_kernels_agree_on_every_lane():
     pk.last_status(0, st)
     assert torch.equal(a, b)
     assert not torch.equal(a, m)
+
+
+def test_configs4_shard_size_2_21_lanes():
+    """BASELINE.json configs[4] per-GPU shard: 2^21 independent pairings in ONE launch (32 work items per workgroup -- twice the
+    largest launch of configs[2]).  (a) fused == split on every lane: k_pairing equals k_fexp(k_miller), (b) the first half equals
+    a separate 2^20 launch of the same inputs (a lane's result does not depend on the launch it ran in), (c) 256 oracle spot
+    checks over the whole index range, guard words."""
+    import os
+    import torch
+    pk = H.pkg()
+    n = 1 << 21
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev)
+    g1 = torch.zeros(8 * n, dtype=torch.int64, device=dev)
+    g2 = torch.zeros(16 * n, dtype=torch.int64, device=dev)
+    pk.generate_pairs_dev(0xB2540041, g1, g2, n, 0, st)
+    a = torch.full((48 * n + 64,), -1, dtype=torch.int64, device=dev)
+    pk.pairing_batch_dev(g1, g2, a, n, 0, st)
+    m = torch.zeros(48 * n, dtype=torch.int64, device=dev)
+    b = torch.zeros(48 * n, dtype=torch.int64, device=dev)
+    pk.miller_loop_batch_dev(g1, g2, m, n, 0, st)
+    pk.final_exp_batch_dev(m, b, n, 0, st)
+    pk.last_status(0, st)
+    assert bool((a[48 * n:] == -1).all())
+    assert torch.equal(a[:48 * n], b)
+    del m, b
+    half = n // 2
+    h1, h2 = g1.view(8, n)[:, :half].contiguous().view(-1), g2.view(16, n)[:, :half].contiguous().view(-1)
+    c = torch.zeros(48 * half, dtype=torch.int64, device=dev)
+    pk.pairing_batch_dev(h1, h2, c, half, 0, st)
+    pk.last_status(0, st)
+    assert torch.equal(a[:48 * n].view(48, n)[:, :half], c.view(48, half))
+    rng = np.random.default_rng(41)
+    pos = np.unique(np.concatenate([rng.choice(n, size=248, replace=False), [0, 65535, 65536, (1 << 20) - 1, 1 << 20, (1 << 20) + 65536, n - 256, n - 1]]))
+    want = H.oracle_pairing(pk.layout.to_aos(_take(g1, 8, n, pos), 8), pk.layout.to_aos(_take(g2, 16, n, pos), 16), len(pos),
+                            threads=min(32, len(os.sched_getaffinity(0))))
+    assert np.array_equal(pk.layout.to_aos(_take(a[:48 * n], 48, n, pos), 48), want)

@@ -130,6 +130,37 @@ def test_bench_launcher_two_ranks_cpu():
     assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
 
 
+def test_bench_launcher_eight_ranks_cpu():
+    """The shape of the driver's 8-GPU run (`--gpus 8`: BASELINE.json configs[4], 2^24 over 8 ranks), rehearsed on CPU over gloo
+    with the stand-in engine: eight ranks, shard bounds, the 7-peer grouped plane-wise scatter and gather, every peer's slice
+    checked on rank 0 (the gathered batch equals the whole-batch recomputation), per-rank kernel times and memory in the line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(BENCH_TEST_ENGINE="fake_engine:Engine", BENCH_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--log2-batch", "5"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["rccl_ranks"] == 8 and rec["scaling"] == "weak"
+    assert rec["config"]["pairings_per_gpu"] == 32 and rec["config"]["pairings_total"] == 256
+    assert rec["exchange"]["bytes_scattered"] == 192 * 7 * 32 and rec["exchange"]["bytes_gathered"] == 384 * 7 * 32
+    assert rec["gathered_equals_whole_batch_recomputation"] is True
+    pr = rec["per_rank"]
+    assert all(len(pr[k]) == 8 for k in ("kernel_ms_avg", "kernel_ms_min", "kernel_ms_max", "peak_device_bytes"))
+    assert rec["value"] > 0 and abs(rec["value"] - 256 * 2 / (rec["ms_per_step"] * 2e-3)) < 1e-6 * rec["value"]
+
+
+def test_bench_refuses_the_engine_hook_outside_pytest():
+    """BENCH_TEST_ENGINE is honoured only under pytest: a plain environment cannot make bench.py print a `value` from a stand-in."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "PYTEST_CURRENT_TEST")}
+    env.update(BENCH_TEST_ENGINE="fake_engine:Engine", BENCH_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--log2-batch", "4"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "refused outside pytest" in (p.stderr + p.stdout)
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
 # ------------------------------------------------------------------------------------------------ GPU: nccl = RCCL
 def _nccl_worker(rank, world, port, n, chunk, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")

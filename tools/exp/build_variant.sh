@@ -1,7 +1,7 @@
 #!/bin/bash
 # build_variant.sh <tag> [ENV=VAL ...] -- regenerates the kernel header under the given generator switches and builds
 # build/variants/lib_<tag>.so (the committed header / library are left untouched).
-set -e
+set -eo pipefail
 cd "$(dirname "$0")/../.."
 tag=$1; shift
 mkdir -p build/variants/$tag
@@ -15,6 +15,13 @@ open("build/variants/$tag/pairing_asm_gen.h", "w").write(text)
 print("$tag", stats)
 PY
 sed -i 's#"../../include/bn254_pairing.h"#"'$PWD'/include/bn254_pairing.h"#' build/variants/$tag/bn254_kernels.hip
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared build/variants/$tag/bn254_kernels.hip -o build/variants/lib_$tag.so 2>&1 | grep -E "error" || true
-rm -rf build/variants/$tag
+rm -f build/variants/lib_$tag.so                  # never leave an older build behind: a failed compile must not be measured
+if ! hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared build/variants/$tag/bn254_kernels.hip -o build/variants/lib_$tag.so.tmp > build/variants/$tag.log 2>&1; then
+    grep -E "error" build/variants/$tag.log | head -20 >&2 || true
+    echo "build of variant $tag FAILED (log: build/variants/$tag.log)" >&2
+    rm -f build/variants/lib_$tag.so.tmp
+    exit 1
+fi
+mv build/variants/lib_$tag.so.tmp build/variants/lib_$tag.so
+rm -rf build/variants/$tag build/variants/$tag.log
 ls -la build/variants/lib_$tag.so
