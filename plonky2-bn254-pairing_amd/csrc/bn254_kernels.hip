@@ -147,6 +147,8 @@ struct StreamCtx {
     std::vector<NafSlot> naf_ring;
     int* status = nullptr;
     int* status_host = nullptr;   // pinned: the status word is read back on the caller's stream
+    size_t last_pitch = 0;        // scratch geometry of the most recent launch (diagnostic builds read their clock stamps back from it)
+    uint32_t last_grid = 0;
     ~StreamCtx() {                // the last holder (bn254_release_stream, after the stream has been synchronised) frees everything
         for (Buf* b : {&scratch, &naf, &tmp}) if (b->p) (void)hipFree(b->p);
         for (Buf& b : stage) if (b.p) (void)hipFree(b.p);
@@ -271,6 +273,8 @@ int ctx_get(int device, void* stream, size_t k, size_t n_items, LaunchCtx* out, 
     out->gen_table = c.gen_table;
     out->grid = grid;
     out->stride = (uint32_t)pitch;
+    sc->last_pitch = pitch;
+    sc->last_grid = grid;
     return BN254_OK;
 }
 
@@ -628,6 +632,24 @@ int bn254_release_stream(int device, void* stream) {
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     return BN254_OK;
 }
+
+#ifdef BN254_DEBUG_STAMPS
+// DIAGNOSTIC builds only (tools/exp/build_variant.sh with KGEN_CLOCK_STAMP=1 and -DBN254_DEBUG_STAMPS; not part of the ABI): the
+// kernels of such a build leave, per wave, (d s_memtime, d s_memrealtime) around their item loop in the slack at the end of their
+// workgroup's scratch block.  out: 4 x u64 per workgroup-wave pair = [wg][wave]{d_memtime, d_memrealtime}; returns the grid size.
+int bn254_debug_stamps(int device, void* stream, uint64_t* out, size_t max_wg) {
+    int rc = check_device(device);
+    if (rc) return rc;
+    std::shared_ptr<StreamCtx> sc = stream_ctx(device, stream);
+    std::lock_guard<std::recursive_mutex> lk(sc->mu);
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    if (!sc->scratch.p || !sc->last_grid) return BN254_ERR_INVALID_ARG;
+    size_t n = sc->last_grid < max_wg ? sc->last_grid : max_wg;
+    for (size_t g = 0; g < n; g++)
+        HIPCHK(hipMemcpy(out + g * 8, (const char*)sc->scratch.p + (g + 1) * sc->last_pitch - BN254_STAMP_OFFSET_FROM_END, 64, hipMemcpyDeviceToHost));
+    return (int)n;
+}
+#endif
 
 int bn254_reserve(int device, void* stream, size_t n, size_t k) {
     if (k == 0 || n * k >= (1ull << 29) || (n && n * k / n != k)) return BN254_ERR_INVALID_ARG;

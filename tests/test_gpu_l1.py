@@ -32,7 +32,7 @@ OUT = {"mul6": list(range(K4.HOME0 + 6 * K4.SLOT_DW, K4.HOME0 + 7 * K4.SLOT_DW))
 
 def _body(name):
     e = AC.Emitter()
-    getattr(K4.L1v4(e), "r_" + name)()
+    K4.routine_body(e, name)
     return AC.align_code(e.finalize())
 
 

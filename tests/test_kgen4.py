@@ -59,7 +59,7 @@ def _m4(vals, rng, slack):
 
 def _body(n):
     e = AC.Emitter()
-    getattr(K4.L1v4(e), "r_" + n)()
+    K4.routine_body(e, n)
     return e.finalize()
 
 

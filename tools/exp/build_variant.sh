@@ -1,6 +1,7 @@
 #!/bin/bash
 # build_variant.sh <tag> [ENV=VAL ...] -- regenerates the kernel header under the given generator switches and builds
-# build/variants/lib_<tag>.so (the committed header / library are left untouched).
+# build/variants/lib_<tag>.so (the committed header / library are left untouched).  HIPCC_EXTRA (from the calling environment) is passed
+# to hipcc, e.g.  HIPCC_EXTRA=-DBN254_DEBUG_STAMPS tools/exp/build_variant.sh stamp KGEN_CLOCK_STAMP=1  for the clock-stamp diagnostic build.
 set -eo pipefail
 cd "$(dirname "$0")/../.."
 tag=$1; shift
@@ -16,7 +17,7 @@ print("$tag", stats)
 PY
 sed -i 's#"../../include/bn254_pairing.h"#"'$PWD'/include/bn254_pairing.h"#' build/variants/$tag/bn254_kernels.hip
 rm -f build/variants/lib_$tag.so                  # never leave an older build behind: a failed compile must not be measured
-if ! hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared build/variants/$tag/bn254_kernels.hip -o build/variants/lib_$tag.so.tmp > build/variants/$tag.log 2>&1; then
+if ! hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared ${HIPCC_EXTRA:-} build/variants/$tag/bn254_kernels.hip -o build/variants/lib_$tag.so.tmp > build/variants/$tag.log 2>&1; then
     grep -E "error" build/variants/$tag.log | head -20 >&2 || true
     echo "build of variant $tag FAILED (log: build/variants/$tag.log)" >&2
     rm -f build/variants/lib_$tag.so.tmp

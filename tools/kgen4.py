@@ -43,6 +43,11 @@ assert REDN_C < (1 << 31)
 
 A0, B0 = 0, 18
 TMP_FIRST, TMP_LAST = 36, 75
+CYC_WIDE_M = bool(int(os.environ.get("KGEN_CYC_WIDE_M", "1")))                     # A/B switch: 32-bit Montgomery digits in the cyclotomic squaring's products
+DBL_LAZY_Y3 = bool(int(os.environ.get("KGEN_DBL_LAZY_Y3", "1")))                   # A/B switch: Y3 of the doubling step with one reduction per component
+ADD_INJECT = bool(int(os.environ.get("KGEN_ADD_INJECT", "1")))                     # A/B switch: theta / mu of the addition step as pass outputs
+MUL3_KEEP_DY = bool(int(os.environ.get("KGEN_MUL3_KEEP_DY", "1")))                 # A/B switch: line-side Karatsuba differences of the sparse multiplications kept across passes
+MUL6_KEEP_DIFFS = bool(int(os.environ.get("KGEN_MUL6_KEEP_DIFFS", "1")))      # A/B switch (tools/exp/build_variant.sh)
 V_LDS = 76          # v76, v77: LDS byte address of the lane's 16-byte chunks (+0, +64 KiB) ; v78: of its 8-byte tail chunks
 V_LTAIL = 78
 V_GOFF = 79         # byte offset of the lane's 16-byte chunks inside a global scratch slot: wave * 4608 + lane * 16 (V_GOFF8 = 246: ... + lane * 8, the tail)
@@ -133,7 +138,7 @@ class L1v4:
         self.e.emit(f"v_ashrrev_i64 {P}, {LB}, {P}", vw=[acc, acc + 1])
 
     # ------------------------------------------------------------------ fused Montgomery column pass
-    def fips(self, prods, out, fillers=(), gap=8, balanced=True):
+    def fips(self, prods, out, fillers=(), gap=8, balanced=True, wide_m=False, inject=()):
         """out[0..NL-1] <- (sum over (a, b) in prods of a*b) / R' mod p, balanced limbs, value in sum/R' +- p/2.
         a, b: lists of NL VGPR numbers.  Result limb j is written after column j + NL, when limb j of every operand is
         dead, so `out` may be one of the first operands a (in place) but must not overlap a second operand b.
@@ -141,7 +146,15 @@ class L1v4:
         fillers: independent instructions [(text, vw, earliest column, latest column)] dropped into the multiply runs
         (work that has to be done anyway -- negations, copies -- and whose operands die / are born inside the pass).
         balanced=False: result limbs in [0, 2^29) instead (one instruction less per limb) -- for results that only feed the
-        64-bit linear-combination chains, never a product."""
+        64-bit linear-combination chains, never a product.
+        inject: [(limb list, inline-constant coefficient)]: coef * value is ADDED to the result (the limbs enter the upper half of
+        the double-width sum, one multiply-add each: out = sum / R' + coef * value +- p/2), which comes out normalised like any
+        pass result -- a subtraction / addition behind a product without a separate limb-wise pass and carry pass.
+        wide_m: the Montgomery digits m_k = lo32(S n0') are used as the signed 32-bit values they are (n0' = -1/p mod 2^32) instead
+        of being cut back to balanced 29-bit digits: any m = S n0' (mod 2^29) clears the low 29 bits of the column, so the bfe is
+        dropped (nine instructions per pass).  The price: |m_k| < 2^31, i.e. the nine reduction products of a column may reach
+        72 units of 2^56 (instead of 9) and the result is sum / R' +- 4 p (instead of +- p/2) -- only for passes whose own
+        products stay below ~50 units per column and whose results go straight into a REDUCING chain."""
         acc, P = self._acc()
         m = [self.pool.alloc() for _ in range(NL)]
         first = True
@@ -179,25 +192,30 @@ class L1v4:
                 for i in range(k):
                     mad(m[i], self.p[k - i])
                 self.e.emit(f"v_mul_lo_u32 v{m[k]}, v{acc}, {self.n0}", vw=[m[k]])
-                self.e.emit(f"v_bfe_i32 v{m[k]}, v{m[k]}, 0, {LB}", vw=[m[k]])
+                if not wide_m:
+                    self.e.emit(f"v_bfe_i32 v{m[k]}, v{m[k]}, 0, {LB}", vw=[m[k]])
                 run = 0
                 mad(m[k], self.p[0])
                 self.e.emit(f"v_ashrrev_i64 {P}, {LB}, {P}", vw=[acc, acc + 1])
             else:
                 for i in range(k - (NL - 1), NL):
                     mad(m[i], self.p[k - i])
+                for vec, coef in inject:
+                    mad(vec[k - NL], self._coef(coef))
                 if balanced:
                     self._digit(acc, P, out[k - NL])
                 else:
                     self.e.emit(f"v_and_b32_e32 v{out[k - NL]}, 0x{MASK:x}, v{acc}", vw=[out[k - NL]])
                     self.e.emit(f"v_ashrrev_i64 {P}, {LB}, {P}", vw=[acc, acc + 1])
                 run = 0
+        for vec, coef in inject:
+            mad(vec[NL - 1], self._coef(coef))
         self.e.emit(f"v_mov_b32_e32 v{out[NL - 1]}, v{acc}", vw=[out[NL - 1]])
         for (text, vw, lo, hi) in todo:
             self.e.emit(text, vw=vw)
         self.pool.free(acc, acc + 1, *m)
 
-    def fips_sq(self, a, out):
+    def fips_sq(self, a, out, wide_m=False):
         """out <- a^2 / R' mod p for ONE Fq value (normalised limbs): the symmetric products once -- column k takes a_i (2 a_j) for
         i < j, i + j = k and a_(k/2)^2: 45 limb products instead of 81.  Same column sweep, reduction and result rules as fips
         (in place over a is fine).  Used by the Fermat inversion (254 squarings per pairing)."""
@@ -218,7 +236,8 @@ class L1v4:
                 for i in range(k):
                     self._mad(acc, P, m[i], self.p[k - i], False)
                 self.e.emit(f"v_mul_lo_u32 v{m[k]}, v{acc}, {self.n0}", vw=[m[k]])
-                self.e.emit(f"v_bfe_i32 v{m[k]}, v{m[k]}, 0, {LB}", vw=[m[k]])
+                if not wide_m:
+                    self.e.emit(f"v_bfe_i32 v{m[k]}, v{m[k]}, 0, {LB}", vw=[m[k]])
                 self._mad(acc, P, m[k], self.p[0], False)
                 self.e.emit(f"v_ashrrev_i64 {P}, {LB}, {P}", vw=[acc, acc + 1])
             else:
@@ -249,11 +268,23 @@ class L1v4:
         Result limb j is written after column j + NL (in place over a FIRST operand x is fine; never over a y)."""
         e = self.e
         nk = len(kterms)
-        dx = [[self.pool.alloc() for _ in range(NL)] for _ in range(nk)]
-        dy = [[self.pool.alloc() for _ in range(NL)] for _ in range(nk)]
-        for k, (x, y) in enumerate(kterms):
-            self.limbwise("v_sub_u32_e32", dx[k], x[1], x[0])
-            self.limbwise("v_sub_u32_e32", dy[k], y[0], y[1])
+        # a term may bring its difference vectors along -- (x, y, x1 - x0, y0 - y1) -- when the caller keeps them across passes
+        # (r_mul6: every operand takes part in three passes); those are neither computed nor freed here
+        own, dx, dy = [], [], []
+        for k, term in enumerate(kterms):
+            x, y = term[0], term[1]
+            gx, gy = (term[2], term[3]) if len(term) == 4 else (None, None)
+            if gx is None:
+                gx = [self.pool.alloc() for _ in range(NL)]
+                own.append(gx)
+                self.limbwise("v_sub_u32_e32", gx, x[1], x[0])
+            if gy is None:
+                gy = [self.pool.alloc() for _ in range(NL)]
+                own.append(gy)
+                self.limbwise("v_sub_u32_e32", gy, y[0], y[1])
+            dx.append(gx)
+            dy.append(gy)
+        kterms = [(t[0], t[1]) for t in kterms]
         nx = []
         for x, y in sterms:
             n_ = [self.pool.alloc() for _ in range(NL)]
@@ -315,7 +346,7 @@ class L1v4:
         e.emit(f"v_mov_b32_e32 v{out_re[NL - 1]}, v{a0}", vw=[out_re[NL - 1]])
         e.emit(f"v_mov_b32_e32 v{out_im[NL - 1]}, v{a1}", vw=[out_im[NL - 1]])
         self.pool.free(a0, a0 + 1, a1, a1 + 1, u, u + 1, w, w + 1, *m0, *m1)
-        for v_ in dx + dy + nx:
+        for v_ in own + nx:
             self.pool.free(*v_)
 
     def lincomb(self, outs, termss, reduce=False):
@@ -407,27 +438,44 @@ class L1v4:
         self.pool.free(c)
 
     # ------------------------------------------------------------------ routines: A <- op(A, B)
-    def _fq2_mul(self, x, y, o, balanced=True):
+    def _fq2_mul(self, x, y, o, balanced=True, wide_m=False):
         """o <- x * y (Fq2; x, y, o = (c0 limbs, c1 limbs)); o may be x itself (in place) or a disjoint block."""
         (x0, x1), (y0, y1), (o0, o1) = x, y, o
         n = [self.pool.alloc() for _ in range(NL)]
         self._neg_into(n, x1)
-        self.fips([(x1, y0), (x0, y1)], o1, balanced=balanced)
-        self.fips([(x0, y0), (n, y1)], o0, balanced=balanced)
+        self.fips([(x1, y0), (x0, y1)], o1, balanced=balanced, wide_m=wide_m)
+        self.fips([(x0, y0), (n, y1)], o0, balanced=balanced, wide_m=wide_m)
         self.pool.free(*n)
 
     def r_mul(self):
         """(a0 + a1 u)(b0 + b1 u): two fused two-product passes, both in place over A."""
         self._fq2_mul(self.fq2(A0), self.fq2(B0), self.fq2(A0))
 
+    # Round 4: the y-side operands of the three-term multiply are the LINE coefficients (block B, home blocks 1 and 3), which stay
+    # put over several of the six passes of a sparse multiplication: their Karatsuba differences y0 - y1 live in 27 registers of the
+    # routine's own scratch (the top half of home block 7 and home block 8) and are formed by the CALLER when such an operand changes
+    # (L1v4.mul3_dy; Prog.mul3 tracks it) -- 45 subtractions per sparse multiplication instead of 162.
+    MUL3_DY = {"B": list(range(HOME0 + 7 * SLOT_DW + NL, HOME0 + 8 * SLOT_DW)),
+               1: list(range(HOME0 + 8 * SLOT_DW, HOME0 + 8 * SLOT_DW + NL)),
+               3: list(range(HOME0 + 8 * SLOT_DW + NL, HOME0 + 9 * SLOT_DW))}
+
+    def mul3_dy(self, which):
+        """difference vector of the y operand `which` ("B", 1 or 3) of r_mul3 <- y.0 - y.1"""
+        y = self.fq2(B0 if which == "B" else HOME0 + SLOT_DW * which)
+        self.limbwise("v_sub_u32_e32", self.MUL3_DY[which], y[0], y[1])
+
     def r_mul3(self):
         """A <- A*B + H0*H1 + H2*H3 (Fq2 products, H_k = home block k), ONE reduction per output component: one dual column
         pass with three Karatsuba products (kfips), in place over A.  The other five operands survive.  Operand limbs below 3.9
         units (the limb-wise differences stay within int32); the column budget is the caller's check (Prog.mul3).  Scratch: the
-        pool and home blocks 6, 7, 8 (80 registers)."""
-        blocks = [(A0, B0), (HOME0, HOME0 + SLOT_DW), (HOME0 + 2 * SLOT_DW, HOME0 + 3 * SLOT_DW)]
-        terms = [(self.fq2(x), self.fq2(y)) for x, y in blocks]
+        pool and home blocks 6, 7, 8 (MUL3_KEEP_DY: of which the 27 registers MUL3_DY hold the y-side differences on entry)."""
+        blocks = [(A0, B0, "B"), (HOME0, HOME0 + SLOT_DW, 1), (HOME0 + 2 * SLOT_DW, HOME0 + 3 * SLOT_DW, 3)]
         extra = list(range(HOME0 + 6 * SLOT_DW, HOME0 + 9 * SLOT_DW))
+        if MUL3_KEEP_DY:
+            terms = [(self.fq2(x), self.fq2(y), None, self.MUL3_DY[w]) for x, y, w in blocks]
+            extra = [r for r in extra if not any(r in v for v in self.MUL3_DY.values())]
+        else:
+            terms = [(self.fq2(x), self.fq2(y)) for x, y, _ in blocks]
         self.pool.free_regs += extra
         a = self.fq2(A0)
         self.kfips(terms, [], a[0], a[1])
@@ -456,11 +504,13 @@ class L1v4:
         once the second product is formed; the chains write limb i of both outputs after reading limb i of every input).
         t = a b ; S = xi b + a (normalised on a 64-bit chain) ; P = (a + b) S ; a^2 + xi b^2 = P - t - xi t.
         t, u, s: three scratch blocks; the pool."""
-        self._fq2_mul(a, b, t, balanced=False)                          # t = a b (a, b stay intact); t and P only feed the chains
+        # (round 4: both products with 32-bit Montgomery digits -- wide_m: their columns hold 18 / 36 units of limb products, their
+        # results, now sum / R' +- 4 p, only feed the reducing chains below, which take up to 8 V_CAP)
+        self._fq2_mul(a, b, t, balanced=False, wide_m=CYC_WIDE_M)       # t = a b (a, b stay intact); t and P only feed the chains
         # S = xi b + a = (9 b0 - b1 + a0, 9 b1 + b0 + a1), normalised
         self.lincomb([s[0], s[1]], [[(9, b[0]), (-1, b[1]), (1, a[0])], [(9, b[1]), (1, b[0]), (1, a[1])]])
         self._lw("v_add_u32_e32", u, a, b)                              # u = a + b (two units)
-        self._fq2_mul(u, s, u, balanced=False)                          # P = u S, in place
+        self._fq2_mul(u, s, u, balanced=False, wide_m=CYC_WIDE_M)       # P = u S, in place
         # oa <- 3 (P - t - xi t) - 2 zc = 3 P - 30 t0 + 3 t1 - 2 zc | 3 P1 - 30 t1 - 3 t0 - 2 zc1
         self.lincomb([oa[0], oa[1]], [[(3, u[0]), (-30, t[0]), (3, t[1]), (-2, zc[0])],
                                       [(3, u[1]), (-30, t[1]), (-3, t[0]), (-2, zc[1])]], reduce=True)
@@ -537,25 +587,73 @@ class L1v4:
 
         def with_regs(extra, fn):
             self.pool.free_regs += extra
+            self.pool.free_regs.sort()
             fn()
             for r in extra:
                 self.pool.free_regs.remove(r)
 
-        with_regs(blk(B0) + blk(HOME0 + 6 * SLOT_DW) + blk(HOME0 + 7 * SLOT_DW),
-                  lambda: self.kfips([(a[0], b[2]), (a[1], b[1]), (a[2], b[0])], [], A[0], A[1]))              # c2 -> block A
-        xi(a[2], xa2)
-        # the other two passes find 76 registers where three Karatsuba products need 80: the four bookkeeping registers (batch
-        # index, thread id, flags) wait in the four spare AGPRs meanwhile
+        if not MUL6_KEEP_DIFFS:
+            with_regs(blk(B0) + blk(HOME0 + 6 * SLOT_DW) + blk(HOME0 + 7 * SLOT_DW),
+                      lambda: self.kfips([(a[0], b[2]), (a[1], b[1]), (a[2], b[0])], [], A[0], A[1]))              # c2 -> block A
+            xi(a[2], xa2)
+            # the other two passes find 76 registers where three Karatsuba products need 80: the four bookkeeping registers (batch
+            # index, thread id, flags) wait in the four spare AGPRs meanwhile
+            park = [V_IDX8, V_IDX, V_TID, V_FLAG]
+            for i, r in enumerate(park):
+                self.e.emit(f"v_accvgpr_write_b32 a{SLOT_DW * N_AGPR_SLOTS + i}, v{r}")
+            with_regs(blk(B0) + blk(HOME0 + 6 * SLOT_DW) + park,
+                      lambda: self.kfips([(a[0], b[1]), (a[1], b[0]), (xa2, b[2])], [], a[2][0], a[2][1]))        # c1 -> home 2 (a2 is dead)
+            xi(a[1], xa1)
+            with_regs(blk(B0) + blk(HOME0 + SLOT_DW) + park,
+                      lambda: self.kfips([(a[0], b[0]), (xa1, b[2]), (xa2, b[1])], [], xa1[0], xa1[1]))           # c0 in place over xi a1
+            for i, r in enumerate(park):
+                self.e.emit(f"v_accvgpr_read_b32 v{r}, a{SLOT_DW * N_AGPR_SLOTS + i}", vw=[r])
+            return
+        # Round 4: the Karatsuba DIFFERENCE vectors are kept across the three passes.  Every operand takes part in three products
+        # (a_i with b_0, b_1, b_2 and the other way round), so forming x1 - x0 / y0 - y1 per pass computed each of them three
+        # times: 162 subtractions per multiplication.  Here the six vectors live in block B and the pool for the whole routine (54
+        # of their 58 registers; the accumulators and quotient digits of a pass take the remaining four plus home blocks 6, 7 in
+        # the first pass, home block 6 / 1 and the four parked bookkeeping registers in the other two: 26 each) and only the two
+        # that change -- xi a2, xi a1 replace a2, a1 -- are formed anew: 72 subtractions, -90 instructions per multiplication.
+        keep = blk(B0) + list(range(TMP_FIRST, TMP_LAST + 1))          # 58 registers that no pass hands out otherwise
+        saved = self.pool.free_regs
+        assert sorted(saved) == list(range(TMP_FIRST, TMP_LAST + 1)), "mul6 expects the whole pool"
+        dregs = keep[:6 * NL]
+        rest = keep[6 * NL:]
+        da = [dregs[NL * k: NL * k + NL] for k in range(3)]
+        db = [dregs[NL * (3 + k): NL * (3 + k) + NL] for k in range(3)]
+        for k in range(3):
+            self.limbwise("v_sub_u32_e32", da[k], a[k][1], a[k][0])
+            self.limbwise("v_sub_u32_e32", db[k], b[k][0], b[k][1])
+        self.pool.free_regs = sorted(rest)
+
+        def run_pass(extra, terms, out):
+            self.pool.free_regs = sorted(rest + extra)
+            self.kfips(terms, [], out[0], out[1])
+            assert sorted(self.pool.free_regs) == sorted(rest + extra)
+            self.pool.free_regs = sorted(rest)
+
+        def xi_diff(src, dst, d):
+            """dst <- xi src (normalised), d <- dst.1 - dst.0; the chain's two accumulator pairs come from the pass workspace"""
+            self.pool.free_regs = sorted(rest + blk(HOME0 + 6 * SLOT_DW)) if dst is xa2 else sorted(rest + park)
+            xi(src, dst)
+            self.pool.free_regs = sorted(rest)
+            self.limbwise("v_sub_u32_e32", d, dst[1], dst[0])
+
         park = [V_IDX8, V_IDX, V_TID, V_FLAG]
+        run_pass(blk(HOME0 + 6 * SLOT_DW) + blk(HOME0 + 7 * SLOT_DW),
+                 [(a[0], b[2], da[0], db[2]), (a[1], b[1], da[1], db[1]), (a[2], b[0], da[2], db[0])], A)                # c2 -> block A
+        xi_diff(a[2], xa2, da[2])                                                                                   # xi a2 -> home 7 (home 6 lends the chain its registers)
         for i, r in enumerate(park):
             self.e.emit(f"v_accvgpr_write_b32 a{SLOT_DW * N_AGPR_SLOTS + i}, v{r}")
-        with_regs(blk(B0) + blk(HOME0 + 6 * SLOT_DW) + park,
-                  lambda: self.kfips([(a[0], b[1]), (a[1], b[0]), (xa2, b[2])], [], a[2][0], a[2][1]))        # c1 -> home 2 (a2 is dead)
-        xi(a[1], xa1)
-        with_regs(blk(B0) + blk(HOME0 + SLOT_DW) + park,
-                  lambda: self.kfips([(a[0], b[0]), (xa1, b[2]), (xa2, b[1])], [], xa1[0], xa1[1]))           # c0 in place over xi a1
+        run_pass(blk(HOME0 + 6 * SLOT_DW) + park,
+                 [(a[0], b[1], da[0], db[1]), (a[1], b[0], da[1], db[0]), (xa2, b[2], da[2], db[2])], a[2])               # c1 -> home 2 (a2 is dead)
+        xi_diff(a[1], xa1, da[1])                                                                                   # xi a1 -> home 6 (a1 itself is dead now)
+        run_pass(blk(HOME0 + SLOT_DW) + park,
+                 [(a[0], b[0], da[0], db[0]), (xa1, b[2], da[1], db[2]), (xa2, b[1], da[2], db[1])], xa1)                 # c0 in place over xi a1
         for i, r in enumerate(park):
             self.e.emit(f"v_accvgpr_read_b32 v{r}, a{SLOT_DW * N_AGPR_SLOTS + i}", vw=[r])
+        self.pool.free_regs = saved
 
 
     # ------------------------------------------------------------------ fused G2 steps of the Miller loop
@@ -667,9 +765,34 @@ class L1v4:
         self.lincomb([X[0], X[1]], [[(18, X[0]), (-2, X[1])], [(18, X[1]), (2, X[0])]], reduce=True)   # X3 = 2 xi X Y T
         self.norm_limbs(A[0])
         self.norm_limbs(A[1])
-        self._fq2_sqr(A, Y)                                                                     # (Y is dead) S^2
-        self._fq2_sqr(N, N)
-        self.lincomb([Y[0], Y[1]], [[(1, Y[0]), (-12, N[0])], [(1, Y[1]), (-12, N[1])]], reduce=True)   # Y3 = S^2 - 12 N^2
+        if not DBL_LAZY_Y3:
+            self._fq2_sqr(A, Y)                                                                 # (Y is dead) S^2
+            self._fq2_sqr(N, N)
+            self.lincomb([Y[0], Y[1]], [[(1, Y[0]), (-12, N[0])], [(1, Y[1]), (-12, N[1])]], reduce=True)   # Y3 = S^2 - 12 N^2
+            return
+        # Round 4: Y3 = S^2 - 12 N^2 = S S + N (-12 N) with ONE reduction per component (two two-product passes) instead of two
+        # squarings (four reductions) and a combining chain: M = -12 N comes normalised off one chain (into the dead block of T),
+        #   re = (S0 + S1)(S0 - S1) + (N0 + N1)(M0 - M1)        im = S1 (2 S0) + N1 (2 M0)
+        # then the result (below 15 p for reduced inputs) goes through the reducing chain like every coordinate.
+        S_ = A
+        M = Bq                                                                                  # (T is dead)
+        self.lincomb([M[0], M[1]], [[(-12, N[0])], [(-12, N[1])]])
+        tN, uM = E                                                                              # (block 8 is dead: X^2 went into L4)
+        self.limbwise("v_add_u32_e32", tN, N[0], N[1])
+        self.limbwise("v_sub_u32_e32", uM, M[0], M[1])
+        tS = [self.pool.alloc() for _ in range(NL)]
+        uS = [self.pool.alloc() for _ in range(NL)]
+        self.limbwise("v_add_u32_e32", tS, S_[0], S_[1])
+        self.limbwise("v_sub_u32_e32", uS, S_[0], S_[1])
+        self.fips([(tS, uS), (tN, uM)], Y[0])
+        self.pool.free(*tS)
+        self.pool.free(*uS)
+        dS, dM = tN, uM                                                                         # (dead now)
+        for i in range(NL):
+            self.e.emit(f"v_lshlrev_b32_e32 v{dS[i]}, 1, v{S_[0][i]}", vw=[dS[i]])
+            self.e.emit(f"v_lshlrev_b32_e32 v{dM[i]}, 1, v{M[0][i]}", vw=[dM[i]])
+        self.fips([(S_[1], dS), (N[1], dM)], Y[1])
+        self.lincomb([Y[0], Y[1]], [[(1, Y[0])], [(1, Y[1])]], reduce=True)
 
     def r_addstep(self):
         """R <- R + Q (mixed addition, Q = (x2, y2) affine) and the chord through the old R and Q evaluated at P:
@@ -683,13 +806,27 @@ class L1v4:
         X, Y, Z, x2, y2, th, mu, L2, L3 = [H(k) for k in range(9)]
         A, Bk = self.fq2(A0), self.fq2(B0)
         Px, Py = self.blk(B0, 0), self.blk(B0, 1)
-        self._fq2_mul(y2, Z, th)
-        self._lw("v_sub_u32_e32", th, Y, th)                           # theta = Y - y2 Z
-        self._fq2_mul(x2, Z, mu)
-        self._lw("v_sub_u32_e32", mu, X, mu)                           # mu = X - x2 Z
-        for v in (th, mu):
-            self.norm_limbs(v[0])
-            self.norm_limbs(v[1])
+        if not ADD_INJECT:
+            self._fq2_mul(y2, Z, th)
+            self._lw("v_sub_u32_e32", th, Y, th)                           # theta = Y - y2 Z
+            self._fq2_mul(x2, Z, mu)
+            self._lw("v_sub_u32_e32", mu, X, mu)                           # mu = X - x2 Z
+            for v in (th, mu):
+                self.norm_limbs(v[0])
+                self.norm_limbs(v[1])
+        else:
+            # Round 4: theta = Y - y2 Z, mu = X - x2 Z straight out of the product passes: the products of the NEGATED affine
+            # coordinate with Z, the projective coordinate injected into the upper half of the sum (fips inject) -- the results
+            # are pass outputs, i.e. normalised: no limb-wise subtraction and no carry pass (-150 instructions per step)
+            n0 = [self.pool.alloc() for _ in range(NL)]
+            n1 = [self.pool.alloc() for _ in range(NL)]
+            for q, dst, W in ((y2, th, Y), (x2, mu, X)):
+                self._neg_into(n0, q[0])
+                self._neg_into(n1, q[1])
+                self.fips([(n1, Z[0]), (n0, Z[1])], dst[1], inject=[(W[1], 1)])      # W1 - (q1 Z0 + q0 Z1)
+                self.fips([(n0, Z[0]), (q[1], Z[1])], dst[0], inject=[(W[0], 1)])    # W0 - (q0 Z0 - q1 Z1)
+            self.pool.free(*n0)
+            self.pool.free(*n1)
         nPy = [self.pool.alloc() for _ in range(NL)]
         self._neg_into(nPy, Py)
         self._fq2_mulfq(mu, nPy, L2)                                    # L2 = -mu Py
@@ -849,6 +986,17 @@ class L1v4:
                 self.e.emit(f"v_lshl_or_b32 v{dst}, v{w[i + 2]}, {sh2}, v{dst}", vw=[dst])
         self.pool.free(msk, t, *w)
         self.pool.free(*d)
+
+
+def routine_body(e, name):
+    """Emits leaf routine `name` the way a stand-alone test has to run it: with the caller-side preparation the kernels do outside
+    the routine (mul3: the kept y-side difference vectors, formed by Prog.mul3 when a line operand changes)."""
+    g = L1v4(e)
+    if name == "mul3" and MUL3_KEEP_DY:
+        for w in ("B", 1, 3):
+            g.mul3_dy(w)
+    getattr(g, "r_" + name)()
+    return g
 
 
 L1V4_NAMES = ["mul", "mul3", "mul6", "dblstep", "addstep", "sqr", "sqr4c", "sqr4cx", "mulfq", "add", "sub", "rsub", "dbl", "neg", "negc1", "mulxi", "mulxir", "norm",

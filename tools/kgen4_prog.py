@@ -27,7 +27,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from asmcore import Emitter, P_INT, BN_X, SIX_U_PLUS_2_NAF, max_branch_distance, place_with_islands  # noqa: E402
-from kgen4 import (A0, B0, HOME0, L1V4_NAMES, L1v4, LB, N0P, N_AGPR_SLOTS, N_HOME, N_LDS_SLOTS, NL, P_L, REDN_C, S_M30, S_N0, S_P, S_REDN,  # noqa: E402
+from kgen4 import (A0, B0, HOME0, L1V4_NAMES, L1v4, LB, MUL3_KEEP_DY, N0P, N_AGPR_SLOTS, N_HOME, N_LDS_SLOTS, NL, P_L, REDN_C, S_M30, S_N0, S_P, S_REDN,  # noqa: E402
                    S_RET1, S_RET2, S_RET3, SLOT_DW, SLOT_BYTES, V_FLAG, V_GOFF, V_GOFF8, V_IDX, V_IDX8, V_LDS, V_LTAIL, V_TID, bal_limbs, hx, mont4)
 
 # ---- scalar registers used by L2/L3 (all inside the clobbered range s36..s99) ----------------
@@ -184,6 +184,12 @@ _marker_n = [0]
 # of a workgroup are contiguous (kernel argument %7 is then the workgroup pitch, the slot pitch a constant).
 SCRATCH_WG = os.environ.get("KGEN_SCRATCH", "wg") == "wg"
 WG_SLOT_PITCH = BLOCK_LANES_SLOT = 256 * SLOT_BYTES            # bytes of one slot of one workgroup (4 waves x 4608 B)
+# DIAGNOSTIC builds only (tools/exp/build_variant.sh stamp KGEN_CLOCK_STAMP=1; never the shipped header): every wave stamps s_memtime (shader
+# cycles) and s_memrealtime (100 MHz) once in front of and once behind its item loop and leaves the two differences at the end of
+# its workgroup's scratch block (the slack behind the last slot: the pitch is rounded up to 2 MiB), where no kernel code reads:
+# the in-kernel clock = d(memtime) / d(memrealtime) x 100 MHz (MI355X guide, 'DVFS give-back' item 6).
+CLOCK_STAMP = bool(int(os.environ.get("KGEN_CLOCK_STAMP", "0")))
+STAMP_OFFSET_FROM_END = 4096
 ALIGN_CODE = bool(int(os.environ.get("KGEN_ALIGN", "1")))     # keep 8-byte instructions 8-byte aligned (asmcore.align_code)
 
 # ---- static bound tracking -------------------------------------------------------------------------------------------
@@ -598,6 +604,7 @@ class Prog:
         self.tagH = [None] * 4
         self.eH = [None] * 4
         self.vH = [V_STORE] * 4
+        self._dy_for = {"B": None, 1: None, 3: None}       # which operand the kept y-side differences of mul3 were formed from
         self._blocks_reserved = True
 
     def release_blocks(self):
@@ -628,6 +635,14 @@ class Prog:
         self._need(max(mag(rA), mag(self.r_of(y)), *(mag(h) for h in self.eH)) <= 3.9, "mul3 operand limbs")
         assert getattr(self, "_scratch_reserved", ()) == self.MUL3_SCRATCH, "mul3 needs home blocks 6, 7, 8 as scratch"
         self.vA = 2 * (self.vA * self.v_of(y) + self.vH[0] * self.vH[1] + self.vH[2] * self.vH[3]) / K_RP + 0.5
+        if MUL3_KEEP_DY:               # the y-side difference vectors live in the routine's scratch across passes: (re)formed when an operand changed
+            for w, tag in (("B", self.tagB), (1, self.tagH[1]), (3, self.tagH[3])):
+                assert tag is not None
+                if self._dy_for[w] is not tag:
+                    self.wait()
+                    L1v4(self.e).mul3_dy(w)
+                    self._dy_for[w] = tag
+                    self._count("mul3_dy")
         self._raw_call("mul3")
         self.rA = self.r_norm()
         return self                                  # (all five other operands survive)
@@ -1276,7 +1291,12 @@ class Prog:
         xb, xh, n = 10 * bq, 10 * hh, 9 * c
         t_ = xb + 3 * n
         self._need(max(xb, xh, t_) <= V_CAP, f"dblstep operand values {xb} {xh} {t_}")
-        self._need(max(4 * ml(xb, xh), 20 * ml(ml(v, v), t_), sq(t_) + 12 * sq(n)) <= 8 * V_CAP, "dblstep: values in front of the reducing chains")
+        # Y3 = S S + N (-12 N): two two-product passes on normalised S, N, M = -12 N (sums / differences of two components: two
+        # units each): 9 (2 2 + 2 2) = 72 units per column; the value in front of its reducing chain
+        m_s, m_n, m_m = max(1.0, t_ / K_TOP), max(1.0, n / K_TOP), max(1.0, 12 * n / K_TOP)       # limb magnitudes (the top limb carries the value)
+        self._need(12 * n <= 2 * V_CAP and NL * (2 * m_s * 2 * m_s + 2 * m_n * 2 * m_m) <= COL_BUDGET, f"dblstep: Y3 passes, S {t_} p, M = -12 N of {12 * n} p")
+        y3 = (4 * t_ * t_ + 48 * n * n) / K_RP + 0.5
+        self._need(max(4 * ml(xb, xh), 20 * ml(ml(v, v), t_), y3, sq(t_) + 12 * sq(n)) <= 8 * V_CAP, "dblstep: values in front of the reducing chains")
         self._step_out_r((0, 1, 2), R, (0.51, 0.51, 0.51), alt_r)
         self._step_out(7, line[0], xb + n, limbs=2.0)
         self._step_out(4, line[1], hh * vp / K_RP + 0.5)
@@ -2095,6 +2115,8 @@ class KernelBuilder:
             p.to(self.F[k])
 
     FQINV_WINDOW = 3
+    FQINV_WIDE_M = bool(int(os.environ.get("KGEN_FQINV_WIDE_M", "1")))
+    FQINV_OUT_V = 4.2 if FQINV_WIDE_M else 0.51       # value bound (units of p) of the inverse the Fermat chain leaves in block A
 
     @staticmethod
     def fqinv_schedule(w):
@@ -2143,16 +2165,20 @@ class KernelBuilder:
             g.pool.free_regs = [r for r in g.pool.free_regs if r < 58]
             return g
 
+        # (round 4: every product of the chain with 32-bit Montgomery digits, L1v4.fips wide_m: one normalised value times another
+        # is 9 units per column, 18 for the doubled operand of a squaring, and a result of v^2 / 169.6 + 4 p stays at 4.1 p from
+        # step to step -- nine instructions less per product, 313 products)
+        W = self.FQINV_WIDE_M
         p.wait()
         p.tagA = p.tagB = None
         for i in range(NL):
             e.emit(f"v_accvgpr_write_b32 a{a9 + i}, v{RA[i]}")                       # a
-        l1().fips_sq(RA, X2)                                                        # a^2
-        l1().fips([(RA, X2)], RB)                                                   # a^3
+        l1().fips_sq(RA, X2, wide_m=W)                                              # a^2
+        l1().fips([(RA, X2)], RB, wide_m=W)                                         # a^3
         for i in range(NL):
             e.emit(f"v_accvgpr_write_b32 a{a9 + NL + i}, v{RB[i]}")
-        l1().fips([(RB, X2)], T5)                                                   # a^5
-        l1().fips([(T5, X2)], T7)                                                   # a^7
+        l1().fips([(RB, X2)], T5, wide_m=W)                                         # a^5
+        l1().fips([(T5, X2)], T7, wide_m=W)                                         # a^7
         src = {1: None, 3: RB, 5: T5, 7: T7}[first]                                # the top window
         if src is not None:
             for i in range(NL):
@@ -2167,7 +2193,7 @@ class KernelBuilder:
         e.salu(f"s_branch {L(f'L_fqinv_done_{uid}')}")
         # subroutine: S_TMP0 + 1 squarings of RA
         e.label(sq_l)
-        l1().fips_sq(RA, RA)
+        l1().fips_sq(RA, RA, wide_m=W)
         e.salu(f"s_sub_u32 s{S_TMP0}, s{S_TMP0}, 1")
         e.salu(f"s_cbranch_scc0 {sq_l}")
         e.salu(f"s_setpc_b64 {S_RET1}")
@@ -2178,12 +2204,12 @@ class KernelBuilder:
                 off = a9 + (NL if v == 3 else 0)
                 for i in range(NL):
                     e.emit(f"v_accvgpr_read_b32 v{RB[i]}, a{off + i}", vw=[RB[i]])
-                l1().fips([(RA, RB)], RA)
+                l1().fips([(RA, RB)], RA, wide_m=W)
             else:
-                l1().fips([(RA, T5 if v == 5 else T7)], RA)
+                l1().fips([(RA, T5 if v == 5 else T7)], RA, wide_m=W)
             e.salu(f"s_setpc_b64 {S_RET1}")
         e.label(L(f"L_fqinv_done_{uid}"))
-        p.set_A_fresh()
+        p.set_A_fresh(self.FQINV_OUT_V)
 
     def _fq2_inv_inline(self, p, src, dst):
         """dst <- 1/src (Fq2): conj(src) / (c0^2 + c1^2); sets the zero-divisor flag when the norm is 0."""
@@ -2218,7 +2244,7 @@ class KernelBuilder:
         e.salu(f"s_mov_b64 {S_RET3}, {S_RET2}")
         e.salu(f"s_call_b64 {S_RET2}, {self.lab('L2_fqinv')}")
         e.salu(f"s_mov_b64 {S_RET2}, {S_RET3}")
-        p.set_A_fresh()
+        p.set_A_fresh(self.FQINV_OUT_V)
         p.tagB = None
         p.to(tmp)
         p.A(src).mulfq(tmp).conj().to(dst)
@@ -2292,6 +2318,11 @@ class KernelBuilder:
     def main_body(self, e):
         L = self.lab
         e.label(L("L_main"))
+        if CLOCK_STAMP:
+            assert SCRATCH_WG
+            e.salu("s_memtime s[72:73]")
+            e.salu("s_memrealtime s[74:75]")
+            e.raw("s_waitcnt lgkmcnt(0)")
         e.label(L("L_item"))
         e.salu(f"s_cmp_ge_u32 s{S_ITEM}, s{S_NITEMS}")
         e.salu(f"s_cbranch_scc1 {L('L_done')}")
@@ -2335,6 +2366,22 @@ class KernelBuilder:
         e.salu(f"s_add_u32 s{S_ITEM}, s{S_ITEM}, s{S_GRID}")
         e.salu(f"s_branch {L('L_item')}")
         e.label(L("L_done"))
+        if CLOCK_STAMP:
+            e.salu("s_memtime s[60:61]")
+            e.salu("s_memrealtime s[88:89]")
+            e.raw("s_waitcnt lgkmcnt(0)")
+            e.salu("s_sub_u32 s60, s60, s72")
+            e.salu("s_subb_u32 s61, s61, s73")
+            e.salu("s_sub_u32 s88, s88, s74")
+            e.salu("s_subb_u32 s89, s89, s75")
+            for i, sr in enumerate((60, 61, 88, 89)):
+                e.emit(f"v_mov_b32_e32 v{36 + i}, s{sr}", vw=[36 + i])
+            e.salu(f"s_sub_u32 s50, %7, {STAMP_OFFSET_FROM_END}")
+            e.emit(f"v_lshrrev_b32_e32 v40, 10, v{V_LDS}", vw=[40])          # wave number (V_LDS = tid * 16)
+            e.emit("v_lshlrev_b32_e32 v40, 4, v40", vw=[40])
+            e.emit("v_add_u32_e32 v40, s50, v40", vw=[40])
+            e.emit(f"global_store_dwordx4 v40, v[36:39], {S_SCRATCH}", kind="vmem")
+            e.raw("s_waitcnt vmcnt(0)")
 
     def load_fq12_into_F(self, e, p, ptr):
         """F <- the lane's MyFq12 of the SoA batch at `ptr` (components 0..5 are the c0 parts of w^0..w^5, 6..11 the c1
