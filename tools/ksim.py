@@ -420,6 +420,13 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None):
                 r = m.vsrc(a[1], False) - m.vsrc(a[2], False)
                 m.sset(a[0], r)
                 m.scc = 1 if r < 0 else 0
+            elif op in ("s_add_i32", "s_sub_i32"):                       # SCC = signed overflow
+                x, y = m.vsrc(a[1], False) & M32, m.vsrc(a[2], False) & M32
+                x = x - (1 << 32) if x >> 31 else x
+                y = y - (1 << 32) if y >> 31 else y
+                r = x + y if op == "s_add_i32" else x - y
+                m.sset(a[0], r & M32)
+                m.scc = 0 if -(1 << 31) <= r < (1 << 31) else 1
             elif op == "s_mul_i32":
                 m.sset(a[0], m.vsrc(a[1], False) * m.vsrc(a[2], False))
             elif op == "s_lshl_b32":
@@ -448,11 +455,11 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None):
             elif op == "s_sext_i32_i8":
                 x = m.vsrc(a[1], False) & 0xFF
                 m.sset(a[0], (x - 256 if x & 0x80 else x) & M32)
-            elif op in ("s_cmp_eq_i32", "s_cmp_gt_i32"):
-                x, y = m.vsrc(a[0], False), m.vsrc(a[1], False)
+            elif op in ("s_cmp_eq_i32", "s_cmp_gt_i32", "s_cmp_lt_i32"):
+                x, y = m.vsrc(a[0], False) & M32, m.vsrc(a[1], False) & M32
                 x = x - (1 << 32) if x >> 31 else x
                 y = y - (1 << 32) if y >> 31 else y
-                m.scc = 1 if (x == y if op == "s_cmp_eq_i32" else x > y) else 0
+                m.scc = 1 if (x == y if op == "s_cmp_eq_i32" else (x > y if op == "s_cmp_gt_i32" else x < y)) else 0
             elif op == "s_cmp_eq_u32":
                 m.scc = 1 if m.vsrc(a[0], False) == m.vsrc(a[1], False) else 0
             elif op == "s_cmp_lg_u32":
