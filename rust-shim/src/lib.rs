@@ -17,6 +17,7 @@ extern "C" {
                                  device: c_int, stream: *mut c_void) -> c_int;
     fn bn254_multi_pairing_check_batch(g1: *const u64, g2: *const u64, verdict: *mut u8, n_groups: usize, k: usize, device: c_int,
                                        stream: *mut c_void) -> c_int;
+    fn bn254_reserve(device: c_int, stream: *mut c_void, n: usize, k: usize) -> c_int;
     fn bn254_pairing_sharded(g1: *const u64, g2: *const u64, out: *mut u64, n: usize, n_devices: c_int) -> c_int;
     // device pointers on devices[0] (NULL: devices 0..n_devices-1); shard i runs on devices[i]; synchronous
     #[allow(dead_code)]
@@ -125,6 +126,10 @@ fn fq12_from_ark_words(w: &[u64]) -> Fq12 {
     Fq12::new(ark_bn254::Fq6::new(f2(0), f2(1), f2(2)), ark_bn254::Fq6::new(f2(3), f2(4), f2(5)))
 }
 /// New: whole batches in one launch (what the engine is for).  Output: MyFq12 per pairing.
+/// Sizes the library's per-(device, stream) buffers for calls of up to `n` lanes x `k` pairs on device 0 / the NULL stream
+/// (the ones every function of this shim uses): no later call of that size allocates device memory.
+pub fn reserve(n: usize, k: usize) { ok(unsafe { bn254_reserve(0, core::ptr::null_mut(), n, k) }) }
+
 pub fn pairing_batch(ps: &[G1Affine], qs: &[G2Affine]) -> Vec<MyFq12> {
     assert_eq!(ps.len(), qs.len()); let n = ps.len();
     let (g1, g2) = (elems_g1(ps), elems_g2(qs)); let mut out = vec![0u64; 48 * n];

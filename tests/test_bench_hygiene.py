@@ -35,8 +35,8 @@ def test_pmc_summary_is_dropped_when_it_does_not_describe_the_run(tmp_path, monk
 
 
 def test_committed_pmc_summaries_are_consistent():
-    """the two committed summaries carry the corrected fields; the Groth16 one counts 4 pairs in and one Fq12 out per unit"""
-    for name, k, log2 in (("r03_pmc.json", 1, 20), ("r03_groth16_pmc.json", 4, 18)):
+    """the committed summaries carry the corrected fields; the Groth16 one counts 4 pairs in and one Fq12 out per unit"""
+    for name, k, log2 in (("r03_pmc.json", 1, 20), ("r03_groth16_pmc.json", 4, 18), ("r04_pmc.json", 1, 20), ("r04_groth16_pmc.json", 4, 18)):
         with open(os.path.join(ROOT, "profiles", name)) as f:
             n = json.load(f)["_notes"]
         assert n["pairs_per_unit"] == k and n["log2_batch"] == log2
@@ -44,3 +44,12 @@ def test_committed_pmc_summaries_are_consistent():
         assert "valu_wave_insts_per_work_item" in n and "cycles_per_valu_instruction_active" not in n
         assert 0.5 < n["valu_issue_utilisation_at_measured_clock"] < 1.0 and 1.5 < n["shader_clock_ghz_measured"] < 2.5
         assert len(n["kernel_header_sha16"]) == 16
+
+
+def test_bench_reads_the_summaries_of_the_shipped_kernels():
+    """bench.py's default PMC summaries (k_pairing and the Groth16 shape) were collected on the kernel code that is in the tree:
+    their digest is the digest of the committed pairing_asm_gen.h -- otherwise `traffic` / `valu_issue` would be dropped on every run."""
+    bench = importlib.import_module("bench")
+    for path in (bench.PMC_SUMMARY, bench.PMC_SUMMARY_GROTH16):
+        with open(path) as f:
+            assert json.load(f)["_notes"]["kernel_header_sha16"] == bench.kernel_header_sha16(), os.path.basename(path)
