@@ -649,6 +649,22 @@ int bn254_debug_stamps(int device, void* stream, uint64_t* out, size_t max_wg) {
         HIPCHK(hipMemcpy(out + g * 8, (const char*)sc->scratch.p + (g + 1) * sc->last_pitch - BN254_STAMP_OFFSET_FROM_END, 64, hipMemcpyDeviceToHost));
     return (int)n;
 }
+#ifdef BN254_PROFILE_IDS
+// per-routine cycle / call counters of a KGEN_PROFILE_L2 build: out = [wg][wave][3][64] dwords (cycles lo, cycles hi, calls; lane = routine id)
+int bn254_debug_profile(int device, void* stream, uint32_t* out, size_t max_wg) {
+    int rc = check_device(device);
+    if (rc) return rc;
+    std::shared_ptr<StreamCtx> sc = stream_ctx(device, stream);
+    std::lock_guard<std::recursive_mutex> lk(sc->mu);
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    if (!sc->scratch.p || !sc->last_grid) return BN254_ERR_INVALID_ARG;
+    size_t n = sc->last_grid < max_wg ? sc->last_grid : max_wg;
+    for (size_t g = 0; g < n; g++)
+        HIPCHK(hipMemcpy(out + g * 768, (const char*)sc->scratch.p + (g + 1) * sc->last_pitch - BN254_PROFILE_OFFSET_FROM_END, 3072, hipMemcpyDeviceToHost));
+    return (int)n;
+}
+const char* bn254_debug_profile_ids(void) { return BN254_PROFILE_IDS; }
+#endif
 #endif
 
 int bn254_reserve(int device, void* stream, size_t n, size_t k) {

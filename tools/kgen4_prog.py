@@ -172,6 +172,10 @@ EXP_NO_SCRATCH = bool(int(os.environ.get("KGEN_EXP_NO_SCRATCH", "0")))      # TI
 # copies are formed straight in the operand blocks) instead of through three AGPR slots and two temporaries: -180 moves per sparse
 # multiplication, no LDS temporary left in it, and the freed slots take the result temporaries.
 LINE_IN_REGS = bool(int(os.environ.get("KGEN_LINE_REGS", "1")))
+# Round 4: the Fq12 inversion of the easy part keeps its temporaries out of home blocks 0..7, so that its four Fq6 multiplications run on the
+# fused L1 routine (mul6) instead of six generic Fq2 multiplications plus glue each
+INV_FUSED = bool(int(os.environ.get("KGEN_INV_FUSED", "1")))
+EXP_FISSION = bool(int(os.environ.get("KGEN_EXP_FISSION", "0")))            # TIMING ONLY: Miller loop as a point-step loop + an f loop (k_pairing / k_miller)
 EXP_NO_SWAIT = bool(int(os.environ.get("KGEN_EXP_NO_SWAIT", "0")))          # no s_waitcnt at the start of a streamed step
 # The next pair's prefetch is issued slot by slot behind the first four passes of the current pair's sparse multiplication instead
 # of as one burst of 25 loads in front of the step: +1.9 % on the Groth16 shape (the four waves of a CU run in step: a burst is
@@ -189,6 +193,21 @@ WG_SLOT_PITCH = BLOCK_LANES_SLOT = 256 * SLOT_BYTES            # bytes of one sl
 # its workgroup's scratch block (the slack behind the last slot: the pitch is rounded up to 2 MiB), where no kernel code reads:
 # the in-kernel clock = d(memtime) / d(memrealtime) x 100 MHz (MI355X guide, 'DVFS give-back' item 6).
 CLOCK_STAMP = bool(int(os.environ.get("KGEN_CLOCK_STAMP", "0")))
+# DIAGNOSTIC builds only (KGEN_PROFILE_L2=1, with KGEN_CLOCK_STAMP=1): every call of an L2 routine from the main program / the x-power
+# control code is bracketed by s_memtime stamps; the wave accumulates, per routine, the shader cycles (inclusive) and the number of
+# calls in lanes of three otherwise unused VGPRs (v248..v250, lane = routine id) and leaves them next to the clock stamps.  With the
+# simulator's per-routine instruction counts (tools/l2_profile.py) this gives cycles per instruction for every routine.
+PROFILE_L2 = bool(int(os.environ.get("KGEN_PROFILE_L2", "0")))
+PROFILE_IDS = {}
+PROFILE_OFFSET_FROM_END = 16384           # [wave][3][64] dwords in front of the clock stamps
+
+
+def profile_id(name):
+    name = name.replace("_%=", "")
+    if name not in PROFILE_IDS:
+        PROFILE_IDS[name] = len(PROFILE_IDS)
+        assert len(PROFILE_IDS) <= 64
+    return PROFILE_IDS[name]
 STAMP_OFFSET_FROM_END = 4096
 # multi-pairing kernels: the first doubling step and the two Frobenius addition steps of every pair run on the resident-slot routines
 # L2_dblmul / L2_addmul -- 3 k - 1 step + sparse-multiplication pairs per group.  As COLD routines (generic point steps, L1 calls)
@@ -1664,6 +1683,18 @@ class KernelBuilder:
 
             self.l2_routine("L2_addmul", lambda p: addmul(p, True), self.miller_temps(extra=line_tmp("L2_addmul")), local=self.LINE)
             self.l2_routine("L2_addmul_last", lambda p: addmul(p, False), self.miller_temps(), local=self.LINE)
+            if EXP_FISSION:
+                # TIMING ONLY (results are wrong: the lines do not travel): the point steps and the f-side work of the main loop as
+                # separate routines, run in two loops -- what would the Miller loop cost if each loop's code fitted the instruction cache?
+                def fake_line(p):
+                    for s_, lim in zip(Prog.LINE_REGS, (2.0, 1.0, 1.0)):
+                        p.slot_r[p.key(s_)], p.slot_v[p.key(s_)] = (-lim, lim), 1.0
+                    return Prog.LINE_REGS
+                tm = self.miller_temps(extra=(*self.LINE, self.SX, self.SY))
+                self.l2_routine("L2_dblonly", lambda p: p.dbl_step(self.R, (self.PX, self.PY), self.LINE, scale=None), tm, local=self.LINE)
+                self.l2_routine("L2_addonly", lambda p: p.add_step(self.R, (self.SX, self.SY), (self.PX, self.PY), self.LINE, scale=None), self.miller_temps(extra=self.LINE), local=self.LINE)
+                self.l2_routine("L2_sp034", lambda p: p.mul_by_034(self.F, *fake_line(p)), tm, local=self.LINE)
+                self.l2_routine("L2_sp235", lambda p: p.mul_by_235(self.F, *fake_line(p)), tm, local=self.LINE)
             if self.multi:
                 self._stream_routines(sc)
             if self.track:
@@ -1684,7 +1715,7 @@ class KernelBuilder:
             self._mulG_routines()
             for k in (1, 2, 3):
                 self.l2_routine(f"L2_frob{k}", lambda p, k=k: self._frobenius(p, k), self.fexp_temps())
-            self.l2_routine("L2_inv", self._fq12_inv, self.fexp_temps(lds=True))
+            self.l2_routine("L2_inv", self._fq12_inv, self.fexp_temps(no_homes=INV_FUSED, lds=True))
             self.l2_routine("L2_cpB", lambda p: [p.A(self.F[i]).to(self.BOP[i]) for i in range(6)], self.fexp_temps())
             self.l2_routine("L2_stL", lambda p: [p.A(self.F[i]).to(self.LREG[i]) for i in range(6)], self.fexp_temps())
             self.l2_routine("L2_ldL", lambda p: [p.A(self.LREG[i]).to(self.F[i]) for i in range(6)], self.fexp_temps())
@@ -1891,26 +1922,26 @@ class KernelBuilder:
         name = {"st": "L2_stG", "ld": "L2_ldG", "mul": "L2_mulG", "mulc": "L2_mulGc", "pf": "L2_pfB", "mul_w": "L2_mulG_w", "mulc_w": "L2_mulGc_w"}
         e.label(L("L3_powx"))
         e.salu(f"s_mov_b32 s{S_PB}, s{S_GBASE}")
-        e.salu(f"s_call_b64 {S_RET2}, {L('L2_stG')}")
+        self.emit_call2(e, L('L2_stG'))
         e.salu(f"s_branch {L('L3_powx_go')}")
         e.label(L("L3_powx_ns"))
         e.salu(f"s_mov_b32 s{S_PB}, s{S_GBASE}")
         e.label(L("L3_powx_go"))
         for op, arg in self.powx_ops(store_base=False):
             if op == "call":
-                e.salu(f"s_call_b64 {S_RET2}, {L(arg)}")
+                self.emit_call2(e, L(arg))
                 continue
             if op == "cyc":                                         # a run of `arg` squarings
                 if arg > 1:
                     e.salu(f"s_mov_b32 s{S_J}, {arg - 1}")
-                e.salu(f"s_call_b64 {S_RET2}, {L('L2_cycN' if arg > 1 else 'L2_cyc')}")
+                self.emit_call2(e, L('L2_cycN' if arg > 1 else 'L2_cyc'))
                 continue
             if op not in ("mul_w", "mulc_w"):                       # (the waiting entries find the operand fetched by "pf")
                 if arg == "base":
                     e.salu(f"s_mov_b32 s{S_GBASE}, s{S_PB}")
                 else:
                     e.salu(f"s_mul_i32 s{S_GBASE}, s{S_GSTRIDE}, {6 * arg}")
-            e.salu(f"s_call_b64 {S_RET2}, {L(name[op])}")
+            self.emit_call2(e, L(name[op]))
         e.salu(f"s_setpc_b64 {S_RET3}")
         self.control_sections.append(e)           # control code: placed next to the main program (it calls L2 routines of both halves)
 
@@ -2095,7 +2126,34 @@ class KernelBuilder:
         e.salu(f"s_mul_i32 s{S_GBASE}, s{S_GSTRIDE}, {6 * j}")
 
     def call2(self, e, name):
-        e.salu(f"s_call_b64 {S_RET2}, {self.lab(name)}")
+        self.emit_call2(e, self.lab(name))
+
+    def emit_call2(self, e, label):
+        """s_call_b64 S_RET2, label -- in profiling builds bracketed by cycle stamps that are accumulated per routine"""
+        if not PROFILE_L2 or self.multi:
+            e.salu(f"s_call_b64 {S_RET2}, {label}")
+            return
+        rid = profile_id(label)
+        e.salu("s_memtime s[72:73]")
+        e.raw("s_waitcnt lgkmcnt(0)")
+        e.salu(f"s_call_b64 {S_RET2}, {label}")
+        e.salu("s_memtime s[60:61]")
+        e.raw("s_waitcnt lgkmcnt(0)")
+        e.salu("s_sub_u32 s60, s60, s72")
+        e.salu("s_subb_u32 s61, s61, s73")
+        e.raw(f"v_readlane_b32 s74, v248, {rid}")
+        e.raw(f"v_readlane_b32 s75, v249, {rid}")
+        e.raw("s_nop 3")
+        e.salu("s_add_u32 s74, s74, s60")
+        e.salu("s_addc_u32 s75, s75, s61")
+        e.raw("s_nop 3")
+        e.raw(f"v_writelane_b32 v248, s74, {rid}")
+        e.raw(f"v_writelane_b32 v249, s75, {rid}")
+        e.raw(f"v_readlane_b32 s74, v250, {rid}")
+        e.raw("s_nop 3")
+        e.salu("s_add_u32 s74, s74, 1")
+        e.raw("s_nop 3")
+        e.raw(f"v_writelane_b32 v250, s74, {rid}")
 
     def io_load_fq2_into_A(self, e, p, c1_present=True):
         """Loads c0 (and c1) of the SoA batch at the walking address, converts to internal form -> block A."""
@@ -2333,10 +2391,14 @@ class KernelBuilder:
     def main_body(self, e):
         L = self.lab
         e.label(L("L_main"))
+        if PROFILE_L2:
+            assert CLOCK_STAMP
+            for r in (248, 249, 250):
+                e.emit(f"v_mov_b32_e32 v{r}, 0")
         if CLOCK_STAMP:
             assert SCRATCH_WG
-            e.salu("s_memtime s[72:73]")
-            e.salu("s_memrealtime s[74:75]")
+            e.salu("s_memtime s[50:51]")                               # (s50..s53: free in every kernel; the k-pair kernels use s72..s74)
+            e.salu("s_memrealtime s[52:53]")
             e.raw("s_waitcnt lgkmcnt(0)")
         e.label(L("L_item"))
         e.salu(f"s_cmp_ge_u32 s{S_ITEM}, s{S_NITEMS}")
@@ -2385,17 +2447,27 @@ class KernelBuilder:
             e.salu("s_memtime s[60:61]")
             e.salu("s_memrealtime s[88:89]")
             e.raw("s_waitcnt lgkmcnt(0)")
-            e.salu("s_sub_u32 s60, s60, s72")
-            e.salu("s_subb_u32 s61, s61, s73")
-            e.salu("s_sub_u32 s88, s88, s74")
-            e.salu("s_subb_u32 s89, s89, s75")
+            e.salu("s_sub_u32 s60, s60, s50")
+            e.salu("s_subb_u32 s61, s61, s51")
+            e.salu("s_sub_u32 s88, s88, s52")
+            e.salu("s_subb_u32 s89, s89, s53")
             for i, sr in enumerate((60, 61, 88, 89)):
                 e.emit(f"v_mov_b32_e32 v{36 + i}, s{sr}", vw=[36 + i])
-            e.salu(f"s_sub_u32 s50, %7, {STAMP_OFFSET_FROM_END}")
+            e.salu(f"s_sub_u32 s72, %7, {STAMP_OFFSET_FROM_END}")
             e.emit(f"v_lshrrev_b32_e32 v40, 10, v{V_LDS}", vw=[40])          # wave number (V_LDS = tid * 16)
             e.emit("v_lshlrev_b32_e32 v40, 4, v40", vw=[40])
-            e.emit("v_add_u32_e32 v40, s50, v40", vw=[40])
+            e.emit("v_add_u32_e32 v40, s72, v40", vw=[40])
             e.emit(f"global_store_dwordx4 v40, v[36:39], {S_SCRATCH}", kind="vmem")
+            if PROFILE_L2:      # [wave][counter][lane]: wave * 768 + counter * 256 + lane * 4
+                e.salu(f"s_sub_u32 s72, %7, {PROFILE_OFFSET_FROM_END}")
+                e.emit(f"v_lshrrev_b32_e32 v40, 10, v{V_LDS}", vw=[40])
+                e.emit("v_mul_u32_u24_e32 v40, 768, v40", vw=[40])
+                e.emit(f"v_lshrrev_b32_e32 v41, 4, v{V_LDS}", vw=[41])
+                e.emit("v_and_b32_e32 v41, 63, v41", vw=[41])
+                e.emit("v_lshl_add_u32 v40, v41, 2, v40", vw=[40])
+                e.emit("v_add_u32_e32 v40, s72, v40", vw=[40])
+                for i, r in enumerate((248, 249, 250)):
+                    e.emit(f"global_store_dword v40, v{r}, {S_SCRATCH} offset:{256 * i}", kind="vmem")
             e.raw("s_waitcnt vmcnt(0)")
 
     def load_fq12_into_F(self, e, p, ptr):
@@ -2511,10 +2583,11 @@ class KernelBuilder:
         p.mov(self.SX, self.QX)
         p.A(self.QY)
         p.wait()
+        u = self.uid()
         e.salu(f"s_bitcmp1_b64 {S_NAF_NEG}, s{S_I}")
-        e.salu(f"s_cbranch_scc0 {L('L_mpos')}")
+        e.salu(f"s_cbranch_scc0 {L(f'L_mpos_{u}')}")
         e.salu(f"s_call_b64 {S_RET1}, {self.labels['neg']}")
-        e.label(L("L_mpos"))
+        e.label(L(f"L_mpos_{u}"))
         p.tagA = None
         p.to(self.SY)
 
@@ -2539,6 +2612,29 @@ class KernelBuilder:
             p.to(self.SCALE)
         p.reset_tags()
         self.call2(e, "L2_dblfirst")
+        if EXP_FISSION:
+            for phase in (0, 1):
+                e.salu(f"s_mov_b32 s{S_I}, 63")
+                e.label(L(f"L_fi{phase}_loop"))
+                e.salu(f"s_cmp_eq_u32 s{S_I}, 63")
+                e.salu(f"s_cbranch_scc1 {L(f'L_fi{phase}_skip')}")
+                if phase == 0:
+                    self.call2(e, "L2_dblonly")
+                else:
+                    self.call2(e, "L2_sqr")
+                    self.call2(e, "L2_sp034")
+                e.label(L(f"L_fi{phase}_skip"))
+                e.salu(f"s_bitcmp1_b64 {S_NAF_NZ}, s{S_I}")
+                e.salu(f"s_cbranch_scc0 {L(f'L_fi{phase}_noadd')}")
+                if phase == 0:
+                    self._select_pm_q(e, p)
+                    self.call2(e, "L2_addonly")
+                else:
+                    self.call2(e, "L2_sp235")
+                e.label(L(f"L_fi{phase}_noadd"))
+                e.salu(f"s_sub_u32 s{S_I}, s{S_I}, 1")
+                e.salu(f"s_cbranch_scc0 {L(f'L_fi{phase}_loop')}")
+            e.salu(f"s_branch {L('L_mend')}")
         e.salu(f"s_mov_b32 s{S_I}, 63")
         e.label(L("L_mloop"))
         e.salu(f"s_cmp_eq_u32 s{S_I}, 63")
@@ -2555,6 +2651,7 @@ class KernelBuilder:
         e.label(L("L_mnoadd"))
         e.salu(f"s_sub_u32 s{S_I}, s{S_I}, 1")
         e.salu(f"s_cbranch_scc0 {L('L_mloop')}")
+        e.label(L("L_mend"))
         self._frobenius_points(p)
         self.call2(e, "L2_addmul")
         p.reset_tags()
@@ -2680,6 +2777,37 @@ class KernelBuilder:
                 p.A(GlobDyn(k_)).to(dst)
             p.wait()
             p.reset_tags()
+        if EXP_FISSION:
+            # TIMING ONLY (wrong results): per pair the whole chain of point steps on resident slots, then the f loop with k sparse
+            # multiplications per step and no pair state at all -- the ceiling of "lines through memory instead of R through memory"
+            def chain():
+                e.salu(f"s_mov_b32 s{S_I}, 63")
+                e.label(L("L_fm0_loop"))
+                e.salu(f"s_cmp_eq_u32 s{S_I}, 63")
+                e.salu(f"s_cbranch_scc1 {L('L_fm0_skip')}")
+                self.call2(e, "L2_dblonly")
+                e.label(L("L_fm0_skip"))
+                e.salu(f"s_bitcmp1_b64 {S_NAF_NZ}, s{S_I}")
+                e.salu(f"s_cbranch_scc0 {L('L_fm0_noadd')}")
+                self.call2(e, "L2_addonly")
+                e.label(L("L_fm0_noadd"))
+                e.salu(f"s_sub_u32 s{S_I}, s{S_I}, 1")
+                e.salu(f"s_cbranch_scc0 {L('L_fm0_loop')}")
+            self.pair_loop(e, "fchain", chain)
+            e.salu(f"s_mov_b32 s{S_I}, 63")
+            e.label(L("L_fm1_loop"))
+            e.salu(f"s_cmp_eq_u32 s{S_I}, 63")
+            e.salu(f"s_cbranch_scc1 {L('L_fm1_skip')}")
+            self.call2(e, "L2_sqr")
+            self.pair_loop(e, "fsp034", lambda: self.call2(e, "L2_sp034"))
+            e.label(L("L_fm1_skip"))
+            e.salu(f"s_bitcmp1_b64 {S_NAF_NZ}, s{S_I}")
+            e.salu(f"s_cbranch_scc0 {L('L_fm1_noadd')}")
+            self.pair_loop(e, "fsp235", lambda: self.call2(e, "L2_sp235"))
+            e.label(L("L_fm1_noadd"))
+            e.salu(f"s_sub_u32 s{S_I}, s{S_I}, 1")
+            e.salu(f"s_cbranch_scc0 {L('L_fm1_loop')}")
+            e.salu(f"s_branch {L('L_mfission_end')}")
         e.salu(f"s_mul_i32 s{self.S_GNEXT}, s{S_GSTRIDE}, {self.PAIR_SLOT0}")      # prime the stream: pair 0
         if self.boustrophedon():
             e.salu(f"s_mov_b32 s{self.S_DIR}, 1")
@@ -2712,6 +2840,9 @@ class KernelBuilder:
         e.salu(f"s_sub_u32 s{S_I}, s{S_I}, 1")
         e.salu(f"s_cbranch_scc0 {L('L_mloop')}")
 
+        if EXP_FISSION:
+            e.label(L("L_mfission_end"))
+            e.salu(f"s_mov_b32 s{self.S_DIR}, 1")
         if self.boustrophedon():
             # the last pass ran upwards (S_DIR has been flipped to -1 behind it) <=> pair k - 1 closed it and its R sits in the
             # prefetch buffer: back to its scratch block for the end steps
