@@ -211,7 +211,11 @@ std::shared_ptr<StreamCtx> stream_ctx(int device, void* stream) {
 // Scratch layout (pairing_asm_gen.h: BN254_SCRATCH_WG_CONTIGUOUS).  Contiguous per workgroup: [workgroup][slot][wave][...], the
 // workgroup pitch rounded up to 2 MiB so that a CU's 80+ slots share one or two pages (the slot-major layout put every slot of
 // a workgroup on a different 2 MiB page: 4.7 MB apart at a full grid); the kernels take the pitch as their stride argument.
-size_t scratch_slots(size_t k) { return (size_t)BN254_GSLOTS + BN254_GSLOTS_PER_PAIR * (k > 1 ? k : 0); }
+// + the line area of the split Miller loop (one slot triple per point step and pair; groups of up to BN254_FIS_MAX_K pairs)
+size_t scratch_slots(size_t k) {
+    size_t lines = (k >= 1 && k <= (size_t)BN254_FIS_MAX_K) ? (size_t)BN254_FIS_LINE_SLOTS * k : 0;
+    return (size_t)BN254_GSLOTS + BN254_GSLOTS_PER_PAIR * (k > 1 ? k : 0) + lines;
+}
 size_t scratch_pitch(size_t k, size_t grid) {
     if (!BN254_SCRATCH_WG_CONTIGUOUS) return grid * BLOCK * SLOT_BYTES;                 // bytes between slots
     size_t wg = scratch_slots(k) * BLOCK * SLOT_BYTES, page = (size_t)2 << 20;
@@ -263,8 +267,9 @@ int ctx_get(int device, void* stream, size_t k, size_t n_items, LaunchCtx* out, 
     uint32_t grid = (uint32_t)(n_items < (size_t)c.n_cu ? n_items : (size_t)c.n_cu);
     if (grid == 0) grid = 1;
     size_t pitch = scratch_pitch(k, grid);
-    // the kernels form a workgroup's scratch base as blockIdx * pitch in 32 bits (s_mul_i32)
-    if (BN254_SCRATCH_WG_CONTIGUOUS && pitch * grid >= (1ull << 32)) return BN254_ERR_INVALID_ARG;
+    // the kernels take the pitch as a 32-bit argument (the workgroup's base blockIdx * pitch is formed in 64 bits) and address
+    // slots inside a block with 32-bit byte offsets
+    if (pitch >= (1ull << 32)) return BN254_ERR_INVALID_ARG;
     if ((rc = ensure(sc.get(), sc->scratch, BN254_SCRATCH_WG_CONTIGUOUS ? pitch * grid : pitch * scratch_slots(k)))) return rc;
     out->s = sc;
     out->n_cu = c.n_cu;
@@ -673,6 +678,16 @@ int bn254_reserve(int device, void* stream, size_t n, size_t k) {
     int rc = ctx_get(device, stream, k > MAX_K ? MAX_K : k, (n + BLOCK - 1) / BLOCK, &c);
     if (rc) return rc;
     StreamCtx* sc = c.s.get();
+    {   // "up to k pairs": the scratch of a smaller group may be LARGER (groups of up to BN254_FIS_MAX_K pairs keep a line area)
+        size_t need = 0, kmax = k > MAX_K ? MAX_K : k;
+        for (size_t kk = 1; kk <= kmax; kk++) {
+            size_t pitch = scratch_pitch(kk, c.grid);
+            if (pitch >= (1ull << 32)) return BN254_ERR_INVALID_ARG;
+            size_t bytes = BN254_SCRATCH_WG_CONTIGUOUS ? pitch * c.grid : pitch * scratch_slots(kk);
+            if (bytes > need) need = bytes;
+        }
+        if ((rc = ensure(sc, sc->scratch, need))) return rc;
+    }
     if ((rc = ensure(sc, sc->tmp, 384 * (n ? n : 1)))) return rc;                                   // the `== one` verdict's Fq12 values
     if ((rc = ensure(sc, sc->naf, 65536 + 64))) return rc;                                          // pow_native digits (16-bit length field)
     if (k > MAX_K && ((rc = ensure(sc, sc->sub[0], 64 * n * MAX_K)) || (rc = ensure(sc, sc->sub[1], 128 * n * MAX_K)) ||

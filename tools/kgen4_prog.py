@@ -94,6 +94,13 @@ class GlobDyn:
         self.kind, self.k = "globdyn", k
 
 
+class GlobLine:
+    """Global slot k of the line triple at the phase-1 cursor S_LOFF (bytes inside the workgroup's scratch block)."""
+
+    def __init__(self, k):
+        self.kind, self.k = "globline", k
+
+
 class Const:
     """Fq2 constant (canonical integers), materialised with literal moves."""
 
@@ -172,10 +179,28 @@ EXP_NO_SCRATCH = bool(int(os.environ.get("KGEN_EXP_NO_SCRATCH", "0")))      # TI
 # copies are formed straight in the operand blocks) instead of through three AGPR slots and two temporaries: -180 moves per sparse
 # multiplication, no LDS temporary left in it, and the freed slots take the result temporaries.
 LINE_IN_REGS = bool(int(os.environ.get("KGEN_LINE_REGS", "1")))
+# Round 4 -- LOOP FISSION of the Miller loop (untracked kernels; groups of up to FIS_MAX_K pairs).  The main loop's code -- f^2 (glue + the
+# fused Fq6 multiplication: 40 KB), the fused doubling step (47 KB) or addition step (62 KB), the sparse multiplication (16 KB) -- is
+# 103 .. 130 KB per iteration against a 64 KB instruction cache: the per-routine cycle counters (profiles/r04_l2_profile.json) show the
+# Miller routines at 4.38 cycles per instruction where every leaf routine alone issues at 4.000 and the cyclotomic-squaring loop (38 KB)
+# at 4.09.  The point steps do not depend on f, so the loop is split: PHASE 1 walks the whole chain of point steps of one pair with R
+# resident in home registers (no LDS / scratch round trip per step) and leaves every step's line coefficients (three slots) in a per-lane
+# line area of the scratch; PHASE 2 is the f loop -- f^2, then per pair one sparse multiplication by a line that was prefetched into three
+# AGPR slots one step ahead.  Each loop's code fits the cache.  For k-pair groups this also REPLACES the R stream (load R / step / store R
+# per pair and step, with its dependent round trip) by a line stream of the same volume that is written once and read once, sequentially.
+# MEASURED, NOT ADOPTED (default off; profiles/r04_ab.txt "fission"): the split loop does what it was built for -- the wave's shader cycles
+# fall (k_pairing 246.5 -> 245.3 M per wave, the Groth16 shape 130.2 -> 128.0 M; L2_sqr 4.28 -> 4.06 cycles per instruction) -- but the
+# 40 GB of line traffic per launch are paid in CLOCK: the in-kernel clock fell from 2.37 to 2.19 GHz on the Groth16 shape and by 3 % on
+# k_pairing (tools/clock_stamp.py, same box), so the launches got 2 .. 4 % slower.  HBM traffic costs package power, and the package is close
+# enough to its limit that power is taken from the shader clock.
+FISSION = bool(int(os.environ.get("KGEN_FISSION", "0")))
+FIS_MAX_K = 4                                  # larger groups keep the streamed loop (the line area is 3 x FIS_STEPS slots per pair)
+FIS_STEPS = 63 + sum(1 for d in SIX_U_PLUS_2_NAF[:64] if d)       # point steps of the main loop: 63 doublings + 26 additions
+S_LOFF, S_LSTEP, S_LOFF2 = 50, 51, 52         # byte offsets (inside the workgroup's scratch block): phase-1 line cursor, its step, phase-2 cursor
+S_LCNT = 53                                    # phase 2: lines not yet fetched
 # Round 4: the Fq12 inversion of the easy part keeps its temporaries out of home blocks 0..7, so that its four Fq6 multiplications run on the
 # fused L1 routine (mul6) instead of six generic Fq2 multiplications plus glue each
 INV_FUSED = bool(int(os.environ.get("KGEN_INV_FUSED", "1")))
-EXP_FISSION = bool(int(os.environ.get("KGEN_EXP_FISSION", "0")))            # TIMING ONLY: Miller loop as a point-step loop + an f loop (k_pairing / k_miller)
 EXP_NO_SWAIT = bool(int(os.environ.get("KGEN_EXP_NO_SWAIT", "0")))          # no s_waitcnt at the start of a streamed step
 # The next pair's prefetch is issued slot by slot behind the first four passes of the current pair's sparse multiplication instead
 # of as one burst of 25 loads in front of the step: +1.9 % on the Groth16 shape (the four waves of a CU run in step: a burst is
@@ -293,8 +318,8 @@ class Prog:
     # ---------------------------------------------------------------- bounds
     @staticmethod
     def key(slot):
-        if slot.kind == "globdyn":
-            return ("globdyn", slot.k)
+        if slot.kind in ("globdyn", "globline"):
+            return (slot.kind, slot.k)
         if slot.kind == "const":
             return ("const", slot.name)
         return (slot.kind, slot.idx)
@@ -349,6 +374,9 @@ class Prog:
     def _glob_base(self, slot):
         if slot.kind == "glob":
             self.e.salu(f"s_mul_i32 s{S_TMP0}, s{S_GSTRIDE}, {slot.idx}")
+        elif slot.kind == "globline":
+            self.e.salu(f"s_mul_i32 s{S_TMP0}, s{S_GSTRIDE}, {slot.k}")
+            self.e.salu(f"s_add_u32 s{S_TMP0}, s{S_TMP0}, s{S_LOFF}")
         else:
             self.e.salu(f"s_mul_i32 s{S_TMP0}, s{S_GSTRIDE}, {slot.k}")
             self.e.salu(f"s_add_u32 s{S_TMP0}, s{S_TMP0}, s{S_GBASE}")
@@ -375,9 +403,9 @@ class Prog:
             w = bal_limbs(mont4(slot.c0)) + bal_limbs(mont4(slot.c1))
             for i in range(SLOT_DW):
                 e.emit(f"v_mov_b32_e32 v{blk + i}, {hx(w[i])}", vw=[blk + i])
-        elif slot.kind in ("glob", "globdyn") and EXP_NO_SCRATCH:
+        elif slot.kind in ("glob", "globdyn", "globline") and EXP_NO_SCRATCH:
             pass
-        elif slot.kind in ("glob", "globdyn"):
+        elif slot.kind in ("glob", "globdyn", "globline"):
             self._glob_base(slot)
             for c in range(self.N_B128):
                 e.emit(f"global_load_dwordx4 v[{blk + 4 * c}:{blk + 4 * c + 3}], v{V_GOFF}, {S_GADDR} offset:{GCHUNK0 + 1024 * c}" + _ldm(), kind="vmem",
@@ -403,9 +431,9 @@ class Prog:
         elif slot.kind == "agpr":
             for i in range(SLOT_DW):
                 e.emit(f"v_accvgpr_write_b32 a{SLOT_DW * slot.idx + i}, v{blk + i}")
-        elif slot.kind in ("glob", "globdyn") and EXP_NO_SCRATCH:
+        elif slot.kind in ("glob", "globdyn", "globline") and EXP_NO_SCRATCH:
             pass
-        elif slot.kind in ("glob", "globdyn"):
+        elif slot.kind in ("glob", "globdyn", "globline"):
             self._glob_base(slot)
             for c in range(self.N_B128):
                 e.emit(f"global_store_dwordx4 v{V_GOFF}, v[{blk + 4 * c}:{blk + 4 * c + 3}], {S_GADDR} offset:{GCHUNK0 + 1024 * c}" + _stm(), kind="vmem",
@@ -1235,7 +1263,8 @@ class Prog:
             base = 0
         for k, s_ in enumerate(slots):
             self._need(mag(self.r_of(s_)) <= 1.0, f"fused step operand {s_} is not normalised")
-            self.load(HOME0 + SLOT_DW * (base + k), s_)
+            if not (s_.kind == "home" and s_.idx == base + k):          # (phase 1 of the split loop: R stays in home blocks 0..2 from step to step)
+                self.load(HOME0 + SLOT_DW * (base + k), s_)
             vs.append(self.v_of(s_))
         return max(vs)
 
@@ -1389,7 +1418,16 @@ class Prog:
             self._step_out(8, line[1], th * vp / K_RP + 0.5)
         self.wait()
 
-    def dbl_step(self, R, Pt, line, scale=None, out=None, after_load=None, load_p=None, alt_r=None):
+    def _store_line(self, dsts):
+        """the line the fused step left in home blocks 7, 4, 5 (LINE_REGS) -> three slots (phase 1 of the split loop: the line area)"""
+        for src, dst in zip(self.LINE_REGS, dsts):
+            self.wait()
+            self.store(HOME0 + SLOT_DW * src.idx, dst)
+            k_ = self.key(dst)
+            self.slot_r[k_], self.slot_v[k_] = self.r_of(src), self.v_of(src)
+            self.max_v = max(self.max_v, self.v_of(src))
+
+    def dbl_step(self, R, Pt, line, scale=None, out=None, after_load=None, load_p=None, alt_r=None, line_store=None):
         """R=(X,Y,Z) <- 2R ; line = (L0, L3, L4) of the tangent at the old R evaluated at P (Pt = (PX, PY) slots, scalar in c0).
         scale: slot of the running line scale s <- s * Z^2 (the caller squares it with f)."""
         X, Y, Z = R
@@ -1400,6 +1438,9 @@ class Prog:
             if LINE_IN_REGS:
                 line = self.LINE_REGS
             self._dbl_step_fused(R, Pt, line, out, after_load, load_p, alt_r, scale_in=(scale if alt_r is not None else None))
+            if line_store is not None:
+                assert LINE_IN_REGS
+                self._store_line(line_store)
             return line
         assert out is None and after_load is None and load_p is None and alt_r is None
         Bq, C, E, Fv, H, T = [self.tmp() for _ in range(6)]
@@ -1426,7 +1467,7 @@ class Prog:
         self.rel(Bq, C, E, Fv, H, T)
         return line
 
-    def add_step(self, R, Q, Pt, line, scale=None, update=True, out=None, after_load=None, load_p=None, load_q=None, alt_r=None):
+    def add_step(self, R, Q, Pt, line, scale=None, update=True, out=None, after_load=None, load_p=None, load_q=None, alt_r=None, line_store=None):
         """R <- R + Q (Q = (x2, y2) affine slots); line = (L2, L3, L5) of the chord through old R and Q at P."""
         X, Y, Z = R
         x2, y2 = Q
@@ -1437,6 +1478,9 @@ class Prog:
             if LINE_IN_REGS:
                 line = self.LINE_REGS
             self._add_step_fused(R, Q, Pt, line, out, after_load, load_p, load_q, alt_r, scale_in=(scale if alt_r is not None else None))
+            if line_store is not None:
+                assert LINE_IN_REGS
+                self._store_line(line_store)
             return line
         assert out is None and after_load is None and load_p is None and load_q is None and alt_r is None
         th, mu, T, U = [self.tmp() for _ in range(4)]
@@ -1568,6 +1612,120 @@ class KernelBuilder:
     def lab(self, name):
         return f"{name}_%="
 
+    @property
+    def fission(self):
+        """split Miller loop (see FISSION): the untracked kernels -- k_pairing, k_mpairing (groups of up to FIS_MAX_K pairs)"""
+        return FISSION and self.do_miller and not self.track and LINE_IN_REGS and Prog.FUSED_STEPS
+
+    # phase 2 of the split loop: the next line waits in three AGPR slots (free there: in the one-pair kernel RZ, PX, PY are parked in LDS meanwhile)
+    LINE_BUF = [AGPR(9, "bLa"), AGPR(10, "bLb"), AGPR(11, "bLc")]
+    FIS_PARK = [LDS(3, "parkRZ"), LDS(4, "parkPX"), LDS(5, "parkPY")]
+
+    def _emit_line_prefetch(self, e):
+        """LINE_BUF <- the line triple at the phase-2 cursor S_LOFF2 (global loads straight into the AGPRs, nobody waits here); cursor += 3 slots.
+        Nothing is fetched behind the last line (S_LCNT counts the lines left)."""
+        skip = self.lab(f"L_lpf_none_{self.uid()}")
+        e.salu(f"s_cmp_eq_u32 s{S_LCNT}, 0")
+        e.salu(f"s_cbranch_scc1 {skip}")
+        e.salu(f"s_sub_u32 s{S_LCNT}, s{S_LCNT}, 1")
+        for k, dst in enumerate(self.LINE_BUF):
+            if EXP_NO_SCRATCH:
+                break
+            a0 = SLOT_DW * dst.idx
+            if k == 0:
+                e.salu(f"s_add_u32 s62, s64, s{S_LOFF2}")
+            else:
+                e.salu(f"s_mul_i32 s{S_TMP0}, s{S_GSTRIDE}, {k}")
+                e.salu(f"s_add_u32 s{S_TMP0}, s{S_TMP0}, s{S_LOFF2}")
+                e.salu(f"s_add_u32 s62, s64, s{S_TMP0}")
+            e.salu("s_addc_u32 s63, s65, 0")
+            for c in range(Prog.N_B128):
+                e.emit(f"global_load_dwordx4 a[{a0 + 4 * c}:{a0 + 4 * c + 3}], v{V_GOFF}, {S_GADDR} offset:{GCHUNK0 + 1024 * c}" + _ldm(), kind="vmem")
+            e.emit(f"global_load_dwordx2 a[{a0 + 16}:{a0 + 17}], v{V_GOFF8}, {S_GADDR} offset:0" + _ldm(), kind="vmem")
+        e.salu(f"s_mul_i32 s{S_TMP0}, s{S_GSTRIDE}, 3")
+        e.salu(f"s_add_u32 s{S_LOFF2}, s{S_LOFF2}, s{S_TMP0}")
+        e.label(skip)
+
+    def _fission_routines(self):
+        """L2 routines of the split Miller loop.  Phase 1: L2_dbl_f / L2_add_f -- one fused point step with R in home blocks 0..2 on entry
+        and exit, its line -> the three slots at the cursor S_LOFF, cursor += S_LSTEP; L2_r2h / L2_h2r move R between its resident
+        slots and the home blocks.  Phase 2: L2_sp034_f / L2_sp235_f -- wait for the prefetched line, take it into home blocks 7, 4, 5,
+        prefetch the next one, sparse multiplication; L2_ln_pf issues the first prefetch."""
+        Hs = [HOME(0, "X"), HOME(1, "Y"), HOME(2, "Z")]
+        LG = [GlobLine(0), GlobLine(1), GlobLine(2)]
+        hkeys = frozenset(Prog.key(h) for h in Hs)
+        lkeys = [Prog.key(g) for g in LG]
+        bounds = {}
+
+        def phase1(kind):
+            def body(p):
+                p.norm_keys = p.norm_keys | hkeys                       # R arrives normalised in the home blocks (the contract of its slots)
+                p.temp_keys = p.temp_keys | frozenset(lkeys)            # the line area has its own contract (checked below), not V_STORE
+                if kind == "dbl":
+                    p.dbl_step(Hs, (self.PX, self.PY), self.LINE, line_store=LG)
+                else:
+                    p.add_step(Hs, (self.SX, self.SY), (self.PX, self.PY), self.LINE, line_store=LG)
+                p.wait()
+                p.e.salu(f"s_add_u32 s{S_LOFF}, s{S_LOFF}, s{S_LSTEP}")
+                for i, k_ in enumerate(lkeys):
+                    r_, v_ = p.slot_r[k_], p.slot_v[k_]
+                    o = bounds.get((kind, i), (0.0, 0.0))
+                    bounds[(kind, i)] = (max(o[0], mag(r_)), max(o[1], v_))
+            return body
+        tm = self.miller_temps(extra=tuple(self.LINE))
+        self.l2_routine("L2_dbl_f", phase1("dbl"), tm, local=self.LINE)
+        self.l2_routine("L2_add_f", phase1("add"), tm, local=self.LINE)
+        self.fis_line_bounds = bounds
+
+        def r2h(p):
+            for k, src in enumerate(self.R):
+                p._need(mag(p.r_of(src)) <= 1.0, f"{src} is not normalised")
+                p.load(HOME0 + SLOT_DW * k, src)
+            p.wait()
+        def h2r(p):
+            p.norm_keys = p.norm_keys | hkeys
+            for k, dst in enumerate(self.R):
+                p.wait()
+                p.store(HOME0 + SLOT_DW * k, dst)
+                p.slot_r[p.key(dst)], p.slot_v[p.key(dst)] = R_NORM, V_STORE
+            p.max_v = max(p.max_v, V_STORE)
+            p.wait()
+        self.l2_routine("L2_r2h", r2h, tm)
+        self.l2_routine("L2_h2r", h2r, tm)
+
+        def phase2(kind):
+            def body(p):
+                e = p.e
+                e.raw("s_waitcnt vmcnt(0)")                               # the prefetched line has landed
+                p.reset_tags()
+                for i, (dst, src) in enumerate(zip(Prog.LINE_REGS, self.LINE_BUF)):
+                    p.load(HOME0 + SLOT_DW * dst.idx, src)
+                    m_, v_ = bounds[(kind, i)]
+                    p._need(v_ <= V_CAP, f"line coefficient of {v_} p")
+                    p.slot_r[p.key(dst)] = (-m_, m_) if m_ > 1.0 else p.r_norm(v_)
+                    p.slot_v[p.key(dst)] = v_
+                p.wait()
+                self._emit_line_prefetch(e)                              # the buffer is free again: the next line travels under this multiplication
+                if kind == "dbl":
+                    p.mul_by_034(self.F, *Prog.LINE_REGS)
+                else:
+                    p.mul_by_235(self.F, *Prog.LINE_REGS)
+            return body
+        tm2 = self.miller_temps(extra=(*self.LINE, self.SX, self.SY))
+        self.l2_routine("L2_sp034_f", phase2("dbl"), tm2, local=self.LINE)
+        self.l2_routine("L2_sp235_f", phase2("add"), tm2, local=self.LINE)
+        self.l2_routine("L2_ln_pf", lambda p: self._emit_line_prefetch(p.e), tm2)
+        if not self.multi:               # one-pair kernel: RZ, PX, PY wait in LDS while their AGPR slots serve as the line buffer
+            def park(p, back):
+                for a_, l_ in zip((self.R[2], self.PX, self.PY), self.FIS_PARK):
+                    if back:
+                        p.A(l_).to(a_)
+                    else:
+                        p.A(a_).to(l_)
+                p.wait()
+            self.l2_routine("L2_fpark", lambda p: park(p, False), tm2)
+            self.l2_routine("L2_funpark", lambda p: park(p, True), tm2)
+
     def uid(self):
         self._uid += 1
         return self._uid
@@ -1583,6 +1741,8 @@ class KernelBuilder:
             keys += [("globdyn", i) for i in range(7)]
             if self.multi and self.r0_resident():
                 keys += [Prog.key(s_) for s_ in self.R0_LDS]
+            if self.fission:
+                keys += [Prog.key(s_) for s_ in self.LINE_BUF] + ([] if self.multi else [Prog.key(s_) for s_ in self.FIS_PARK])
         return frozenset(keys)
 
     def new_prog(self, temps, phase=None):
@@ -1613,7 +1773,8 @@ class KernelBuilder:
         self.l2_bodies[name] = (body, temps)
         self.l2_phase[name] = self._phase
         # (home registers never carry a value across a routine boundary: they are every routine's workspace)
-        self.l2_exit[name] = {k: v for k, v in p.slot_v.items() if k not in tk and k[0] != "home"}
+        # (... nor does the line area of the split loop: its bounds travel from the phase-1 routines to the phase-2 ones, _fission_routines)
+        self.l2_exit[name] = {k: v for k, v in p.slot_v.items() if k not in tk and k[0] not in ("home", "globline")}
         self.l2_maxv[name] = p.max_v
         return p
 
@@ -1623,6 +1784,8 @@ class KernelBuilder:
         scratch slots only as overflow."""
         homes = [HOME(8)] if no_homes else [HOME(i) for i in range(N_HOME)]
         fa, fl = self.MILLER_FREE
+        if self.fission and not self.multi:      # LDS 3..5 hold RZ, PX, PY during phase 2 of the split loop
+            fl = []
         return (homes + fa + ([] if self.track else ([self.SCALE] if self.SCALE.kind == "agpr" else [])) + list(extra) + fl
                 + ([] if self.track or self.SCALE.kind == "agpr" else [self.SCALE]) + [GLOB(GLOB_TMP0 + i) for i in range(8)])
 
@@ -1670,8 +1833,9 @@ class KernelBuilder:
             # (routines that run the fused steps hand the line over in registers: the LINE slots are then ordinary temporaries)
             hot = lambda name: LINE_IN_REGS and Prog.FUSED_STEPS and name not in self.COLD
             line_tmp = lambda name: tuple(self.LINE) if hot(name) else ()
-            self.l2_routine("L2_dblmul", lambda p: p.mul_by_034(self.F, *p.dbl_step(self.R, (self.PX, self.PY), self.LINE, scale=sc)),
-                            self.miller_temps(extra=(*line_tmp("L2_dblmul"), self.SX, self.SY)), local=self.LINE)
+            if not (self.fission and not self.multi):           # (the one-pair split loop has no use for it)
+                self.l2_routine("L2_dblmul", lambda p: p.mul_by_034(self.F, *p.dbl_step(self.R, (self.PX, self.PY), self.LINE, scale=sc)),
+                                self.miller_temps(extra=(*line_tmp("L2_dblmul"), self.SX, self.SY)), local=self.LINE)
             self.l2_routine("L2_dblfirst", lambda p: self._dbl_first(p), self.miller_temps(), local=self.LINE)
 
             def addmul(p, update):
@@ -1683,18 +1847,8 @@ class KernelBuilder:
 
             self.l2_routine("L2_addmul", lambda p: addmul(p, True), self.miller_temps(extra=line_tmp("L2_addmul")), local=self.LINE)
             self.l2_routine("L2_addmul_last", lambda p: addmul(p, False), self.miller_temps(), local=self.LINE)
-            if EXP_FISSION:
-                # TIMING ONLY (results are wrong: the lines do not travel): the point steps and the f-side work of the main loop as
-                # separate routines, run in two loops -- what would the Miller loop cost if each loop's code fitted the instruction cache?
-                def fake_line(p):
-                    for s_, lim in zip(Prog.LINE_REGS, (2.0, 1.0, 1.0)):
-                        p.slot_r[p.key(s_)], p.slot_v[p.key(s_)] = (-lim, lim), 1.0
-                    return Prog.LINE_REGS
-                tm = self.miller_temps(extra=(*self.LINE, self.SX, self.SY))
-                self.l2_routine("L2_dblonly", lambda p: p.dbl_step(self.R, (self.PX, self.PY), self.LINE, scale=None), tm, local=self.LINE)
-                self.l2_routine("L2_addonly", lambda p: p.add_step(self.R, (self.SX, self.SY), (self.PX, self.PY), self.LINE, scale=None), self.miller_temps(extra=self.LINE), local=self.LINE)
-                self.l2_routine("L2_sp034", lambda p: p.mul_by_034(self.F, *fake_line(p)), tm, local=self.LINE)
-                self.l2_routine("L2_sp235", lambda p: p.mul_by_235(self.F, *fake_line(p)), tm, local=self.LINE)
+            if self.fission:
+                self._fission_routines()
             if self.multi:
                 self._stream_routines(sc)
             if self.track:
@@ -1790,7 +1944,36 @@ class KernelBuilder:
                 seq.append("L2_fqinv")           # nested: the Fq inversion (fixed exponent)
 
         assert self.main_prog.max_v <= V_STORE, "the main program stores across routine boundaries only"
-        if self.do_miller:
+        fis = self.fission and k_pairs <= FIS_MAX_K
+        if self.do_miller and fis:
+            run("L2_dblfirst")
+            for _ in range(k_pairs - 1):
+                run("L2_dblmul")
+            for _ in range(k_pairs):                                    # phase 1: every pair's chain of point steps
+                run("L2_r2h")
+                for i in range(63, -1, -1):
+                    if i != 63:
+                        run("L2_dbl_f")
+                    if SIX_U_PLUS_2_NAF[i] != 0:
+                        run("L2_add_f")
+                run("L2_h2r")
+            if not self.multi:
+                run("L2_fpark")
+            run("L2_ln_pf")
+            for i in range(63, -1, -1):                                 # phase 2: the f loop
+                if i != 63:
+                    run("L2_sqr")
+                    for _ in range(k_pairs):
+                        run("L2_sp034_f")
+                if SIX_U_PLUS_2_NAF[i] != 0:
+                    for _ in range(k_pairs):
+                        run("L2_sp235_f")
+            if not self.multi:
+                run("L2_funpark")
+            for _ in range(k_pairs):
+                run("L2_addmul")
+                run("L2_addmul_last")
+        if self.do_miller and not fis:
             run("L2_dblfirst")
             for _ in range(k_pairs - 1):
                 run("L2_dblmul")
@@ -2055,10 +2238,12 @@ class KernelBuilder:
         e.salu(f"s_mov_b32 s{S_ITEM}, %10")
         e.salu(f"s_mov_b32 s{S_GRID}, %11")
         # scratch base of this workgroup: scratch + block * 256 * 72 ; lane offset = tid * 72
+        # (64-bit product: with the line area of the split loop a full grid of k = 4 scratch blocks passes 4 GiB)
         e.salu(f"s_mul_i32 s{S_TMP0}, %10, " + ("%7" if SCRATCH_WG else f"{BLOCK * SLOT_BYTES}"))
+        e.salu(f"s_mul_hi_u32 s{S_TMP1}, %10, " + ("%7" if SCRATCH_WG else f"{BLOCK * SLOT_BYTES}"))
         e.salu(f"s_mov_b64 {S_SCRATCH}, %6")
         e.salu(f"s_add_u32 s64, s64, s{S_TMP0}")
-        e.salu("s_addc_u32 s65, s65, 0")
+        e.salu(f"s_addc_u32 s65, s65, s{S_TMP1}")
         # scratch slot of a workgroup = 4 waves x 4608 B; inside a wave's part the 64 lanes' 8-byte tails come first (512 B),
         # then the four 16-byte chunks as [chunk][lane] (1 KiB each): every slot access instruction touches ONE contiguous
         # 1 KiB (16 cache lines) instead of 64 lines at a 72-byte lane stride
@@ -2397,9 +2582,12 @@ class KernelBuilder:
                 e.emit(f"v_mov_b32_e32 v{r}, 0")
         if CLOCK_STAMP:
             assert SCRATCH_WG
-            e.salu("s_memtime s[50:51]")                               # (s50..s53: free in every kernel; the k-pair kernels use s72..s74)
-            e.salu("s_memrealtime s[52:53]")
+            # (no scalar register is free in every kernel any more: the start stamps wait in four lanes of v251)
+            e.salu("s_memtime s[60:61]")
+            e.salu("s_memrealtime s[88:89]")
             e.raw("s_waitcnt lgkmcnt(0)")
+            for i, sr in enumerate((60, 61, 88, 89)):
+                e.raw(f"v_writelane_b32 v251, s{sr}, {i}")
         e.label(L("L_item"))
         e.salu(f"s_cmp_ge_u32 s{S_ITEM}, s{S_NITEMS}")
         e.salu(f"s_cbranch_scc1 {L('L_done')}")
@@ -2447,10 +2635,13 @@ class KernelBuilder:
             e.salu("s_memtime s[60:61]")
             e.salu("s_memrealtime s[88:89]")
             e.raw("s_waitcnt lgkmcnt(0)")
-            e.salu("s_sub_u32 s60, s60, s50")
-            e.salu("s_subb_u32 s61, s61, s51")
-            e.salu("s_sub_u32 s88, s88, s52")
-            e.salu("s_subb_u32 s89, s89, s53")
+            for i in range(4):
+                e.raw(f"v_readlane_b32 s{72 + i}, v251, {i}")
+            e.raw("s_nop 3")
+            e.salu("s_sub_u32 s60, s60, s72")
+            e.salu("s_subb_u32 s61, s61, s73")
+            e.salu("s_sub_u32 s88, s88, s74")
+            e.salu("s_subb_u32 s89, s89, s75")
             for i, sr in enumerate((60, 61, 88, 89)):
                 e.emit(f"v_mov_b32_e32 v{36 + i}, s{sr}", vw=[36 + i])
             e.salu(f"s_sub_u32 s72, %7, {STAMP_OFFSET_FROM_END}")
@@ -2591,6 +2782,81 @@ class KernelBuilder:
         p.tagA = None
         p.to(self.SY)
 
+    def _fission_loops(self, e, p, single):
+        """The main loop of the Miller loop, split (FISSION).  PHASE 1: for every pair the whole chain of point steps, R in home
+        registers, one line triple per step into the line area (layout [step][pair][3 slots]: phase 2 reads it sequentially).
+        PHASE 2: the f loop.  single: the one-pair kernel (resident point state; RZ, PX, PY parked in LDS during phase 2);
+        otherwise the pairs' state is in their scratch blocks (S_K pairs), as the first steps left it and the end steps expect it."""
+        L = self.lab
+        u = self.uid()
+        if single:
+            e.salu(f"s_mul_i32 s{S_LSTEP}, s{S_GSTRIDE}, 3")
+            e.salu(f"s_mul_i32 s{S_LOFF}, s{S_GSTRIDE}, {N_GSLOTS}")
+        else:
+            e.salu(f"s_mul_i32 s{S_TMP0}, s{S_K}, 3")
+            e.salu(f"s_mul_i32 s{S_LSTEP}, s{S_GSTRIDE}, s{S_TMP0}")                     # a step's triples of all pairs lie together
+
+        def chain():
+            if not single:
+                self.pair_in(e, p, with_q=True)
+                # line area: behind the pairs' blocks; pair j starts at triple j
+                e.salu(f"s_mul_i32 s{S_TMP0}, s{S_K}, 7")
+                e.salu(f"s_add_u32 s{S_TMP0}, s{S_TMP0}, {self.PAIR_SLOT0}")
+                e.salu(f"s_mul_i32 s{S_TMP1}, s{S_JP}, 3")
+                e.salu(f"s_add_u32 s{S_TMP0}, s{S_TMP0}, s{S_TMP1}")
+                e.salu(f"s_mul_i32 s{S_LOFF}, s{S_TMP0}, s{S_GSTRIDE}")
+            self.call2(e, "L2_r2h")
+            e.salu(f"s_mov_b32 s{S_I}, 63")
+            e.label(L(f"L_f1_loop_{u}"))
+            e.salu(f"s_cmp_eq_u32 s{S_I}, 63")
+            e.salu(f"s_cbranch_scc1 {L(f'L_f1_skip_{u}')}")
+            self.call2(e, "L2_dbl_f")
+            e.label(L(f"L_f1_skip_{u}"))
+            e.salu(f"s_bitcmp1_b64 {S_NAF_NZ}, s{S_I}")
+            e.salu(f"s_cbranch_scc0 {L(f'L_f1_noadd_{u}')}")
+            self._select_pm_q(e, p)
+            self.call2(e, "L2_add_f")
+            e.label(L(f"L_f1_noadd_{u}"))
+            e.salu(f"s_sub_u32 s{S_I}, s{S_I}, 1")
+            e.salu(f"s_cbranch_scc0 {L(f'L_f1_loop_{u}')}")
+            self.call2(e, "L2_h2r")
+            if not single:
+                self.pair_out(e, p)
+        if single:
+            chain()
+            self.call2(e, "L2_fpark")
+            e.salu(f"s_mul_i32 s{S_LOFF2}, s{S_GSTRIDE}, {N_GSLOTS}")
+        else:
+            self.pair_loop(e, f"fis1_{u}", chain)
+            e.salu(f"s_mul_i32 s{S_TMP0}, s{S_K}, 7")
+            e.salu(f"s_add_u32 s{S_TMP0}, s{S_TMP0}, {self.PAIR_SLOT0}")
+            e.salu(f"s_mul_i32 s{S_LOFF2}, s{S_TMP0}, s{S_GSTRIDE}")
+            e.raw("s_waitcnt vmcnt(0)")                                                    # every line has been written
+        p.reset_tags()
+        if single:
+            e.salu(f"s_mov_b32 s{S_LCNT}, {FIS_STEPS}")
+        else:
+            e.salu(f"s_mul_i32 s{S_LCNT}, s{S_K}, {FIS_STEPS}")
+        self.call2(e, "L2_ln_pf")
+        per_pair = (lambda name: self.call2(e, name)) if single else (lambda name: self.pair_loop(e, f"{name}_{u}", lambda: self.call2(e, name)))
+        e.salu(f"s_mov_b32 s{S_I}, 63")
+        e.label(L(f"L_f2_loop_{u}"))
+        e.salu(f"s_cmp_eq_u32 s{S_I}, 63")
+        e.salu(f"s_cbranch_scc1 {L(f'L_f2_skip_{u}')}")
+        self.call2(e, "L2_sqr")
+        per_pair("L2_sp034_f")
+        e.label(L(f"L_f2_skip_{u}"))
+        e.salu(f"s_bitcmp1_b64 {S_NAF_NZ}, s{S_I}")
+        e.salu(f"s_cbranch_scc0 {L(f'L_f2_noadd_{u}')}")
+        per_pair("L2_sp235_f")
+        e.label(L(f"L_f2_noadd_{u}"))
+        e.salu(f"s_sub_u32 s{S_I}, s{S_I}, 1")
+        e.salu(f"s_cbranch_scc0 {L(f'L_f2_loop_{u}')}")
+        e.raw("s_waitcnt vmcnt(0)")                                                        # the last (unused) prefetch
+        if single:
+            self.call2(e, "L2_funpark")
+        p.reset_tags()
+
     def miller_main(self, e, p):
         L = self.lab
         self.io_walk_begin(e, S_G1)
@@ -2612,29 +2878,9 @@ class KernelBuilder:
             p.to(self.SCALE)
         p.reset_tags()
         self.call2(e, "L2_dblfirst")
-        if EXP_FISSION:
-            for phase in (0, 1):
-                e.salu(f"s_mov_b32 s{S_I}, 63")
-                e.label(L(f"L_fi{phase}_loop"))
-                e.salu(f"s_cmp_eq_u32 s{S_I}, 63")
-                e.salu(f"s_cbranch_scc1 {L(f'L_fi{phase}_skip')}")
-                if phase == 0:
-                    self.call2(e, "L2_dblonly")
-                else:
-                    self.call2(e, "L2_sqr")
-                    self.call2(e, "L2_sp034")
-                e.label(L(f"L_fi{phase}_skip"))
-                e.salu(f"s_bitcmp1_b64 {S_NAF_NZ}, s{S_I}")
-                e.salu(f"s_cbranch_scc0 {L(f'L_fi{phase}_noadd')}")
-                if phase == 0:
-                    self._select_pm_q(e, p)
-                    self.call2(e, "L2_addonly")
-                else:
-                    self.call2(e, "L2_sp235")
-                e.label(L(f"L_fi{phase}_noadd"))
-                e.salu(f"s_sub_u32 s{S_I}, s{S_I}, 1")
-                e.salu(f"s_cbranch_scc0 {L(f'L_fi{phase}_loop')}")
-            e.salu(f"s_branch {L('L_mend')}")
+        if self.fission:
+            self._fission_loops(e, p, single=True)
+            return self._miller_end_steps(e, p)
         e.salu(f"s_mov_b32 s{S_I}, 63")
         e.label(L("L_mloop"))
         e.salu(f"s_cmp_eq_u32 s{S_I}, 63")
@@ -2651,7 +2897,10 @@ class KernelBuilder:
         e.label(L("L_mnoadd"))
         e.salu(f"s_sub_u32 s{S_I}, s{S_I}, 1")
         e.salu(f"s_cbranch_scc0 {L('L_mloop')}")
-        e.label(L("L_mend"))
+        self._miller_end_steps(e, p)
+
+    def _miller_end_steps(self, e, p):
+        """+ pi(Q), then the line through the result and -pi^2(Q) (miller_loop_native.rs:176-187)"""
         self._frobenius_points(p)
         self.call2(e, "L2_addmul")
         p.reset_tags()
@@ -2763,6 +3012,13 @@ class KernelBuilder:
             self.pair_out(e, p)
 
         self.pair_loop(e, "first", first_step)
+        if self.fission:                 # groups of up to FIS_MAX_K pairs: the split loop (no pair state on chip, no R stream)
+            e.raw("s_waitcnt vmcnt(0)")
+            e.salu(f"s_cmp_le_u32 s{S_K}, {FIS_MAX_K}")
+            e.salu(f"s_cbranch_scc0 {L('L_mf_streamed')}")
+            self._fission_loops(e, p, single=False)
+            e.salu(f"s_branch {L('L_mf_ends')}")
+            e.label(L("L_mf_streamed"))
         # resident-P mode: the evaluation points move into the LDS slots the one-pair routines above no longer need
         e.salu(f"s_cmp_le_u32 s{S_K}, {self.RES_K}")
         e.salu(f"s_cbranch_scc0 {L('L_mf_nopack')}")
@@ -2777,37 +3033,6 @@ class KernelBuilder:
                 p.A(GlobDyn(k_)).to(dst)
             p.wait()
             p.reset_tags()
-        if EXP_FISSION:
-            # TIMING ONLY (wrong results): per pair the whole chain of point steps on resident slots, then the f loop with k sparse
-            # multiplications per step and no pair state at all -- the ceiling of "lines through memory instead of R through memory"
-            def chain():
-                e.salu(f"s_mov_b32 s{S_I}, 63")
-                e.label(L("L_fm0_loop"))
-                e.salu(f"s_cmp_eq_u32 s{S_I}, 63")
-                e.salu(f"s_cbranch_scc1 {L('L_fm0_skip')}")
-                self.call2(e, "L2_dblonly")
-                e.label(L("L_fm0_skip"))
-                e.salu(f"s_bitcmp1_b64 {S_NAF_NZ}, s{S_I}")
-                e.salu(f"s_cbranch_scc0 {L('L_fm0_noadd')}")
-                self.call2(e, "L2_addonly")
-                e.label(L("L_fm0_noadd"))
-                e.salu(f"s_sub_u32 s{S_I}, s{S_I}, 1")
-                e.salu(f"s_cbranch_scc0 {L('L_fm0_loop')}")
-            self.pair_loop(e, "fchain", chain)
-            e.salu(f"s_mov_b32 s{S_I}, 63")
-            e.label(L("L_fm1_loop"))
-            e.salu(f"s_cmp_eq_u32 s{S_I}, 63")
-            e.salu(f"s_cbranch_scc1 {L('L_fm1_skip')}")
-            self.call2(e, "L2_sqr")
-            self.pair_loop(e, "fsp034", lambda: self.call2(e, "L2_sp034"))
-            e.label(L("L_fm1_skip"))
-            e.salu(f"s_bitcmp1_b64 {S_NAF_NZ}, s{S_I}")
-            e.salu(f"s_cbranch_scc0 {L('L_fm1_noadd')}")
-            self.pair_loop(e, "fsp235", lambda: self.call2(e, "L2_sp235"))
-            e.label(L("L_fm1_noadd"))
-            e.salu(f"s_sub_u32 s{S_I}, s{S_I}, 1")
-            e.salu(f"s_cbranch_scc0 {L('L_fm1_loop')}")
-            e.salu(f"s_branch {L('L_mfission_end')}")
         e.salu(f"s_mul_i32 s{self.S_GNEXT}, s{S_GSTRIDE}, {self.PAIR_SLOT0}")      # prime the stream: pair 0
         if self.boustrophedon():
             e.salu(f"s_mov_b32 s{self.S_DIR}, 1")
@@ -2840,9 +3065,6 @@ class KernelBuilder:
         e.salu(f"s_sub_u32 s{S_I}, s{S_I}, 1")
         e.salu(f"s_cbranch_scc0 {L('L_mloop')}")
 
-        if EXP_FISSION:
-            e.label(L("L_mfission_end"))
-            e.salu(f"s_mov_b32 s{self.S_DIR}, 1")
         if self.boustrophedon():
             # the last pass ran upwards (S_DIR has been flipped to -1 behind it) <=> pair k - 1 closed it and its R sits in the
             # prefetch buffer: back to its scratch block for the end steps
@@ -2867,6 +3089,9 @@ class KernelBuilder:
             p.wait()
             e.raw("s_waitcnt vmcnt(0)")                               # acknowledged before the end steps read the block back
             p.reset_tags()
+
+        if self.fission:
+            e.label(L("L_mf_ends"))
 
         def end_pair():
             self.pair_in(e, p, with_q=True)

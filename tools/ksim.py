@@ -427,6 +427,8 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None):
                 r = x + y if op == "s_add_i32" else x - y
                 m.sset(a[0], r & M32)
                 m.scc = 0 if -(1 << 31) <= r < (1 << 31) else 1
+            elif op == "s_mul_hi_u32":
+                m.sset(a[0], ((m.vsrc(a[1], False) & M32) * (m.vsrc(a[2], False) & M32)) >> 32)
             elif op == "s_mul_i32":
                 m.sset(a[0], m.vsrc(a[1], False) * m.vsrc(a[2], False))
             elif op == "s_lshl_b32":
