@@ -49,6 +49,10 @@ inline void pack_fq12(const MyFq12& a, uint64_t* buf, size_t n, size_t i) { for 
 inline MyFq12 unpack_fq12(const uint64_t* buf, size_t n, size_t i) { MyFq12 r; for (int c = 0; c < 12; c++) get(r.coeffs[c], buf + 4 * c * n + i, n); return r; }
 }  // namespace detail
 
+// Sizes what the library keeps for (device, NULL stream) -- the stream every function of this header uses -- for calls of up to n units x k
+// pairs: no later call of that size allocates device memory (bn254_reserve).
+inline void reserve(size_t n, size_t k = 1, int device = 0) { check(bn254_reserve(device, nullptr, n, k)); }
+
 inline MyFq12 miller_loop_native(const G2Affine& Q, const G1Affine& P, int device = 0) {
     uint64_t g1[8], g2[16], out[48];
     detail::pack_g1(P, g1, 1, 0); detail::pack_g2(Q, g2, 1, 0);

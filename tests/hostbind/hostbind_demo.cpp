@@ -9,6 +9,7 @@
 //     frobc index                    naf n_limbs exp[n]
 //     batch n (g1[8] g2[16])*n       -> pairing_batch_fq12 (ark order) and pairing_batch (MyFq12 order), n lines each
 //     check k n_groups (g1[8] g2[16])*(k*n_groups)  -> multi_pairing_check_batch verdicts
+//     reserve n k                    -> bn254_reserve for the NULL stream (hex words)
 #include <cinttypes>
 #include <cstdio>
 #include <iostream>
@@ -35,7 +36,11 @@ int main() {
         std::string op;
         if (!(in >> op)) continue;
         try {
-            if (op == "pairing") {
+            if (op == "reserve") {                                        // reserve n k: no later call of that size allocates device memory
+                size_t n = rd(in), k = rd(in);
+                reserve(n, k);
+                std::printf("reserved\n");
+            } else if (op == "pairing") {
                 G1Affine p = rd_g1(in); G2Affine q = rd_g2(in);
                 Fq12 e = pairing(p, q);                                   // ark flat order (`.into()` at pairing.rs:21)
                 std::printf("pairing"); for (auto& c : e.flat) pr_fq(c); std::printf("\n");
