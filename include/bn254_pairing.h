@@ -33,7 +33,8 @@
  * ERRORS     0 = success, negative = failure (bn254_strerror).  The reference panics on
  *            the same conditions (division by zero in ark's `/`); the Rust shim turns a
  *            negative status back into a panic.  Points at infinity are outside the
- *            reference's contract (it reads raw x/y) and outside this one.
+ *            reference's contract (it reads raw x/y) and outside the hot path's; bn254_check_points
+ *            gives them a distinct status (BN254_ERR_INFINITY) for callers that ask.
  * THREADING  Re-entrant.  The only state is what the library keeps per (device, stream):
  *            scratch, the status word, the staging buffers of the host-pointer calls.  Each
  *            such context has a mutex: a `_dev` call holds it from the look-up of its
@@ -69,6 +70,7 @@ extern "C" {
 #define BN254_ERR_ZERO_DIVISOR (-4) /* reference: ark `/` panics (final_exp_native.rs:74,200) */
 #define BN254_ERR_NAF_CARRY (-5)    /* reference: get_naf assert at final_exp_native.rs:123 */
 #define BN254_ERR_ALLOC (-6)
+#define BN254_ERR_INFINITY (-7)     /* bn254_check_points: a point at infinity (ark affine form x = y = 0) in the batch */
 
 /* number of visible HIP devices (0 when none / no driver) */
 int bn254_device_count(void);
@@ -199,6 +201,16 @@ int bn254_multi_pairing_sharded_elems(const uint64_t* g1, const uint64_t* g2, ui
 /* the product-of-pairings check (final_exp_native.rs:245-263) on element-major pairs: one byte per group */
 int bn254_multi_pairing_check_batch_elems(const uint64_t* g1, const uint64_t* g2, uint8_t* verdict, size_t n_groups, size_t k, int device,
                                           void* stream);
+
+/* ---- input validation (optional) ----------------------------------------------------------
+ * The reference never checks for the point at infinity: its line functions read raw x / y (src/miller_loop_native.rs:10-44) and
+ * ignore `G1Affine::infinity` / `G2Affine::infinity`, so an infinite input is outside its contract and outside the hot path's.
+ * A caller that wants a DISTINCT status for it runs this check on the same limb-major batches: a pair whose G1 or G2
+ * coordinates are all zero (ark's affine identity) makes the `_dev` form set the stream's sticky status -- the next
+ * bn254_last_status returns BN254_ERR_INFINITY -- and the host-pointer form return BN254_ERR_INFINITY.  One HBM pass over the
+ * inputs; nothing is computed from them.  (The Rust shim tests the `infinity` flag of the structs it is handed instead.) */
+int bn254_check_points_dev(const uint64_t* g1, const uint64_t* g2, size_t n, int device, void* stream);
+int bn254_check_points(const uint64_t* g1, const uint64_t* g2, size_t n, int device, void* stream);
 
 /* ---- synthetic inputs (bench / tests): on-device subgroup points ------------------------ */
 /* P_i = [s_i] G1, Q_i = [t_i] G2 with s_i, t_i from SplitMix64(seed, i) (non-zero, < 2^128);

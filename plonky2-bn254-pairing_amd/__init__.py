@@ -32,6 +32,7 @@ ERR_HIP = -3
 ERR_ZERO_DIVISOR = -4
 ERR_NAF_CARRY = -5
 ERR_ALLOC = -6
+ERR_INFINITY = -7
 
 P = 21888242871839275222246405745257275088696311157297823662689037894645226208583
 R_ORDER = 21888242871839275222246405745257275088548364400416034343698204186575808495617
@@ -79,6 +80,8 @@ _PROTOS = {
     "bn254_multi_pairing_sharded_dev": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                                                        ctypes.c_void_p]),
     "bn254_release_stream": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p]),
+    "bn254_check_points_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_check_points": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "bn254_reserve": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t]),
     "bn254_fq12_mul_batch_dev": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "bn254_fq12_mul_batch": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
@@ -417,6 +420,17 @@ def multi_pairing_sharded_dev(g1, g2, out, n_groups, k, devices, do_final_exp=Tr
 
 def release_stream(device=0, stream=None):
     _check(load_library().bn254_release_stream(device, _stream(stream)), "release_stream")
+
+
+def check_points(g1, g2, n, device=0):
+    """Raises Bn254Error(ERR_INFINITY) when a pair of the limb-major host batch holds the point at infinity (x = y = 0) in G1 or G2."""
+    g1, g2 = _np_in(g1, G1_WORDS, n), _np_in(g2, G2_WORDS, n)
+    _check(load_library().bn254_check_points(_ptr(g1), _ptr(g2), n, device, None), "check_points")
+
+
+def check_points_dev(g1, g2, n, device=0, stream=None):
+    """device batches: sets the stream's sticky status (last_status then raises ERR_INFINITY)"""
+    _check(load_library().bn254_check_points_dev(_dev(g1), _dev(g2), n, device, _stream(stream)), "check_points")
 
 
 def reserve(n, k=1, device=0, stream=None):

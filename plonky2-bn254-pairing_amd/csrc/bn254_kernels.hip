@@ -84,6 +84,18 @@ __global__ void __launch_bounds__(256) k_subgroup(const uint64_t* __restrict__ s
     }
 }
 
+// status |= 2 when a point of the batch is the point at infinity in ark's affine form (x = y = 0, all limbs zero): the reference reads
+// raw x / y and never looks at the `infinity` flag, so such an input is outside its contract; callers that want
+// the distinct status SURVEY 8(b) asks for run this check (HBM-bound: every input word is read once).
+__global__ void __launch_bounds__(256) k_check_points(const uint64_t* __restrict__ g1, const uint64_t* __restrict__ g2, size_t n, int* status) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint64_t a = 0, b = 0;
+        for (int w = 0; w < 8; w++) a |= g1[(size_t)w * n + i];
+        for (int w = 0; w < 16; w++) b |= g2[(size_t)w * n + i];
+        if (a == 0 || b == 0) atomicOr(status, 2);
+    }
+}
+
 enum { OP_MUL = 0, OP_FROB = 1, OP_POW = 2 };
 
 // Element-major <-> limb-major.  The reference's callers hold `&[G1Affine]`, `Vec<(&G1Affine, &G2Affine)>`, `Vec<MyFq12>`,
@@ -485,6 +497,7 @@ const char* bn254_strerror(int status) {
         case BN254_ERR_ZERO_DIVISOR: return "division by zero in Fq12 (the reference panics here)";
         case BN254_ERR_NAF_CARRY: return "get_naf: carry out of the top limb (the reference panics here)";
         case BN254_ERR_ALLOC: return "device allocation failed";
+        case BN254_ERR_INFINITY: return "a point at infinity in the batch (outside the reference's contract: it reads raw x / y)";
         default: return "unknown status";
     }
 }
@@ -509,9 +522,10 @@ int bn254_last_status(int device, void* stream) {
     HIPCHK(hipStreamSynchronize(st));
     free_retired(sc.get());
     if (*sc->status_host) {
+        int v = *sc->status_host;
         HIPCHK(hipMemsetAsync(sc->status, 0, sizeof(int), st));
         HIPCHK(hipStreamSynchronize(st));
-        return BN254_ERR_ZERO_DIVISOR;
+        return (v & 2) ? BN254_ERR_INFINITY : BN254_ERR_ZERO_DIVISOR;      // (an infinite input makes everything behind it meaningless)
     }
     return BN254_OK;
 }
@@ -600,6 +614,27 @@ int bn254_generate_pairs_dev(uint64_t seed, uint64_t* g1_out, uint64_t* g2_out, 
                        (const uint64_t*)c.gen_table, (uint64_t*)(uintptr_t)seed, (uint32_t)n, 1u, c.scratch, c.stride, c.status);
     HIPCHK(hipGetLastError());
     return BN254_OK;
+}
+
+int bn254_check_points_dev(const uint64_t* g1, const uint64_t* g2, size_t n, int device, void* stream) {
+    if (n == 0) return BN254_OK;
+    if (!g1 || !g2 || n >= (1ull << 29)) return BN254_ERR_INVALID_ARG;
+    LaunchCtx c;
+    int rc = ctx_get(device, stream, 1, 1, &c);
+    if (rc) return rc;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_check_points, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, g1, g2, n, c.status);
+    HIPCHK(hipGetLastError());
+    return BN254_OK;
+}
+int bn254_check_points(const uint64_t* g1, const uint64_t* g2, size_t n, int device, void* stream) {
+    if (n == 0) return BN254_OK;
+    if (!g1 || !g2) return BN254_ERR_INVALID_ARG;
+    Stage s; uint64_t *d1, *d2; int rc;
+    if ((rc = s.init(device, stream)) || (rc = s.up(g1, 64 * n, &d1)) || (rc = s.up(g2, 128 * n, &d2))) return rc;
+    if ((rc = bn254_check_points_dev(d1, d2, n, device, stream))) return rc;
+    return bn254_last_status(device, stream);
 }
 
 int bn254_multi_pairing_check_batch_dev(const uint64_t* g1, const uint64_t* g2, uint8_t* verdict, size_t n_groups, size_t k, int device,

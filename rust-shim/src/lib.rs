@@ -18,6 +18,7 @@ extern "C" {
     fn bn254_multi_pairing_check_batch(g1: *const u64, g2: *const u64, verdict: *mut u8, n_groups: usize, k: usize, device: c_int,
                                        stream: *mut c_void) -> c_int;
     fn bn254_reserve(device: c_int, stream: *mut c_void, n: usize, k: usize) -> c_int;
+    fn bn254_check_points(g1: *const u64, g2: *const u64, n: usize, device: c_int, stream: *mut c_void) -> c_int;
     fn bn254_pairing_sharded(g1: *const u64, g2: *const u64, out: *mut u64, n: usize, n_devices: c_int) -> c_int;
     // device pointers on devices[0] (NULL: devices 0..n_devices-1); shard i runs on devices[i]; synchronous
     #[allow(dead_code)]
@@ -129,6 +130,15 @@ fn fq12_from_ark_words(w: &[u64]) -> Fq12 {
 /// Sizes the library's per-(device, stream) buffers for calls of up to `n` lanes x `k` pairs on device 0 / the NULL stream
 /// (the ones every function of this shim uses): no later call of that size allocates device memory.
 pub fn reserve(n: usize, k: usize) { ok(unsafe { bn254_reserve(0, core::ptr::null_mut(), n, k) }) }
+
+/// The reference never looks at `infinity` (its line functions read raw x / y, miller_loop_native.rs:10-44): an infinite input is outside
+/// its contract.  Callers that want it REPORTED use this: the flags of the structs first (no device work), then the engine's check of the
+/// coordinates (ark's affine identity is x = y = 0); `Err(-7)` = BN254_ERR_INFINITY.
+pub fn check_points(ps: &[G1Affine], qs: &[G2Affine]) -> Result<(), i32> {
+    if ps.iter().any(|p| p.infinity) || qs.iter().any(|q| q.infinity) { return Err(-7); }
+    let (g1, g2) = (pack_g1(ps), pack_g2(qs));
+    match unsafe { bn254_check_points(g1.as_ptr(), g2.as_ptr(), ps.len(), 0, core::ptr::null_mut()) } { 0 => Ok(()), rc => Err(rc) }
+}
 
 pub fn pairing_batch(ps: &[G1Affine], qs: &[G2Affine]) -> Vec<MyFq12> {
     assert_eq!(ps.len(), qs.len()); let n = ps.len();

@@ -329,3 +329,37 @@ def test_scratch_geometry():
     sb = pk.load_library().bn254_scratch_bytes
     assert sb(1 << 20, 1) == 512 << 20 and sb(1 << 20, 64) == 2560 << 20
     assert sb(1 << 20, 4) < sb(1 << 20, 5) < sb(1 << 20, 64)
+
+
+def test_points_at_infinity_get_a_distinct_status():
+    """'Infinity flags: out of contract -- return a distinct status'.  The reference never checks (its line functions read
+    raw x / y, /root/reference/src/miller_loop_native.rs:10-44); bn254_check_points flags ark's affine identity (x = y = 0) in either group."""
+    import torch
+    pk = H.pkg()
+    n = 1000
+    g1a, g2a = _pairs(n)
+    g1, g2 = H.to_soa(g1a, 8), H.to_soa(g2a, 16)
+    pk.check_points(g1, g2, n)                                    # clean batch: no error
+    bad1 = g1.copy().reshape(8, n)
+    bad1[:, 777] = 0
+    with pytest.raises(pk.Bn254Error) as ei:
+        pk.check_points(bad1.reshape(-1), g2, n)
+    assert ei.value.status == pk.ERR_INFINITY
+    bad2 = g2.copy().reshape(16, n)
+    bad2[:, n - 1] = 0
+    with pytest.raises(pk.Bn254Error) as ei:
+        pk.check_points(g1, bad2.reshape(-1), n)
+    assert ei.value.status == pk.ERR_INFINITY
+    bad3 = g2.copy().reshape(16, n)
+    bad3[:8, 5] = 0                                               # x = 0 alone is a legitimate coordinate
+    pk.check_points(g1, bad3.reshape(-1), n)
+    # device form: sticky status on the stream, cleared by last_status
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev)
+    d1 = torch.from_numpy(bad1.reshape(-1).view(np.int64)).to(dev)
+    d2 = torch.from_numpy(g2.view(np.int64)).to(dev)
+    pk.check_points_dev(d1, d2, n, 0, st)
+    with pytest.raises(pk.Bn254Error) as ei:
+        pk.last_status(0, st)
+    assert ei.value.status == pk.ERR_INFINITY
+    pk.last_status(0, st)                                         # cleared
