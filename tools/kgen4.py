@@ -127,6 +127,8 @@ class L1v4:
     @staticmethod
     def _coef(c):
         """operand text of a small integer coefficient: inline constant (-16..64) or the SGPR that holds it"""
+        if isinstance(c, tuple):            # ("v", register number): a per-lane coefficient (the lane-cooperative kernels' LIN rounds)
+            return f"v{c[1]}"
         if -16 <= c <= 64:
             return str(c)
         return {-30: f"s{S_M30}"}[c]
@@ -248,7 +250,7 @@ class L1v4:
         self.pool.free(acc, acc + 1, *m)
         self.pool.free(*d)
 
-    def kfips(self, kterms, sterms, out_re, out_im):
+    def kfips(self, kterms, sterms, out_re, out_im, inject=None):
         """(out_re, out_im) <- both components of the sum of the Fq2 products x y over kterms + sterms, divided by R' (one
         Montgomery reduction per component).  x = (x0, x1), y = (y0, y1): limb lists.
         kterms use KARATSUBA per limb pair: per column
@@ -265,7 +267,8 @@ class L1v4:
         products (up to 4 mx units each, 36 k mx in all), then U and W, which cancel most of them: with two-unit operands
         it may pass 2^63 in between.  That is harmless -- 64-bit sums are exact mod 2^64 and the value that is finally
         shifted out is the true one, <= 18 (k + s) mx -- and it is what the simulator's accumulator check verifies.
-        Result limb j is written after column j + NL (in place over a FIRST operand x is fine; never over a y)."""
+        Result limb j is written after column j + NL (in place over a FIRST operand x is fine; never over a y).
+        inject = (re limbs, im limbs): a normalised value that is ADDED to the result (its limbs enter the upper half of the sums)."""
         e = self.e
         nk = len(kterms)
         # a term may bring its difference vectors along -- (x, y, x1 - x0, y0 - y1) -- when the caller keeps them across passes
@@ -342,7 +345,12 @@ class L1v4:
                 else:
                     for i in range(c - (NL - 1), NL):
                         self._mad(acc, P, m[i], self.p[c - i], False)
+                    if inject is not None:
+                        self._mad(acc, P, inject[0 if acc == a0 else 1][c - NL], "1", False)
                     self._digit(acc, P, out[c - NL])
+        if inject is not None:
+            self._mad(a0, P0, inject[0][NL - 1], "1", False)
+            self._mad(a1, P1, inject[1][NL - 1], "1", False)
         e.emit(f"v_mov_b32_e32 v{out_re[NL - 1]}, v{a0}", vw=[out_re[NL - 1]])
         e.emit(f"v_mov_b32_e32 v{out_im[NL - 1]}, v{a1}", vw=[out_im[NL - 1]])
         self.pool.free(a0, a0 + 1, a1, a1 + 1, u, u + 1, w, w + 1, *m0, *m1)
@@ -361,7 +369,7 @@ class L1v4:
             # quotient estimate from the top limbs alone: the lower limbs shift the combination's top limb by at most
             # sum|coef| / 2 units of 2^232, i.e. the quotient by < 1e-5
             for terms, (acc, P) in zip(termss, accs):
-                if len(terms) == 1 and terms[0][0] == 1:
+                if len(terms) == 1 and terms[0][0] == 1 and not isinstance(terms[0][0], tuple):
                     q = self.pool.alloc()
                     self.e.emit(f"v_mov_b32_e32 v{q}, v{terms[0][1][NL - 1]}", vw=[q])
                 else:
