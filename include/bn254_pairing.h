@@ -86,6 +86,12 @@ size_t bn254_scratch_bytes(size_t n, size_t k);
  * slots -- for calls of up to n lanes (units) x k pairs.  Afterwards `_dev` calls of that size or smaller neither allocate
  * nor wait.  Does not wait for the stream either (buffers that must grow are retired, see STREAM). */
 int bn254_reserve(int device, void* stream, size_t n, size_t k);
+/* LATENCY PATH.  pairing() (src/pairing.rs:20-22) has two kernels behind bn254_pairing_batch[_dev]: the throughput kernel (one
+ * pairing per lane: 3.6 M dependent instructions, 6.3 ms however small the batch) and the lane-cooperative kernel (one pairing on
+ * sixteen lanes, four per wave: 0.57 M instructions deep; same values, bit for bit).  Batches of at most `n` pairings take the
+ * second one; 0 turns it off.  Process-wide; the default is the measured crossover. */
+void bn254_set_latency_threshold(size_t n);
+size_t bn254_get_latency_threshold(void);
 /* Scratch and the status word are kept per (device, stream), so calls on different streams are independent;
  * this frees what the library holds for `stream` (call it before destroying a stream you used). */
 int bn254_release_stream(int device, void* stream);

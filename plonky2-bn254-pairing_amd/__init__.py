@@ -83,6 +83,8 @@ _PROTOS = {
     "bn254_check_points_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "bn254_check_points": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "bn254_reserve": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t]),
+    "bn254_set_latency_threshold": (None, [ctypes.c_size_t]),
+    "bn254_get_latency_threshold": (ctypes.c_size_t, []),
     "bn254_fq12_mul_batch_dev": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "bn254_fq12_mul_batch": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "bn254_frobenius_map_batch_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
@@ -436,6 +438,15 @@ def check_points_dev(g1, g2, n, device=0, stream=None):
 def reserve(n, k=1, device=0, stream=None):
     """Sizes the per-(device, stream) buffers for `_dev` calls of up to n lanes x k pairs: no later call of that size allocates."""
     _check(load_library().bn254_reserve(device, _stream(stream), n, k), "reserve")
+
+
+def set_latency_threshold(n):
+    """Batches of at most n pairings take the lane-cooperative (latency) kernel; 0 turns it off (include/bn254_pairing.h)."""
+    load_library().bn254_set_latency_threshold(n)
+
+
+def get_latency_threshold():
+    return load_library().bn254_get_latency_threshold()
 
 
 def generate_pairs_dev(seed, g1_out, g2_out, n, device=0, stream=None):

@@ -10,6 +10,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -18,6 +19,7 @@
 #include "bn254_consts_gen.h"
 #include "gen_table_gen.h"
 #include "pairing_asm_gen.h"
+#include "cvm_asm_gen.h"
 #include "../../include/bn254_pairing.h"
 
 namespace {
@@ -25,6 +27,9 @@ constexpr int BLOCK = 256;                              // 4 waves, one per SIMD
 constexpr size_t LDS_BYTES = BN254_LDS_BYTES;           // 8 slots x 72 B x 256 lanes
 constexpr size_t SLOT_BYTES = BN254_SLOT_BYTES;         // one Fq2: 2 x 9 balanced 29-bit limbs
 constexpr size_t MAX_K = 64;                            // pairs per group of the multi-pairing kernels
+#ifndef BN254_LATENCY_THRESHOLD_DEFAULT
+#define BN254_LATENCY_THRESHOLD_DEFAULT 8192            // the measured crossover (profiles/r04_latency.json): 4.9 ms against 6.5 ms at 8192, 8.8 against 6.5 at 16384
+#endif
 
 // ------------------------------------------------------------------ kernels
 // Where a kernel's code starts matters: the same kernel text ran up to 3 % slower from one library build to the next (the
@@ -59,6 +64,20 @@ BN254_ASM_KERNEL(k_mpairing, BN254_ASM_MPAIRING)    // k pairs per lane, shared 
 BN254_ASM_KERNEL(k_mmiller, BN254_ASM_MMILLER)      // k pairs per lane, exact multi_miller_loop_native value
 BN254_ASM_KERNEL(k_op, BN254_ASM_OP)                // MyFq12 Mul / frobenius_map_native / pow_native (k = op | power << 8 | naf_len << 16)
 BN254_ASM_KERNEL(k_generate, BN254_ASM_GENERATE)    // synthetic subgroup points: g1 / g2 = outputs, f_in = table, out = seed
+
+// The LATENCY path of pairing() (src/pairing.rs:20-22): one pairing on sixteen lanes, four per wave, one wave per workgroup.  The
+// kernel is an interpreter of the round program in cvm_asm_gen.h (tools/cvm.py: the same Miller loop and final exponentiation,
+// scheduled over sixteen lanes: 0.57 M instructions deep instead of 3.6 M).  f_in = the device copy of the program blob.
+__global__ void __launch_bounds__(64) __attribute__((aligned(BN254_KERNEL_ALIGN)))
+k_cpairing(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in, uint64_t* out, uint32_t n, uint32_t k, uint4* scratch,
+           uint32_t gslot_stride, int* status) {
+    uint32_t tid = threadIdx.x, bid = blockIdx.x, grid = gridDim.x;
+    asm volatile(BN254_ASM_CPAIRING
+                 :
+                 : "s"(g1), "s"(g2), "s"(f_in), "s"(out), "s"(n), "s"(k), "s"(scratch), "s"(gslot_stride), "s"(status), "v"(tid), "s"(bid),
+                   "s"(grid)
+                 : BN254_CVM_CLOBBERS);
+}
 
 // verdict[i] = 1 iff Fq12 element i equals MyFq12::one (coeffs[0] = R mod p in ark's Montgomery limbs, the rest 0):
 // the check pattern of final_exp_native.rs:245-263 (a Groth16-style product of pairings == 1), one byte per group.
@@ -177,6 +196,7 @@ struct DeviceCtx {
     int n_cu = 0;
     std::mutex table_mu;       // the generator table upload (138 KB, blocking) has its own lock
     int32_t* gen_table = nullptr;
+    uint32_t* cvm_blob = nullptr;   // the latency path's round program (0.7 MB, uploaded on first use, same lock)
     std::map<hipStream_t, std::shared_ptr<StreamCtx>> streams;   // shared: a call keeps its context alive across a concurrent release
     std::mutex pipe_mu;        // one host-pointer pipeline at a time per device (its two workers fill the chip anyway)
     hipStream_t pipe_stream[2] = {nullptr, nullptr};   // the workers' private streams: created once, their scratch and staging kept
@@ -298,6 +318,30 @@ int ctx_get(int device, void* stream, size_t k, size_t n_items, LaunchCtx* out, 
 int launch_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, size_t power, const int8_t* naf_host, int naf_len,
               int device, void* stream);
 
+// Batches of at most this many pairings take the lane-cooperative kernel (bn254_set_latency_threshold; 0: never).
+std::atomic<size_t> g_latency_threshold{BN254_LATENCY_THRESHOLD_DEFAULT};
+
+int launch_cpairing(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n, int device, void* stream) {
+    LaunchCtx c;
+    int rc = ctx_get(device, stream, 1, 1, &c);          // the status word and the stream context; the kernel needs no scratch
+    if (rc) return rc;
+    DeviceCtx& d = g_ctx[device];
+    {
+        std::lock_guard<std::mutex> lk(d.table_mu);
+        if (!d.cvm_blob) {
+            uint32_t* t = nullptr;
+            if (hipMalloc(&t, sizeof(BN254_CVM_PAIRING_BLOB)) != hipSuccess) { (void)hipGetLastError(); return BN254_ERR_ALLOC; }
+            if (hipMemcpy(t, BN254_CVM_PAIRING_BLOB, sizeof(BN254_CVM_PAIRING_BLOB), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(t); return BN254_ERR_HIP; }
+            d.cvm_blob = t;
+        }
+    }
+    uint32_t grid = (uint32_t)((n + BN254_CVM_GROUPS - 1) / BN254_CVM_GROUPS);
+    hipLaunchKernelGGL(k_cpairing, dim3(grid), dim3(64), BN254_CVM_PAIRING_LDS_BYTES, (hipStream_t)stream, g1, g2, (const uint64_t*)d.cvm_blob, out,
+                       (uint32_t)n, 1u, c.scratch, c.stride, c.status);
+    HIPCHK(hipGetLastError());
+    return BN254_OK;
+}
+
 template <bool M, bool F>
 int launch_pairing(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in, uint64_t* out, size_t n_groups, size_t k, int device, void* stream) {
     if (n_groups == 0) return BN254_OK;
@@ -334,6 +378,7 @@ int launch_pairing(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in,
         if (F) return launch_pairing<false, true>(nullptr, nullptr, acc, out, n_groups, 1, device, stream);
         return BN254_OK;
     }
+    if (M && F && k == 1 && n_groups <= g_latency_threshold.load()) return launch_cpairing(g1, g2, out, n_groups, device, stream);
     LaunchCtx c;
     int rc = ctx_get(device, stream, k, (n_groups + BLOCK - 1) / BLOCK, &c);
     if (rc) return rc;
@@ -545,6 +590,9 @@ size_t bn254_scratch_bytes(size_t n, size_t k) {
     size_t kk = k > MAX_K ? MAX_K : k;                                // larger groups are walked in sub-groups of MAX_K pairs
     return BN254_SCRATCH_WG_CONTIGUOUS ? scratch_pitch(kk, grid) * grid : scratch_pitch(kk, grid) * scratch_slots(kk);
 }
+
+void bn254_set_latency_threshold(size_t n) { g_latency_threshold.store(n); }
+size_t bn254_get_latency_threshold(void) { return g_latency_threshold.load(); }
 
 int bn254_pairing_batch_dev(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n, int device, void* stream) {
     return launch_pairing<true, true>(g1, g2, nullptr, out, n, 1, device, stream);

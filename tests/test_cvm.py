@@ -1,0 +1,136 @@
+"""The lane-cooperative pairing (tools/cvm.py, tools/cvm_kernel.py) on the CPU: the Fq2 graph, its lowering to Fq operations and
+the scheduled sixteen-lane program against the Python restatement of the reference (oracle/bn254_pyref.py), and the interpreter
+kernel's generated assembly on the instruction simulator (sixteen lanes, run round by round: tools/cvm_sim.py)."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import bn254_pyref as R  # noqa: E402
+import cvm  # noqa: E402
+import cvm_kernel as CK  # noqa: E402
+import cvm_sim as CS  # noqa: E402
+import sched_model as SM  # noqa: E402
+
+P_PT = R.g1_mul(R.G1_GEN, 12345)
+Q_PT = R.g2_mul(R.G2_GEN, 67890)
+FLAT = [P_PT[0], P_PT[1], Q_PT[0][0], Q_PT[0][1], Q_PT[1][0], Q_PT[1][1]]
+
+
+def _graph(build, ins):
+    g = cvm.Graph()
+    g.const((0, 0))
+    g.const((1, 0))
+    iv = [g.inp(f"i{i}") for i in range(len(ins))]
+    g.outputs = build(g, iv)
+    return g.evaluate(ins)
+
+
+def test_graph_builders_against_the_schedule_model():
+    f = R.fq12_to_fp2s(R.miller_loop_native(Q_PT, P_PT))
+    b = [R.fq2_mul(x, (3, 5)) for x in f[::-1]]
+    assert _graph(lambda g, iv: g.fq12_mul(iv[:6], iv[6:]), f + b) == SM.fq12_mul(f, b)
+    assert _graph(lambda g, iv: g.fq12_sqr(iv), f) == SM.fq12_sqr(f)
+    assert _graph(lambda g, iv: g.fq12_inv(iv), f) == SM.fq12_inv(f)
+    for k in (1, 2, 3):
+        assert _graph(lambda g, iv: g.frobenius(iv, k), f) == SM.frobenius(f, k)
+    m = R.fq12_to_fp2s(R.easy_part(R.fq12_from_fp2s(f)))
+    assert _graph(lambda g, iv: g.cyc_sqr(iv), m) == SM.cyclotomic_sqr(m)
+    assert _graph(lambda g, iv: g.pow_x(iv), m) == SM.pow_x_cyclotomic(m)
+    L = (f[0], f[3], f[4])
+    assert _graph(lambda g, iv: g.mul_by_034(iv[:6], iv[6:]), f + list(L)) == SM.mul_by_034(f, L)
+    assert _graph(lambda g, iv: g.mul_by_235(iv[:6], iv[6:]), f + list(L)) == SM.mul_by_235(f, L)
+    # final_exp_native itself (the reference's function, not the model)
+    assert _graph(lambda g, iv: g.final_exp(iv), f) == R.fq12_to_fp2s(R.final_exp_native(R.fq12_from_fp2s(f)))
+
+
+def test_pairing_program_equals_the_reference_pairing():
+    """graph -> Fq operations -> sixteen-lane schedule with slot allocation: each level evaluates to pairing(P, Q)"""
+    want = R.fq12_to_fp2s(R.pairing_myfq12(P_PT, Q_PT))
+    g = cvm.build_pairing()
+    assert g.evaluate([(P_PT[0], 0), (P_PT[1], 0), Q_PT[0], Q_PT[1]]) == want
+    low = cvm.Lowered(g)
+    flat_want = [c for x in want for c in x]
+    assert low.evaluate(FLAT) == flat_want
+    assert max(v.bound for v in low.fv) <= cvm.Lowered.V_MAX
+    pr = cvm.Program(low, nr=CK.NR)
+    assert pr.run(FLAT) == flat_want
+    st = pr.stats()
+    assert st["rounds"] < 1400 and st["slots"] <= 256
+    # no slot is written in a round that still reads it (what lets the kernel do without barriers, and the simulator run lane by lane)
+    for rnd, (kind, take) in enumerate(pr.rounds):
+        written = {w.slot for v in take for w in (v, v.twin) if w is not None}
+        read = {s.slot for v in take for s in v.srcs()}
+        assert not (written & read), rnd
+
+
+def _mini():
+    g = cvm.Graph()
+    g.const((0, 0))
+    g.const((1, 0))
+    px, py, qx, qy = g.inp("px", real=True), g.inp("py", real=True), g.inp("qx"), g.inp("qy")
+    a = g.mul((qx, qy))
+    b = g.mul((qx, qy), (a, qx), (qy, qy), add=a)
+    c = g.lin((a, cvm.mxi()), (b, cvm.mk(-27)), (qx, cvm.CONJ), (qy, (3, -5, 7, 11)))
+    d = g.fq2_inv(c)
+    e_ = g.mul((d, px), (b, py))
+    f = g.mul((e_, g.const((12345, 67890))))
+    g.outputs = [a, b, c, d, e_, f]
+    return g
+
+
+def _sim(pr, want_flat):
+    blob = CK.make_blob(pr.encode())
+    lines = CK.VMKernel().build()
+    g1 = [w for c in P_PT for w in R.limbs4(R.to_mont(c))]
+    g2 = [w for c in (Q_PT[0][0], Q_PT[0][1], Q_PT[1][0], Q_PT[1][1]) for w in R.limbs4(R.to_mont(c))]
+    gmem, ms, rounds = CS.simulate(lines, blob, g1, g2)
+    out = []
+    for c in range(12):
+        v = 0
+        for l in range(4):
+            a = CS.OUTB + (c * 4 + l) * 8
+            v |= (gmem[a] | (gmem[a + 4] << 32)) << (64 * l)
+        out.append(R.from_mont(v))
+    assert out == [want_flat[2 * k] for k in range(6)] + [want_flat[2 * k + 1] for k in range(6)]
+    assert CS.STAT not in gmem                       # no zero divisor
+    assert max(m.max_acc for m in ms) < (1 << 63)
+    return ms, rounds
+
+
+def test_interpreter_kernel_every_round_kind_on_the_simulator():
+    low = cvm.Lowered(_mini())
+    pr = cvm.Program(low, nr=CK.NR)
+    kinds = {cvm.KIND_NAME[k] for k, _ in pr.rounds}
+    assert {"m2", "m6", "l4", "l8", "inv"} <= kinds
+    _sim(pr, low.evaluate(FLAT))
+
+
+def test_zero_divisor_raises_the_status_flag_on_the_simulator():
+    g = cvm.Graph()
+    g.const((0, 0))
+    g.const((1, 0))
+    px, py, qx, qy = g.inp("px", real=True), g.inp("py", real=True), g.inp("qx"), g.inp("qy")
+    z = g.lin((qx, cvm.ID), (qx, cvm.NEG))          # 0
+    g.outputs = [g.fq2_inv(z)] + [qx] * 5
+    pr = cvm.Program(cvm.Lowered(g), nr=CK.NR)
+    blob = CK.make_blob(pr.encode())
+    g1 = [w for c in P_PT for w in R.limbs4(R.to_mont(c))]
+    g2 = [w for c in (Q_PT[0][0], Q_PT[0][1], Q_PT[1][0], Q_PT[1][1]) for w in R.limbs4(R.to_mont(c))]
+    gmem, ms, rounds = CS.simulate(CK.VMKernel().build(), blob, g1, g2)
+    assert gmem.get(CS.STAT) == 1
+
+
+def test_whole_pairing_on_the_simulator():
+    """the shipped program (csrc/cvm_asm_gen.h) on sixteen simulated lanes: pairing(P, Q), bit for bit"""
+    low = cvm.Lowered(cvm.build_pairing())
+    pr = cvm.Program(low, nr=CK.NR)
+    want = [c for x in R.fq12_to_fp2s(R.pairing_myfq12(P_PT, Q_PT)) for c in x]
+    ms, rounds = _sim(pr, want)
+    assert rounds == len(pr.rounds) + 2
+    assert ms[0].count < 600_000                     # instructions per lane (the throughput kernel: 3.59 M)

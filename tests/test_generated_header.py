@@ -17,3 +17,12 @@ def test_committed_header_is_the_generator_output():
     import kgen4_prog as K4P
     for kw in (dict(generate=True), dict(do_miller=True, do_fexp=False, track=True)):
         assert K4P.KernelBuilder(**kw).build() == K4P.KernelBuilder(**kw).build(), "the generator is not deterministic"
+
+
+def test_committed_latency_header_is_the_generator_output():
+    """csrc/cvm_asm_gen.h (the lane-cooperative kernel and its round program) likewise"""
+    import gen_kernels
+    text, stats = gen_kernels.render_cvm()
+    with open(gen_kernels.OUT_CVM) as f:
+        committed = f.read()
+    assert text == committed, "cvm_asm_gen.h is stale: run python tools/gen_kernels.py"

@@ -1,0 +1,869 @@
+#!/usr/bin/env python3
+"""cvm.py -- the lane-cooperative ("latency") pairing: one pairing on EIGHT lanes instead of one.
+
+The throughput kernels (tools/kgen4_prog.py) put one pairing on one lane: 3.6 M dependent instructions, 6.3 ms however few
+pairings there are.  A single signature check wants the opposite trade: this file spreads ONE pairing over a group of eight
+lanes (eight groups per wave) and runs it as a table-driven sequence of ROUNDS.  In a round every lane of the group does one
+operation of the same kind on Fq2 values that live in an LDS slot array shared by the group:
+
+    MUL   dst <- x0 y0 [+ x1 y1 + x2 y2] [+ addend]        (one dual Karatsuba column pass, L1v4.kfips)
+    LIN   dst <- sum over up to four sources of a 2x2 small-integer matrix applied to (c0, c1), reduced to (-0.51 p, 0.51 p)
+    INV   dst <- (1 / src.c0, 0)                            (Fermat chain; sets the zero-divisor flag)
+
+Which slots and coefficients: a per-round, per-lane table row (32 bytes) in global memory.  The kernel is a small interpreter
+(tools/cvm_kernel.py); the PROGRAM -- the reference's pairing, miller_loop_native.rs:320-322 followed by final_exp_native.rs:209-213,
+in the schedule of tests/sched_model.py -- is data, produced here:
+
+    Graph      SSA builder over Fq2 values (the field tower, G2 steps, sparse products, cyclotomic squaring, Frobenius, inversion)
+    schedule   list scheduling of the DAG into rounds (critical path first), slot allocation by liveness
+    Program    rounds + constant pool; `run` executes it on big integers (the check of scheduling and allocation);
+               `encode` packs the table the kernel reads
+
+Nothing here is on the throughput path; tools/gen_kernels.py calls `build_tables()` and writes csrc/cvm_tables_gen.h.
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from asmcore import P_INT, BN_X, SIX_U_PLUS_2_NAF  # noqa: E402
+
+P = P_INT
+XI = (9, 1)
+NR = 8                      # lanes (roles) per pairing
+T_END, T_MUL1, T_MUL3, T_LIN, T_INV = 0, 1, 2, 3, 4
+COST = {"m1": 950, "m3": 2000, "lin": 420, "inv": 46000}     # instructions per round (scheduling weights; tools/cvm_kernel.py prints the real ones)
+MAX_LIN_SRC = 4
+SLOT_STRIDE = 80            # bytes per LDS slot (72 used: 2 x 9 limbs)
+
+
+# ------------------------------------------------------------------ Fq2 on integers (the emulator's arithmetic)
+def f2mul(a, b):
+    return ((a[0] * b[0] - a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
+
+
+def f2add(a, b):
+    return ((a[0] + b[0]) % P, (a[1] + b[1]) % P)
+
+
+def f2mat(m, s):
+    a, b, c, d = m
+    return ((a * s[0] + b * s[1]) % P, (c * s[0] + d * s[1]) % P)
+
+
+def f2pow(a, e):
+    r = (1, 0)
+    while e:
+        if e & 1:
+            r = f2mul(r, a)
+        a = f2mul(a, a)
+        e >>= 1
+    return r
+
+
+ID, NEG, CONJ, NCONJ = (1, 0, 0, 1), (-1, 0, 0, -1), (1, 0, 0, -1), (-1, 0, 0, 1)
+
+
+def mxi(k=1):
+    """matrix of multiplication by k (9 + u)"""
+    return (9 * k, -k, k, 9 * k)
+
+
+def mk(k):
+    return (k, 0, 0, k)
+
+
+class V:
+    __slots__ = ("id", "kind", "args", "bound", "users", "name", "real")
+
+    def __init__(self, id_, kind, args, bound):
+        self.id, self.kind, self.args, self.bound = id_, kind, args, bound
+        self.users, self.name, self.real = [], None, False
+
+    def srcs(self):
+        if self.kind in ("m1", "m3"):
+            t, add = self.args
+            return [v for xy in t for v in xy] + ([add] if add is not None else [])
+        if self.kind == "lin":
+            return [s for s, _ in self.args]
+        if self.kind == "inv":
+            return [self.args]
+        return []
+
+
+class Graph:
+    """SSA builder over Fq2 values (lowered to Fq operations, where the value bounds are tracked, by `Lowered`)."""
+
+    def __init__(self):
+        self.vals = []
+        self.consts = {}
+        self.inputs = []
+        self.outputs = []
+
+    def _new(self, kind, args, bound):
+        v = V(len(self.vals), kind, args, bound)
+        self.vals.append(v)
+        for s in v.srcs():
+            s.users.append(v)
+        return v
+
+    def inp(self, name, real=False):
+        v = self._new("in", None, 1.01)
+        v.name = name
+        v.real = real
+        self.inputs.append(v)
+        return v
+
+    def const(self, c):
+        c = (c[0] % P, c[1] % P)
+        if c not in self.consts:
+            v = self._new("const", c, 0.51)
+            self.consts[c] = v
+        return self.consts[c]
+
+    def mul(self, *terms, add=None):
+        assert 1 <= len(terms) <= 3
+        return self._new("m1" if len(terms) == 1 else "m3", (list(terms), add), 0)
+
+    def lin(self, *pairs):
+        assert 1 <= len(pairs) <= MAX_LIN_SRC
+        for s, m in pairs:
+            assert all(-128 <= c <= 127 for c in m)
+        return self._new("lin", list(pairs), 0)
+
+    def inv(self, x):
+        return self._new("inv", x, 4.2)
+
+    # -------------------------------------------------------------- Fq2 helpers
+    def xi(self, x, k=1):
+        return self.lin((x, mxi(k)))
+
+    def neg(self, x):
+        return self.lin((x, NEG))
+
+    def conj(self, x):
+        return self.lin((x, CONJ))
+
+    def fq2_inv(self, x):
+        """1/x = conj(x) / (c0^2 + c1^2): the norm as the product x conj(x) (its c1 is 0), one Fq inversion"""
+        xc = self.conj(x)
+        n = self.mul((x, xc))
+        return self.mul((xc, self.inv(n)))
+
+    # -------------------------------------------------------------- Fq6 / Fq12 (w-basis: six Fq2 coefficients, w^6 = xi)
+    def fq6_mul(self, a, b, ax=None):
+        """(a0 + a1 v + a2 v^2)(b0 + b1 v + b2 v^2), v^3 = xi: three sums of three products (ax = (xi a1, xi a2))"""
+        a1x, a2x = ax if ax is not None else (self.xi(a[1]), self.xi(a[2]))
+        return (self.mul((a[0], b[0]), (a1x, b[2]), (a2x, b[1])),
+                self.mul((a[0], b[1]), (a[1], b[0]), (a2x, b[2])),
+                self.mul((a[0], b[2]), (a[1], b[1]), (a[2], b[0])))
+
+    def fq12_mul(self, a, b, bx=None):
+        """dense product: c_k = sum_i a_i B(k - i), B(j) = b_j (j >= 0) or xi b_(j+6); two chained three-term sums per coefficient"""
+        if bx is None:
+            bx = [None] + [self.xi(b[j]) for j in range(1, 6)]
+
+        def B(k, i):
+            return b[k - i] if i <= k else bx[k - i + 6]
+        out = []
+        for k in range(6):
+            t = self.mul(*[(a[i], B(k, i)) for i in range(3)])
+            out.append(self.mul(*[(a[i], B(k, i)) for i in range(3, 6)], add=t))
+        return out
+
+    def fq12_mul_pre(self, b):
+        return [None] + [self.xi(b[j]) for j in range(1, 6)]
+
+    def fq12_sqr(self, f):
+        """complex squaring over Fq6 (tests/sched_model.py fq12_sqr): t = A0 A1, u = (A0 + A1)(A0 + v A1);
+        f^2 = (u - t - v t) + 2 t w: six three-term sums between two layers of linear combinations"""
+        A0, A1 = (f[0], f[2], f[4]), (f[1], f[3], f[5])
+        ax0 = (self.xi(A0[1]), self.xi(A0[2]))
+        t = self.fq6_mul(A0, A1, ax0)
+        s = tuple(self.lin((A0[i], ID), (A1[i], ID)) for i in range(3))                      # A0 + A1
+        sx = (self.lin((A0[1], mxi()), (A1[1], mxi())), self.lin((A0[2], mxi()), (A1[2], mxi())))
+        vA1 = (self.xi(A1[2]), A1[0], A1[1])                                                # v A1 = (xi a2, a0, a1)
+        r = (self.lin((A0[0], ID), (A1[2], mxi())), self.lin((A0[1], ID), (A1[0], ID)), self.lin((A0[2], ID), (A1[1], ID)))
+        del vA1
+        u = self.fq6_mul(s, r, sx)
+        # c0 part: u - t - v t ; v t = (xi t2, t0, t1)
+        e0 = self.lin((u[0], ID), (t[0], NEG), (t[2], mxi(-1)))
+        e1 = self.lin((u[1], ID), (t[1], NEG), (t[0], NEG))
+        e2 = self.lin((u[2], ID), (t[2], NEG), (t[1], NEG))
+        o = [self.lin((t[i], mk(2))) for i in range(3)]
+        return [e0, o[0], e1, o[1], e2, o[2]]
+
+    def fq12_conj(self, f):
+        return [f[i] if i % 2 == 0 else self.neg(f[i]) for i in range(6)]
+
+    def cyc_sqr(self, f):
+        """Granger-Scott squaring in the cyclotomic subgroup, three units (a, b) = (f0, f3), (f1, f4), (f2, f5):
+        P = (a + b)(a + xi b), t = a b;  a^2 + xi b^2 = P - (1 + xi) t;  outputs 3 (..) - 2 z and 6 t [xi] + 2 z"""
+        out = [None] * 6
+        for (ia, ib, iza, izb, x) in ((0, 3, 0, 3, False), (1, 4, 2, 5, False), (2, 5, 4, 1, True)):
+            a, b = f[ia], f[ib]
+            u = self.lin((a, ID), (b, ID))
+            s = self.lin((a, ID), (b, mxi()))
+            Pv = self.mul((u, s))
+            t = self.mul((a, b))
+            out[iza] = self.lin((Pv, mk(3)), (t, (-30, 3, -3, -30)), (f[iza], mk(-2)))
+            out[izb] = self.lin((t, mxi(6) if x else mk(6)), (f[izb], mk(2)))
+        return out
+
+    def frobenius(self, f, k):
+        """frobenius_map_native (final_exp_native.rs:17-54): conj^k of each coefficient times frob_coeffs(k)^i"""
+        g1 = f2pow(XI, (P ** k - 1) // 6)
+        out = []
+        for i in range(6):
+            g = f2pow(g1, i)
+            a = f[i]
+            if g == (1, 0):
+                out.append(self.conj(a) if k % 2 else a)
+                continue
+            if k % 2:
+                # conj(a) g: fold the conjugation into the constant where the constant is real or purely imaginary; else one LIN first
+                a = self.conj(a)
+            out.append(self.mul((a, self.const(g))))
+        return out
+
+    def fq6_inv(self, a):
+        a0, a1, a2 = a
+        a1x, a2x = self.xi(a1), self.xi(a2)
+        na0 = self.neg(a0)
+        t0 = self.mul((a0, a0), (self.neg(a1x), a2))
+        t1 = self.mul((a2x, a2), (na0, a1))
+        t2 = self.mul((a1, a1), (na0, a2))
+        n = self.mul((a0, t0), (a2x, t1), (a1x, t2))
+        ni = self.fq2_inv(n)
+        return (self.mul((t0, ni)), self.mul((t1, ni)), self.mul((t2, ni)))
+
+    def fq12_inv(self, f):
+        """ark Fq12 inverse through the Fq6 norm: 1 / (A0 + A1 w) = (A0 - A1 w) / (A0^2 - v A1^2)"""
+        A0, A1 = (f[0], f[2], f[4]), (f[1], f[3], f[5])
+        s0 = self.fq6_mul(A0, A0)
+        s1 = self.fq6_mul(A1, A1)
+        d = (self.lin((s0[0], ID), (s1[2], mxi(-1))), self.lin((s0[1], ID), (s1[0], NEG)), self.lin((s0[2], ID), (s1[1], NEG)))
+        di = self.fq6_inv(d)
+        r0 = self.fq6_mul(A0, di)
+        nA1 = tuple(self.neg(x) for x in A1)
+        r1 = self.fq6_mul(nA1, di)
+        return [r0[0], r1[0], r0[1], r1[1], r0[2], r1[2]]
+
+    # -------------------------------------------------------------- G2 steps and sparse products (tests/sched_model.py)
+    def dbl_step(self, Rp, px, py):
+        """homogeneous projective doubling, the point scaled by xi^2 (L1v4.r_dblstep); line (L0, L3, L4) (miller_loop_native.rs:30-44).
+        px, py: the G1 point's coordinates as Fq2 values (c1 = 0)."""
+        X, Y, Z = Rp
+        B = self.mul((Y, Y))
+        C = self.mul((Z, Z))
+        XX = self.mul((X, X))
+        XY = self.mul((X, Y))
+        YZ = self.mul((Y, Z))
+        # N = 9 C, xB = xi B, T = xB - 3 N, S = xB + 3 N, H = 2 Y Z
+        T = self.lin((B, mxi()), (C, mk(-27)))
+        S = self.lin((B, mxi()), (C, mk(27)))
+        N = self.lin((C, mk(9)))
+        N12 = self.lin((C, mk(-108)))
+        xB = self.xi(B)
+        xH4 = self.lin((YZ, mxi(8)))                 # 4 xi H
+        XYx2 = self.lin((XY, mxi(2)))
+        X3 = self.mul((XYx2, T))
+        Y3 = self.mul((S, S), (N, N12))
+        Z3 = self.mul((xB, xH4))
+        L0 = self.lin((B, mxi()), (C, mk(-9)))
+        H = self.lin((YZ, mk(2)))
+        L3 = self.mul((H, py))
+        XX3n = self.lin((XX, mk(-3)))
+        L4 = self.mul((XX3n, px))
+        return (X3, Y3, Z3), (L0, L3, L4)
+
+    def add_step(self, Rp, Q, px, py, nQy=None):
+        """mixed addition R + Q, line (L2, L3, L5) (miller_loop_native.rs:10-28)"""
+        X, Y, Z = Rp
+        x2, y2 = Q
+        ny2 = nQy if nQy is not None else self.neg(y2)
+        nx2 = self.neg(x2)
+        theta = self.mul((ny2, Z), add=Y)
+        mu = self.mul((nx2, Z), add=X)
+        L5 = self.mul((X, y2), (nx2, Y))
+        nmu = self.neg(mu)
+        L2 = self.mul((nmu, py))
+        L3 = self.mul((theta, px))
+        C = self.mul((theta, theta))
+        D = self.mul((mu, mu))
+        E = self.mul((mu, D))
+        F = self.mul((Z, C))
+        G = self.mul((X, D))
+        H = self.lin((E, ID), (F, ID), (G, mk(-2)))
+        GH = self.lin((G, ID), (H, NEG))
+        nE = self.neg(E)
+        X3 = self.mul((mu, H))
+        Y3 = self.mul((theta, GH), (nE, Y))
+        Z3 = self.mul((Z, E))
+        return (X3, Y3, Z3), (L2, L3, L5)
+
+    def mul_by_034(self, a, L):
+        b0, b3, b4 = L
+        b3x, b4x = self.xi(b3), self.xi(b4)
+        return [self.mul((a[0], b0), (a[3], b3x), (a[2], b4x)),
+                self.mul((a[1], b0), (a[4], b3x), (a[3], b4x)),
+                self.mul((a[2], b0), (a[5], b3x), (a[4], b4x)),
+                self.mul((a[3], b0), (a[0], b3), (a[5], b4x)),
+                self.mul((a[4], b0), (a[1], b3), (a[0], b4)),
+                self.mul((a[5], b0), (a[2], b3), (a[1], b4))]
+
+    def mul_by_235(self, a, L):
+        b2, b3, b5 = L
+        b2x, b3x, b5x = self.xi(b2), self.xi(b3), self.xi(b5)
+        return [self.mul((a[4], b2x), (a[3], b3x), (a[1], b5x)),
+                self.mul((a[5], b2x), (a[4], b3x), (a[2], b5x)),
+                self.mul((a[0], b2), (a[5], b3x), (a[3], b5x)),
+                self.mul((a[1], b2), (a[0], b3), (a[4], b5x)),
+                self.mul((a[2], b2), (a[1], b3), (a[5], b5x)),
+                self.mul((a[3], b2), (a[2], b3), (a[0], b5))]
+
+    # -------------------------------------------------------------- the reference's functions
+    def miller_loop(self, px, py, Q):
+        """miller_loop_native(Q, P) up to an Fq2 factor (projective lines; the final exponentiation removes it):
+        tests/sched_model.py miller_projective with one pair."""
+        enc = SIX_U_PLUS_2_NAF                        # the reference's digit table (miller_loop_native.rs:314-318), not the canonical NAF
+        one = self.const((1, 0))
+        nQy = self.neg(Q[1])
+        Rp = (Q[0], Q[1], one)
+        Rp, L = self.dbl_step(Rp, px, py)
+        zero = self.const((0, 0))
+        f = [L[0], zero, zero, L[1], L[2], zero]
+        for i in range(63, -1, -1):
+            if i != 63:
+                f = self.fq12_sqr(f)
+                Rp, L = self.dbl_step(Rp, px, py)
+                f = self.mul_by_034(f, L)
+            if enc[i] != 0:
+                Qs = (Q[0], Q[1]) if enc[i] == 1 else (Q[0], nQy)
+                Rp, L = self.add_step(Rp, Qs, px, py, nQy=nQy if enc[i] == 1 else Q[1])
+                f = self.mul_by_235(f, L)
+        c2, c3 = end_constants()
+        Q1 = (self.mul((self.conj(Q[0]), self.const(c2))), self.mul((self.conj(Q[1]), self.const(c3))))
+        nQ2 = (self.mul((self.conj(Q1[0]), self.const(c2))), self.mul((self.lin((Q1[1], NCONJ)), self.const(c3))))
+        Rp, L = self.add_step(Rp, Q1, px, py)
+        f = self.mul_by_235(f, L)
+        _, L = self.add_step(Rp, nQ2, px, py)
+        f = self.mul_by_235(f, L)
+        return f
+
+    def pow_x(self, a):
+        """pow_native(a, [BN_X]) for a in the cyclotomic subgroup: cyclotomic squarings, the inverse as the conjugate"""
+        naf = naf_of(BN_X)
+        top = max(i for i, z in enumerate(naf) if z)
+        assert naf[top] == 1
+        ac = self.fq12_conj(a)
+        pre = {1: (a, self.fq12_mul_pre(a)), -1: (ac, self.fq12_mul_pre(ac))}
+        res = a
+        for i in range(top - 1, -1, -1):
+            res = self.cyc_sqr(res)
+            if naf[i]:
+                b, bx = pre[naf[i]]
+                res = self.fq12_mul(res, b, bx)
+        return res
+
+    def final_exp(self, f):
+        """final_exp_native (final_exp_native.rs:209-213): easy part, then hard_part_BN_native (:130-169) in the kernels' schedule
+        (tests/sched_model.py final_exp_gpu)"""
+        f2 = self.fq12_mul(self.fq12_conj(f), self.fq12_inv(f))
+        m = self.fq12_mul(self.frobenius(f2, 2), f2)
+        mp, mp2, mp3 = self.frobenius(m, 1), self.frobenius(m, 2), self.frobenius(m, 3)
+        y0 = self.fq12_mul(mp, self.fq12_mul(mp2, mp3))
+        y1 = self.fq12_conj(m)
+        mx = self.pow_x(m)
+        mxp = self.frobenius(mx, 1)
+        mx2 = self.pow_x(mx)
+        mx2p = self.frobenius(mx2, 1)
+        y2 = self.frobenius(mx2, 2)
+        y5 = self.fq12_conj(mx2)
+        mx3 = self.pow_x(mx2)
+        mx3p = self.frobenius(mx3, 1)
+        y3 = self.fq12_conj(mxp)
+        y4 = self.fq12_conj(self.fq12_mul(mx, mx2p))
+        y6 = self.fq12_conj(self.fq12_mul(mx3, mx3p))
+        T0 = self.cyc_sqr(y6)
+        T0 = self.fq12_mul(T0, y4)
+        T0 = self.fq12_mul(T0, y5)
+        T1 = self.fq12_mul(y3, y5)
+        T1 = self.fq12_mul(T1, T0)
+        T0 = self.fq12_mul(y2, T0)
+        T1 = self.cyc_sqr(T1)
+        T1 = self.fq12_mul(T1, T0)
+        T1 = self.cyc_sqr(T1)
+        T0 = self.fq12_mul(T1, y1)
+        T1 = self.fq12_mul(T1, y0)
+        T0 = self.cyc_sqr(T0)
+        return self.fq12_mul(T0, T1)
+
+    # -------------------------------------------------------------- evaluation on integers (no schedule: the DAG's meaning)
+    def evaluate(self, inputs):
+        val = {}
+        for v, x in zip(self.inputs, inputs):
+            val[v.id] = (x[0] % P, x[1] % P)
+        for v in self.vals:
+            if v.kind == "const":
+                val[v.id] = v.args
+            elif v.kind in ("m1", "m3"):
+                t, add = v.args
+                acc = val[add.id] if add is not None else (0, 0)
+                for x, y in t:
+                    acc = f2add(acc, f2mul(val[x.id], val[y.id]))
+                val[v.id] = acc
+            elif v.kind == "lin":
+                acc = (0, 0)
+                for s, m in v.args:
+                    acc = f2add(acc, f2mat(m, val[s.id]))
+                val[v.id] = acc
+            elif v.kind == "inv":
+                val[v.id] = (pow(val[v.args.id][0], P - 2, P), 0)
+        return [val[o.id] for o in self.outputs]
+
+
+def naf_of(e):
+    out = []
+    while e:
+        if e & 1:
+            z = 2 - (e % 4)
+            e -= z
+        else:
+            z = 0
+        out.append(z)
+        e >>= 1
+    return out
+
+
+def end_constants():
+    """(xi^((p-1)/3), xi^((p-1)/2)) (miller_loop_native.rs:176-181)"""
+    return f2pow(XI, (P - 1) // 3), f2pow(XI, (P - 1) // 2)
+
+
+# ------------------------------------------------------------------ lowering to Fq operations
+class FV:
+    """one Fq value: kind in / const / mul / lin / inv, or `negof` (the negated twin its producer's lane writes beside the result)"""
+    __slots__ = ("id", "kind", "args", "bound", "users", "rnd", "slot", "height", "last", "twin", "cost")
+
+    def __init__(self, id_, kind, args, bound):
+        self.id, self.kind, self.args, self.bound = id_, kind, args, bound
+        self.users, self.rnd, self.slot, self.height, self.last, self.twin, self.cost = [], None, None, 0, -1, None, None
+
+    def srcs(self):
+        if self.kind == "mul":
+            t, add = self.args
+            return [v for xy in t for v in xy] + ([add] if add is not None else [])
+        if self.kind == "lin":
+            return [s for s, _ in self.args]
+        if self.kind in ("inv", "negof"):
+            return [self.args]
+        return []
+
+
+class Lowered:
+    """The Fq2 graph as Fq operations (one lane each):
+        mul  dst <- sum of up to six products x y (+ addend)             (fips: one Montgomery column pass)
+        lin  dst <- sum of up to eight coef * src, reduced to (-0.51 p, 0.51 p)
+        inv  dst <- 1 / src
+    An Fq2 value is (c0, c1) with c1 = None when it is known to be zero (G1 coordinates, inverses, real constants): products with
+    a zero component are never formed.  The c0 part of a product needs -x1 y1: any value may have a NEGATED TWIN, written by the
+    lane that produces it (nine subtractions) -- negations and conjugations of the graph cost nothing else.
+    Bounds (units of p): mul sum|x||y| / 169.6 + 0.51 (+ addend), lin 0.51; checked against the column pass's and the reducing
+    chain's limits."""
+    MUL_BUDGET = 300.0
+    LIN_BUDGET = 500.0
+    V_MAX = 6.0
+
+    def __init__(self, g):
+        self.g = g
+        self.fv = []
+        self.fconst = {}
+        self.inputs = []
+        self.map = {}            # Fq2 value id -> (c0 FV, c1 FV | None)
+        self.zero = self.const(0)
+        for v in g.vals:
+            self.map[v.id] = self._lower(v)
+        self.outputs = []
+        for o in g.outputs:
+            c0, c1 = self.map[o.id]
+            self.outputs += [c0, c1 if c1 is not None else self.zero]
+
+    def _new(self, kind, args, bound):
+        v = FV(len(self.fv), kind, args, bound)
+        assert bound <= self.V_MAX, bound
+        self.fv.append(v)
+        for s in dict.fromkeys(v.srcs()):
+            s.users.append(v)
+        return v
+
+    def const(self, c):
+        c %= P
+        if c not in self.fconst:
+            self.fconst[c] = self._new("const", c, 0.51)
+        return self.fconst[c]
+
+    def neg(self, x):
+        if x.kind == "const":
+            return self.const(-x.args)
+        if x.kind == "negof":
+            return x.args
+        if x.kind == "in":                       # no lane produces an input: its negation is an operation of its own
+            key = ("negin", x.id)
+            if key not in self.fconst:
+                self.fconst[key] = self._new("lin", [(x, -1)], 0.51)
+            return self.fconst[key]
+        if x.twin is None:
+            x.twin = self._new("negof", x, x.bound)
+        return x.twin
+
+    def _has_neg(self, x):
+        return x.kind in ("const", "negof") or x.twin is not None or ("negin", x.id) in self.fconst
+
+    def _mul(self, prods, add):
+        prods = [(x, y) for x, y in prods]
+        if not prods:
+            return add
+        load = sum(x.bound * y.bound for x, y in prods)
+        assert load <= self.MUL_BUDGET and len(prods) <= 6, (load, len(prods))
+        return self._new("mul", (prods, add), load / 169.6 + 0.51 + (add.bound if add is not None else 0))
+
+    def _lin(self, terms):
+        terms = [(s, c) for s, c in terms if c != 0]
+        if not terms:
+            return None
+        if len(terms) == 1 and terms[0][1] == 1:
+            return terms[0][0]                                     # a copy: the same value
+        if len(terms) == 1 and terms[0][1] == -1:
+            return self.neg(terms[0][0])
+        load = sum(s.bound * abs(c) for s, c in terms)
+        assert load <= self.LIN_BUDGET and len(terms) <= 8, (load, len(terms))
+        merged = {}
+        for s, c in terms:
+            merged[s.id] = (s, merged.get(s.id, (s, 0))[1] + c)
+        return self._new("lin", [t for t in merged.values() if t[1] != 0], 0.51)
+
+    def _lower(self, v):
+        if v.kind == "in":
+            c0 = self._new("in", v.name + ".c0", 1.01)
+            self.inputs.append(c0)
+            c1 = None
+            if not v.real:
+                c1 = self._new("in", v.name + ".c1", 1.01)
+                self.inputs.append(c1)
+            return c0, c1
+        if v.kind == "const":
+            return self.const(v.args[0]), (self.const(v.args[1]) if v.args[1] else None)
+        if v.kind in ("m1", "m3"):
+            t, add = v.args
+            p0, p1 = [], []
+            for x, y in t:
+                x0, x1 = self.map[x.id]
+                y0, y1 = self.map[y.id]
+                p0.append((x0, y0))
+                if x1 is not None and y1 is not None:
+                    if self._has_neg(y1) and not self._has_neg(x1):
+                        p0.append((x1, self.neg(y1)))
+                    else:
+                        p0.append((self.neg(x1), y1))
+                if y1 is not None:
+                    p1.append((x0, y1))
+                if x1 is not None:
+                    p1.append((x1, y0))
+            a0, a1 = self.map[add.id] if add is not None else (None, None)
+            return self._mul(p0, a0), self._mul(p1, a1)
+        if v.kind == "lin":
+            out = []
+            for h in range(2):
+                terms = []
+                for s, m in v.args:
+                    s0, s1 = self.map[s.id]
+                    terms.append((s0, m[2 * h]))
+                    if s1 is not None:
+                        terms.append((s1, m[2 * h + 1]))
+                out.append(self._lin(terms))
+            return (out[0] if out[0] is not None else self.zero), out[1]
+        if v.kind == "inv":
+            return self._new("inv", self.map[v.args.id][0], 1.01), None
+        raise ValueError(v.kind)
+
+    def evaluate(self, inputs):
+        """the Fq graph on integers: inputs in the order of self.inputs"""
+        val = {}
+        for v, x in zip(self.inputs, inputs):
+            val[v.id] = x % P
+        for v in self.fv:
+            if v.kind == "const":
+                val[v.id] = v.args
+            elif v.kind == "mul":
+                t, add = v.args
+                val[v.id] = (sum(val[x.id] * val[y.id] for x, y in t) + (val[add.id] if add is not None else 0)) % P
+            elif v.kind == "lin":
+                val[v.id] = sum(val[s.id] * c for s, c in v.args) % P
+            elif v.kind == "inv":
+                val[v.id] = pow(val[v.args.id], P - 2, P)
+            elif v.kind == "negof":
+                val[v.id] = -val[v.args.id] % P
+        return [val[o.id] for o in self.outputs]
+
+
+# ------------------------------------------------------------------ scheduling
+K_END, K_M2, K_M4, K_M6, K_L4, K_L8, K_INV = 0, 1, 2, 3, 4, 5, 6
+KIND_NAME = {K_M2: "m2", K_M4: "m4", K_M6: "m6", K_L4: "l4", K_L8: "l8", K_INV: "inv"}
+COST = {K_M2: 385, K_M4: 565, K_M6: 750, K_L4: 160, K_L8: 225, K_INV: 61000}       # instructions per round (tools/cvm_kernel.py prints the real ones)
+FAMILY = {K_M2: "m", K_M4: "m", K_M6: "m", K_L4: "l", K_L8: "l", K_INV: "i"}
+
+
+def op_kind(v):
+    if v.kind == "mul":
+        n = len(v.args[0])
+        return K_M2 if n <= 2 else K_M4 if n <= 4 else K_M6
+    if v.kind == "lin":
+        return K_L4 if len(v.args) <= 4 else K_L8
+    return K_INV
+
+
+class Program:
+    """rounds: [(kind, [FV] (one per lane, at most nr))] + slot numbers"""
+
+    def __init__(self, low, nr=16, greedy_fill=True):
+        self.low = low
+        self.nr = nr
+        self.greedy_fill = greedy_fill
+        self._prune()
+        self._heights()
+        self._schedule()
+        self._allocate()
+
+    def _prune(self):
+        low = self.low
+        live = set()
+        stack = list(low.outputs)
+        while stack:
+            v = stack.pop()
+            if v.id in live:
+                continue
+            live.add(v.id)
+            stack.extend(v.srcs())
+        live |= {low.zero.id, low.const(1).id}         # what idle lanes read
+        self.live = live
+        for v in low.fv:
+            v.users = [u for u in v.users if u.id in live]
+            if v.twin is not None and v.twin.id not in live:
+                v.twin = None
+        self.ops = [v for v in low.fv if v.id in live and v.kind in ("mul", "lin", "inv")]
+        for v in self.ops:
+            v.cost = op_kind(v)
+
+    @staticmethod
+    def _consumers(v):
+        """operations that wait for v's lane: its own users and its twin's"""
+        out = list(v.users)
+        if v.twin is not None:
+            out += v.twin.users
+        return [u for u in out if u.kind != "negof"]
+
+    def _heights(self):
+        for v in reversed(self.low.fv):
+            if v.id not in self.live or v.kind not in ("mul", "lin", "inv"):
+                continue
+            v.height = COST[v.cost] + max((u.height for u in self._consumers(v)), default=0)
+
+    @staticmethod
+    def _producer(s):
+        return s.args if s.kind == "negof" else s
+
+    def _schedule(self):
+        pending = {}
+        for v in self.ops:
+            pr = {self._producer(s).id for s in v.srcs()}
+            pending[v.id] = sum(1 for i in pr if self.low.fv[i].kind in ("mul", "lin", "inv"))
+        ready = [v for v in self.ops if pending[v.id] == 0]
+        rounds = []
+        done = 0
+        while done < len(self.ops):
+            assert ready
+            ready.sort(key=lambda v: -v.height)
+            fam = FAMILY[ready[0].cost]
+            cands = [v for v in ready if FAMILY[v.cost] == fam]
+            if not self.greedy_fill:
+                top = ready[0].cost
+                cands = [v for v in cands if v.cost <= top]
+            take = cands[:self.nr]
+            kind = max(v.cost for v in take)
+            rnd = len(rounds)
+            rounds.append((kind, take))
+            taken = {v.id for v in take}
+            ready = [v for v in ready if v.id not in taken]
+            for v in take:
+                v.rnd = rnd
+                done += 1
+                seen = set()
+                for u in self._consumers(v):
+                    if u.id in seen:
+                        continue
+                    seen.add(u.id)
+                    pending[u.id] -= 1
+                    if pending[u.id] == 0:
+                        ready.append(u)
+        self.rounds = rounds
+
+    def _allocate(self):
+        low = self.low
+        nxt = 0
+        for v in low.fv:                        # constants first, then inputs: fixed slots
+            if v.kind == "const" and v.id in self.live:
+                v.slot = nxt
+                nxt += 1
+        self.n_const = nxt
+        for v in low.inputs:
+            v.slot = nxt
+            nxt += 1
+        self.first_dyn = nxt
+        n_rounds = len(self.rounds)
+        for v in low.fv:
+            if v.id in self.live:
+                v.last = max((u.rnd for u in v.users if u.kind != "negof"), default=-1)
+        for o in low.outputs:
+            o.last = n_rounds
+        free, expire = [], {}
+        for rnd, (kind, take) in enumerate(self.rounds):
+            free += expire.pop(rnd, [])
+            free.sort(reverse=True)
+            for v in take:
+                for w in (v, v.twin):
+                    if w is None:
+                        continue
+                    if w.last <= rnd and w.last < n_rounds:
+                        assert w is v and v.twin is not None, (w.kind, w.id)     # a value only its twin's users want: it still needs a slot to be written to
+                    w.slot = free.pop() if free else nxt
+                    if w.slot == nxt:
+                        nxt += 1
+                    if w.last < n_rounds:
+                        expire.setdefault(max(w.last, rnd) + 1, []).append(w.slot)
+        self.n_slots = nxt                       # + 1: the trash slot idle lanes write
+
+    # -------------------------------------------------------------- execution of the scheduled program on integers
+    def run(self, inputs):
+        low = self.low
+        slots = {}
+        for v in low.fv:
+            if v.kind == "const" and v.id in self.live:
+                slots[v.slot] = v.args
+        for v, x in zip(low.inputs, inputs):
+            slots[v.slot] = x % P
+        for kind, take in self.rounds:
+            res = []
+            for v in take:
+                if v.kind == "mul":
+                    t, add = v.args
+                    acc = (sum(slots[x.slot] * slots[y.slot] for x, y in t) + (slots[add.slot] if add is not None else 0)) % P
+                elif v.kind == "lin":
+                    acc = sum(slots[s.slot] * c for s, c in v.args) % P
+                else:
+                    acc = pow(slots[v.args.slot], P - 2, P)
+                res.append((v.slot, acc))
+                if v.twin is not None:
+                    res.append((v.twin.slot, -acc % P))
+            for s, a in res:                     # a round reads everything before it writes anything (one wave, lockstep)
+                slots[s] = a
+        return [slots[o.slot] for o in low.outputs]
+
+    # -------------------------------------------------------------- the table
+    def encode(self):
+        """-> (kinds: one int per round + K_END, rows: per round nr x 8 dwords, consts: list of Fq integers, inputs / outputs: slots)
+        row layout (eight dwords per lane per round; slot numbers, 16 bits each):
+          mul:  dw0..5 = x_i | y_i << 16 (six products), dw6 = addend | dst << 16, dw7 = twin | 0 << 16
+          lin:  dw0..3 = s_2i | s_(2i+1) << 16 (eight sources), dw4..5 = eight int8 coefficients, dw6 = _ | dst << 16, dw7 = twin
+          inv:  dw0 = src, dw6 = _ | dst << 16, dw7 = twin
+        Unused products / sources name the ZERO slot; lanes without work and results without a twin write the TRASH slot."""
+        zero = self.low.zero.slot
+        one = self.low.const(1).slot
+        assert one is not None
+        trash = self.n_slots
+        kinds, rows = [], []
+        for kind, take in self.rounds:
+            kinds.append(kind)
+            row = []
+            for r in range(self.nr):
+                dw = [0] * 8
+                v = take[r] if r < len(take) else None
+                dst = v.slot if v is not None else trash
+                twin = v.twin.slot if v is not None and v.twin is not None else trash
+                dw[7] = twin
+                if FAMILY[kind] == "m":
+                    t, add = v.args if v is not None else ([], None)
+                    for i in range(6):
+                        x, y = (t[i][0].slot, t[i][1].slot) if i < len(t) else (zero, zero)
+                        dw[i] = x | y << 16
+                    dw[6] = (add.slot if add is not None else zero) | dst << 16
+                elif FAMILY[kind] == "l":
+                    ss, co = [zero] * 8, [0] * 8
+                    for i, (s, c) in enumerate(v.args if v is not None else []):
+                        ss[i], co[i] = s.slot, c
+                        assert -128 <= c <= 127
+                    for i in range(4):
+                        dw[i] = ss[2 * i] | ss[2 * i + 1] << 16
+                    dw[4] = sum((co[j] & 0xFF) << (8 * j) for j in range(4))
+                    dw[5] = sum((co[4 + j] & 0xFF) << (8 * j) for j in range(4))
+                    dw[6] = dst << 16
+                else:
+                    dw[0] = v.args.slot if v is not None else one
+                    dw[6] = dst << 16
+                row.append(dw)
+            rows.append(row)
+        kinds.append(K_END)
+        consts = [None] * self.n_const
+        for v in self.low.fv:
+            if v.kind == "const" and v.id in self.live:
+                consts[v.slot] = v.args
+        return {"kinds": kinds, "rows": rows, "consts": consts, "inputs": [v.slot for v in self.low.inputs],
+                "outputs": [v.slot for v in self.low.outputs], "n_slots": self.n_slots + 1, "nr": self.nr}
+
+    def stats(self):
+        from collections import Counter
+        c = Counter(KIND_NAME[k] for k, _ in self.rounds)
+        instr = sum(COST[k] for k, _ in self.rounds)
+        fill = sum(len(t) for _, t in self.rounds) / (self.nr * len(self.rounds))
+        return {"rounds": len(self.rounds), "by_kind": dict(c), "instr_est": instr, "fill": round(fill, 3), "slots": self.n_slots + 1,
+                "consts": self.n_const, "ops": len(self.ops)}
+
+
+# ------------------------------------------------------------------ the programs
+def build_pairing():
+    """inputs: P.x, P.y (c1 = 0), Q.x, Q.y  ->  outputs: the six Fq2 coefficients of pairing(P, Q) in MyFq12 order"""
+    g = Graph()
+    g.const((0, 0))
+    g.const((1, 0))
+    px, py, qx, qy = g.inp("px", real=True), g.inp("py", real=True), g.inp("qx"), g.inp("qy")
+    f = g.miller_loop(px, py, (qx, qy))
+    g.outputs = g.final_exp(f)
+    return g
+
+
+def build_final_exp():
+    g = Graph()
+    g.const((0, 0))
+    g.const((1, 0))
+    f = [g.inp(f"f{i}") for i in range(6)]
+    g.outputs = g.final_exp(f)
+    return g
+
+
+def build_fq12_mul():
+    g = Graph()
+    g.const((0, 0))
+    g.const((1, 0))
+    a = [g.inp(f"a{i}") for i in range(6)]
+    b = [g.inp(f"b{i}") for i in range(6)]
+    g.outputs = g.fq12_mul(a, b)
+    return g
+
+
+if __name__ == "__main__":
+    import time
+    for name, fn in (("fq12_mul", build_fq12_mul), ("final_exp", build_final_exp), ("pairing", build_pairing)):
+        for nr in (16, 32):
+            for gf in (True, False):
+                t0 = time.time()
+                pr = Program(Lowered(fn()), nr=nr, greedy_fill=gf)
+                print(name, nr, gf, pr.stats(), f"{time.time() - t0:.1f} s")

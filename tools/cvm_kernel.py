@@ -1,0 +1,392 @@
+#!/usr/bin/env python3
+"""cvm_kernel.py -- the interpreter kernel of the lane-cooperative pairing (tools/cvm.py has the design and the program).
+
+One wave per workgroup, GROUPS = 4 pairings per wave, NR = 16 lanes per pairing.  Every lane executes the same instruction stream;
+what differs per lane is its table row (which LDS slots it reads and writes).  Per round:
+
+    wait for the row / kind prefetched during the previous round, start the loads of the next ones
+    branch on the round's kind (scalar):  m2 / m4 / m6: one Montgomery column pass over 2 / 4 / 6 limb-vector products (+ addend)
+                                          l4 / l8:      one reducing 64-bit chain over 4 / 8 (coefficient, source) pairs
+                                          inv:          the Fermat chain (sliding window, as KernelBuilder._fq_inv)
+    write the result (and its negation, the `twin`) to the LDS slots the row names
+
+LDS: per group n_slots x 48 bytes (nine limbs + a pad dword, 16-byte aligned for the 128-bit accesses).  A wave's LDS operations
+execute in order, and the four groups never touch each other's slots, so no barrier is needed; the schedule guarantees that no slot
+is written in the round that reads it last (tools/cvm.py: Program._allocate).
+
+asm operands: %0 g1  %1 g2  %2 program blob  %3 out  %4 n  %8 status  %9 threadIdx.x  %10 blockIdx.x   (the throughput kernels' list;
+%5, %6, %7, %11 unused).  Field arithmetic: tools/kgen4.py L1v4 on an explicit register plan (below).
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from asmcore import Emitter, Pool, P_INT  # noqa: E402
+import kgen4 as K4  # noqa: E402
+from kgen4 import NL, L1v4, hx, bal_limbs, S_P, S_N0, S_REDN, S_M30, P_L, N0P, REDN_C, S_RET1  # noqa: E402
+import cvm  # noqa: E402
+
+NR = 16
+GROUPS = 4
+SLOT_BYTES = 48
+ROW_DW = 8
+HDR_DW = 40            # n_rounds, n_const, kinds_off, rows_off, consts_off, n_slots, trash, n_in, 16 input slots, 16 output slots
+CONST_DW = 10
+
+
+def OP(i):
+    """operand block i: v[10 i : 10 i + 9] (nine limbs + the pad dword of the 8-byte tail access)"""
+    return list(range(10 * i, 10 * i + NL))
+
+
+OUT0, NEG0 = 130, 140
+POOL_FIRST, POOL_LAST = 150, 219
+ROW, ROWN = 220, 228
+V_LBASE, V_ROWOFF, V_ROLE, V_ITEM8, V_FLAG, V_T0, V_DST, V_TWIN, V_VALID, V_T1 = 236, 237, 238, 239, 240, 241, 242, 243, 244, 245
+S_BLOB, S_ROWS, S_NROUNDS, S_KIND, S_KINDS, S_KNEXT, S_NCONST, S_NSLOTS, S_TMP = "s[48:49]", "s[50:51]", 52, 53, "s[62:63]", 64, 65, 66, 67
+S_CONSTS, S_G1, S_G2, S_OUT, S_N, S_NSTRIDE, S_STATUS = "s[68:69]", "s[70:71]", "s[72:73]", "s[74:75]", 76, 77, "s[78:79]"
+S_H = 80               # s80..s87: header words / scratch
+S_CNT = 88
+S_SAVE = "s[60:61]"
+
+
+class VMKernel:
+    def __init__(self):
+        self.e = Emitter()
+        self.sizes = {}
+
+    def l1(self):
+        g = L1v4(self.e)
+        g.pool = Pool(POOL_FIRST, POOL_LAST)
+        return g
+
+    # -------------------------------------------------------------- small helpers
+    def slot_addr(self, dst, row_reg, hi):
+        e = self.e
+        if hi:
+            e.emit(f"v_lshrrev_b32_e32 v{V_T0}, 16, v{row_reg}", vw=[V_T0])
+        else:
+            e.emit(f"v_and_b32_e32 v{V_T0}, 0xffff, v{row_reg}", vw=[V_T0])
+        e.emit(f"v_mad_u32_u24 v{dst}, v{V_T0}, {SLOT_BYTES}, v{V_LBASE}", vw=[dst])
+
+    def lds_load(self, blk0, addr):
+        e = self.e
+        e.emit(f"ds_read_b128 v[{blk0}:{blk0 + 3}], v{addr}", kind="lds", vw=list(range(blk0, blk0 + 4)))
+        e.emit(f"ds_read_b128 v[{blk0 + 4}:{blk0 + 7}], v{addr} offset:16", kind="lds", vw=list(range(blk0 + 4, blk0 + 8)))
+        e.emit(f"ds_read_b64 v[{blk0 + 8}:{blk0 + 9}], v{addr} offset:32", kind="lds", vw=[blk0 + 8, blk0 + 9])
+
+    def lds_store(self, addr, blk0):
+        e = self.e
+        e.emit(f"ds_write_b128 v{addr}, v[{blk0}:{blk0 + 3}]", kind="lds")
+        e.emit(f"ds_write_b128 v{addr}, v[{blk0 + 4}:{blk0 + 7}] offset:16", kind="lds")
+        e.emit(f"ds_write_b64 v{addr}, v[{blk0 + 8}:{blk0 + 9}] offset:32", kind="lds")
+
+    def operand(self, i, row_reg, hi):
+        """operand block i <- the slot named by one half of a row dword"""
+        self.slot_addr(V_T1, row_reg, hi)
+        self.lds_load(10 * i, V_T1)
+
+    def dst_addrs(self):
+        self.slot_addr(V_DST, ROW + 6, True)
+        self.slot_addr(V_TWIN, ROW + 7, False)
+
+    # -------------------------------------------------------------- prologue
+    def prologue(self):
+        e = self.e
+        e.salu(f"s_mov_b64 {S_G1}, %0")
+        e.salu(f"s_mov_b64 {S_G2}, %1")
+        e.salu(f"s_mov_b64 {S_BLOB}, %2")
+        e.salu(f"s_mov_b64 {S_OUT}, %3")
+        e.salu(f"s_mov_b32 s{S_N}, %4")
+        e.salu(f"s_mov_b64 {S_STATUS}, %8")
+        e.salu(f"s_mov_b32 s{S_TMP}, %10")
+        for i, dst in enumerate((S_NROUNDS, S_NCONST, S_H, S_H + 1, S_H + 2, S_NSLOTS, S_H + 3)):
+            e.salu(f"s_load_dword s{dst}, {S_BLOB}, 0x{4 * i:x}")
+        for i in range(NL):
+            e.salu(f"s_mov_b32 s{S_P + i}, {hx(P_L[i])}")
+        e.salu(f"s_mov_b32 s{S_N0}, 0x{N0P:x}")
+        e.salu(f"s_mov_b32 s{S_REDN}, 0x{REDN_C:x}")
+        e.salu(f"s_mov_b32 s{S_M30}, -30")
+        e.salu(f"s_lshl_b32 s{S_NSTRIDE}, s{S_N}, 3")
+        e.emit(f"v_and_b32_e32 v{V_ROLE}, {NR - 1}, %9", vw=[V_ROLE])
+        e.emit(f"v_lshrrev_b32_e32 v{V_T0}, 4, %9", vw=[V_T0])                             # group of the lane
+        e.salu(f"s_lshl_b32 s{S_TMP}, s{S_TMP}, 2")
+        e.emit(f"v_add_u32_e32 v{V_ITEM8}, s{S_TMP}, v{V_T0}", vw=[V_ITEM8])                # item = block * 4 + group
+        e.emit(f"v_cmp_gt_u32_e32 vcc, s{S_N}, v{V_ITEM8}", w=["vcc"])
+        e.emit(f"v_cndmask_b32_e64 v{V_VALID}, 0, 1, vcc", r=["vcc"], vw=[V_VALID])
+        e.salu(f"s_sub_u32 s{S_TMP}, s{S_N}, 1")
+        e.emit(f"v_min_u32_e32 v{V_ITEM8}, s{S_TMP}, v{V_ITEM8}", vw=[V_ITEM8])             # lanes past the end redo the last item (they never store)
+        e.emit(f"v_lshlrev_b32_e32 v{V_ITEM8}, 3, v{V_ITEM8}", vw=[V_ITEM8])
+        e.raw("s_waitcnt lgkmcnt(0)")
+        e.salu(f"s_mul_i32 s{S_TMP}, s{S_NSLOTS}, {SLOT_BYTES}")
+        e.emit(f"v_mul_lo_u32 v{V_LBASE}, v{V_T0}, s{S_TMP}", vw=[V_LBASE])
+        e.emit(f"v_lshlrev_b32_e32 v{V_ROWOFF}, 5, v{V_ROLE}", vw=[V_ROWOFF])
+        e.emit(f"v_mov_b32_e32 v{V_FLAG}, 0", vw=[V_FLAG])
+        for r in (OUT0 + 9, NEG0 + 9):
+            e.emit(f"v_mov_b32_e32 v{r}, 0", vw=[r])
+        e.salu(f"s_add_u32 s62, s48, s{S_H}")                # kinds
+        e.salu("s_addc_u32 s63, s49, 0")
+        e.salu(f"s_add_u32 s50, s48, s{S_H + 1}")            # rows
+        e.salu("s_addc_u32 s51, s49, 0")
+        e.salu(f"s_add_u32 s68, s48, s{S_H + 2}")            # constants
+        e.salu("s_addc_u32 s69, s49, 0")
+        # ---- constant pool -> the group's slots [0, n_const): lane r copies constants r, r + 16, ... (clamped: the last one again)
+        e.emit(f"v_mov_b32_e32 v{V_T1}, v{V_ROLE}", vw=[V_T1])
+        e.salu(f"s_add_u32 s{S_CNT}, s{S_NCONST}, {NR - 1}")
+        e.salu(f"s_lshr_b32 s{S_CNT}, s{S_CNT}, 4")
+        e.salu(f"s_sub_u32 s{S_TMP}, s{S_NCONST}, 1")
+        e.label("LC_const_%=")
+        e.emit(f"v_min_u32_e32 v{V_T0}, s{S_TMP}, v{V_T1}", vw=[V_T0])
+        e.emit(f"v_mul_u32_u24_e32 v{V_DST}, {4 * CONST_DW}, v{V_T0}", vw=[V_DST])
+        e.emit(f"global_load_dwordx4 v[0:3], v{V_DST}, {S_CONSTS}", kind="vmem", vw=[0, 1, 2, 3])
+        e.emit(f"global_load_dwordx4 v[4:7], v{V_DST}, {S_CONSTS} offset:16", kind="vmem", vw=[4, 5, 6, 7])
+        e.emit(f"global_load_dwordx2 v[8:9], v{V_DST}, {S_CONSTS} offset:32", kind="vmem", vw=[8, 9])
+        e.emit(f"v_mad_u32_u24 v{V_TWIN}, v{V_T0}, {SLOT_BYTES}, v{V_LBASE}", vw=[V_TWIN])
+        e.raw("s_waitcnt vmcnt(0)")
+        self.lds_store(V_TWIN, 0)
+        e.emit(f"v_add_u32_e32 v{V_T1}, {NR}, v{V_T1}", vw=[V_T1])
+        e.salu(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
+        e.salu(f"s_cmp_lg_u32 s{S_CNT}, 0")
+        e.salu("s_cbranch_scc1 LC_const_%=")
+        # ---- inputs: lane r < 6 converts Fq number r of (P.x, P.y, Q.x.c0, Q.x.c1, Q.y.c0, Q.y.c1); the others write the trash slot
+        # both sources are read by every lane (clamped indices) and the right one kept: no divergent addressing
+        e.emit(f"v_min_u32_e32 v{V_T0}, 1, v{V_ROLE}", vw=[V_T0])                           # G1: Fq 0, 1
+        e.emit(f"v_lshlrev_b32_e32 v{V_T0}, 2, v{V_T0}", vw=[V_T0])
+        e.emit(f"v_mul_lo_u32 v{V_T0}, v{V_T0}, s{S_NSTRIDE}", vw=[V_T0])
+        e.emit(f"v_add_u32_e32 v{V_T0}, v{V_T0}, v{V_ITEM8}", vw=[V_T0])
+        for l in range(4):
+            e.emit(f"global_load_dwordx2 v[{2 * l}:{2 * l + 1}], v{V_T0}, {S_G1}", kind="vmem", vw=[2 * l, 2 * l + 1])
+            if l < 3:
+                e.emit(f"v_add_u32_e32 v{V_T0}, s{S_NSTRIDE}, v{V_T0}", vw=[V_T0])
+        e.emit(f"v_max_u32_e32 v{V_T0}, 2, v{V_ROLE}", vw=[V_T0])                           # G2: Fq (r - 2) clamped to 0..3
+        e.emit(f"v_min_u32_e32 v{V_T0}, 5, v{V_T0}", vw=[V_T0])
+        e.emit(f"v_subrev_u32_e32 v{V_T0}, 2, v{V_T0}", vw=[V_T0])
+        e.emit(f"v_lshlrev_b32_e32 v{V_T0}, 2, v{V_T0}", vw=[V_T0])
+        e.emit(f"v_mul_lo_u32 v{V_T0}, v{V_T0}, s{S_NSTRIDE}", vw=[V_T0])
+        e.emit(f"v_add_u32_e32 v{V_T0}, v{V_T0}, v{V_ITEM8}", vw=[V_T0])
+        for l in range(4):
+            e.emit(f"global_load_dwordx2 v[{10 + 2 * l}:{11 + 2 * l}], v{V_T0}, {S_G2}", kind="vmem", vw=[10 + 2 * l, 11 + 2 * l])
+            if l < 3:
+                e.emit(f"v_add_u32_e32 v{V_T0}, s{S_NSTRIDE}, v{V_T0}", vw=[V_T0])
+        e.emit(f"v_lshlrev_b32_e32 v{V_T1}, 2, v{V_ROLE}", vw=[V_T1])
+        e.emit(f"global_load_dword v{V_DST}, v{V_T1}, {S_BLOB} offset:32", kind="vmem", vw=[V_DST])       # the lane's input slot
+        e.raw("s_waitcnt vmcnt(0)")
+        e.emit(f"v_cmp_gt_u32_e32 vcc, 2, v{V_ROLE}", w=["vcc"])
+        for i in range(8):
+            e.emit(f"v_cndmask_b32_e32 v{i}, v{10 + i}, v{i}, vcc", r=["vcc"], vw=[i])
+        self.l1().r_cvtin()
+        e.emit("v_mov_b32_e32 v9, 0", vw=[9])
+        e.emit(f"v_mad_u32_u24 v{V_DST}, v{V_DST}, {SLOT_BYTES}, v{V_LBASE}", vw=[V_DST])
+        self.lds_store(V_DST, 0)
+        # ---- first row / kind
+        e.salu(f"s_load_dword s{S_KNEXT}, {S_KINDS}, 0x0")
+        e.emit(f"global_load_dwordx4 v[{ROWN}:{ROWN + 3}], v{V_ROWOFF}, {S_ROWS}", kind="vmem", vw=list(range(ROWN, ROWN + 4)))
+        e.emit(f"global_load_dwordx4 v[{ROWN + 4}:{ROWN + 7}], v{V_ROWOFF}, {S_ROWS} offset:16", kind="vmem", vw=list(range(ROWN + 4, ROWN + 8)))
+
+    # -------------------------------------------------------------- the round loop
+    def round_loop(self):
+        e = self.e
+        e.label("LC_round_%=")
+        e.raw("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        e.salu(f"s_mov_b32 s{S_KIND}, s{S_KNEXT}")
+        for i in range(ROW_DW):
+            e.emit(f"v_mov_b32_e32 v{ROW + i}, v{ROWN + i}", vw=[ROW + i])
+        e.salu(f"s_cmp_eq_u32 s{S_KIND}, {cvm.K_END}")
+        e.salu("s_cbranch_scc1 LC_end_%=")
+        # prefetch: the table has one row more than rounds (the END row), so the last prefetch stays inside it
+        e.salu("s_add_u32 s62, s62, 4")
+        e.salu("s_addc_u32 s63, s63, 0")
+        e.salu(f"s_add_u32 s50, s50, {NR * ROW_DW * 4}")
+        e.salu("s_addc_u32 s51, s51, 0")
+        e.salu(f"s_load_dword s{S_KNEXT}, {S_KINDS}, 0x0")
+        e.emit(f"global_load_dwordx4 v[{ROWN}:{ROWN + 3}], v{V_ROWOFF}, {S_ROWS}", kind="vmem", vw=list(range(ROWN, ROWN + 4)))
+        e.emit(f"global_load_dwordx4 v[{ROWN + 4}:{ROWN + 7}], v{V_ROWOFF}, {S_ROWS} offset:16", kind="vmem", vw=list(range(ROWN + 4, ROWN + 8)))
+        for kind in (cvm.K_M6, cvm.K_L4, cvm.K_M2, cvm.K_M4, cvm.K_L8):
+            e.salu(f"s_cmp_eq_u32 s{S_KIND}, {kind}")
+            e.salu(f"s_cbranch_scc1 LC_k{kind}_%=")
+        e.salu(f"s_branch LC_k{cvm.K_INV}_%=")
+
+    def tail(self):
+        """result in OUT -> dst slot, its negation -> twin slot; next round"""
+        e = self.e
+        e.label("LC_tail_%=")
+        for i in range(NL):
+            e.emit(f"v_sub_u32_e32 v{NEG0 + i}, 0, v{OUT0 + i}", vw=[NEG0 + i])
+        self.lds_store(V_DST, OUT0)
+        self.lds_store(V_TWIN, NEG0)
+        e.salu("s_branch LC_round_%=")
+
+    def mul_handler(self, kind, nprod):
+        e = self.e
+        n0 = len(e.ins)
+        e.label(f"LC_k{kind}_%=")
+        for i in range(nprod):
+            self.operand(2 * i, ROW + i, False)
+            self.operand(2 * i + 1, ROW + i, True)
+        self.operand(12, ROW + 6, False)
+        self.dst_addrs()
+        e.raw("s_waitcnt lgkmcnt(0)")
+        g = self.l1()
+        out = list(range(OUT0, OUT0 + NL))
+        g.fips([(OP(2 * i), OP(2 * i + 1)) for i in range(nprod)], out, inject=[(OP(12), 1)])
+        e.salu("s_branch LC_tail_%=")
+        self.sizes[cvm.KIND_NAME[kind]] = len(e.ins) - n0
+
+    def lin_handler(self, kind, nsrc):
+        e = self.e
+        n0 = len(e.ins)
+        e.label(f"LC_k{kind}_%=")
+        for i in range(nsrc):
+            self.operand(i, ROW + i // 2, i % 2 == 1)
+        self.dst_addrs()
+        g = self.l1()
+        co = [g.pool.alloc() for _ in range(nsrc)]
+        for i in range(nsrc):
+            e.emit(f"v_bfe_i32 v{co[i]}, v{ROW + 4 + i // 4}, {8 * (i % 4)}, 8", vw=[co[i]])
+        e.raw("s_waitcnt lgkmcnt(0)")
+        out = list(range(OUT0, OUT0 + NL))
+        g.lincomb([out], [[(("v", co[i]), OP(i)) for i in range(nsrc)]], reduce=True)
+        g.pool.free(*co)
+        e.salu("s_branch LC_tail_%=")
+        self.sizes[cvm.KIND_NAME[kind]] = len(e.ins) - n0
+
+    def inv_handler(self):
+        """OUT <- src^(p - 2): KernelBuilder._fq_inv's sliding window on plain register blocks; the zero-divisor flag is raised when
+        src == 0 mod p (tested on the canonical form, like the throughput kernels' inversions)."""
+        e = self.e
+        n0 = len(e.ins)
+        e.label(f"LC_k{cvm.K_INV}_%=")
+        self.operand(5, ROW + 0, False)                                  # a -> block 5
+        self.dst_addrs()
+        e.raw("s_waitcnt lgkmcnt(0)")
+        RA, X2, RB, T5, T7, A1, A3 = OP(0), OP(1), OP(2), OP(3), OP(4), OP(5), OP(6)
+        for i in range(NL):
+            e.emit(f"v_mov_b32_e32 v{RA[i]}, v{A1[i]}", vw=[RA[i]])
+        self.l1().r_cvtout()                                             # v0..7: canonical words
+        e.emit(f"v_or3_b32 v{V_T0}, v0, v1, v2", vw=[V_T0])
+        e.emit(f"v_or3_b32 v{V_T0}, v{V_T0}, v3, v4", vw=[V_T0])
+        e.emit(f"v_or3_b32 v{V_T0}, v{V_T0}, v5, v6", vw=[V_T0])
+        e.emit(f"v_or_b32_e32 v{V_T0}, v{V_T0}, v7", vw=[V_T0])
+        e.emit(f"v_cmp_eq_u32_e32 vcc, 0, v{V_T0}", w=["vcc"])
+        e.emit(f"v_cndmask_b32_e64 v{V_T0}, 0, 1, vcc", r=["vcc"], vw=[V_T0])
+        e.emit(f"v_or_b32_e32 v{V_FLAG}, v{V_FLAG}, v{V_T0}", vw=[V_FLAG])
+        for i in range(NL):
+            e.emit(f"v_mov_b32_e32 v{RA[i]}, v{A1[i]}", vw=[RA[i]])
+        from kgen4_prog import KernelBuilder
+        first, sched = KernelBuilder.fqinv_schedule(3)
+        self.l1().fips_sq(RA, X2)                                        # a^2
+        self.l1().fips([(RA, X2)], A3)                                   # a^3
+        self.l1().fips([(A3, X2)], T5)                                   # a^5
+        self.l1().fips([(T5, X2)], T7)                                   # a^7
+        src = {1: None, 3: A3, 5: T5, 7: T7}[first]
+        if src is not None:
+            for i in range(NL):
+                e.emit(f"v_mov_b32_e32 v{RA[i]}, v{src[i]}", vw=[RA[i]])
+        for nsq, val in sched:
+            e.salu(f"s_mov_b32 s{S_CNT}, {nsq}")
+            e.salu(f"s_call_b64 {S_RET1}, LC_inv_sq_%=")
+            if val:
+                e.salu(f"s_call_b64 {S_RET1}, LC_inv_m{val}_%=")
+        for i in range(NL):
+            e.emit(f"v_mov_b32_e32 v{OUT0 + i}, v{RA[i]}", vw=[OUT0 + i])
+        e.salu("s_branch LC_tail_%=")
+        e.label("LC_inv_sq_%=")
+        self.l1().fips_sq(RA, RA)
+        e.salu(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
+        e.salu(f"s_cmp_lg_u32 s{S_CNT}, 0")
+        e.salu("s_cbranch_scc1 LC_inv_sq_%=")
+        e.salu(f"s_setpc_b64 {S_RET1}")
+        for v, blk in ((1, A1), (3, A3), (5, T5), (7, T7)):
+            e.label(f"LC_inv_m{v}_%=")
+            self.l1().fips([(RA, blk)], RA)
+            e.salu(f"s_setpc_b64 {S_RET1}")
+        del RB
+        self.sizes["inv"] = len(e.ins) - n0
+
+    # -------------------------------------------------------------- epilogue
+    def epilogue(self):
+        """lane r < 12 of a valid item converts result number r (c0 / c1 of the six coefficients, interleaved) and stores it as
+        Fq number (r & 1) * 6 + (r >> 1) of the MyFq12 output; the zero-divisor flag goes to the status word"""
+        e = self.e
+        e.label("LC_end_%=")
+        e.emit(f"v_lshlrev_b32_e32 v{V_T1}, 2, v{V_ROLE}", vw=[V_T1])
+        e.emit(f"global_load_dword v{V_DST}, v{V_T1}, {S_BLOB} offset:96", kind="vmem", vw=[V_DST])       # the lane's output slot
+        e.raw("s_waitcnt vmcnt(0)")
+        e.emit(f"v_mad_u32_u24 v{V_DST}, v{V_DST}, {SLOT_BYTES}, v{V_LBASE}", vw=[V_DST])
+        self.lds_load(0, V_DST)
+        e.raw("s_waitcnt lgkmcnt(0)")
+        self.l1().r_cvtout()
+        e.emit(f"v_and_b32_e32 v{V_T0}, 1, v{V_ROLE}", vw=[V_T0])
+        e.emit(f"v_mul_u32_u24_e32 v{V_T0}, 6, v{V_T0}", vw=[V_T0])
+        e.emit(f"v_lshrrev_b32_e32 v{V_T1}, 1, v{V_ROLE}", vw=[V_T1])
+        e.emit(f"v_add_u32_e32 v{V_T0}, v{V_T0}, v{V_T1}", vw=[V_T0])
+        e.emit(f"v_lshlrev_b32_e32 v{V_T0}, 2, v{V_T0}", vw=[V_T0])
+        e.emit(f"v_mul_lo_u32 v{V_T0}, v{V_T0}, s{S_NSTRIDE}", vw=[V_T0])
+        e.emit(f"v_add_u32_e32 v{V_T0}, v{V_T0}, v{V_ITEM8}", vw=[V_T0])
+        e.emit(f"v_cmp_gt_u32_e32 vcc, 12, v{V_ROLE}", w=["vcc"])
+        e.emit(f"v_cndmask_b32_e32 v{V_T1}, 0, v{V_VALID}, vcc", r=["vcc"], vw=[V_T1])
+        e.emit(f"v_cmp_ne_u32_e32 vcc, 0, v{V_T1}", w=["vcc"])
+        e.raw("s_nop 1")
+        e.salu(f"s_and_saveexec_b64 {S_SAVE}, vcc")
+        for l in range(4):
+            e.emit(f"global_store_dwordx2 v{V_T0}, v[{2 * l}:{2 * l + 1}], {S_OUT}", kind="vmem")
+            if l < 3:
+                e.emit(f"v_add_u32_e32 v{V_T0}, s{S_NSTRIDE}, v{V_T0}", vw=[V_T0])
+        e.emit(f"v_cmp_ne_u32_e32 vcc, 0, v{V_FLAG}", w=["vcc"])
+        e.raw("s_nop 1")
+        e.salu("s_and_saveexec_b64 s[58:59], vcc")
+        e.emit(f"v_mov_b32_e32 v{V_T0}, 1", vw=[V_T0])
+        e.emit(f"v_mov_b32_e32 v{V_T1}, 0", vw=[V_T1])
+        e.emit(f"global_store_dword v{V_T1}, v{V_T0}, {S_STATUS}", kind="vmem")
+        e.salu(f"s_mov_b64 exec, {S_SAVE}")
+        e.raw("s_waitcnt vmcnt(0)")
+
+    def build(self):
+        self.prologue()
+        self.round_loop()
+        self.mul_handler(cvm.K_M6, 6)
+        self.mul_handler(cvm.K_M4, 4)
+        self.mul_handler(cvm.K_M2, 2)
+        self.lin_handler(cvm.K_L4, 4)
+        self.lin_handler(cvm.K_L8, 8)
+        self.inv_handler()
+        self.tail()
+        self.epilogue()
+        lines = self.e.finalize()
+        return [l if l.endswith(":") is False else l for l in lines]
+
+
+def make_blob(enc):
+    """the program blob as a list of dwords: header, kinds, rows (one END row more than rounds), constants (internal form:
+    nine balanced 29-bit limbs of c R' mod p, + a pad dword)"""
+    assert enc["nr"] == NR
+    n_rounds = len(enc["rows"])
+    kinds = list(enc["kinds"])
+    assert len(kinds) == n_rounds + 1
+    while len(kinds) % 4:
+        kinds.append(0)
+    rows = []
+    for row in enc["rows"]:
+        for dw in row:
+            rows += dw
+    rows += [0] * (NR * ROW_DW)
+    consts = []
+    for c in enc["consts"]:
+        consts += [w & 0xFFFFFFFF for w in bal_limbs(c * K4.RP % P_INT)] + [0]
+    trash = enc["n_slots"] - 1
+    kinds_off = 4 * HDR_DW
+    rows_off = kinds_off + 4 * len(kinds)
+    rows_off = (rows_off + 15) // 16 * 16
+    pad = (rows_off - kinds_off) // 4 - len(kinds)
+    consts_off = rows_off + 4 * len(rows)
+    hdr = [n_rounds, len(enc["consts"]), kinds_off, rows_off, consts_off, enc["n_slots"], trash, len(enc["inputs"])]
+    hdr += [enc["inputs"][i] if i < len(enc["inputs"]) else trash for i in range(16)]
+    hdr += [enc["outputs"][i] if i < len(enc["outputs"]) else trash for i in range(16)]
+    assert len(hdr) == HDR_DW
+    return hdr + kinds + [0] * pad + rows + consts
+
+
+if __name__ == "__main__":
+    k = VMKernel()
+    lines = k.build()
+    print(len(lines), "lines;", k.sizes)

@@ -171,8 +171,14 @@ class Machine:
         self.exact.pop(r & ~1, None)
 
 
-def run(lines, m, entry=None, max_steps=200_000_000, trace=None):
-    """Execute `lines` on machine `m` until s_endpgm."""
+_PARSED = {}
+
+
+def _parse(lines):
+    key = id(lines)
+    hit = _PARSED.get(key)
+    if hit is not None and hit[0] is lines:
+        return hit[1], hit[2]
     prog = []
     labels = {}
     for ln in lines:
@@ -188,7 +194,19 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None):
         if op.endswith("_e64"):
             op = op[:-4] + "_e32"                     # VOP3 re-encodings of VOP1/VOP2 instructions (kgen.align_code)
         prog.append((op, _split_args(rest.strip()), ln))
-    pc = labels[entry] if entry else 0
+    _PARSED.clear()
+    _PARSED[key] = (lines, prog, labels)
+    return prog, labels
+
+
+def run(lines, m, entry=None, max_steps=200_000_000, trace=None, start_pc=None, stop_label=None):
+    """Execute `lines` on machine `m` until s_endpgm (returns None), or -- stop_label -- until control ARRIVES at that label
+    (returns the program counter to resume from with start_pc): the lane-cooperative kernels are run one lane at a time, round
+    by round (tests/test_cvm.py)."""
+    prog, labels = _parse(lines)
+    pc = start_pc if start_pc is not None else (labels[entry] if entry else 0)
+    stop_pc = labels[stop_label] if stop_label is not None else None
+    fresh = True
     v = m.v
     steps = 0
     region = None
@@ -204,6 +222,9 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None):
     while True:
         if pc >= len(prog):
             raise SimError("fell off the end of the program")
+        if pc == stop_pc and not fresh:
+            return pc
+        fresh = False
         op, a, text = prog[pc]
         if region is not None:
             k_ = (region[pc], op)
