@@ -772,7 +772,7 @@ class Program:
     def encode(self):
         """-> (kinds: one int per round + K_END, rows: per round nr x 8 dwords, consts: list of Fq integers, inputs / outputs: slots)
         row layout (eight dwords per lane per round; slot numbers, 16 bits each):
-          mul:  dw0..5 = x_i | y_i << 16 (six products), dw6 = addend | dst << 16, dw7 = twin | 0 << 16
+          mul:  dw0..5 = x_i | y_i << 16 (six products), dw6 = addend | dst << 16, dw7 = twin | kind << 16 (every kind)
           lin:  dw0..3 = s_2i | s_(2i+1) << 16 (eight sources), dw4..5 = eight int8 coefficients, dw6 = _ | dst << 16, dw7 = twin
           inv:  dw0 = src, dw6 = _ | dst << 16, dw7 = twin
         Unused products / sources name the ZERO slot; lanes without work and results without a twin write the TRASH slot."""
@@ -789,7 +789,7 @@ class Program:
                 v = take[r] if r < len(take) else None
                 dst = v.slot if v is not None else trash
                 twin = v.twin.slot if v is not None and v.twin is not None else trash
-                dw[7] = twin
+                dw[7] = twin | kind << 16
                 if FAMILY[kind] == "m":
                     t, add = v.args if v is not None else ([], None)
                     for i in range(6):
@@ -856,6 +856,32 @@ def build_fq12_mul():
     a = [g.inp(f"a{i}") for i in range(6)]
     b = [g.inp(f"b{i}") for i in range(6)]
     g.outputs = g.fq12_mul(a, b)
+    return g
+
+
+def build_synth(kind, count):
+    """DIAGNOSTIC program (tools/exp/lat_variant.sh, CVM_SYNTH): `count` rounds in which all sixteen lanes do one operation of
+    `kind` (m2 / m6 / l4 / l8) on the previous round's values -- the per-round cost of the interpreter, kind by kind"""
+    g = Graph()
+    g.const((0, 0))
+    g.const((1, 0))
+    px, py, qx, qy = g.inp("px", real=True), g.inp("py", real=True), g.inp("qx"), g.inp("qy")
+    v = [g.mul((qx, qy)), g.mul((qy, qy)), g.mul((qx, qx)), g.lin((qx, ID), (qy, mxi())), g.lin((qx, mxi()), (qy, ID)), g.lin((qx, CONJ), (qy, ID)),
+         g.lin((qx, mk(2)), (qy, CONJ)), g.lin((qx, mk(3)), (qy, NEG))]
+    for _ in range(count):
+        nv = []
+        for j in range(8):
+            a = [v[(j + i) % 8] for i in range(6)]
+            if kind == "m6":
+                nv.append(g.mul((a[0], a[1]), (a[2], a[3]), (a[4], a[5])))
+            elif kind == "m2":
+                nv.append(g.mul((a[0], a[1])))
+            elif kind == "l4":
+                nv.append(g.lin((a[0], (1, 2, -1, 1)), (a[1], (2, -1, 1, 3))))
+            else:
+                nv.append(g.lin((a[0], (1, 2, -1, 1)), (a[1], (2, -1, 1, 3)), (a[2], (1, 1, -2, 1)), (a[3], (-1, 2, 1, 1))))
+        v = nv
+    g.outputs = v[:6]
     return g
 
 

@@ -9,6 +9,7 @@ what differs per lane is its table row (which LDS slots it reads and writes).  P
                                           l4 / l8:      one reducing 64-bit chain over 4 / 8 (coefficient, source) pairs
                                           inv:          the Fermat chain (sliding window, as KernelBuilder._fq_inv)
     write the result (and its negation, the `twin`) to the LDS slots the row names
+(the kind of a round travels in its row; rows are fetched three rounds ahead)
 
 LDS: per group n_slots x 48 bytes (nine limbs + a pad dword, 16-byte aligned for the 128-bit accesses).  A wave's LDS operations
 execute in order, and the four groups never touch each other's slots, so no barrier is needed; the schedule guarantees that no slot
@@ -21,7 +22,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from asmcore import Emitter, Pool, P_INT  # noqa: E402
+from asmcore import Emitter, Pool, P_INT, align_code  # noqa: E402
 import kgen4 as K4  # noqa: E402
 from kgen4 import NL, L1v4, hx, bal_limbs, S_P, S_N0, S_REDN, S_M30, P_L, N0P, REDN_C, S_RET1  # noqa: E402
 import cvm  # noqa: E402
@@ -40,10 +41,17 @@ def OP(i):
 
 
 OUT0, NEG0 = 130, 140
-POOL_FIRST, POOL_LAST = 150, 219
-ROW, ROWN = 220, 228
+POOL_FIRST, POOL_LAST = 150, 203
+# Row look-ahead.  1: the next row is fetched into the row registers as soon as the current one has been decoded (shipped).
+# 3: three row buffers in flight, the round's own copied to the executing row -- measured SLOWER (1.336 ms against 1.277 ms for one
+# pairing, profiles/r04_latency_ab.txt): the rows come from L2 within a round; what a round waits for is the LDS (operand fetch).
+ROW_DEPTH = int(os.environ.get("CVM_ROW_DEPTH", "1"))
+OVERLAP = bool(int(os.environ.get("CVM_OVERLAP", "1")))      # operand limbs that a pass needs late are fetched inside it
+ROWN = 204 if ROW_DEPTH > 1 else 228
+ROWB = [212, 220, 228]
 V_LBASE, V_ROWOFF, V_ROLE, V_ITEM8, V_FLAG, V_T0, V_DST, V_TWIN, V_VALID, V_T1 = 236, 237, 238, 239, 240, 241, 242, 243, 244, 245
 S_BLOB, S_ROWS, S_NROUNDS, S_KIND, S_KINDS, S_KNEXT, S_NCONST, S_NSLOTS, S_TMP = "s[48:49]", "s[50:51]", 52, 53, "s[62:63]", 64, 65, 66, 67
+S_PHASE = 89
 S_CONSTS, S_G1, S_G2, S_OUT, S_N, S_NSTRIDE, S_STATUS = "s[68:69]", "s[70:71]", "s[72:73]", "s[74:75]", 76, 77, "s[78:79]"
 S_H = 80               # s80..s87: header words / scratch
 S_CNT = 88
@@ -75,20 +83,48 @@ class VMKernel:
         e.emit(f"ds_read_b128 v[{blk0 + 4}:{blk0 + 7}], v{addr} offset:16", kind="lds", vw=list(range(blk0 + 4, blk0 + 8)))
         e.emit(f"ds_read_b64 v[{blk0 + 8}:{blk0 + 9}], v{addr} offset:32", kind="lds", vw=[blk0 + 8, blk0 + 9])
 
+    def lds_load_parts(self, blk0, addr):
+        """the three accesses of lds_load as (text, registers written): limbs 0..3, 4..7, 8 (+ pad)"""
+        return [(f"ds_read_b128 v[{blk0}:{blk0 + 3}], v{addr}", list(range(blk0, blk0 + 4))),
+                (f"ds_read_b128 v[{blk0 + 4}:{blk0 + 7}], v{addr} offset:16", list(range(blk0 + 4, blk0 + 8))),
+                (f"ds_read_b64 v[{blk0 + 8}:{blk0 + 9}], v{addr} offset:32", [blk0 + 8, blk0 + 9])]
+
     def lds_store(self, addr, blk0):
         e = self.e
         e.emit(f"ds_write_b128 v{addr}, v[{blk0}:{blk0 + 3}]", kind="lds")
         e.emit(f"ds_write_b128 v{addr}, v[{blk0 + 4}:{blk0 + 7}] offset:16", kind="lds")
         e.emit(f"ds_write_b64 v{addr}, v[{blk0 + 8}:{blk0 + 9}] offset:32", kind="lds")
 
-    def operand(self, i, row_reg, hi):
-        """operand block i <- the slot named by one half of a row dword"""
-        self.slot_addr(V_T1, row_reg, hi)
-        self.lds_load(10 * i, V_T1)
+    def decode(self, g, fields):
+        """address registers (from the pool) of the slots named by `fields` = [(row dword, high half?)], read from the row registers
+        BEFORE the next row is fetched into them"""
+        regs = []
+        for dw, hi in fields:
+            r = g.pool.alloc()
+            self.slot_addr(r, ROWN + dw, hi)
+            regs.append(r)
+        return regs
 
-    def dst_addrs(self):
-        self.slot_addr(V_DST, ROW + 6, True)
-        self.slot_addr(V_TWIN, ROW + 7, False)
+    def prefetch_row(self, buf):
+        """the row three rounds ahead into row buffer `buf` (whose previous content has been copied to the executing row)"""
+        e = self.e
+        b = ROWB[buf]
+        e.emit(f"global_load_dwordx4 v[{b}:{b + 3}], v{V_ROWOFF}, {S_ROWS}", kind="vmem", vw=list(range(b, b + 4)))
+        e.emit(f"global_load_dwordx4 v[{b + 4}:{b + 7}], v{V_ROWOFF}, {S_ROWS} offset:16", kind="vmem", vw=list(range(b + 4, b + 8)))
+        e.emit(f"v_add_u32_e32 v{V_ROWOFF}, {NR * ROW_DW * 4}, v{V_ROWOFF}", vw=[V_ROWOFF])
+
+    def next_row(self):
+        if ROW_DEPTH == 1:
+            self.prefetch_row(2)
+
+    def finish(self, dst, twin):
+        """result in OUT -> dst slot, its negation -> twin slot; next round"""
+        e = self.e
+        for i in range(NL):
+            e.emit(f"v_sub_u32_e32 v{NEG0 + i}, 0, v{OUT0 + i}", vw=[NEG0 + i])
+        self.lds_store(dst, OUT0)
+        self.lds_store(twin, NEG0)
+        e.salu("s_branch LC_round_%=")
 
     # -------------------------------------------------------------- prologue
     def prologue(self):
@@ -124,8 +160,6 @@ class VMKernel:
         e.emit(f"v_mov_b32_e32 v{V_FLAG}, 0", vw=[V_FLAG])
         for r in (OUT0 + 9, NEG0 + 9):
             e.emit(f"v_mov_b32_e32 v{r}, 0", vw=[r])
-        e.salu(f"s_add_u32 s62, s48, s{S_H}")                # kinds
-        e.salu("s_addc_u32 s63, s49, 0")
         e.salu(f"s_add_u32 s50, s48, s{S_H + 1}")            # rows
         e.salu("s_addc_u32 s51, s49, 0")
         e.salu(f"s_add_u32 s68, s48, s{S_H + 2}")            # constants
@@ -178,76 +212,93 @@ class VMKernel:
         e.emit("v_mov_b32_e32 v9, 0", vw=[9])
         e.emit(f"v_mad_u32_u24 v{V_DST}, v{V_DST}, {SLOT_BYTES}, v{V_LBASE}", vw=[V_DST])
         self.lds_store(V_DST, 0)
-        # ---- first row / kind
-        e.salu(f"s_load_dword s{S_KNEXT}, {S_KINDS}, 0x0")
-        e.emit(f"global_load_dwordx4 v[{ROWN}:{ROWN + 3}], v{V_ROWOFF}, {S_ROWS}", kind="vmem", vw=list(range(ROWN, ROWN + 4)))
-        e.emit(f"global_load_dwordx4 v[{ROWN + 4}:{ROWN + 7}], v{V_ROWOFF}, {S_ROWS} offset:16", kind="vmem", vw=list(range(ROWN + 4, ROWN + 8)))
+        # ---- the first rows (the round's kind travels in the row: dword 7, high half)
+        for b in range(ROW_DEPTH):
+            self.prefetch_row(b if ROW_DEPTH > 1 else 2)
+        e.salu(f"s_mov_b32 s{S_PHASE}, 0")
 
     # -------------------------------------------------------------- the round loop
     def round_loop(self):
+        """Rows are fetched ROW_DEPTH rounds ahead (a short round is over before an L2 hit returns): three row buffers take the
+        loads in turn; the round's own buffer is copied to the executing row and refilled at once."""
         e = self.e
         e.label("LC_round_%=")
-        e.raw("s_waitcnt vmcnt(0) lgkmcnt(0)")
-        e.salu(f"s_mov_b32 s{S_KIND}, s{S_KNEXT}")
-        for i in range(ROW_DW):
-            e.emit(f"v_mov_b32_e32 v{ROW + i}, v{ROWN + i}", vw=[ROW + i])
-        e.salu(f"s_cmp_eq_u32 s{S_KIND}, {cvm.K_END}")
-        e.salu("s_cbranch_scc1 LC_end_%=")
-        # prefetch: the table has one row more than rounds (the END row), so the last prefetch stays inside it
-        e.salu("s_add_u32 s62, s62, 4")
-        e.salu("s_addc_u32 s63, s63, 0")
-        e.salu(f"s_add_u32 s50, s50, {NR * ROW_DW * 4}")
-        e.salu("s_addc_u32 s51, s51, 0")
-        e.salu(f"s_load_dword s{S_KNEXT}, {S_KINDS}, 0x0")
-        e.emit(f"global_load_dwordx4 v[{ROWN}:{ROWN + 3}], v{V_ROWOFF}, {S_ROWS}", kind="vmem", vw=list(range(ROWN, ROWN + 4)))
-        e.emit(f"global_load_dwordx4 v[{ROWN + 4}:{ROWN + 7}], v{V_ROWOFF}, {S_ROWS} offset:16", kind="vmem", vw=list(range(ROWN + 4, ROWN + 8)))
-        for kind in (cvm.K_M6, cvm.K_L4, cvm.K_M2, cvm.K_M4, cvm.K_L8):
+        if ROW_DEPTH == 1:
+            e.raw("s_waitcnt vmcnt(0)")
+        for b in range(ROW_DEPTH if ROW_DEPTH > 1 else 0):
+            if b < ROW_DEPTH - 1:
+                e.salu(f"s_cmp_eq_u32 s{S_PHASE}, {b}")
+                e.salu(f"s_cbranch_scc0 LC_ph{b + 1}_%=")
+            e.raw(f"s_waitcnt vmcnt({2 * (ROW_DEPTH - 1)})")
+            for i in range(ROW_DW):
+                e.emit(f"v_mov_b32_e32 v{ROWN + i}, v{ROWB[b] + i}", vw=[ROWN + i])
+            self.prefetch_row(b)
+            e.salu(f"s_mov_b32 s{S_PHASE}, {(b + 1) % ROW_DEPTH}")
+            if b < ROW_DEPTH - 1:
+                e.salu("s_branch LC_go_%=")
+                e.label(f"LC_ph{b + 1}_%=")
+        e.label("LC_go_%=")
+        e.emit(f"v_readfirstlane_b32 s{S_KIND}, v{ROWN + 7}", kind="valu")
+        e.salu(f"s_lshr_b32 s{S_KIND}, s{S_KIND}, 16")
+        for kind in (cvm.K_L4, cvm.K_M6, cvm.K_M2, cvm.K_M4, cvm.K_L8, cvm.K_INV):      # by frequency in the pairing program
             e.salu(f"s_cmp_eq_u32 s{S_KIND}, {kind}")
             e.salu(f"s_cbranch_scc1 LC_k{kind}_%=")
-        e.salu(f"s_branch LC_k{cvm.K_INV}_%=")
-
-    def tail(self):
-        """result in OUT -> dst slot, its negation -> twin slot; next round"""
-        e = self.e
-        e.label("LC_tail_%=")
-        for i in range(NL):
-            e.emit(f"v_sub_u32_e32 v{NEG0 + i}, 0, v{OUT0 + i}", vw=[NEG0 + i])
-        self.lds_store(V_DST, OUT0)
-        self.lds_store(V_TWIN, NEG0)
-        e.salu("s_branch LC_round_%=")
+        e.salu("s_branch LC_end_%=")
 
     def mul_handler(self, kind, nprod):
         e = self.e
         n0 = len(e.ins)
         e.label(f"LC_k{kind}_%=")
-        for i in range(nprod):
-            self.operand(2 * i, ROW + i, False)
-            self.operand(2 * i + 1, ROW + i, True)
-        self.operand(12, ROW + 6, False)
-        self.dst_addrs()
-        e.raw("s_waitcnt lgkmcnt(0)")
         g = self.l1()
+        ad = self.decode(g, [(i, h) for i in range(nprod) for h in (False, True)] + [(6, False), (6, True), (7, False)])
+        self.next_row()
         out = list(range(OUT0, OUT0 + NL))
-        g.fips([(OP(2 * i), OP(2 * i + 1)) for i in range(nprod)], out, inject=[(OP(12), 1)])
-        e.salu("s_branch LC_tail_%=")
+        prods = [(OP(2 * i), OP(2 * i + 1)) for i in range(nprod)]
+        if OVERLAP:
+            # column k of the pass needs limbs 0..k only: the low quarters of the product operands are fetched up front, everything else
+            # -- the upper limbs, the addend (which enters behind column 8) -- rides in the multiply runs of columns 0..3
+            parts = [self.lds_load_parts(10 * i, ad[i]) for i in range(2 * nprod)] + [self.lds_load_parts(10 * 12, ad[2 * nprod])]
+            for pt in parts[:-1]:
+                e.emit(pt[0][0], kind="lds", vw=pt[0][1])
+            later = [pt[1] for pt in parts[:-1]] + [parts[-1][0], parts[-1][1]] + [pt[2] for pt in parts]
+            fillers = [(t, vw, 0, 3) for t, vw in later] + [("s_waitcnt lgkmcnt(0)", [], 99, 4)]
+            e.raw("s_waitcnt lgkmcnt(0)")
+            g.fips(prods, out, inject=[(OP(12), 1)], fillers=fillers, gap=2)
+        else:
+            for i in range(2 * nprod):
+                self.lds_load(10 * i, ad[i])
+            self.lds_load(10 * 12, ad[2 * nprod])
+            e.raw("s_waitcnt lgkmcnt(0)")
+            g.fips(prods, out, inject=[(OP(12), 1)])
+        self.finish(ad[2 * nprod + 1], ad[2 * nprod + 2])
         self.sizes[cvm.KIND_NAME[kind]] = len(e.ins) - n0
 
     def lin_handler(self, kind, nsrc):
         e = self.e
         n0 = len(e.ins)
         e.label(f"LC_k{kind}_%=")
-        for i in range(nsrc):
-            self.operand(i, ROW + i // 2, i % 2 == 1)
-        self.dst_addrs()
         g = self.l1()
+        ad = self.decode(g, [(i // 2, i % 2 == 1) for i in range(nsrc)] + [(6, True), (7, False)])
         co = [g.pool.alloc() for _ in range(nsrc)]
         for i in range(nsrc):
-            e.emit(f"v_bfe_i32 v{co[i]}, v{ROW + 4 + i // 4}, {8 * (i % 4)}, 8", vw=[co[i]])
-        e.raw("s_waitcnt lgkmcnt(0)")
+            e.emit(f"v_bfe_i32 v{co[i]}, v{ROWN + 4 + i // 4}, {8 * (i % 4)}, 8", vw=[co[i]])
+        self.next_row()
         out = list(range(OUT0, OUT0 + NL))
-        g.lincomb([out], [[(("v", co[i]), OP(i)) for i in range(nsrc)]], reduce=True)
-        g.pool.free(*co)
-        e.salu("s_branch LC_tail_%=")
+        terms = [[(("v", co[i]), OP(i)) for i in range(nsrc)]]
+        if OVERLAP:
+            # the chain starts from the TOP limbs (the quotient estimate), then walks up from limb 0: tails first, upper quarters last
+            parts = [self.lds_load_parts(10 * i, ad[i]) for i in range(nsrc)]
+            for k in (2, 0, 1):
+                for pt in parts:
+                    e.emit(pt[k][0], kind="lds", vw=pt[k][1])
+            e.raw(f"s_waitcnt lgkmcnt({nsrc})")
+            g.lincomb([out], terms, reduce=True, hooks={4: ["s_waitcnt lgkmcnt(0)"]})
+        else:
+            for i in range(nsrc):
+                self.lds_load(10 * i, ad[i])
+            e.raw("s_waitcnt lgkmcnt(0)")
+            g.lincomb([out], terms, reduce=True)
+        self.finish(ad[nsrc], ad[nsrc + 1])
         self.sizes[cvm.KIND_NAME[kind]] = len(e.ins) - n0
 
     def inv_handler(self):
@@ -256,8 +307,12 @@ class VMKernel:
         e = self.e
         n0 = len(e.ins)
         e.label(f"LC_k{cvm.K_INV}_%=")
-        self.operand(5, ROW + 0, False)                                  # a -> block 5
-        self.dst_addrs()
+        g0 = self.l1()
+        ad = self.decode(g0, [(0, False), (6, True), (7, False)])
+        for i, r in enumerate((V_T1, V_DST, V_TWIN)):                    # (the chain below takes the whole pool)
+            e.emit(f"v_mov_b32_e32 v{r}, v{ad[i]}", vw=[r])
+        self.next_row()
+        self.lds_load(10 * 5, V_T1)                                      # a -> block 5
         e.raw("s_waitcnt lgkmcnt(0)")
         RA, X2, RB, T5, T7, A1, A3 = OP(0), OP(1), OP(2), OP(3), OP(4), OP(5), OP(6)
         for i in range(NL):
@@ -289,7 +344,7 @@ class VMKernel:
                 e.salu(f"s_call_b64 {S_RET1}, LC_inv_m{val}_%=")
         for i in range(NL):
             e.emit(f"v_mov_b32_e32 v{OUT0 + i}, v{RA[i]}", vw=[OUT0 + i])
-        e.salu("s_branch LC_tail_%=")
+        self.finish(V_DST, V_TWIN)
         e.label("LC_inv_sq_%=")
         self.l1().fips_sq(RA, RA)
         e.salu(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
@@ -350,10 +405,10 @@ class VMKernel:
         self.lin_handler(cvm.K_L4, 4)
         self.lin_handler(cvm.K_L8, 8)
         self.inv_handler()
-        self.tail()
         self.epilogue()
-        lines = self.e.finalize()
-        return [l if l.endswith(":") is False else l for l in lines]
+        # every 8-byte instruction 8-byte aligned (asmcore.align_code: a straddling one costs a cycle on average -- measured on this
+        # kernel: 5.1 cycles per instruction of the column passes without it)
+        return [".p2align 3"] + align_code(self.e.finalize())
 
 
 def make_blob(enc):
@@ -369,7 +424,7 @@ def make_blob(enc):
     for row in enc["rows"]:
         for dw in row:
             rows += dw
-    rows += [0] * (NR * ROW_DW)
+    rows += [0] * (NR * ROW_DW * (1 + ROW_DEPTH))          # the END row, and what the look-ahead reads behind it
     consts = []
     for c in enc["consts"]:
         consts += [w & 0xFFFFFFFF for w in bal_limbs(c * K4.RP % P_INT)] + [0]

@@ -357,11 +357,13 @@ class L1v4:
         for v_ in own + nx:
             self.pool.free(*v_)
 
-    def lincomb(self, outs, termss, reduce=False):
+    def lincomb(self, outs, termss, reduce=False, hooks=None):
         """outs[j] <- sum of coef * vec over termss[j] (lists of (inline-constant coefficient, limb list)), NORMALISED
         (balanced limbs; top limb: the rest), on one 64-bit carry chain per output, the chains interleaved limb by limb so
         that outputs may overwrite inputs (limb i of every input is dead once limb i of every output is written).
-        reduce: also subtract q p with q = round(top limb of the combination * 2^232 / p): result in (-0.51 p, 0.51 p)."""
+        reduce: also subtract q p with q = round(top limb of the combination * 2^232 / p): result in (-0.51 p, 0.51 p).
+        hooks: {limb index: [instruction text]} emitted before that limb's work (the lane-cooperative kernel waits there for
+        operand limbs that were still in flight)."""
         n = len(outs)
         accs = [self._acc() for _ in range(n)]
         qs = []
@@ -380,6 +382,8 @@ class L1v4:
                 self._quot(q)
                 qs.append(q)
         for i in range(NL):
+            for text in (hooks or {}).get(i, ()):
+                self.e.raw(text)
             for j, terms in enumerate(termss):
                 acc, P = accs[j]
                 first = i == 0

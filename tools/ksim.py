@@ -337,6 +337,10 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None, start_pc=None, 
             elif op == "v_mov_b32_e32":
                 m.vset(a[0], m.vsrc(a[1]))
                 m.count_valu += 1
+            elif op == "v_readfirstlane_b32":       # one simulated lane: the value must be wave-uniform (the lane-cooperative kernel's round kind)
+                m.sset(a[0], m.vsrc(a[1]))
+                m.valu_w[a[0]] = m.count
+                m.count_valu += 1
             elif op == "v_mul_hi_i32":
                 x, y = m.vsrc(a[1]), m.vsrc(a[2])
                 x = x - (1 << 32) if x >> 31 else x
