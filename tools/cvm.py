@@ -30,7 +30,7 @@ from asmcore import P_INT, BN_X, SIX_U_PLUS_2_NAF  # noqa: E402
 P = P_INT
 XI = (9, 1)
 NR = 8                      # lanes (roles) per pairing
-T_END, T_MUL1, T_MUL3, T_LIN, T_INV = 0, 1, 2, 3, 4
+ARR_G1, ARR_G2, ARR_F, ARR_NONE = 0, 1, 2, 3
 COST = {"m1": 950, "m3": 2000, "lin": 420, "inv": 46000}     # instructions per round (scheduling weights; tools/cvm_kernel.py prints the real ones)
 MAX_LIN_SRC = 4
 SLOT_STRIDE = 80            # bytes per LDS slot (72 used: 2 x 9 limbs)
@@ -73,11 +73,11 @@ def mk(k):
 
 
 class V:
-    __slots__ = ("id", "kind", "args", "bound", "users", "name", "real")
+    __slots__ = ("id", "kind", "args", "bound", "users", "name", "real", "src", "early", "after")
 
     def __init__(self, id_, kind, args, bound):
         self.id, self.kind, self.args, self.bound = id_, kind, args, bound
-        self.users, self.name, self.real = [], None, False
+        self.users, self.name, self.real, self.src, self.early, self.after = [], None, False, None, False, None
 
     def srcs(self):
         if self.kind in ("m1", "m3"):
@@ -93,11 +93,12 @@ class V:
 class Graph:
     """SSA builder over Fq2 values (lowered to Fq operations, where the value bounds are tracked, by `Lowered`)."""
 
-    def __init__(self):
+    def __init__(self, run_ahead=None):
         self.vals = []
         self.consts = {}
         self.inputs = []
         self.outputs = []
+        self.run_ahead = run_ahead        # iterations the Miller loop's point chain may run ahead of f's (None: as far as lanes are free)
 
     def _new(self, kind, args, bound):
         v = V(len(self.vals), kind, args, bound)
@@ -106,12 +107,24 @@ class Graph:
             s.users.append(v)
         return v
 
-    def inp(self, name, real=False):
+    def inp(self, name, real=False, src=None):
+        """src = (array, Fq number of c0, Fq number of c1 | None, pair): where the kernel finds the value -- array 0 = g1 (Fq 0..1 per
+        point), 1 = g2 (0..3), 2 = f_in (0..11, MyFq12 order); pair = index inside the item's group of k pairs"""
         v = self._new("in", None, 1.01)
         v.name = name
         v.real = real
+        v.src = src
         self.inputs.append(v)
         return v
+
+    def g1_point(self, j=0):
+        return self.inp(f"p{j}x", real=True, src=(ARR_G1, 0, None, j)), self.inp(f"p{j}y", real=True, src=(ARR_G1, 1, None, j))
+
+    def g2_point(self, j=0):
+        return self.inp(f"q{j}x", src=(ARR_G2, 0, 1, j)), self.inp(f"q{j}y", src=(ARR_G2, 2, 3, j))
+
+    def fq12_input(self):
+        return [self.inp(f"f{i}", src=(ARR_F, i, i + 6, 0)) for i in range(6)]
 
     def const(self, c):
         c = (c[0] % P, c[1] % P)
@@ -120,9 +133,13 @@ class Graph:
             self.consts[c] = v
         return self.consts[c]
 
-    def mul(self, *terms, add=None):
+    def mul(self, *terms, add=None, after=None):
+        """after: a value this operation must not be scheduled before (no data flows; Graph.run_ahead: the Miller loop's point chain
+        can be kept within a few iterations of f's chain, so that its lines do not pile up in LDS)"""
         assert 1 <= len(terms) <= 3
-        return self._new("m1" if len(terms) == 1 else "m3", (list(terms), add), 0)
+        v = self._new("m1" if len(terms) == 1 else "m3", (list(terms), add), 0)
+        v.after = after
+        return v
 
     def lin(self, *pairs):
         assert 1 <= len(pairs) <= MAX_LIN_SRC
@@ -249,15 +266,15 @@ class Graph:
         return [r0[0], r1[0], r0[1], r1[1], r0[2], r1[2]]
 
     # -------------------------------------------------------------- G2 steps and sparse products (tests/sched_model.py)
-    def dbl_step(self, Rp, px, py):
+    def dbl_step(self, Rp, px, py, after=None):
         """homogeneous projective doubling, the point scaled by xi^2 (L1v4.r_dblstep); line (L0, L3, L4) (miller_loop_native.rs:30-44).
         px, py: the G1 point's coordinates as Fq2 values (c1 = 0)."""
         X, Y, Z = Rp
-        B = self.mul((Y, Y))
-        C = self.mul((Z, Z))
-        XX = self.mul((X, X))
-        XY = self.mul((X, Y))
-        YZ = self.mul((Y, Z))
+        B = self.mul((Y, Y), after=after)
+        C = self.mul((Z, Z), after=after)
+        XX = self.mul((X, X), after=after)
+        XY = self.mul((X, Y), after=after)
+        YZ = self.mul((Y, Z), after=after)
         # N = 9 C, xB = xi B, T = xB - 3 N, S = xB + 3 N, H = 2 Y Z
         T = self.lin((B, mxi()), (C, mk(-27)))
         S = self.lin((B, mxi()), (C, mk(27)))
@@ -322,33 +339,69 @@ class Graph:
                 self.mul((a[3], b2), (a[2], b3), (a[0], b5))]
 
     # -------------------------------------------------------------- the reference's functions
-    def miller_loop(self, px, py, Q):
-        """miller_loop_native(Q, P) up to an Fq2 factor (projective lines; the final exponentiation removes it):
-        tests/sched_model.py miller_projective with one pair."""
+    def multi_miller_loop(self, pairs, exact=False):
+        """multi_miller_loop_native over pairs [((px, py), (qx, qy))] (miller_loop_native.rs:192-282; one pair: miller_loop_native,
+        :320-322), shared f, projective lines: tests/sched_model.py miller_projective.  The lines carry an Fq2 factor each (lam = Z^2
+        of a doubling, Z of an addition), which the final exponentiation removes; exact=True tracks their product and divides it
+        out at the end -- the reference's value itself."""
         enc = SIX_U_PLUS_2_NAF                        # the reference's digit table (miller_loop_native.rs:314-318), not the canonical NAF
-        one = self.const((1, 0))
-        nQy = self.neg(Q[1])
-        Rp = (Q[0], Q[1], one)
-        Rp, L = self.dbl_step(Rp, px, py)
-        zero = self.const((0, 0))
-        f = [L[0], zero, zero, L[1], L[2], zero]
+        one, zero = self.const((1, 0)), self.const((0, 0))
+        nQy = [self.neg(Q[1]) for _, Q in pairs]
+        Rs = [(Q[0], Q[1], one) for _, Q in pairs]
+        scale = None
+        f = None
+        hist = []                                     # f at the start of every iteration (run_ahead)
+
+        def dbl(j):
+            nonlocal f, scale
+            (px, py), _ = pairs[j]
+            lam = Rs[j][2]
+            ra = self.run_ahead
+            Rs[j], L = self.dbl_step(Rs[j], px, py, after=hist[-ra][0] if ra is not None and len(hist) >= ra else None)
+            f = [L[0], zero, zero, L[1], L[2], zero] if f is None else self.mul_by_034(f, L)
+            if exact and lam is not one:
+                # the factor is lam = Z^2 and the scale is squared right after the iteration's doublings: (scale Z)^2 = scale^2 lam --
+                # two dependent products per doubling instead of three, as many as f's own chain has rounds for
+                scale = lam if scale is None else self.mul((scale, lam))
+
+        def add(j, Qs, nQsy):
+            nonlocal f, scale
+            (px, py), _ = pairs[j]
+            lam = Rs[j][2]
+            Rs[j], L = self.add_step(Rs[j], Qs, px, py, nQy=nQsy)
+            f = self.mul_by_235(f, L)
+            if exact:
+                scale = lam if scale is None else self.mul((scale, lam))
+
+        for j in range(len(pairs)):
+            dbl(j)
         for i in range(63, -1, -1):
             if i != 63:
+                hist.append(f)
                 f = self.fq12_sqr(f)
-                Rp, L = self.dbl_step(Rp, px, py)
-                f = self.mul_by_034(f, L)
+                for j in range(len(pairs)):
+                    dbl(j)
+                if exact and scale is not None:           # scale <- (scale * prod Z_j)^2 = scale^2 * prod lam_j
+                    scale = self.mul((scale, scale))
             if enc[i] != 0:
-                Qs = (Q[0], Q[1]) if enc[i] == 1 else (Q[0], nQy)
-                Rp, L = self.add_step(Rp, Qs, px, py, nQy=nQy if enc[i] == 1 else Q[1])
-                f = self.mul_by_235(f, L)
+                for j, (_, Q) in enumerate(pairs):
+                    if enc[i] == 1:
+                        add(j, (Q[0], Q[1]), nQy[j])
+                    else:
+                        add(j, (Q[0], nQy[j]), Q[1])
         c2, c3 = end_constants()
-        Q1 = (self.mul((self.conj(Q[0]), self.const(c2))), self.mul((self.conj(Q[1]), self.const(c3))))
-        nQ2 = (self.mul((self.conj(Q1[0]), self.const(c2))), self.mul((self.lin((Q1[1], NCONJ)), self.const(c3))))
-        Rp, L = self.add_step(Rp, Q1, px, py)
-        f = self.mul_by_235(f, L)
-        _, L = self.add_step(Rp, nQ2, px, py)
-        f = self.mul_by_235(f, L)
+        for j, (_, Q) in enumerate(pairs):
+            Q1 = (self.mul((self.conj(Q[0]), self.const(c2))), self.mul((self.conj(Q[1]), self.const(c3))))
+            nQ2 = (self.mul((self.conj(Q1[0]), self.const(c2))), self.mul((self.lin((Q1[1], NCONJ)), self.const(c3))))
+            add(j, Q1, None)
+            add(j, nQ2, None)
+        if exact:
+            si = self.fq2_inv(scale)
+            f = [self.mul((c, si)) for c in f]
         return f
+
+    def miller_loop(self, px, py, Q, exact=False):
+        return self.multi_miller_loop([((px, py), Q)], exact=exact)
 
     def pow_x(self, a):
         """pow_native(a, [BN_X]) for a in the cyclotomic subgroup: cyclotomic squarings, the inverse as the conjugate"""
@@ -443,11 +496,11 @@ def end_constants():
 # ------------------------------------------------------------------ lowering to Fq operations
 class FV:
     """one Fq value: kind in / const / mul / lin / inv, or `negof` (the negated twin its producer's lane writes beside the result)"""
-    __slots__ = ("id", "kind", "args", "bound", "users", "rnd", "slot", "height", "last", "twin", "cost")
+    __slots__ = ("id", "kind", "args", "bound", "users", "rnd", "slot", "height", "last", "twin", "cost", "after")
 
     def __init__(self, id_, kind, args, bound):
         self.id, self.kind, self.args, self.bound = id_, kind, args, bound
-        self.users, self.rnd, self.slot, self.height, self.last, self.twin, self.cost = [], None, None, 0, -1, None, None
+        self.users, self.rnd, self.slot, self.height, self.last, self.twin, self.cost, self.after = [], None, None, 0, -1, None, None, None
 
     def srcs(self):
         if self.kind == "mul":
@@ -544,11 +597,12 @@ class Lowered:
 
     def _lower(self, v):
         if v.kind == "in":
-            c0 = self._new("in", v.name + ".c0", 1.01)
+            arr, fq0, fq1, pair = v.src if v.src is not None else (ARR_NONE, 0, 0, 0)
+            c0 = self._new("in", (v.name + ".c0", arr, fq0, pair), 1.01)
             self.inputs.append(c0)
             c1 = None
             if not v.real:
-                c1 = self._new("in", v.name + ".c1", 1.01)
+                c1 = self._new("in", (v.name + ".c1", arr, fq1, pair), 1.01)
                 self.inputs.append(c1)
             return c0, c1
         if v.kind == "const":
@@ -570,7 +624,13 @@ class Lowered:
                 if x1 is not None:
                     p1.append((x1, y0))
             a0, a1 = self.map[add.id] if add is not None else (None, None)
-            return self._mul(p0, a0), self._mul(p1, a1)
+            n0 = len(self.fv)
+            r0, r1 = self._mul(p0, a0), self._mul(p1, a1)
+            if v.after is not None:
+                for r in self.fv[n0:]:
+                    if r.kind == "mul":
+                        r.after = self.map[v.after.id][0]
+            return r0, r1
         if v.kind == "lin":
             out = []
             for h in range(2):
@@ -677,6 +737,12 @@ class Program:
         for v in self.ops:
             pr = {self._producer(s).id for s in v.srcs()}
             pending[v.id] = sum(1 for i in pr if self.low.fv[i].kind in ("mul", "lin", "inv"))
+        waiters = {}
+        for v in self.ops:
+            t = self._producer(v.after) if v.after is not None else None
+            if t is not None and t.kind in ("mul", "lin", "inv") and t.id in self.live:
+                pending[v.id] += 1
+                waiters.setdefault(t.id, []).append(v)
         ready = [v for v in self.ops if pending[v.id] == 0]
         rounds = []
         done = 0
@@ -702,6 +768,10 @@ class Program:
                     if u.id in seen:
                         continue
                     seen.add(u.id)
+                    pending[u.id] -= 1
+                    if pending[u.id] == 0:
+                        ready.append(u)
+                for u in waiters.get(v.id, ()):
                     pending[u.id] -= 1
                     if pending[u.id] == 0:
                         ready.append(u)
@@ -816,7 +886,7 @@ class Program:
         for v in self.low.fv:
             if v.kind == "const" and v.id in self.live:
                 consts[v.slot] = v.args
-        return {"kinds": kinds, "rows": rows, "consts": consts, "inputs": [v.slot for v in self.low.inputs],
+        return {"kinds": kinds, "rows": rows, "consts": consts, "inputs": [(v.slot,) + tuple(v.args[1:]) for v in self.low.inputs],
                 "outputs": [v.slot for v in self.low.outputs], "n_slots": self.n_slots + 1, "nr": self.nr}
 
     def stats(self):
@@ -829,23 +899,43 @@ class Program:
 
 
 # ------------------------------------------------------------------ the programs
-def build_pairing():
-    """inputs: P.x, P.y (c1 = 0), Q.x, Q.y  ->  outputs: the six Fq2 coefficients of pairing(P, Q) in MyFq12 order"""
-    g = Graph()
+def _graph(**kw):
+    g = Graph(**kw)
     g.const((0, 0))
     g.const((1, 0))
-    px, py, qx, qy = g.inp("px", real=True), g.inp("py", real=True), g.inp("qx"), g.inp("qy")
-    f = g.miller_loop(px, py, (qx, qy))
-    g.outputs = g.final_exp(f)
+    return g
+
+
+def build_pairing():
+    """pairing(p, q) (src/pairing.rs:20-22): the six Fq2 coefficients in MyFq12 order"""
+    g = _graph()
+    (px, py), Q = g.g1_point(), g.g2_point()
+    g.outputs = g.final_exp(g.miller_loop(px, py, Q))
+    return g
+
+
+def build_miller(run_ahead=None):
+    """miller_loop_native(q, p) (miller_loop_native.rs:320-322), the exact value"""
+    g = _graph(run_ahead=run_ahead)
+    (px, py), Q = g.g1_point(), g.g2_point()
+    g.outputs = g.miller_loop(px, py, Q, exact=True)
     return g
 
 
 def build_final_exp():
-    g = Graph()
-    g.const((0, 0))
-    g.const((1, 0))
-    f = [g.inp(f"f{i}") for i in range(6)]
-    g.outputs = g.final_exp(f)
+    """final_exp_native(f) (final_exp_native.rs:209-213)"""
+    g = _graph()
+    g.outputs = g.final_exp(g.fq12_input())
+    return g
+
+
+def build_multi(k, final_exp=True, run_ahead=None):
+    """multi_miller_loop_native over k pairs (miller_loop_native.rs:324-326), then final_exp_native (the Groth16-style product of
+    pairings, final_exp_native.rs:245-263) or -- final_exp=False -- the exact Miller value"""
+    g = _graph(run_ahead=run_ahead)
+    pairs = [(g.g1_point(j), g.g2_point(j)) for j in range(k)]
+    f = g.multi_miller_loop(pairs, exact=not final_exp)
+    g.outputs = g.final_exp(f) if final_exp else f
     return g
 
 
@@ -862,10 +952,8 @@ def build_fq12_mul():
 def build_synth(kind, count):
     """DIAGNOSTIC program (tools/exp/lat_variant.sh, CVM_SYNTH): `count` rounds in which all sixteen lanes do one operation of
     `kind` (m2 / m6 / l4 / l8) on the previous round's values -- the per-round cost of the interpreter, kind by kind"""
-    g = Graph()
-    g.const((0, 0))
-    g.const((1, 0))
-    px, py, qx, qy = g.inp("px", real=True), g.inp("py", real=True), g.inp("qx"), g.inp("qy")
+    g = _graph()
+    (px, py), (qx, qy) = g.g1_point(), g.g2_point()
     v = [g.mul((qx, qy)), g.mul((qy, qy)), g.mul((qx, qx)), g.lin((qx, ID), (qy, mxi())), g.lin((qx, mxi()), (qy, ID)), g.lin((qx, CONJ), (qy, ID)),
          g.lin((qx, mk(2)), (qy, CONJ)), g.lin((qx, mk(3)), (qy, NEG))]
     for _ in range(count):
