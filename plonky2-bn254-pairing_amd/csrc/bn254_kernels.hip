@@ -28,6 +28,9 @@ constexpr size_t LDS_BYTES = BN254_LDS_BYTES;           // 8 slots x 72 B x 256 
 constexpr size_t SLOT_BYTES = BN254_SLOT_BYTES;         // one Fq2: 2 x 9 balanced 29-bit limbs
 constexpr size_t MAX_K = 64;                            // pairs per group of the multi-pairing kernels
 #ifndef BN254_LATENCY_THRESHOLD_DEFAULT
+#define BN254_CVM_PM_MILLER 500       // per mille of the threshold: the exact Miller programs hold more state in LDS (one wave per CU)
+#define BN254_CVM_PM_FEXP 1000
+#define BN254_CVM_PM_MMILLER 250
 #define BN254_LATENCY_THRESHOLD_DEFAULT 8192            // the measured crossover (profiles/r04_latency.json): 4.9 ms against 6.5 ms at 8192, 8.8 against 6.5 at 16384
 #endif
 
@@ -65,14 +68,15 @@ BN254_ASM_KERNEL(k_mmiller, BN254_ASM_MMILLER)      // k pairs per lane, exact m
 BN254_ASM_KERNEL(k_op, BN254_ASM_OP)                // MyFq12 Mul / frobenius_map_native / pow_native (k = op | power << 8 | naf_len << 16)
 BN254_ASM_KERNEL(k_generate, BN254_ASM_GENERATE)    // synthetic subgroup points: g1 / g2 = outputs, f_in = table, out = seed
 
-// The LATENCY path of pairing() (src/pairing.rs:20-22): one pairing on sixteen lanes, four per wave, one wave per workgroup.  The
-// kernel is an interpreter of the round program in cvm_asm_gen.h (tools/cvm.py: the same Miller loop and final exponentiation,
-// scheduled over sixteen lanes: 0.57 M instructions deep instead of 3.6 M).  f_in = the device copy of the program blob.
+// The LATENCY path of the scalar signatures (pairing, miller_loop_native, multi_miller_loop_native, final_exp_native): one item on
+// sixteen lanes, four items per wave, one wave per workgroup.  The kernel is an interpreter of the round programs in cvm_asm_gen.h
+// (tools/cvm.py: the same Miller loop and final exponentiation, scheduled over sixteen lanes -- pairing: 0.57 M instructions deep
+// instead of 3.6 M).  `scratch` = the device copy of the program's blob; k = pairs per item.
 __global__ void __launch_bounds__(64) __attribute__((aligned(BN254_KERNEL_ALIGN)))
-k_cpairing(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in, uint64_t* out, uint32_t n, uint32_t k, uint4* scratch,
-           uint32_t gslot_stride, int* status) {
+k_cvm(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in, uint64_t* out, uint32_t n, uint32_t k, uint4* scratch,
+      uint32_t gslot_stride, int* status) {
     uint32_t tid = threadIdx.x, bid = blockIdx.x, grid = gridDim.x;
-    asm volatile(BN254_ASM_CPAIRING
+    asm volatile(BN254_ASM_CVM
                  :
                  : "s"(g1), "s"(g2), "s"(f_in), "s"(out), "s"(n), "s"(k), "s"(scratch), "s"(gslot_stride), "s"(status), "v"(tid), "s"(bid),
                    "s"(grid)
@@ -196,7 +200,8 @@ struct DeviceCtx {
     int n_cu = 0;
     std::mutex table_mu;       // the generator table upload (138 KB, blocking) has its own lock
     int32_t* gen_table = nullptr;
-    uint32_t* cvm_blob = nullptr;   // the latency path's round program (0.7 MB, uploaded on first use, same lock)
+    uint32_t* cvm_blob[9] = {};     // the latency path's round programs (0.3 - 1.1 MB each, uploaded on first use, same lock)
+    bool cvm_init = false;
     std::map<hipStream_t, std::shared_ptr<StreamCtx>> streams;   // shared: a call keeps its context alive across a concurrent release
     std::mutex pipe_mu;        // one host-pointer pipeline at a time per device (its two workers fill the chip anyway)
     hipStream_t pipe_stream[2] = {nullptr, nullptr};   // the workers' private streams: created once, their scratch and staging kept
@@ -318,26 +323,50 @@ int ctx_get(int device, void* stream, size_t k, size_t n_items, LaunchCtx* out, 
 int launch_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, size_t power, const int8_t* naf_host, int naf_len,
               int device, void* stream);
 
-// Batches of at most this many pairings take the lane-cooperative kernel (bn254_set_latency_threshold; 0: never).
+// Batches of at most this many items take the lane-cooperative kernel where a program exists (bn254_set_latency_threshold; 0: never).
 std::atomic<size_t> g_latency_threshold{BN254_LATENCY_THRESHOLD_DEFAULT};
 
-int launch_cpairing(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n, int device, void* stream) {
+struct CvmProgram {
+    const uint32_t* blob;
+    size_t bytes;
+    uint32_t lds_bytes;
+    uint32_t per_mille;       // share of the threshold this program takes batches up to (its own crossover against the throughput kernel)
+};
+#define CVM_PROGRAM(NAME, PM) {BN254_CVM_##NAME##_BLOB, sizeof(BN254_CVM_##NAME##_BLOB), BN254_CVM_##NAME##_LDS_BYTES, PM}
+const CvmProgram CVM_PROGRAMS[9] = {CVM_PROGRAM(PAIRING, 1000), CVM_PROGRAM(MILLER, BN254_CVM_PM_MILLER), CVM_PROGRAM(FEXP, BN254_CVM_PM_FEXP),
+                                    CVM_PROGRAM(MULTI2, 1000), CVM_PROGRAM(MULTI3, 1000), CVM_PROGRAM(MULTI4, 1000),
+                                    CVM_PROGRAM(MMILLER2, BN254_CVM_PM_MMILLER), CVM_PROGRAM(MMILLER3, BN254_CVM_PM_MMILLER), CVM_PROGRAM(MMILLER4, BN254_CVM_PM_MMILLER)};
+
+// which program serves (Miller loop?, final exponentiation?, k pairs); -1: none
+template <bool M, bool F>
+int cvm_program(size_t k) {
+    if (M && F) return k == 1 ? 0 : (k <= 4 ? 1 + (int)k : -1);
+    if (M) return k == 1 ? 1 : (k <= 4 ? 4 + (int)k : -1);
+    return k == 1 ? 2 : -1;
+}
+
+int launch_cvm(int prog, const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in, uint64_t* out, size_t n, size_t k, int device, void* stream) {
     LaunchCtx c;
     int rc = ctx_get(device, stream, 1, 1, &c);          // the status word and the stream context; the kernel needs no scratch
     if (rc) return rc;
     DeviceCtx& d = g_ctx[device];
+    const CvmProgram& p = CVM_PROGRAMS[prog];
     {
         std::lock_guard<std::mutex> lk(d.table_mu);
-        if (!d.cvm_blob) {
+        if (!d.cvm_init) {
+            HIPCHK(hipFuncSetAttribute((const void*)k_cvm, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            d.cvm_init = true;
+        }
+        if (!d.cvm_blob[prog]) {
             uint32_t* t = nullptr;
-            if (hipMalloc(&t, sizeof(BN254_CVM_PAIRING_BLOB)) != hipSuccess) { (void)hipGetLastError(); return BN254_ERR_ALLOC; }
-            if (hipMemcpy(t, BN254_CVM_PAIRING_BLOB, sizeof(BN254_CVM_PAIRING_BLOB), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(t); return BN254_ERR_HIP; }
-            d.cvm_blob = t;
+            if (hipMalloc(&t, p.bytes) != hipSuccess) { (void)hipGetLastError(); return BN254_ERR_ALLOC; }
+            if (hipMemcpy(t, p.blob, p.bytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(t); return BN254_ERR_HIP; }
+            d.cvm_blob[prog] = t;
         }
     }
     uint32_t grid = (uint32_t)((n + BN254_CVM_GROUPS - 1) / BN254_CVM_GROUPS);
-    hipLaunchKernelGGL(k_cpairing, dim3(grid), dim3(64), BN254_CVM_PAIRING_LDS_BYTES, (hipStream_t)stream, g1, g2, (const uint64_t*)d.cvm_blob, out,
-                       (uint32_t)n, 1u, c.scratch, c.stride, c.status);
+    hipLaunchKernelGGL(k_cvm, dim3(grid), dim3(64), p.lds_bytes, (hipStream_t)stream, g1, g2, f_in, out, (uint32_t)n, (uint32_t)k,
+                       (uint4*)d.cvm_blob[prog], 0u, c.status);
     HIPCHK(hipGetLastError());
     return BN254_OK;
 }
@@ -378,7 +407,11 @@ int launch_pairing(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in,
         if (F) return launch_pairing<false, true>(nullptr, nullptr, acc, out, n_groups, 1, device, stream);
         return BN254_OK;
     }
-    if (M && F && k == 1 && n_groups <= g_latency_threshold.load()) return launch_cpairing(g1, g2, out, n_groups, device, stream);
+    {
+        int prog = cvm_program<M, F>(k);
+        if (prog >= 0 && n_groups * 1000 <= g_latency_threshold.load() * CVM_PROGRAMS[prog].per_mille && n_groups * k < (1u << 22))
+            return launch_cvm(prog, g1, g2, f_in, out, n_groups, k, device, stream);
+    }
     LaunchCtx c;
     int rc = ctx_get(device, stream, k, (n_groups + BLOCK - 1) / BLOCK, &c);
     if (rc) return rc;

@@ -73,7 +73,7 @@ def _mini():
     g = cvm.Graph()
     g.const((0, 0))
     g.const((1, 0))
-    px, py, qx, qy = g.inp("px", real=True), g.inp("py", real=True), g.inp("qx"), g.inp("qy")
+    (px, py), (qx, qy) = g.g1_point(), g.g2_point()
     a = g.mul((qx, qy))
     b = g.mul((qx, qy), (a, qx), (qy, qy), add=a)
     c = g.lin((a, cvm.mxi()), (b, cvm.mk(-27)), (qx, cvm.CONJ), (qy, (3, -5, 7, 11)))
@@ -115,7 +115,7 @@ def test_zero_divisor_raises_the_status_flag_on_the_simulator():
     g = cvm.Graph()
     g.const((0, 0))
     g.const((1, 0))
-    px, py, qx, qy = g.inp("px", real=True), g.inp("py", real=True), g.inp("qx"), g.inp("qy")
+    (px, py), (qx, qy) = g.g1_point(), g.g2_point()
     z = g.lin((qx, cvm.ID), (qx, cvm.NEG))          # 0
     g.outputs = [g.fq2_inv(z)] + [qx] * 5
     pr = cvm.Program(cvm.Lowered(g), nr=CK.NR)
@@ -124,6 +124,69 @@ def test_zero_divisor_raises_the_status_flag_on_the_simulator():
     g2 = [w for c in (Q_PT[0][0], Q_PT[0][1], Q_PT[1][0], Q_PT[1][1]) for w in R.limbs4(R.to_mont(c))]
     gmem, ms, rounds = CS.simulate(CK.VMKernel().build(), blob, g1, g2)
     assert gmem.get(CS.STAT) == 1
+
+
+def test_input_descriptors_pairs_items_and_fq12_on_the_simulator():
+    """k = 2 pairs per item, n = 3 items, the lanes of item 1; and an Fq12 input (f_in) with null G1 / G2 pointers"""
+    pts = [(R.g1_mul(R.G1_GEN, 3 + i), R.g2_mul(R.G2_GEN, 5 + i)) for i in range(6)]
+    g = cvm._graph()
+    prs = [(g.g1_point(j), g.g2_point(j)) for j in range(2)]
+    (p0, q0), (p1, q1) = prs
+    g.outputs = [g.mul((q0[0], q1[1])), g.mul((q0[1], p1[0]), (q1[0], p0[1])), g.lin((q1[0], cvm.mxi()), (q0[1], cvm.CONJ)), q1[1], g.mul((p0[0], p1[1])),
+                 g.mul((q1[0], q1[0]), add=q0[0])]
+    low = cvm.Lowered(g)
+    pr = cvm.Program(low, nr=CK.NR)
+    item = 1
+    flat = []
+    for j in range(2):
+        P, Q = pts[2 * item + j]
+        flat += [P[0], P[1], Q[0][0], Q[0][1], Q[1][0], Q[1][1]]
+    want = low.evaluate(flat)
+    W = lambda x: R.limbs4(R.to_mont(x))
+    g1 = CS.soa([[W(P[0]), W(P[1])] for P, _ in pts], 2)
+    g2 = CS.soa([[W(Q[0][0]), W(Q[0][1]), W(Q[1][0]), W(Q[1][1])] for _, Q in pts], 4)
+    gmem, ms, _ = CS.simulate(CK.VMKernel().build(), CK.make_blob(pr.encode()), g1, g2, n=3, k=2, tids=range(16, 32))
+    got = [R.from_mont(v) for v in CS.read_fq12(gmem, n=3, item=item)]
+    assert got == [want[2 * i] for i in range(6)] + [want[2 * i + 1] for i in range(6)]
+    assert all((CS.OUTB + 8 * other) not in gmem for other in (0, 2))          # only item 1's lanes ran: nothing else is written
+    # Fq12 input
+    g = cvm._graph()
+    f = g.fq12_input()
+    g.outputs = [g.mul((f[i], f[(i + 1) % 6])) for i in range(6)]
+    low = cvm.Lowered(g)
+    pr = cvm.Program(low, nr=CK.NR)
+    x = [(7 + 3 * i) * 0x123456789ABCDEF123456789 % R.P for i in range(12)]              # MyFq12 coefficient order
+    flat = [x[i + 6 * h] for i in range(6) for h in range(2)]
+    want = low.evaluate(flat)
+    gmem, ms, _ = CS.simulate(CK.VMKernel().build(), CK.make_blob(pr.encode()), fin_words=CS.soa([[W(c) for c in x]], 12))
+    got = [R.from_mont(v) for v in CS.read_fq12(gmem)]
+    assert got == [want[2 * i] for i in range(6)] + [want[2 * i + 1] for i in range(6)]
+
+
+def test_other_programs_equal_the_reference_functions():
+    """the exact Miller value (one pair and k = 2, 3 pairs with the shared f), the product of pairings, final_exp_native: graph, Fq
+    lowering and schedule on big integers"""
+    P = [R.g1_mul(R.G1_GEN, 11 + 7 * j) for j in range(3)]
+    Q = [R.g2_mul(R.G2_GEN, 5 + 3 * j) for j in range(3)]
+
+    def flat(k):
+        return [c for j in range(k) for c in (P[j][0], P[j][1], Q[j][0][0], Q[j][0][1], Q[j][1][0], Q[j][1][1])]
+
+    def check(g, ins, want12):
+        low = cvm.Lowered(g)
+        pr = cvm.Program(low, nr=CK.NR)
+        want = [c for x in R.fq12_to_fp2s(want12) for c in x]
+        assert low.evaluate(ins) == want and pr.run(ins) == want
+        assert max(v.bound for v in low.fv) <= cvm.Lowered.V_MAX
+        return pr
+    check(cvm.build_miller(), flat(1), R.miller_loop_native(Q[0], P[0]))
+    check(cvm.build_miller(run_ahead=2), flat(1), R.miller_loop_native(Q[0], P[0]))
+    for k in (2, 3):
+        m = R.multi_miller_loop_native([(P[j], Q[j]) for j in range(k)])
+        check(cvm.build_multi(k, final_exp=False), flat(k), m)
+        check(cvm.build_multi(k, final_exp=True), flat(k), R.final_exp_native(m))
+    f = R.miller_loop_native(Q[1], P[2])
+    check(cvm.build_final_exp(), [c for x in R.fq12_to_fp2s(f) for c in x], R.final_exp_native(f))
 
 
 def test_whole_pairing_on_the_simulator():

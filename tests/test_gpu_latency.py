@@ -104,3 +104,96 @@ def test_threshold_selects_the_kernel(pk):
         pk.pairing_batch_dev(g1, g2, o, n)
         outs.append(o)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def _dev_pairs(pk, n, seed):
+    import torch
+    dev = torch.device("cuda:0")
+    g1 = torch.empty(8 * n, dtype=torch.int64, device=dev)
+    g2 = torch.empty(16 * n, dtype=torch.int64, device=dev)
+    pk.generate_pairs_dev(seed, g1, g2, n)
+    return g1, g2
+
+
+def _both(pk, fn, words, n):
+    """fn(out) under both kernels -> (throughput result, latency result)"""
+    import torch
+    outs = []
+    for thr in (0, 1 << 20):
+        o = torch.empty(words * n, dtype=torch.int64, device=torch.device("cuda:0"))
+        pk.set_latency_threshold(thr)
+        fn(o)
+        pk.last_status()
+        outs.append(o)
+    return outs
+
+
+@pytest.mark.parametrize("n", [1, 5, 257])
+def test_miller_loop_and_final_exp_on_the_latency_kernel(pk, n):
+    """miller_loop_native (the exact value) and final_exp_native: lane-cooperative programs == throughput kernels, every lane"""
+    import torch
+    g1, g2 = _dev_pairs(pk, n, 0xB2540001)
+    a, b = _both(pk, lambda o: pk.miller_loop_batch_dev(g1, g2, o, n), 48, n)
+    assert torch.equal(a, b)
+    c, d = _both(pk, lambda o: pk.final_exp_batch_dev(a, o, n), 48, n)
+    assert torch.equal(c, d)
+    e, f = _both(pk, lambda o: pk.pairing_batch_dev(g1, g2, o, n), 48, n)
+    assert torch.equal(e, f) and torch.equal(c, e)                 # pairing = final_exp(miller)
+
+
+def test_golden_miller_and_final_exp_on_the_latency_kernel(pk):
+    vec = H.load_golden("bn254_vectors.json")
+    P = [tuple(HX(p)) for p in vec["g1"]]
+    Q = [((int(q[0], 16), int(q[1], 16)), (int(q[2], 16), int(q[3], 16))) for q in vec["g2"]]
+    n = len(P)
+    pk.set_latency_threshold(1 << 20)
+    got_m = H.fq12_from_aos(H.to_aos(pk.miller_loop_batch(H.to_soa(H.g1_aos(P), 8), H.to_soa(H.g2_aos(Q), 16), n), 48), n)
+    assert got_m == [HX(m) for m in vec["miller"]]
+    f = H.to_soa(H.fq12_aos([HX(m) for m in vec["miller"]]), 48)
+    assert H.fq12_from_aos(H.to_aos(pk.final_exp_batch(f, n), 48), n) == [HX(p) for p in vec["pairing"]]
+    # final_exp_native on arbitrary (non-Miller) Fq12 values
+    x = H.rand_fq12(5, seed=11)
+    rc, want = H.oracle_final_exp(H.fq12_aos(x), 5)
+    assert rc == 0
+    assert np.array_equal(H.to_aos(pk.final_exp_batch(H.to_soa(H.fq12_aos(x), 48), 5), 48), want)
+
+
+@pytest.mark.parametrize("k", [2, 3, 4])
+def test_multi_pairing_on_the_latency_kernel(pk, k):
+    """multi_miller_loop_native over k pairs (shared f), exact value and with final_exp_native: == throughput kernels on every
+    lane, == the C oracle on a few groups; the == one verdict of a Groth16-style product"""
+    import torch
+    n = 37
+    g1, g2 = _dev_pairs(pk, n * k, 0xC0FFEE + k)
+    for fe in (False, True):
+        a, b = _both(pk, lambda o: pk.multi_pairing_batch_dev(g1, g2, o, n, k, do_final_exp=fe), 48, n)
+        assert torch.equal(a, b), (k, fe)
+    # oracle, host path
+    base_P, base_Q = H.subgroup_points(8)
+    ng = 3
+    P = [base_P[(g * k + j) % 8] for g in range(ng) for j in range(k)]
+    Q = [base_Q[(3 * g + j + 1) % 8] for g in range(ng) for j in range(k)]
+    g1a, g2a = H.g1_aos(P), H.g2_aos(Q)
+    pk.set_latency_threshold(1 << 20)
+    got = H.to_aos(pk.multi_pairing_batch(H.to_soa(g1a, 8), H.to_soa(g2a, 16), ng, k, do_final_exp=False), 48)
+    assert np.array_equal(got, H.oracle_multi_miller(g1a, g2a, ng, k))
+    got = H.to_aos(pk.multi_pairing_batch(H.to_soa(g1a, 8), H.to_soa(g2a, 16), ng, k, do_final_exp=True), 48)
+    assert np.array_equal(got, H.oracle_multi_pairing(g1a, g2a, ng, k))
+
+
+def test_groth16_style_check_on_the_latency_kernel(pk):
+    """e(aP, bQ) e(-abP, Q) e(cP, dQ) e(-cdP, Q) == 1 (final_exp_native.rs:245-263 pattern) and a broken group, verdict bytes"""
+    R_ = H.R
+    a, b, c, d = 1234567, 7654321, 424242, 99991
+    G1, G2 = R_.G1_GEN, R_.G2_GEN
+    good = [(R_.g1_mul(G1, a), R_.g2_mul(G2, b)), (R_.g1_neg(R_.g1_mul(G1, a * b % R_.R_ORDER)), G2),
+            (R_.g1_mul(G1, c), R_.g2_mul(G2, d)), (R_.g1_neg(R_.g1_mul(G1, c * d % R_.R_ORDER)), G2)]
+    bad = list(good)
+    bad[2] = (R_.g1_mul(G1, c + 1), good[2][1])
+    groups = [good, bad, good]
+    P = [p for g in groups for p, _ in g]
+    Q = [q for g in groups for _, q in g]
+    for thr in (0, 1 << 20):
+        pk.set_latency_threshold(thr)
+        v = pk.multi_pairing_check_batch(H.to_soa(H.g1_aos(P), 8), H.to_soa(H.g2_aos(Q), 16), 3, 4)
+        assert list(v) == [1, 0, 1], thr

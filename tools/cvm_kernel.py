@@ -15,8 +15,8 @@ LDS: per group n_slots x 48 bytes (nine limbs + a pad dword, 16-byte aligned for
 execute in order, and the four groups never touch each other's slots, so no barrier is needed; the schedule guarantees that no slot
 is written in the round that reads it last (tools/cvm.py: Program._allocate).
 
-asm operands: %0 g1  %1 g2  %2 program blob  %3 out  %4 n  %8 status  %9 threadIdx.x  %10 blockIdx.x   (the throughput kernels' list;
-%5, %6, %7, %11 unused).  Field arithmetic: tools/kgen4.py L1v4 on an explicit register plan (below).
+asm operands: %0 g1  %1 g2  %2 f_in  %3 out  %4 n  %5 k (pairs per item)  %6 program blob  %8 status  %9 threadIdx.x  %10 blockIdx.x
+(the throughput kernels' list; %7, %11 unused).  Which inputs a program reads (G1 / G2 points of its k pairs, an Fq12) is in its blob.  Field arithmetic: tools/kgen4.py L1v4 on an explicit register plan (below).
 """
 import os
 import sys
@@ -31,7 +31,7 @@ NR = 16
 GROUPS = 4
 SLOT_BYTES = 48
 ROW_DW = 8
-HDR_DW = 40            # n_rounds, n_const, kinds_off, rows_off, consts_off, n_slots, trash, n_in, 16 input slots, 16 output slots
+HDR_DW = 24            # n_rounds, n_const, inputs_off, rows_off, consts_off, n_slots, trash, input chunks, 16 output slots (bytes offsets from the blob)
 CONST_DW = 10
 
 
@@ -50,9 +50,11 @@ OVERLAP = bool(int(os.environ.get("CVM_OVERLAP", "1")))      # operand limbs tha
 ROWN = 204 if ROW_DEPTH > 1 else 228
 ROWB = [212, 220, 228]
 V_LBASE, V_ROWOFF, V_ROLE, V_ITEM8, V_FLAG, V_T0, V_DST, V_TWIN, V_VALID, V_T1 = 236, 237, 238, 239, 240, 241, 242, 243, 244, 245
+V_ELEM, V_DESC = 246, 247
 S_BLOB, S_ROWS, S_NROUNDS, S_KIND, S_KINDS, S_KNEXT, S_NCONST, S_NSLOTS, S_TMP = "s[48:49]", "s[50:51]", 52, 53, "s[62:63]", 64, 65, 66, 67
 S_PHASE = 89
 S_CONSTS, S_G1, S_G2, S_OUT, S_N, S_NSTRIDE, S_STATUS = "s[68:69]", "s[70:71]", "s[72:73]", "s[74:75]", 76, 77, "s[78:79]"
+S_FIN, S_INS, S_K, S_PITCH_IN, S_NCHUNK = "s[90:91]", "s[92:93]", 94, 95, 96
 S_H = 80               # s80..s87: header words / scratch
 S_CNT = 88
 S_SAVE = "s[60:61]"
@@ -131,19 +133,22 @@ class VMKernel:
         e = self.e
         e.salu(f"s_mov_b64 {S_G1}, %0")
         e.salu(f"s_mov_b64 {S_G2}, %1")
-        e.salu(f"s_mov_b64 {S_BLOB}, %2")
+        e.salu(f"s_mov_b64 {S_BLOB}, %6")
+        e.salu(f"s_mov_b64 {S_FIN}, %2")
         e.salu(f"s_mov_b64 {S_OUT}, %3")
         e.salu(f"s_mov_b32 s{S_N}, %4")
+        e.salu(f"s_mov_b32 s{S_K}, %5")
         e.salu(f"s_mov_b64 {S_STATUS}, %8")
         e.salu(f"s_mov_b32 s{S_TMP}, %10")
-        for i, dst in enumerate((S_NROUNDS, S_NCONST, S_H, S_H + 1, S_H + 2, S_NSLOTS, S_H + 3)):
+        for i, dst in enumerate((S_NROUNDS, S_NCONST, S_H, S_H + 1, S_H + 2, S_NSLOTS, S_H + 3, S_NCHUNK)):
             e.salu(f"s_load_dword s{dst}, {S_BLOB}, 0x{4 * i:x}")
         for i in range(NL):
             e.salu(f"s_mov_b32 s{S_P + i}, {hx(P_L[i])}")
         e.salu(f"s_mov_b32 s{S_N0}, 0x{N0P:x}")
         e.salu(f"s_mov_b32 s{S_REDN}, 0x{REDN_C:x}")
         e.salu(f"s_mov_b32 s{S_M30}, -30")
-        e.salu(f"s_lshl_b32 s{S_NSTRIDE}, s{S_N}, 3")
+        e.salu(f"s_lshl_b32 s{S_NSTRIDE}, s{S_N}, 3")               # bytes between the planes of the output (n items)
+        e.salu(f"s_mul_i32 s{S_PITCH_IN}, s{S_NSTRIDE}, s{S_K}")      # ... of the inputs (n k elements: pair j of item g is element g k + j)
         e.emit(f"v_and_b32_e32 v{V_ROLE}, {NR - 1}, %9", vw=[V_ROLE])
         e.emit(f"v_lshrrev_b32_e32 v{V_T0}, 4, %9", vw=[V_T0])                             # group of the lane
         e.salu(f"s_lshl_b32 s{S_TMP}, s{S_TMP}, 2")
@@ -152,6 +157,7 @@ class VMKernel:
         e.emit(f"v_cndmask_b32_e64 v{V_VALID}, 0, 1, vcc", r=["vcc"], vw=[V_VALID])
         e.salu(f"s_sub_u32 s{S_TMP}, s{S_N}, 1")
         e.emit(f"v_min_u32_e32 v{V_ITEM8}, s{S_TMP}, v{V_ITEM8}", vw=[V_ITEM8])             # lanes past the end redo the last item (they never store)
+        e.emit(f"v_mul_lo_u32 v{V_ELEM}, v{V_ITEM8}, s{S_K}", vw=[V_ELEM])                  # first input element of the item
         e.emit(f"v_lshlrev_b32_e32 v{V_ITEM8}, 3, v{V_ITEM8}", vw=[V_ITEM8])
         e.raw("s_waitcnt lgkmcnt(0)")
         e.salu(f"s_mul_i32 s{S_TMP}, s{S_NSLOTS}, {SLOT_BYTES}")
@@ -164,6 +170,8 @@ class VMKernel:
         e.salu("s_addc_u32 s51, s49, 0")
         e.salu(f"s_add_u32 s68, s48, s{S_H + 2}")            # constants
         e.salu("s_addc_u32 s69, s49, 0")
+        e.salu(f"s_add_u32 s92, s48, s{S_H}")                # input descriptors
+        e.salu("s_addc_u32 s93, s49, 0")
         # ---- constant pool -> the group's slots [0, n_const): lane r copies constants r, r + 16, ... (clamped: the last one again)
         e.emit(f"v_mov_b32_e32 v{V_T1}, v{V_ROLE}", vw=[V_T1])
         e.salu(f"s_add_u32 s{S_CNT}, s{S_NCONST}, {NR - 1}")
@@ -182,36 +190,42 @@ class VMKernel:
         e.salu(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
         e.salu(f"s_cmp_lg_u32 s{S_CNT}, 0")
         e.salu("s_cbranch_scc1 LC_const_%=")
-        # ---- inputs: lane r < 6 converts Fq number r of (P.x, P.y, Q.x.c0, Q.x.c1, Q.y.c0, Q.y.c1); the others write the trash slot
-        # both sources are read by every lane (clamped indices) and the right one kept: no divergent addressing
-        e.emit(f"v_min_u32_e32 v{V_T0}, 1, v{V_ROLE}", vw=[V_T0])                           # G1: Fq 0, 1
-        e.emit(f"v_lshlrev_b32_e32 v{V_T0}, 2, v{V_T0}", vw=[V_T0])
-        e.emit(f"v_mul_lo_u32 v{V_T0}, v{V_T0}, s{S_NSTRIDE}", vw=[V_T0])
-        e.emit(f"v_add_u32_e32 v{V_T0}, v{V_T0}, v{V_ITEM8}", vw=[V_T0])
-        for l in range(4):
-            e.emit(f"global_load_dwordx2 v[{2 * l}:{2 * l + 1}], v{V_T0}, {S_G1}", kind="vmem", vw=[2 * l, 2 * l + 1])
-            if l < 3:
-                e.emit(f"v_add_u32_e32 v{V_T0}, s{S_NSTRIDE}, v{V_T0}", vw=[V_T0])
-        e.emit(f"v_max_u32_e32 v{V_T0}, 2, v{V_ROLE}", vw=[V_T0])                           # G2: Fq (r - 2) clamped to 0..3
-        e.emit(f"v_min_u32_e32 v{V_T0}, 5, v{V_T0}", vw=[V_T0])
-        e.emit(f"v_subrev_u32_e32 v{V_T0}, 2, v{V_T0}", vw=[V_T0])
-        e.emit(f"v_lshlrev_b32_e32 v{V_T0}, 2, v{V_T0}", vw=[V_T0])
-        e.emit(f"v_mul_lo_u32 v{V_T0}, v{V_T0}, s{S_NSTRIDE}", vw=[V_T0])
-        e.emit(f"v_add_u32_e32 v{V_T0}, v{V_T0}, v{V_ITEM8}", vw=[V_T0])
-        for l in range(4):
-            e.emit(f"global_load_dwordx2 v[{10 + 2 * l}:{11 + 2 * l}], v{V_T0}, {S_G2}", kind="vmem", vw=[10 + 2 * l, 11 + 2 * l])
-            if l < 3:
-                e.emit(f"v_add_u32_e32 v{V_T0}, s{S_NSTRIDE}, v{V_T0}", vw=[V_T0])
+        # ---- inputs: sixteen descriptors per chunk, one per lane: slot | Fq number << 16 | array << 20 | pair << 22.  The lane reads the
+        # four words of that Fq from its array (the section of another array is skipped under EXEC: its pointer may be null), converts,
+        # stores to the slot (padding descriptors: array 3, the trash slot).
         e.emit(f"v_lshlrev_b32_e32 v{V_T1}, 2, v{V_ROLE}", vw=[V_T1])
-        e.emit(f"global_load_dword v{V_DST}, v{V_T1}, {S_BLOB} offset:32", kind="vmem", vw=[V_DST])       # the lane's input slot
-        e.raw("s_waitcnt vmcnt(0)")
-        e.emit(f"v_cmp_gt_u32_e32 vcc, 2, v{V_ROLE}", w=["vcc"])
+        e.label("LC_in_%=")
+        e.emit(f"global_load_dword v{V_DESC}, v{V_T1}, {S_INS}", kind="vmem", vw=[V_DESC])
         for i in range(8):
-            e.emit(f"v_cndmask_b32_e32 v{i}, v{10 + i}, v{i}, vcc", r=["vcc"], vw=[i])
+            e.emit(f"v_mov_b32_e32 v{i}, 0", vw=[i])
+        e.raw("s_waitcnt vmcnt(0)")
+        e.emit(f"v_bfe_u32 v{V_T0}, v{V_DESC}, 16, 4", vw=[V_T0])                           # Fq number
+        e.emit(f"v_lshlrev_b32_e32 v{V_T0}, 2, v{V_T0}", vw=[V_T0])
+        e.emit(f"v_mul_lo_u32 v{V_T0}, v{V_T0}, s{S_PITCH_IN}", vw=[V_T0])
+        e.emit(f"v_lshrrev_b32_e32 v{V_DST}, 22, v{V_DESC}", vw=[V_DST])                    # pair
+        e.emit(f"v_add_u32_e32 v{V_DST}, v{V_DST}, v{V_ELEM}", vw=[V_DST])
+        e.emit(f"v_lshl_add_u32 v{V_T0}, v{V_DST}, 3, v{V_T0}", vw=[V_T0])                  # byte offset of word 0
+        e.emit(f"v_bfe_u32 v{V_TWIN}, v{V_DESC}, 20, 2", vw=[V_TWIN])                       # array
+        for arr, base in ((cvm.ARR_G1, S_G1), (cvm.ARR_G2, S_G2), (cvm.ARR_F, S_FIN)):
+            e.emit(f"v_cmp_eq_u32_e32 vcc, {arr}, v{V_TWIN}", w=["vcc"])
+            e.raw("s_nop 1")
+            e.salu(f"s_and_saveexec_b64 {S_SAVE}, vcc")
+            e.emit(f"v_mov_b32_e32 v{V_DST}, v{V_T0}", vw=[V_DST])
+            for l in range(4):
+                e.emit(f"global_load_dwordx2 v[{2 * l}:{2 * l + 1}], v{V_DST}, {base}", kind="vmem", vw=[2 * l, 2 * l + 1])
+                if l < 3:
+                    e.emit(f"v_add_u32_e32 v{V_DST}, s{S_PITCH_IN}, v{V_DST}", vw=[V_DST])
+            e.salu(f"s_mov_b64 exec, {S_SAVE}")
+        e.raw("s_waitcnt vmcnt(0)")
         self.l1().r_cvtin()
         e.emit("v_mov_b32_e32 v9, 0", vw=[9])
+        e.emit(f"v_and_b32_e32 v{V_DST}, 0xffff, v{V_DESC}", vw=[V_DST])
         e.emit(f"v_mad_u32_u24 v{V_DST}, v{V_DST}, {SLOT_BYTES}, v{V_LBASE}", vw=[V_DST])
         self.lds_store(V_DST, 0)
+        e.emit(f"v_add_u32_e32 v{V_T1}, {4 * NR}, v{V_T1}", vw=[V_T1])
+        e.salu(f"s_sub_u32 s{S_NCHUNK}, s{S_NCHUNK}, 1")
+        e.salu(f"s_cmp_lg_u32 s{S_NCHUNK}, 0")
+        e.salu("s_cbranch_scc1 LC_in_%=")
         # ---- the first rows (the round's kind travels in the row: dword 7, high half)
         for b in range(ROW_DEPTH):
             self.prefetch_row(b if ROW_DEPTH > 1 else 2)
@@ -365,7 +379,7 @@ class VMKernel:
         e = self.e
         e.label("LC_end_%=")
         e.emit(f"v_lshlrev_b32_e32 v{V_T1}, 2, v{V_ROLE}", vw=[V_T1])
-        e.emit(f"global_load_dword v{V_DST}, v{V_T1}, {S_BLOB} offset:96", kind="vmem", vw=[V_DST])       # the lane's output slot
+        e.emit(f"global_load_dword v{V_DST}, v{V_T1}, {S_BLOB} offset:32", kind="vmem", vw=[V_DST])       # the lane's output slot
         e.raw("s_waitcnt vmcnt(0)")
         e.emit(f"v_mad_u32_u24 v{V_DST}, v{V_DST}, {SLOT_BYTES}, v{V_LBASE}", vw=[V_DST])
         self.lds_load(0, V_DST)
@@ -412,14 +426,15 @@ class VMKernel:
 
 
 def make_blob(enc):
-    """the program blob as a list of dwords: header, kinds, rows (one END row more than rounds), constants (internal form:
-    nine balanced 29-bit limbs of c R' mod p, + a pad dword)"""
+    """the program blob as a list of dwords: header, input descriptors, rows (one END row more than rounds, + the look-ahead's reach),
+    constants (internal form: nine balanced 29-bit limbs of c R' mod p, + a pad dword)"""
     assert enc["nr"] == NR
     n_rounds = len(enc["rows"])
-    kinds = list(enc["kinds"])
-    assert len(kinds) == n_rounds + 1
-    while len(kinds) % 4:
-        kinds.append(0)
+    trash = enc["n_slots"] - 1
+    ins = [slot | fq << 16 | arr << 20 | pair << 22 for slot, arr, fq, pair in enc["inputs"]]
+    assert all(fq < 16 and pair < 64 for _, _, fq, pair in enc["inputs"])
+    while len(ins) % NR:
+        ins.append(trash | cvm.ARR_NONE << 20)
     rows = []
     for row in enc["rows"]:
         for dw in row:
@@ -428,17 +443,15 @@ def make_blob(enc):
     consts = []
     for c in enc["consts"]:
         consts += [w & 0xFFFFFFFF for w in bal_limbs(c * K4.RP % P_INT)] + [0]
-    trash = enc["n_slots"] - 1
-    kinds_off = 4 * HDR_DW
-    rows_off = kinds_off + 4 * len(kinds)
-    rows_off = (rows_off + 15) // 16 * 16
-    pad = (rows_off - kinds_off) // 4 - len(kinds)
+    ins_off = 4 * HDR_DW
+    rows_off = (ins_off + 4 * len(ins) + 15) // 16 * 16
+    pad = (rows_off - ins_off) // 4 - len(ins)
     consts_off = rows_off + 4 * len(rows)
-    hdr = [n_rounds, len(enc["consts"]), kinds_off, rows_off, consts_off, enc["n_slots"], trash, len(enc["inputs"])]
-    hdr += [enc["inputs"][i] if i < len(enc["inputs"]) else trash for i in range(16)]
-    hdr += [enc["outputs"][i] if i < len(enc["outputs"]) else trash for i in range(16)]
+    assert len(enc["outputs"]) == 12
+    hdr = [n_rounds, len(enc["consts"]), ins_off, rows_off, consts_off, enc["n_slots"], trash, len(ins) // NR]
+    hdr += [enc["outputs"][i] if i < 12 else trash for i in range(16)]
     assert len(hdr) == HDR_DW
-    return hdr + kinds + [0] * pad + rows + consts
+    return hdr + ins + [0] * pad + rows + consts
 
 
 if __name__ == "__main__":

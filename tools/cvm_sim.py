@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import ksim as S  # noqa: E402
 import cvm_kernel as CK  # noqa: E402
 
-G1B, G2B, BLOBB, OUTB, STAT = 0x10000, 0x20000, 0x1000000, 0x30000, 0x40000
+G1B, G2B, FINB, BLOBB, OUTB, STAT = 0x10000, 0x20000, 0x28000, 0x1000000, 0x30000, 0x40000
 
 
 def concretize(lines):
@@ -24,13 +24,14 @@ def concretize(lines):
     return out
 
 
-def simulate(lines, blob, g1_words, g2_words, n=1, block=0, tids=range(CK.NR)):
-    """-> (out: dict Fq index -> integer (ark Montgomery words joined) for item `block * 4 + tid // 16`, machines)"""
+def simulate(lines, blob, g1_words=(), g2_words=(), n=1, block=0, tids=range(CK.NR), k=1, fin_words=None):
+    """One group of lanes on the program `blob`; g1 / g2 / f_in: the SoA u64 words of the batch (n items of k pairs; a missing
+    array is a null pointer, as at the C boundary) -> (global memory, machines, rounds run)"""
     lines = concretize(lines) + ["s_endpgm"]
     lds, gmem = {}, {}
     for i, w in enumerate(blob):
         gmem[BLOBB + 4 * i] = w & 0xFFFFFFFF
-    for base, words in ((G1B, g1_words), (G2B, g2_words)):
+    for base, words in ((G1B, g1_words), (G2B, g2_words), (FINB, fin_words or ())):
         for i, w in enumerate(words):
             gmem[base + 8 * i] = w & 0xFFFFFFFF
             gmem[base + 8 * i + 4] = (w >> 32) & 0xFFFFFFFF
@@ -38,7 +39,8 @@ def simulate(lines, blob, g1_words, g2_words, n=1, block=0, tids=range(CK.NR)):
     for t in tids:
         m = S.Machine()
         m.lds, m.gmem = lds, gmem
-        for name, val in (("s[2:3]", G1B), ("s[4:5]", G2B), ("s[6:7]", BLOBB), ("s[8:9]", OUTB), ("s10", n), ("s11", 1), ("s[12:13]", 0),
+        for name, val in (("s[2:3]", G1B if g1_words else 0), ("s[4:5]", G2B if g2_words else 0), ("s[6:7]", FINB if fin_words else 0), ("s[8:9]", OUTB),
+                          ("s10", n), ("s11", k), ("s[12:13]", BLOBB),
                           ("s14", 0), ("s[16:17]", STAT), ("s18", block), ("s19", 1)):
             m.sset(name, val)
         m.v[255] = t
@@ -57,3 +59,24 @@ def simulate(lines, blob, g1_words, g2_words, n=1, block=0, tids=range(CK.NR)):
                 pcs[i] = r
         rounds += 1
     return gmem, ms, rounds
+
+
+def soa(elems, n_fq):
+    """elems: per element a list of n_fq canonical-Montgomery 4-word tuples -> the SoA word list (plane = Fq number * 4 + word)"""
+    out = []
+    for fq in range(n_fq):
+        for l in range(4):
+            out += [e[fq][l] for e in elems]
+    return out
+
+
+def read_fq12(gmem, n=1, item=0):
+    """the twelve output Fq of `item` as integers (Montgomery words joined)"""
+    out = []
+    for c in range(12):
+        v = 0
+        for l in range(4):
+            a = OUTB + ((c * 4 + l) * n + item) * 8
+            v |= (gmem[a] | (gmem[a + 4] << 32)) << (64 * l)
+        out.append(v)
+    return out

@@ -580,7 +580,7 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None, start_pc=None, 
                     addr = m.sget(sbase) + m.vsrc(voff) + off
                     mm = re.match(r"([va])\[?(\d+)", dst)               # gfx90a+: loads can target AGPRs directly
                     lo, bank = int(mm.group(2)), (v if mm.group(1) == "v" else m.a)
-                    for k in range(n):
+                    for k in range(n if m.exec else 0):               # a lane that EXEC masks off neither reads nor faults
                         x = m.gmem.get(addr + 4 * k)
                         if x is None:
                             raise SimError(f"global read of unwritten address {hex(addr + 4 * k)}: {text}")
