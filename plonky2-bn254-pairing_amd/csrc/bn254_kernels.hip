@@ -28,9 +28,9 @@ constexpr size_t LDS_BYTES = BN254_LDS_BYTES;           // 8 slots x 72 B x 256 
 constexpr size_t SLOT_BYTES = BN254_SLOT_BYTES;         // one Fq2: 2 x 9 balanced 29-bit limbs
 constexpr size_t MAX_K = 64;                            // pairs per group of the multi-pairing kernels
 #ifndef BN254_LATENCY_THRESHOLD_DEFAULT
-#define BN254_CVM_PM_MILLER 500       // per mille of the threshold: the exact Miller programs hold more state in LDS (one wave per CU)
+#define BN254_CVM_PM_MILLER 1000      // per mille of the threshold each program takes batches up to: its own measured crossover (profiles/r04_latency.json)
 #define BN254_CVM_PM_FEXP 1000
-#define BN254_CVM_PM_MMILLER 250
+#define BN254_CVM_PM_MMILLER 500
 #define BN254_LATENCY_THRESHOLD_DEFAULT 8192            // the measured crossover (profiles/r04_latency.json): 4.9 ms against 6.5 ms at 8192, 8.8 against 6.5 at 16384
 #endif
 
@@ -72,16 +72,19 @@ BN254_ASM_KERNEL(k_generate, BN254_ASM_GENERATE)    // synthetic subgroup points
 // sixteen lanes, four items per wave, one wave per workgroup.  The kernel is an interpreter of the round programs in cvm_asm_gen.h
 // (tools/cvm.py: the same Miller loop and final exponentiation, scheduled over sixteen lanes -- pairing: 0.57 M instructions deep
 // instead of 3.6 M).  `scratch` = the device copy of the program's blob; k = pairs per item.
-__global__ void __launch_bounds__(64) __attribute__((aligned(BN254_KERNEL_ALIGN)))
-k_cvm(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in, uint64_t* out, uint32_t n, uint32_t k, uint4* scratch,
-      uint32_t gslot_stride, int* status) {
-    uint32_t tid = threadIdx.x, bid = blockIdx.x, grid = gridDim.x;
-    asm volatile(BN254_ASM_CVM
-                 :
-                 : "s"(g1), "s"(g2), "s"(f_in), "s"(out), "s"(n), "s"(k), "s"(scratch), "s"(gslot_stride), "s"(status), "v"(tid), "s"(bid),
-                   "s"(grid)
-                 : BN254_CVM_CLOBBERS);
-}
+#define BN254_CVM_KERNEL(NAME, BLOB)                                                                                       \
+    __global__ void __launch_bounds__(64) __attribute__((aligned(BN254_KERNEL_ALIGN)))                                     \
+    NAME(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in, uint64_t* out, uint32_t n, uint32_t k, uint4* scratch, \
+         uint32_t gslot_stride, int* status) {                                                                             \
+        uint32_t tid = threadIdx.x, bid = blockIdx.x, grid = gridDim.x;                                                    \
+        asm volatile(BLOB                                                                                                  \
+                     :                                                                                                     \
+                     : "s"(g1), "s"(g2), "s"(f_in), "s"(out), "s"(n), "s"(k), "s"(scratch), "s"(gslot_stride), "s"(status), \
+                       "v"(tid), "s"(bid), "s"(grid)                                                                       \
+                     : BN254_CVM_CLOBBERS);                                                                                \
+    }
+BN254_CVM_KERNEL(k_cvm, BN254_ASM_CVM)               // LDS slots of 48 contiguous bytes: the fastest round (launches of up to three waves per CU)
+BN254_CVM_KERNEL(k_cvm_split, BN254_ASM_CVM_SPLIT)   // 36 bytes per slot: four waves of the pairing program per CU (larger launches)
 
 // verdict[i] = 1 iff Fq12 element i equals MyFq12::one (coeffs[0] = R mod p in ark's Montgomery limbs, the rest 0):
 // the check pattern of final_exp_native.rs:245-263 (a Groth16-style product of pairings == 1), one byte per group.
@@ -329,12 +332,12 @@ std::atomic<size_t> g_latency_threshold{BN254_LATENCY_THRESHOLD_DEFAULT};
 struct CvmProgram {
     const uint32_t* blob;
     size_t bytes;
-    uint32_t lds_bytes;
+    uint32_t slots;
     uint32_t per_mille;       // share of the threshold this program takes batches up to (its own crossover against the throughput kernel)
 };
-#define CVM_PROGRAM(NAME, PM) {BN254_CVM_##NAME##_BLOB, sizeof(BN254_CVM_##NAME##_BLOB), BN254_CVM_##NAME##_LDS_BYTES, PM}
+#define CVM_PROGRAM(NAME, PM) {BN254_CVM_##NAME##_BLOB, sizeof(BN254_CVM_##NAME##_BLOB), BN254_CVM_##NAME##_SLOTS, PM}
 const CvmProgram CVM_PROGRAMS[9] = {CVM_PROGRAM(PAIRING, 1000), CVM_PROGRAM(MILLER, BN254_CVM_PM_MILLER), CVM_PROGRAM(FEXP, BN254_CVM_PM_FEXP),
-                                    CVM_PROGRAM(MULTI2, 1000), CVM_PROGRAM(MULTI3, 1000), CVM_PROGRAM(MULTI4, 1000),
+                                    CVM_PROGRAM(MULTI2, 1000), CVM_PROGRAM(MULTI3, 1500), CVM_PROGRAM(MULTI4, 2000),
                                     CVM_PROGRAM(MMILLER2, BN254_CVM_PM_MMILLER), CVM_PROGRAM(MMILLER3, BN254_CVM_PM_MMILLER), CVM_PROGRAM(MMILLER4, BN254_CVM_PM_MMILLER)};
 
 // which program serves (Miller loop?, final exponentiation?, k pairs); -1: none
@@ -355,6 +358,7 @@ int launch_cvm(int prog, const uint64_t* g1, const uint64_t* g2, const uint64_t*
         std::lock_guard<std::mutex> lk(d.table_mu);
         if (!d.cvm_init) {
             HIPCHK(hipFuncSetAttribute((const void*)k_cvm, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIPCHK(hipFuncSetAttribute((const void*)k_cvm_split, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             d.cvm_init = true;
         }
         if (!d.cvm_blob[prog]) {
@@ -364,9 +368,17 @@ int launch_cvm(int prog, const uint64_t* g1, const uint64_t* g2, const uint64_t*
             d.cvm_blob[prog] = t;
         }
     }
+    // One wave per workgroup.  The contiguous slot layout is the faster one (one address computation less per operand); the split
+    // layout needs 3/4 of the LDS, so more waves fit a CU: taken when the launch has more waves than the contiguous layout can hold
+    // resident AND the split layout holds more.
     uint32_t grid = (uint32_t)((n + BN254_CVM_GROUPS - 1) / BN254_CVM_GROUPS);
-    hipLaunchKernelGGL(k_cvm, dim3(grid), dim3(64), p.lds_bytes, (hipStream_t)stream, g1, g2, f_in, out, (uint32_t)n, (uint32_t)k,
-                       (uint4*)d.cvm_blob[prog], 0u, c.status);
+    size_t lds = (size_t)BN254_CVM_GROUPS * p.slots * BN254_CVM_SLOT_BYTES, lds_split = (size_t)BN254_CVM_GROUPS * p.slots * BN254_CVM_SLOT_BYTES_SPLIT;
+    size_t per_cu = (160 * 1024) / lds, per_cu_split = (160 * 1024) / lds_split;
+    if (per_cu > 8) per_cu = 8;                           // (two waves per SIMD: 248 registers each)
+    if (per_cu_split > 8) per_cu_split = 8;
+    bool split = per_cu_split > per_cu && (size_t)grid > per_cu * (size_t)c.n_cu;
+    hipLaunchKernelGGL(split ? k_cvm_split : k_cvm, dim3(grid), dim3(64), split ? lds_split : lds, (hipStream_t)stream, g1, g2, f_in, out,
+                       (uint32_t)n, (uint32_t)k, (uint4*)d.cvm_blob[prog], 0u, c.status);
     HIPCHK(hipGetLastError());
     return BN254_OK;
 }

@@ -84,9 +84,9 @@ def _mini():
     return g
 
 
-def _sim(pr, want_flat):
+def _sim(pr, want_flat, layout="aos48"):
     blob = CK.make_blob(pr.encode())
-    lines = CK.VMKernel().build()
+    lines = CK.VMKernel(layout).build()
     g1 = [w for c in P_PT for w in R.limbs4(R.to_mont(c))]
     g2 = [w for c in (Q_PT[0][0], Q_PT[0][1], Q_PT[1][0], Q_PT[1][1]) for w in R.limbs4(R.to_mont(c))]
     gmem, ms, rounds = CS.simulate(lines, blob, g1, g2)
@@ -103,12 +103,13 @@ def _sim(pr, want_flat):
     return ms, rounds
 
 
-def test_interpreter_kernel_every_round_kind_on_the_simulator():
+@pytest.mark.parametrize("layout", ["aos48", "split36"])
+def test_interpreter_kernel_every_round_kind_on_the_simulator(layout):
     low = cvm.Lowered(_mini())
     pr = cvm.Program(low, nr=CK.NR)
     kinds = {cvm.KIND_NAME[k] for k, _ in pr.rounds}
     assert {"m2", "m6", "l4", "l8", "inv"} <= kinds
-    _sim(pr, low.evaluate(FLAT))
+    _sim(pr, low.evaluate(FLAT), layout)
 
 
 def test_zero_divisor_raises_the_status_flag_on_the_simulator():
@@ -145,7 +146,7 @@ def test_input_descriptors_pairs_items_and_fq12_on_the_simulator():
     W = lambda x: R.limbs4(R.to_mont(x))
     g1 = CS.soa([[W(P[0]), W(P[1])] for P, _ in pts], 2)
     g2 = CS.soa([[W(Q[0][0]), W(Q[0][1]), W(Q[1][0]), W(Q[1][1])] for _, Q in pts], 4)
-    gmem, ms, _ = CS.simulate(CK.VMKernel().build(), CK.make_blob(pr.encode()), g1, g2, n=3, k=2, tids=range(16, 32))
+    gmem, ms, _ = CS.simulate(CK.VMKernel("split36").build(), CK.make_blob(pr.encode()), g1, g2, n=3, k=2, tids=range(16, 32))
     got = [R.from_mont(v) for v in CS.read_fq12(gmem, n=3, item=item)]
     assert got == [want[2 * i] for i in range(6)] + [want[2 * i + 1] for i in range(6)]
     assert all((CS.OUTB + 8 * other) not in gmem for other in (0, 2))          # only item 1's lanes ran: nothing else is written

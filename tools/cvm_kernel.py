@@ -60,10 +60,22 @@ S_CNT = 88
 S_SAVE = "s[60:61]"
 
 
+# LDS layouts.  "aos48": a slot is 48 contiguous bytes (nine limbs + a pad dword; two 128-bit and one 64-bit access).  "split36": limbs
+# 0..7 in a 32-byte slot, limb 8 in a separate array of dwords (two 128-bit and one 32-bit access, one more address computation
+# per operand): 36 bytes per slot -- the pairing program's 242 slots are 35 KB per wave instead of 46, so FOUR waves fit a CU's
+# 160 KB instead of three.  The host takes aos48 while a launch is at most three waves per CU and split36 beyond.
+LAYOUTS = {"aos48": 48, "split36": 36}
+V_LTOP, V_DST_T, V_TWIN_T, V_T1_T = 204, 205, 206, 207          # split36: base of the group's limb-8 array; companions of the fixed address registers
+
+
 class VMKernel:
-    def __init__(self):
+    def __init__(self, layout="aos48"):
+        assert layout in LAYOUTS and ROW_DEPTH == 1
         self.e = Emitter()
         self.sizes = {}
+        self.layout = layout
+        self.split = layout == "split36"
+        self.slot_bytes = LAYOUTS[layout]
 
     def l1(self):
         g = L1v4(self.e)
@@ -71,41 +83,58 @@ class VMKernel:
         return g
 
     # -------------------------------------------------------------- small helpers
+    # An ADDRESS is (main register, limb-8 register | None).
+    def addr_of_slot(self, dst, slot_reg):
+        """dst <- address of the slot whose number is in slot_reg"""
+        e = self.e
+        if self.split:
+            e.emit(f"v_lshl_add_u32 v{dst[0]}, v{slot_reg}, 5, v{V_LBASE}", vw=[dst[0]])
+            e.emit(f"v_lshl_add_u32 v{dst[1]}, v{slot_reg}, 2, v{V_LTOP}", vw=[dst[1]])
+        else:
+            e.emit(f"v_mad_u32_u24 v{dst[0]}, v{slot_reg}, {SLOT_BYTES}, v{V_LBASE}", vw=[dst[0]])
+
     def slot_addr(self, dst, row_reg, hi):
         e = self.e
         if hi:
             e.emit(f"v_lshrrev_b32_e32 v{V_T0}, 16, v{row_reg}", vw=[V_T0])
         else:
             e.emit(f"v_and_b32_e32 v{V_T0}, 0xffff, v{row_reg}", vw=[V_T0])
-        e.emit(f"v_mad_u32_u24 v{dst}, v{V_T0}, {SLOT_BYTES}, v{V_LBASE}", vw=[dst])
-
-    def lds_load(self, blk0, addr):
-        e = self.e
-        e.emit(f"ds_read_b128 v[{blk0}:{blk0 + 3}], v{addr}", kind="lds", vw=list(range(blk0, blk0 + 4)))
-        e.emit(f"ds_read_b128 v[{blk0 + 4}:{blk0 + 7}], v{addr} offset:16", kind="lds", vw=list(range(blk0 + 4, blk0 + 8)))
-        e.emit(f"ds_read_b64 v[{blk0 + 8}:{blk0 + 9}], v{addr} offset:32", kind="lds", vw=[blk0 + 8, blk0 + 9])
+        self.addr_of_slot(dst, V_T0)
 
     def lds_load_parts(self, blk0, addr):
-        """the three accesses of lds_load as (text, registers written): limbs 0..3, 4..7, 8 (+ pad)"""
-        return [(f"ds_read_b128 v[{blk0}:{blk0 + 3}], v{addr}", list(range(blk0, blk0 + 4))),
-                (f"ds_read_b128 v[{blk0 + 4}:{blk0 + 7}], v{addr} offset:16", list(range(blk0 + 4, blk0 + 8))),
-                (f"ds_read_b64 v[{blk0 + 8}:{blk0 + 9}], v{addr} offset:32", [blk0 + 8, blk0 + 9])]
+        """the three accesses of one operand as (text, registers written): limbs 0..3, 4..7, 8 (+ the pad dword in aos48)"""
+        main, top = addr
+        tail = (f"ds_read_b32 v{blk0 + 8}, v{top}", [blk0 + 8]) if self.split else (f"ds_read_b64 v[{blk0 + 8}:{blk0 + 9}], v{main} offset:32", [blk0 + 8, blk0 + 9])
+        return [(f"ds_read_b128 v[{blk0}:{blk0 + 3}], v{main}", list(range(blk0, blk0 + 4))),
+                (f"ds_read_b128 v[{blk0 + 4}:{blk0 + 7}], v{main} offset:16", list(range(blk0 + 4, blk0 + 8))), tail]
+
+    def lds_load(self, blk0, addr):
+        for text, vw in self.lds_load_parts(blk0, addr):
+            self.e.emit(text, kind="lds", vw=vw)
 
     def lds_store(self, addr, blk0):
         e = self.e
-        e.emit(f"ds_write_b128 v{addr}, v[{blk0}:{blk0 + 3}]", kind="lds")
-        e.emit(f"ds_write_b128 v{addr}, v[{blk0 + 4}:{blk0 + 7}] offset:16", kind="lds")
-        e.emit(f"ds_write_b64 v{addr}, v[{blk0 + 8}:{blk0 + 9}] offset:32", kind="lds")
+        main, top = addr
+        e.emit(f"ds_write_b128 v{main}, v[{blk0}:{blk0 + 3}]", kind="lds")
+        e.emit(f"ds_write_b128 v{main}, v[{blk0 + 4}:{blk0 + 7}] offset:16", kind="lds")
+        if self.split:
+            e.emit(f"ds_write_b32 v{top}, v{blk0 + 8}", kind="lds")
+        else:
+            e.emit(f"ds_write_b64 v{main}, v[{blk0 + 8}:{blk0 + 9}] offset:32", kind="lds")
+
+    def fixed(self, reg):
+        """the address held in one of the fixed registers V_DST / V_TWIN / V_T1"""
+        return (reg, {V_DST: V_DST_T, V_TWIN: V_TWIN_T, V_T1: V_T1_T}[reg] if self.split else None)
 
     def decode(self, g, fields):
-        """address registers (from the pool) of the slots named by `fields` = [(row dword, high half?)], read from the row registers
+        """addresses (registers from the pool) of the slots named by `fields` = [(row dword, high half?)], read from the row registers
         BEFORE the next row is fetched into them"""
-        regs = []
+        out = []
         for dw, hi in fields:
-            r = g.pool.alloc()
-            self.slot_addr(r, ROWN + dw, hi)
-            regs.append(r)
-        return regs
+            a = (g.pool.alloc(), g.pool.alloc() if self.split else None)
+            self.slot_addr(a, ROWN + dw, hi)
+            out.append(a)
+        return out
 
     def prefetch_row(self, buf):
         """the row three rounds ahead into row buffer `buf` (whose previous content has been copied to the executing row)"""
@@ -160,8 +189,16 @@ class VMKernel:
         e.emit(f"v_mul_lo_u32 v{V_ELEM}, v{V_ITEM8}, s{S_K}", vw=[V_ELEM])                  # first input element of the item
         e.emit(f"v_lshlrev_b32_e32 v{V_ITEM8}, 3, v{V_ITEM8}", vw=[V_ITEM8])
         e.raw("s_waitcnt lgkmcnt(0)")
-        e.salu(f"s_mul_i32 s{S_TMP}, s{S_NSLOTS}, {SLOT_BYTES}")
-        e.emit(f"v_mul_lo_u32 v{V_LBASE}, v{V_T0}, s{S_TMP}", vw=[V_LBASE])
+        if self.split:
+            e.salu(f"s_lshl_b32 s{S_TMP}, s{S_NSLOTS}, 5")                                  # a group's 32-byte slots
+            e.emit(f"v_mul_lo_u32 v{V_LBASE}, v{V_T0}, s{S_TMP}", vw=[V_LBASE])
+            e.salu(f"s_lshl_b32 s{S_TMP}, s{S_NSLOTS}, 2")                                  # its limb-8 dwords, behind the four groups' slots
+            e.emit(f"v_mul_lo_u32 v{V_LTOP}, v{V_T0}, s{S_TMP}", vw=[V_LTOP])
+            e.salu(f"s_lshl_b32 s{S_TMP}, s{S_NSLOTS}, {5 + 2}")
+            e.emit(f"v_add_u32_e32 v{V_LTOP}, s{S_TMP}, v{V_LTOP}", vw=[V_LTOP])
+        else:
+            e.salu(f"s_mul_i32 s{S_TMP}, s{S_NSLOTS}, {SLOT_BYTES}")
+            e.emit(f"v_mul_lo_u32 v{V_LBASE}, v{V_T0}, s{S_TMP}", vw=[V_LBASE])
         e.emit(f"v_lshlrev_b32_e32 v{V_ROWOFF}, 5, v{V_ROLE}", vw=[V_ROWOFF])
         e.emit(f"v_mov_b32_e32 v{V_FLAG}, 0", vw=[V_FLAG])
         for r in (OUT0 + 9, NEG0 + 9):
@@ -183,9 +220,9 @@ class VMKernel:
         e.emit(f"global_load_dwordx4 v[0:3], v{V_DST}, {S_CONSTS}", kind="vmem", vw=[0, 1, 2, 3])
         e.emit(f"global_load_dwordx4 v[4:7], v{V_DST}, {S_CONSTS} offset:16", kind="vmem", vw=[4, 5, 6, 7])
         e.emit(f"global_load_dwordx2 v[8:9], v{V_DST}, {S_CONSTS} offset:32", kind="vmem", vw=[8, 9])
-        e.emit(f"v_mad_u32_u24 v{V_TWIN}, v{V_T0}, {SLOT_BYTES}, v{V_LBASE}", vw=[V_TWIN])
+        self.addr_of_slot(self.fixed(V_TWIN), V_T0)
         e.raw("s_waitcnt vmcnt(0)")
-        self.lds_store(V_TWIN, 0)
+        self.lds_store(self.fixed(V_TWIN), 0)
         e.emit(f"v_add_u32_e32 v{V_T1}, {NR}, v{V_T1}", vw=[V_T1])
         e.salu(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
         e.salu(f"s_cmp_lg_u32 s{S_CNT}, 0")
@@ -219,9 +256,9 @@ class VMKernel:
         e.raw("s_waitcnt vmcnt(0)")
         self.l1().r_cvtin()
         e.emit("v_mov_b32_e32 v9, 0", vw=[9])
-        e.emit(f"v_and_b32_e32 v{V_DST}, 0xffff, v{V_DESC}", vw=[V_DST])
-        e.emit(f"v_mad_u32_u24 v{V_DST}, v{V_DST}, {SLOT_BYTES}, v{V_LBASE}", vw=[V_DST])
-        self.lds_store(V_DST, 0)
+        e.emit(f"v_and_b32_e32 v{V_T0}, 0xffff, v{V_DESC}", vw=[V_T0])
+        self.addr_of_slot(self.fixed(V_DST), V_T0)
+        self.lds_store(self.fixed(V_DST), 0)
         e.emit(f"v_add_u32_e32 v{V_T1}, {4 * NR}, v{V_T1}", vw=[V_T1])
         e.salu(f"s_sub_u32 s{S_NCHUNK}, s{S_NCHUNK}, 1")
         e.salu(f"s_cmp_lg_u32 s{S_NCHUNK}, 0")
@@ -324,9 +361,11 @@ class VMKernel:
         g0 = self.l1()
         ad = self.decode(g0, [(0, False), (6, True), (7, False)])
         for i, r in enumerate((V_T1, V_DST, V_TWIN)):                    # (the chain below takes the whole pool)
-            e.emit(f"v_mov_b32_e32 v{r}, v{ad[i]}", vw=[r])
+            for src, dst in zip(ad[i], self.fixed(r)):
+                if src is not None:
+                    e.emit(f"v_mov_b32_e32 v{dst}, v{src}", vw=[dst])
         self.next_row()
-        self.lds_load(10 * 5, V_T1)                                      # a -> block 5
+        self.lds_load(10 * 5, self.fixed(V_T1))                          # a -> block 5
         e.raw("s_waitcnt lgkmcnt(0)")
         RA, X2, RB, T5, T7, A1, A3 = OP(0), OP(1), OP(2), OP(3), OP(4), OP(5), OP(6)
         for i in range(NL):
@@ -358,7 +397,7 @@ class VMKernel:
                 e.salu(f"s_call_b64 {S_RET1}, LC_inv_m{val}_%=")
         for i in range(NL):
             e.emit(f"v_mov_b32_e32 v{OUT0 + i}, v{RA[i]}", vw=[OUT0 + i])
-        self.finish(V_DST, V_TWIN)
+        self.finish(self.fixed(V_DST), self.fixed(V_TWIN))
         e.label("LC_inv_sq_%=")
         self.l1().fips_sq(RA, RA)
         e.salu(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
@@ -381,8 +420,9 @@ class VMKernel:
         e.emit(f"v_lshlrev_b32_e32 v{V_T1}, 2, v{V_ROLE}", vw=[V_T1])
         e.emit(f"global_load_dword v{V_DST}, v{V_T1}, {S_BLOB} offset:32", kind="vmem", vw=[V_DST])       # the lane's output slot
         e.raw("s_waitcnt vmcnt(0)")
-        e.emit(f"v_mad_u32_u24 v{V_DST}, v{V_DST}, {SLOT_BYTES}, v{V_LBASE}", vw=[V_DST])
-        self.lds_load(0, V_DST)
+        e.emit(f"v_mov_b32_e32 v{V_T0}, v{V_DST}", vw=[V_T0])
+        self.addr_of_slot(self.fixed(V_DST), V_T0)
+        self.lds_load(0, self.fixed(V_DST))
         e.raw("s_waitcnt lgkmcnt(0)")
         self.l1().r_cvtout()
         e.emit(f"v_and_b32_e32 v{V_T0}, 1, v{V_ROLE}", vw=[V_T0])

@@ -529,6 +529,25 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None, start_pc=None, 
                 m.count += 1
                 return
             # ------------------------------------------------------------ memory
+            elif op in ("ds_read_b32", "ds_write_b32"):
+                off = 0
+                for t in a:
+                    for part in t.split():
+                        if part.startswith("offset:"):
+                            off = int(part[7:], 0)
+                toks = [t.split()[0] for t in a]
+                if op == "ds_read_b32":
+                    x = m.lds.get(m.vsrc(toks[1]) + off)
+                    if x is None:
+                        raise SimError(f"LDS read of unwritten address {m.vsrc(toks[1]) + off}: {text}")
+                    m.vset(toks[0], x)
+                else:
+                    base = m.vsrc(toks[0]) + off
+                    if base % 4:
+                        raise SimError("misaligned ds_write")
+                    x = m.vsrc(toks[1])
+                    if m.exec:
+                        m.lds[base] = x
             elif op in ("ds_read_b128", "ds_write_b128", "ds_read_b64", "ds_write_b64"):
                 ndw = 4 if op.endswith("b128") else 2
                 off = 0
