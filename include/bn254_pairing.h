@@ -86,10 +86,15 @@ size_t bn254_scratch_bytes(size_t n, size_t k);
  * slots -- for calls of up to n lanes (units) x k pairs.  Afterwards `_dev` calls of that size or smaller neither allocate
  * nor wait.  Does not wait for the stream either (buffers that must grow are retired, see STREAM). */
 int bn254_reserve(int device, void* stream, size_t n, size_t k);
-/* LATENCY PATH.  pairing() (src/pairing.rs:20-22) has two kernels behind bn254_pairing_batch[_dev]: the throughput kernel (one
- * pairing per lane: 3.6 M dependent instructions, 6.3 ms however small the batch) and the lane-cooperative kernel (one pairing on
- * sixteen lanes, four per wave: 0.57 M instructions deep; same values, bit for bit).  Batches of at most `n` pairings take the
- * second one; 0 turns it off.  Process-wide; the default is the measured crossover. */
+/* LATENCY PATH.  The reference's functions are scalar: pairing(p, q) (src/pairing.rs:20-22), miller_loop_native(q, p)
+ * (miller_loop_native.rs:320-322), multi_miller_loop_native(pairs) (:324-326), final_exp_native(a) (final_exp_native.rs:209-213).
+ * The throughput kernels put one item on one lane: 3.6 M dependent instructions for a pairing, 6.5 ms however small the batch.
+ * Behind the same entry points -- bn254_pairing_batch, bn254_miller_loop_batch, bn254_final_exp_batch, bn254_multi_pairing_batch
+ * with k <= 4 pairs (both values of do_final_exp), bn254_multi_pairing_check_batch, their `_dev` and `_elems` forms -- sits a second,
+ * lane-cooperative kernel: one item on sixteen lanes, four items per wave (pairing: 0.57 M instructions deep, 1.14 ms; a four-pair
+ * product check 1.9 ms instead of 13.6), the same values bit for bit.  Batches of at most `n` items take it (per function scaled by
+ * its measured crossover against the throughput kernel: x1 pairing / Miller loop / final exponentiation / two pairs, x1.5 three
+ * pairs, x2 four pairs, x0.5 the exact multi-pair Miller values); 0 turns it off.  Process-wide; default 8192. */
 void bn254_set_latency_threshold(size_t n);
 size_t bn254_get_latency_threshold(void);
 /* Scratch and the status word are kept per (device, stream), so calls on different streams are independent;
