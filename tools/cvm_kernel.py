@@ -46,6 +46,7 @@ POOL_FIRST, POOL_LAST = 150, 203
 # 3: three row buffers in flight, the round's own copied to the executing row -- measured SLOWER (1.336 ms against 1.277 ms for one
 # pairing, profiles/r04_latency_ab.txt): the rows come from L2 within a round; what a round waits for is the LDS (operand fetch).
 ROW_DEPTH = int(os.environ.get("CVM_ROW_DEPTH", "1"))
+INV_SAFEGCD = bool(int(os.environ.get("CVM_INV_SAFEGCD", "1")))  # the inversion by divsteps instead of the Fermat chain
 OVERLAP = bool(int(os.environ.get("CVM_OVERLAP", "1")))      # operand limbs that a pass needs late are fetched inside it
 ROWN = 204 if ROW_DEPTH > 1 else 228
 ROWB = [212, 220, 228]
@@ -353,8 +354,9 @@ class VMKernel:
         self.sizes[cvm.KIND_NAME[kind]] = len(e.ins) - n0
 
     def inv_handler(self):
-        """OUT <- src^(p - 2): KernelBuilder._fq_inv's sliding window on plain register blocks; the zero-divisor flag is raised when
-        src == 0 mod p (tested on the canonical form, like the throughput kernels' inversions)."""
+        """OUT <- 1 / src; the zero-divisor flag is raised when src == 0 mod p.  INV_SAFEGCD: Bernstein-Yang divsteps
+        (L1v4.fq_inv_safegcd, 17.5 k instructions); otherwise the Fermat chain src^(p - 2) (KernelBuilder._fq_inv's sliding window on
+        plain register blocks, 61 k instructions; zero tested on the canonical form, like the throughput kernels' inversions)."""
         e = self.e
         n0 = len(e.ins)
         e.label(f"LC_k{cvm.K_INV}_%=")
@@ -365,9 +367,17 @@ class VMKernel:
                 if src is not None:
                     e.emit(f"v_mov_b32_e32 v{dst}, v{src}", vw=[dst])
         self.next_row()
+        if INV_SAFEGCD:
+            self.lds_load(0, self.fixed(V_T1))
+            e.raw("s_waitcnt lgkmcnt(0)")
+            self.l1().fq_inv_safegcd(OP(0), OP(1), OP(2), OP(3), list(range(OUT0, OUT0 + NL)), f"s{S_CNT}", "LC_sg_%=", bad=V_T0)
+            e.emit(f"v_or_b32_e32 v{V_FLAG}, v{V_FLAG}, v{V_T0}", vw=[V_FLAG])
+            self.finish(self.fixed(V_DST), self.fixed(V_TWIN))
+            self.sizes["inv"] = len(e.ins) - n0
+            return
         self.lds_load(10 * 5, self.fixed(V_T1))                          # a -> block 5
         e.raw("s_waitcnt lgkmcnt(0)")
-        RA, X2, RB, T5, T7, A1, A3 = OP(0), OP(1), OP(2), OP(3), OP(4), OP(5), OP(6)
+        RA, X2, T5, T7, A1, A3 = OP(0), OP(1), OP(3), OP(4), OP(5), OP(6)
         for i in range(NL):
             e.emit(f"v_mov_b32_e32 v{RA[i]}, v{A1[i]}", vw=[RA[i]])
         self.l1().r_cvtout()                                             # v0..7: canonical words
@@ -408,7 +418,6 @@ class VMKernel:
             e.label(f"LC_inv_m{v}_%=")
             self.l1().fips([(RA, blk)], RA)
             e.salu(f"s_setpc_b64 {S_RET1}")
-        del RB
         self.sizes["inv"] = len(e.ins) - n0
 
     # -------------------------------------------------------------- epilogue

@@ -291,6 +291,12 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None, start_pc=None, 
             elif op == "v_lshl_add_u32":
                 m.vset(a[0], (m.vsrc(a[1]) << (m.vsrc(a[2]) & 31)) + m.vsrc(a[3]))
                 m.count_valu += 1
+            elif op == "v_xad_u32":                 # (a ^ b) + c
+                m.vset(a[0], (m.vsrc(a[1]) ^ m.vsrc(a[2])) + m.vsrc(a[3]))
+                m.count_valu += 1
+            elif op == "v_add_lshl_u32":            # (a + b) << c
+                m.vset(a[0], ((m.vsrc(a[1]) + m.vsrc(a[2])) & M32) << (m.vsrc(a[3]) & 31))
+                m.count_valu += 1
             elif op == "v_lshl_or_b32":
                 m.vset(a[0], (m.vsrc(a[1]) << (m.vsrc(a[2]) & 31)) | m.vsrc(a[3]))
                 m.count_valu += 1
