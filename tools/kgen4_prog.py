@@ -2374,7 +2374,8 @@ class KernelBuilder:
 
     FQINV_WINDOW = 3
     FQINV_WIDE_M = bool(int(os.environ.get("KGEN_FQINV_WIDE_M", "1")))
-    FQINV_OUT_V = 4.2 if FQINV_WIDE_M else 0.51       # value bound (units of p) of the inverse the Fermat chain leaves in block A
+    INV_SAFEGCD = bool(int(os.environ.get("KGEN_INV_SAFEGCD", "1")))   # A/B switch: the Fq inversion by divsteps (L1v4.fq_inv_safegcd) instead of the Fermat chain
+    FQINV_OUT_V = 0.56 if INV_SAFEGCD else (4.2 if FQINV_WIDE_M else 0.51)       # value bound (units of p) of the inverse left in block A
 
     @staticmethod
     def fqinv_schedule(w):
@@ -2411,6 +2412,15 @@ class KernelBuilder:
         e = p.e
         L = self.lab
         uid = self.uid()
+        if self.INV_SAFEGCD:
+            # round 4: Bernstein-Yang divsteps, 17.5 k instructions (most of them 32-bit logic) against the chain's 87 k slots with
+            # their 30 k multiply-adds; f, d, e of the iteration in A.c1 and block B, the rest in the pool
+            p.wait()
+            p.tagA = p.tagB = None
+            L1v4(e).fq_inv_safegcd(L1v4.blk(A0, 0), L1v4.blk(A0, 1), L1v4.blk(B0, 0), L1v4.blk(B0, 1), L1v4.blk(A0, 0), f"s{S_TMP0}",
+                                   L(f"L_fqinv_sg_{uid}"))
+            p.set_A_fresh(self.FQINV_OUT_V)
+            return
         base = self.FQINV_BASE
         first, sched = self.fqinv_schedule(self.FQINV_WINDOW)
         assert self.FQINV_WINDOW == 3 and all(v in (1, 3, 5, 7) for _, v in sched) and first in (1, 3, 5, 7)
