@@ -44,12 +44,12 @@ def _run(which, env_extra):
 
 def test_split_miller_loop_builds_and_is_exact():
     n_split = _run("single", {"KGEN_FISSION": "1"})
-    assert 3_550_000 < n_split < 3_650_000                 # the shipped kernel's work (3.59 M instructions), plus the line stores / loads
+    assert 3_480_000 < n_split < 3_600_000                 # the shipped kernel's work (3.52 M instructions), plus the line stores / loads
     _run("multi", {"KGEN_FISSION": "1"})
 
 
 def test_round3_baseline_switches():
     off = {k: "0" for k in ("KGEN_MUL6_KEEP_DIFFS", "KGEN_DBL_LAZY_Y3", "KGEN_CYC_WIDE_M", "KGEN_FQINV_WIDE_M", "KGEN_MUL3_KEEP_DY", "KGEN_ADD_INJECT",
-                            "KGEN_BOUSTRO", "KGEN_INV_FUSED")}
+                            "KGEN_BOUSTRO", "KGEN_INV_FUSED", "KGEN_INV_SAFEGCD")}
     n_r3 = _run("single", off)
     assert 3_660_000 < n_r3 < 3_680_000                    # round 3: 3.672 M instructions per pairing (profiles/r03_instr_histogram.json)
