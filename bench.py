@@ -313,6 +313,40 @@ def extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n, sample_power=F
         lay[name] = {"ms": ms, "GB_per_s": 2 * 8 * words * n / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": 2 * 8 * words * n / (ms * 1e-3) / HBM_PEAK}
         del dst
     out["layout kernels at 2^20 elements (roofline bound: hbm, 8 TB/s)"] = lay
+    # the reference's functions are SCALAR (one pairing / one group per call): wall time of one call on one item, launch to completion,
+    # on the throughput kernel (one item per lane) and on the lane-cooperative kernel that small batches take
+    if hasattr(pkg, "set_latency_threshold"):
+        import time as _t
+        keep = pkg.get_latency_threshold()
+        o4 = torch.zeros(48, dtype=torch.int64, device=dev)
+        f4 = torch.zeros(48, dtype=torch.int64, device=dev)
+        one = lambda t, planes, cnt: t.view(planes, n)[:, :cnt].contiguous().view(-1)
+        p1, q1, p4, q4 = one(g1, 8, 1), one(g2, 16, 1), one(g1, 8, 4), one(g2, 16, 4)
+        pkg.set_latency_threshold(0)
+        pkg.miller_loop_batch_dev(p1, q1, f4, 1, device=local_rank, stream=stream)
+        calls = {"pairing(p, q)": lambda: pkg.pairing_batch_dev(p1, q1, o4, 1, device=local_rank, stream=stream),
+                 "miller_loop_native(q, p)": lambda: pkg.miller_loop_batch_dev(p1, q1, o4, 1, device=local_rank, stream=stream),
+                 "final_exp_native(f)": lambda: pkg.final_exp_batch_dev(f4, o4, 1, device=local_rank, stream=stream),
+                 "final_exp_native(multi_miller_loop_native(4 pairs))": lambda: pkg.multi_pairing_batch_dev(p4, q4, o4, 1, 4, True, device=local_rank, stream=stream)}
+        lat = {}
+        for name, fn in calls.items():
+            row = {}
+            for kern, thr in (("throughput_kernel_ms", 0), ("lane_cooperative_kernel_ms", 1 << 20)):
+                pkg.set_latency_threshold(thr)
+                ts = []
+                for _ in range(7):
+                    torch.cuda.synchronize(dev)
+                    t0 = _t.perf_counter()
+                    fn()
+                    torch.cuda.synchronize(dev)
+                    ts.append(_t.perf_counter() - t0)
+                row[kern] = min(ts[2:]) * 1e3
+                row.setdefault("_ref", o4.clone())
+                row["same_limbs"] = bool(torch.equal(row["_ref"], o4))
+            del row["_ref"]
+            lat[name] = row
+        pkg.set_latency_threshold(keep)
+        out["scalar signatures: one item per call, wall ms (launch to completion, inputs resident)"] = lat
     pkg.last_status(local_rank, stream)
     return out
 
