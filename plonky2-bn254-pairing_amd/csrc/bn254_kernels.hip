@@ -348,26 +348,33 @@ int cvm_program(size_t k) {
     return k == 1 ? 2 : -1;
 }
 
+// The program's blob on the device: uploaded once (a blocking copy of 0.3 - 1.1 MB on the first call that needs it; bn254_reserve does it
+// for every program up front).
+int cvm_upload(int device, int prog) {
+    DeviceCtx& d = g_ctx[device];
+    const CvmProgram& p = CVM_PROGRAMS[prog];
+    std::lock_guard<std::mutex> lk(d.table_mu);
+    if (!d.cvm_init) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_cvm, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)k_cvm_split, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        d.cvm_init = true;
+    }
+    if (!d.cvm_blob[prog]) {
+        uint32_t* t = nullptr;
+        if (hipMalloc(&t, p.bytes) != hipSuccess) { (void)hipGetLastError(); return BN254_ERR_ALLOC; }
+        if (hipMemcpy(t, p.blob, p.bytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(t); return BN254_ERR_HIP; }
+        d.cvm_blob[prog] = t;
+    }
+    return BN254_OK;
+}
+
 int launch_cvm(int prog, const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in, uint64_t* out, size_t n, size_t k, int device, void* stream) {
     LaunchCtx c;
     int rc = ctx_get(device, stream, 1, 1, &c);          // the status word and the stream context; the kernel needs no scratch
     if (rc) return rc;
     DeviceCtx& d = g_ctx[device];
     const CvmProgram& p = CVM_PROGRAMS[prog];
-    {
-        std::lock_guard<std::mutex> lk(d.table_mu);
-        if (!d.cvm_init) {
-            HIPCHK(hipFuncSetAttribute((const void*)k_cvm, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            HIPCHK(hipFuncSetAttribute((const void*)k_cvm_split, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            d.cvm_init = true;
-        }
-        if (!d.cvm_blob[prog]) {
-            uint32_t* t = nullptr;
-            if (hipMalloc(&t, p.bytes) != hipSuccess) { (void)hipGetLastError(); return BN254_ERR_ALLOC; }
-            if (hipMemcpy(t, p.blob, p.bytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(t); return BN254_ERR_HIP; }
-            d.cvm_blob[prog] = t;
-        }
-    }
+    if ((rc = cvm_upload(device, prog))) return rc;
     // One wave per workgroup.  The contiguous slot layout is the faster one (one address computation less per operand); the split
     // layout needs 3/4 of the LDS, so more waves fit a CU: taken when the launch has more waves than the contiguous layout can hold
     // resident AND the split layout holds more.
@@ -829,6 +836,9 @@ int bn254_reserve(int device, void* stream, size_t n, size_t k) {
         sc->naf_ring.push_back(ns);
     }
     if (!sc->status_host && hipHostMalloc((void**)&sc->status_host, sizeof(int), hipHostMallocDefault) != hipSuccess) return BN254_ERR_ALLOC;
+    if (g_latency_threshold.load())                    // the latency path's round programs (6 MB in all): small calls upload nothing later
+        for (int prog = 0; prog < 9; prog++)
+            if ((rc = cvm_upload(device, prog))) return rc;
     return BN254_OK;
 }
 

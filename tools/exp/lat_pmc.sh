@@ -1,5 +1,5 @@
 #!/bin/bash
-# lat_pmc.sh [n] -- rocprofv3 counters of the lane-cooperative kernel (k_cpairing) at batch size n (default 1), run on the GPU box.
+# lat_pmc.sh [n] -- rocprofv3 counters of the lane-cooperative kernel (k_cvm) at batch size n (default 1), run on the GPU box.
 set -eo pipefail
 : "${GRAFT_REPO_ROOT:?lat_pmc.sh runs on the GPU box through gpurun}"
 N=${1:-1}
@@ -17,9 +17,9 @@ import csv, glob, collections
 agg = collections.defaultdict(list)
 for f in sorted(glob.glob("$OUT/pmc_*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        if "k_cpairing" in r["Kernel_Name"]:
+        if "k_cvm" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-print("== k_cpairing n=$N")
+print("== k_cvm (pairing program) n=$N")
 for k, v in sorted(agg.items()):
     print(f"{k:36s} {sum(v)/len(v):18.1f}  (n={len(v)})")
 PY
