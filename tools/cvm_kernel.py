@@ -127,14 +127,20 @@ class VMKernel:
         """the address held in one of the fixed registers V_DST / V_TWIN / V_T1"""
         return (reg, {V_DST: V_DST_T, V_TWIN: V_TWIN_T, V_T1: V_T1_T}[reg] if self.split else None)
 
-    def decode(self, g, fields):
+    def decode(self, g, fields, first=None):
         """addresses (registers from the pool) of the slots named by `fields` = [(row dword, high half?)], read from the row registers
-        BEFORE the next row is fetched into them"""
+        BEFORE the next row is fetched into them.  first (optional): {field index: (operand block, part numbers)} -- those parts of the
+        operand are requested as soon as its address exists, so that the LDS works while the remaining addresses are computed."""
         out = []
-        for dw, hi in fields:
+        for j, (dw, hi) in enumerate(fields):
             a = (g.pool.alloc(), g.pool.alloc() if self.split else None)
             self.slot_addr(a, ROWN + dw, hi)
             out.append(a)
+            if first and j in first:
+                blk0, which = first[j]
+                pts = self.lds_load_parts(blk0, a)
+                for k in which:
+                    self.e.emit(pts[k][0], kind="lds", vw=pts[k][1])
         return out
 
     def prefetch_row(self, buf):
@@ -302,21 +308,23 @@ class VMKernel:
         n0 = len(e.ins)
         e.label(f"LC_k{kind}_%=")
         g = self.l1()
-        ad = self.decode(g, [(i, h) for i in range(nprod) for h in (False, True)] + [(6, False), (6, True), (7, False)])
-        self.next_row()
+        fields = [(i, h) for i in range(nprod) for h in (False, True)] + [(6, False), (6, True), (7, False)]
         out = list(range(OUT0, OUT0 + NL))
         prods = [(OP(2 * i), OP(2 * i + 1)) for i in range(nprod)]
         if OVERLAP:
-            # column k of the pass needs limbs 0..k only: the low quarters of the product operands are fetched up front, everything else
-            # -- the upper limbs, the addend (which enters behind column 8) -- rides in the multiply runs of columns 0..3
+            # column k of the pass needs limbs 0..k only: the low quarters of the product operands are fetched up front (each as soon as
+            # its address is known), everything else -- the upper limbs, the addend (which enters behind column 8) -- rides in the
+            # multiply runs of columns 0..3
+            ad = self.decode(g, fields, first={i: (10 * i, (0,)) for i in range(2 * nprod)})
+            self.next_row()
             parts = [self.lds_load_parts(10 * i, ad[i]) for i in range(2 * nprod)] + [self.lds_load_parts(10 * 12, ad[2 * nprod])]
-            for pt in parts[:-1]:
-                e.emit(pt[0][0], kind="lds", vw=pt[0][1])
             later = [pt[1] for pt in parts[:-1]] + [parts[-1][0], parts[-1][1]] + [pt[2] for pt in parts]
             fillers = [(t, vw, 0, 3) for t, vw in later] + [("s_waitcnt lgkmcnt(0)", [], 99, 4)]
             e.raw("s_waitcnt lgkmcnt(0)")
             g.fips(prods, out, inject=[(OP(12), 1)], fillers=fillers, gap=2)
         else:
+            ad = self.decode(g, fields)
+            self.next_row()
             for i in range(2 * nprod):
                 self.lds_load(10 * i, ad[i])
             self.lds_load(10 * 12, ad[2 * nprod])
@@ -330,7 +338,10 @@ class VMKernel:
         n0 = len(e.ins)
         e.label(f"LC_k{kind}_%=")
         g = self.l1()
-        ad = self.decode(g, [(i // 2, i % 2 == 1) for i in range(nsrc)] + [(6, True), (7, False)])
+        fields = [(i // 2, i % 2 == 1) for i in range(nsrc)] + [(6, True), (7, False)]
+        # the chain starts from the TOP limbs (the quotient estimate), then walks up from limb 0: every source's tail and low quarter are
+        # requested as soon as its address is known, the upper quarters last (waited for before limb 4)
+        ad = self.decode(g, fields, first={i: (10 * i, (2, 0)) for i in range(nsrc)} if OVERLAP else None)
         co = [g.pool.alloc() for _ in range(nsrc)]
         for i in range(nsrc):
             e.emit(f"v_bfe_i32 v{co[i]}, v{ROWN + 4 + i // 4}, {8 * (i % 4)}, 8", vw=[co[i]])
@@ -338,11 +349,9 @@ class VMKernel:
         out = list(range(OUT0, OUT0 + NL))
         terms = [[(("v", co[i]), OP(i)) for i in range(nsrc)]]
         if OVERLAP:
-            # the chain starts from the TOP limbs (the quotient estimate), then walks up from limb 0: tails first, upper quarters last
-            parts = [self.lds_load_parts(10 * i, ad[i]) for i in range(nsrc)]
-            for k in (2, 0, 1):
-                for pt in parts:
-                    e.emit(pt[k][0], kind="lds", vw=pt[k][1])
+            for i in range(nsrc):
+                pt = self.lds_load_parts(10 * i, ad[i])[1]
+                e.emit(pt[0], kind="lds", vw=pt[1])
             e.raw(f"s_waitcnt lgkmcnt({nsrc})")
             g.lincomb([out], terms, reduce=True, hooks={4: ["s_waitcnt lgkmcnt(0)"]})
         else:
