@@ -61,7 +61,7 @@ def test_pairing_program_equals_the_reference_pairing():
     pr = cvm.Program(low, nr=CK.NR)
     assert pr.run(FLAT) == flat_want
     st = pr.stats()
-    assert st["rounds"] < 1400 and st["slots"] <= 256
+    assert st["rounds"] < 1400 and st["slots"] <= 277          # 277 slots of 48 bytes: three waves per CU; of 36 bytes: four
     # no slot is written in a round that still reads it (what lets the kernel do without barriers, and the simulator run lane by lane)
     for rnd, (kind, take) in enumerate(pr.rounds):
         written = {w.slot for v in take for w in (v, v.twin) if w is not None}
