@@ -70,7 +70,7 @@ BN254_ASM_KERNEL(k_generate, BN254_ASM_GENERATE)    // synthetic subgroup points
 
 // The LATENCY path of the scalar signatures (pairing, miller_loop_native, multi_miller_loop_native, final_exp_native): one item on
 // sixteen lanes, four items per wave, one wave per workgroup.  The kernel is an interpreter of the round programs in cvm_asm_gen.h
-// (tools/cvm.py: the same Miller loop and final exponentiation, scheduled over sixteen lanes -- pairing: 0.57 M instructions deep
+// (tools/cvm.py: the same Miller loop and final exponentiation, scheduled over sixteen lanes -- pairing: 0.49 M instructions deep
 // instead of 3.6 M).  `scratch` = the device copy of the program's blob; k = pairs per item.
 #define BN254_CVM_KERNEL(NAME, BLOB)                                                                                       \
     __global__ void __launch_bounds__(64) __attribute__((aligned(BN254_KERNEL_ALIGN)))                                     \
