@@ -85,6 +85,8 @@ _PROTOS = {
     "bn254_reserve": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t]),
     "bn254_set_latency_threshold": (None, [ctypes.c_size_t]),
     "bn254_get_latency_threshold": (ctypes.c_size_t, []),
+    "bn254_set_latency_lanes": (None, [ctypes.c_int]),
+    "bn254_get_latency_lanes": (ctypes.c_int, []),
     "bn254_fq12_mul_batch_dev": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "bn254_fq12_mul_batch": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "bn254_frobenius_map_batch_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
@@ -447,6 +449,15 @@ def set_latency_threshold(n):
 
 def get_latency_threshold():
     return load_library().bn254_get_latency_threshold()
+
+
+def set_latency_lanes(lanes):
+    """0: the lane-cooperative program family by launch size (thirty-two lanes per item for the smallest launches); 16 / 32: fixed."""
+    load_library().bn254_set_latency_lanes(lanes)
+
+
+def get_latency_lanes():
+    return load_library().bn254_get_latency_lanes()
 
 
 def generate_pairs_dev(seed, g1_out, g2_out, n, device=0, stream=None):

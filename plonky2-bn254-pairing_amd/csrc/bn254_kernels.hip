@@ -85,6 +85,7 @@ BN254_ASM_KERNEL(k_generate, BN254_ASM_GENERATE)    // synthetic subgroup points
     }
 BN254_CVM_KERNEL(k_cvm, BN254_ASM_CVM)               // LDS slots of 48 contiguous bytes: the fastest round (launches of up to three waves per CU)
 BN254_CVM_KERNEL(k_cvm_split, BN254_ASM_CVM_SPLIT)   // 36 bytes per slot: four waves of the pairing program per CU (larger launches)
+BN254_CVM_KERNEL(k_cvm_wide, BN254_ASM_CVM_WIDE)     // thirty-two lanes per item, two items per wave (launches of at most one wave per SIMD)
 
 // verdict[i] = 1 iff Fq12 element i equals MyFq12::one (coeffs[0] = R mod p in ark's Montgomery limbs, the rest 0):
 // the check pattern of final_exp_native.rs:245-263 (a Groth16-style product of pairings == 1), one byte per group.
@@ -203,7 +204,7 @@ struct DeviceCtx {
     int n_cu = 0;
     std::mutex table_mu;       // the generator table upload (138 KB, blocking) has its own lock
     int32_t* gen_table = nullptr;
-    uint32_t* cvm_blob[9] = {};     // the latency path's round programs (0.3 - 1.1 MB each, uploaded on first use, same lock)
+    uint32_t* cvm_blob[13] = {};    // the latency path's round programs (0.3 - 1.4 MB each, uploaded on first use, same lock)
     bool cvm_init = false;
     std::map<hipStream_t, std::shared_ptr<StreamCtx>> streams;   // shared: a call keeps its context alive across a concurrent release
     std::mutex pipe_mu;        // one host-pointer pipeline at a time per device (its two workers fill the chip anyway)
@@ -328,17 +329,22 @@ int launch_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_
 
 // Batches of at most this many items take the lane-cooperative kernel where a program exists (bn254_set_latency_threshold; 0: never).
 std::atomic<size_t> g_latency_threshold{BN254_LATENCY_THRESHOLD_DEFAULT};
+std::atomic<int> g_latency_lanes{0};       // bn254_set_latency_lanes: 0 = by launch size, 16 / 32 = that program family whatever the size
 
 struct CvmProgram {
     const uint32_t* blob;
     size_t bytes;
     uint32_t slots;
     uint32_t per_mille;       // share of the threshold this program takes batches up to (its own crossover against the throughput kernel)
+    int wide;                 // index of the same function's thirty-two-lane program, or -1
 };
-#define CVM_PROGRAM(NAME, PM) {BN254_CVM_##NAME##_BLOB, sizeof(BN254_CVM_##NAME##_BLOB), BN254_CVM_##NAME##_SLOTS, PM}
-const CvmProgram CVM_PROGRAMS[9] = {CVM_PROGRAM(PAIRING, 1000), CVM_PROGRAM(MILLER, BN254_CVM_PM_MILLER), CVM_PROGRAM(FEXP, BN254_CVM_PM_FEXP),
-                                    CVM_PROGRAM(MULTI2, 1000), CVM_PROGRAM(MULTI3, 1500), CVM_PROGRAM(MULTI4, 2000),
-                                    CVM_PROGRAM(MMILLER2, BN254_CVM_PM_MMILLER), CVM_PROGRAM(MMILLER3, BN254_CVM_PM_MMILLER), CVM_PROGRAM(MMILLER4, BN254_CVM_PM_MMILLER)};
+#define CVM_PROGRAM(NAME, PM, WIDE) {BN254_CVM_##NAME##_BLOB, sizeof(BN254_CVM_##NAME##_BLOB), BN254_CVM_##NAME##_SLOTS, PM, WIDE}
+constexpr int CVM_N_PROGRAMS = 13;
+const CvmProgram CVM_PROGRAMS[CVM_N_PROGRAMS] = {
+    CVM_PROGRAM(PAIRING, 1000, 9), CVM_PROGRAM(MILLER, BN254_CVM_PM_MILLER, 10), CVM_PROGRAM(FEXP, BN254_CVM_PM_FEXP, 11),
+    CVM_PROGRAM(MULTI2, 1000, -1), CVM_PROGRAM(MULTI3, 1500, -1), CVM_PROGRAM(MULTI4, 2000, 12),
+    CVM_PROGRAM(MMILLER2, BN254_CVM_PM_MMILLER, -1), CVM_PROGRAM(MMILLER3, BN254_CVM_PM_MMILLER, -1), CVM_PROGRAM(MMILLER4, BN254_CVM_PM_MMILLER, -1),
+    CVM_PROGRAM(PAIRING_W, 0, -1), CVM_PROGRAM(MILLER_W, 0, -1), CVM_PROGRAM(FEXP_W, 0, -1), CVM_PROGRAM(MULTI4_W, 0, -1)};
 
 // which program serves (Miller loop?, final exponentiation?, k pairs); -1: none
 template <bool M, bool F>
@@ -357,6 +363,7 @@ int cvm_upload(int device, int prog) {
     if (!d.cvm_init) {
         HIPCHK(hipFuncSetAttribute((const void*)k_cvm, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)k_cvm_split, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)k_cvm_wide, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         d.cvm_init = true;
     }
     if (!d.cvm_blob[prog]) {
@@ -373,6 +380,18 @@ int launch_cvm(int prog, const uint64_t* g1, const uint64_t* g2, const uint64_t*
     int rc = ctx_get(device, stream, 1, 1, &c);          // the status word and the stream context; the kernel needs no scratch
     if (rc) return rc;
     DeviceCtx& d = g_ctx[device];
+    // The smallest launches -- at most one wave per SIMD with two items per wave -- take the function's thirty-two-lane program where
+    // there is one: fewer, fuller rounds (pairing: 979 instead of 1 326).
+    int lanes = g_latency_lanes.load();
+    if (CVM_PROGRAMS[prog].wide >= 0 && (lanes == 32 || (lanes == 0 && n <= (size_t)2 * 4 * (size_t)c.n_cu))) {
+        int w = CVM_PROGRAMS[prog].wide;
+        if ((rc = cvm_upload(device, w))) return rc;
+        const CvmProgram& pw = CVM_PROGRAMS[w];
+        hipLaunchKernelGGL(k_cvm_wide, dim3((uint32_t)((n + 1) / 2)), dim3(64), (size_t)2 * pw.slots * BN254_CVM_SLOT_BYTES, (hipStream_t)stream, g1, g2, f_in,
+                           out, (uint32_t)n, (uint32_t)k, (uint4*)d.cvm_blob[w], 0u, c.status);
+        HIPCHK(hipGetLastError());
+        return BN254_OK;
+    }
     const CvmProgram& p = CVM_PROGRAMS[prog];
     if ((rc = cvm_upload(device, prog))) return rc;
     // One wave per workgroup.  The contiguous slot layout is the faster one (one address computation less per operand); the split
@@ -643,6 +662,8 @@ size_t bn254_scratch_bytes(size_t n, size_t k) {
     return BN254_SCRATCH_WG_CONTIGUOUS ? scratch_pitch(kk, grid) * grid : scratch_pitch(kk, grid) * scratch_slots(kk);
 }
 
+void bn254_set_latency_lanes(int lanes) { g_latency_lanes.store(lanes == 16 || lanes == 32 ? lanes : 0); }
+int bn254_get_latency_lanes(void) { return g_latency_lanes.load(); }
 void bn254_set_latency_threshold(size_t n) { g_latency_threshold.store(n); }
 size_t bn254_get_latency_threshold(void) { return g_latency_threshold.load(); }
 
@@ -837,7 +858,7 @@ int bn254_reserve(int device, void* stream, size_t n, size_t k) {
     }
     if (!sc->status_host && hipHostMalloc((void**)&sc->status_host, sizeof(int), hipHostMallocDefault) != hipSuccess) return BN254_ERR_ALLOC;
     if (g_latency_threshold.load())                    // the latency path's round programs (6 MB in all): small calls upload nothing later
-        for (int prog = 0; prog < 9; prog++)
+        for (int prog = 0; prog < CVM_N_PROGRAMS; prog++)
             if ((rc = cvm_upload(device, prog))) return rc;
     return BN254_OK;
 }

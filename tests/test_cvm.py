@@ -86,10 +86,10 @@ def _mini():
 
 def _sim(pr, want_flat, layout="aos48"):
     blob = CK.make_blob(pr.encode())
-    lines = CK.VMKernel(layout).build()
+    lines = CK.VMKernel(layout, nr=pr.nr).build()
     g1 = [w for c in P_PT for w in R.limbs4(R.to_mont(c))]
     g2 = [w for c in (Q_PT[0][0], Q_PT[0][1], Q_PT[1][0], Q_PT[1][1]) for w in R.limbs4(R.to_mont(c))]
-    gmem, ms, rounds = CS.simulate(lines, blob, g1, g2)
+    gmem, ms, rounds = CS.simulate(lines, blob, g1, g2, tids=range(pr.nr))
     out = []
     for c in range(12):
         v = 0
@@ -103,10 +103,10 @@ def _sim(pr, want_flat, layout="aos48"):
     return ms, rounds
 
 
-@pytest.mark.parametrize("layout", ["aos48", "split36"])
-def test_interpreter_kernel_every_round_kind_on_the_simulator(layout):
+@pytest.mark.parametrize("layout,nr", [("aos48", 16), ("split36", 16), ("aos48", 32)])
+def test_interpreter_kernel_every_round_kind_on_the_simulator(layout, nr):
     low = cvm.Lowered(_mini())
-    pr = cvm.Program(low, nr=CK.NR)
+    pr = cvm.Program(low, nr=nr)
     kinds = {cvm.KIND_NAME[k] for k, _ in pr.rounds}
     assert {"m2", "m6", "l4", "l8", "inv"} <= kinds
     _sim(pr, low.evaluate(FLAT), layout)
@@ -188,6 +188,25 @@ def test_other_programs_equal_the_reference_functions():
         check(cvm.build_multi(k, final_exp=True), flat(k), R.final_exp_native(m))
     f = R.miller_loop_native(Q[1], P[2])
     check(cvm.build_final_exp(), [c for x in R.fq12_to_fp2s(f) for c in x], R.final_exp_native(f))
+
+
+def test_wide_programs_equal_the_reference_functions():
+    """the thirty-two-lane programs (monomial cyclotomic squarings, four-bit windows): pairing and the four-pair product"""
+    want = [c for x in R.fq12_to_fp2s(R.pairing_myfq12(P_PT, Q_PT)) for c in x]
+    low = cvm.Lowered(cvm.build_pairing(wide=True, pow_window=4))
+    pr = cvm.Program(low, nr=32)
+    assert low.evaluate(FLAT) == want and pr.run(FLAT) == want
+    assert len(pr.rounds) < 1000 and max(v.bound for v in low.fv) <= cvm.Lowered.V_MAX
+    for rnd, (kind, take) in enumerate(pr.rounds):
+        written = {w.slot for v in take for w in (v, v.twin) if w is not None}
+        assert not (written & {s.slot for v in take for s in v.srcs()}), rnd
+    P = [R.g1_mul(R.G1_GEN, 11 + 7 * j) for j in range(4)]
+    Q = [R.g2_mul(R.G2_GEN, 5 + 3 * j) for j in range(4)]
+    flat = [c for j in range(4) for c in (P[j][0], P[j][1], Q[j][0][0], Q[j][0][1], Q[j][1][0], Q[j][1][1])]
+    m = R.final_exp_native(R.multi_miller_loop_native([(P[j], Q[j]) for j in range(4)]))
+    low = cvm.Lowered(cvm.build_multi(4, True, pow_window=4, wide=True))
+    pr = cvm.Program(low, nr=32)
+    assert pr.run(flat) == [c for x in R.fq12_to_fp2s(m) for c in x]
 
 
 def test_whole_pairing_on_the_simulator():

@@ -11,12 +11,16 @@ pytestmark = pytest.mark.gpu
 HX = lambda xs: [int(x, 16) for x in xs]
 
 
-@pytest.fixture()
-def pk():
+@pytest.fixture(params=[16, 32], ids=["16-lanes", "32-lanes"])
+def pk(request):
+    """the package with the lane-cooperative program family pinned (sixteen / thirty-two lanes per item; functions without a
+    thirty-two-lane program take their sixteen-lane one); threshold and family are restored afterwards"""
     p = H.pkg()
     old = p.get_latency_threshold()
+    p.set_latency_lanes(request.param)
     yield p
     p.set_latency_threshold(old)
+    p.set_latency_lanes(0)
 
 
 def test_threshold_is_settable(pk):
@@ -24,6 +28,30 @@ def test_threshold_is_settable(pk):
     assert pk.get_latency_threshold() == 12345
     pk.set_latency_threshold(0)
     assert pk.get_latency_threshold() == 0
+    for lanes, want in ((16, 16), (32, 32), (0, 0), (7, 0)):
+        pk.set_latency_lanes(lanes)
+        assert pk.get_latency_lanes() == want
+
+
+def test_program_family_follows_the_launch_size():
+    """default (0): thirty-two lanes per item up to one wave per SIMD, sixteen beyond -- same limbs either way, on both sides of the edge"""
+    import torch
+    pk = H.pkg()
+    assert pk.get_latency_lanes() == 0
+    old = pk.get_latency_threshold()
+    try:
+        for n in (2047, 2048, 2049, 3000):
+            g1, g2 = _dev_pairs(pk, n, 0x5EED + n)
+            outs = []
+            for thr in (0, 1 << 20):
+                o = torch.empty(48 * n, dtype=torch.int64, device=torch.device("cuda:0"))
+                pk.set_latency_threshold(thr)
+                pk.pairing_batch_dev(g1, g2, o, n)
+                outs.append(o)
+            pk.last_status()
+            assert torch.equal(outs[0], outs[1]), n
+    finally:
+        pk.set_latency_threshold(old)
 
 
 def test_golden_vectors_on_the_latency_kernel(pk):

@@ -32,7 +32,7 @@ XI = (9, 1)
 NR = 8                      # lanes (roles) per pairing
 ARR_G1, ARR_G2, ARR_F, ARR_NONE = 0, 1, 2, 3
 COST = {"m1": 950, "m3": 2000, "lin": 420, "inv": 46000}     # instructions per round (scheduling weights; tools/cvm_kernel.py prints the real ones)
-MAX_LIN_SRC = 4
+MAX_LIN_SRC = 6             # sources of an Fq2-level combination (the Fq operation it lowers to takes eight terms)
 SLOT_STRIDE = 80            # bytes per LDS slot (72 used: 2 x 9 limbs)
 
 
@@ -93,7 +93,8 @@ class V:
 class Graph:
     """SSA builder over Fq2 values (lowered to Fq operations, where the value bounds are tracked, by `Lowered`)."""
 
-    def __init__(self, run_ahead=None, pow_window=None):
+    def __init__(self, run_ahead=None, pow_window=None, wide=False):
+        self.wide = wide                  # the program is scheduled for thirty-two lanes: formulations that trade operations for depth
         self.pow_window = pow_window or self.POW_X_WINDOW          # signed window of the hard part's x-powers (pow_x)
         self.vals = []
         self.consts = {}
@@ -217,6 +218,22 @@ class Graph:
         """Granger-Scott squaring in the cyclotomic subgroup, three units (a, b) = (f0, f3), (f1, f4), (f2, f5):
         P = (a + b)(a + xi b), t = a b;  a^2 + xi b^2 = P - (1 + xi) t;  outputs 3 (..) - 2 z and 6 t [xi] + 2 z"""
         out = [None] * 6
+        if self.wide:
+            # thirty-two lanes: no sums in front of the products -- a^2 + xi b^2 from the monomials a0^2 - a1^2, b0^2 - b1^2, a0 a1, b0 b1
+            # (real parts as values of their own: aliases, no operation), 18 product operations in ONE round instead of 12 behind a
+            # round of 12 sums: two rounds per squaring instead of three
+            RE, IM = (1, 0, 0, 0), (0, 1, 0, 0)
+            for (ia, ib, iza, izb, x) in ((0, 3, 0, 3, False), (1, 4, 2, 5, False), (2, 5, 4, 1, True)):
+                a, b = f[ia], f[ib]
+                a0, a1, b0, b1 = self.lin((a, RE)), self.lin((a, IM)), self.lin((b, RE)), self.lin((b, IM))
+                sqa = self.mul((a0, a0), (self.neg(a1), a1))
+                sqb = self.mul((b0, b0), (self.neg(b1), b1))
+                pbb, paa = self.mul((b0, b1)), self.mul((a0, a1))
+                t = self.mul((a, b))
+                # a^2 + xi b^2 = (sqa + 9 sqb - 2 pbb) + (2 paa + 18 pbb + sqb) u
+                out[iza] = self.lin((sqa, (3, 0, 0, 0)), (sqb, (27, 0, 3, 0)), (pbb, (-6, 0, 54, 0)), (paa, (0, 0, 6, 0)), (f[iza], mk(-2)))
+                out[izb] = self.lin((t, mxi(6) if x else mk(6)), (f[izb], mk(2)))
+            return out
         for (ia, ib, iza, izb, x) in ((0, 3, 0, 3, False), (1, 4, 2, 5, False), (2, 5, 4, 1, True)):
             a, b = f[ia], f[ib]
             u = self.lin((a, ID), (b, ID))
@@ -934,33 +951,33 @@ def _graph(**kw):
     return g
 
 
-def build_pairing():
+def build_pairing(**kw):
     """pairing(p, q) (src/pairing.rs:20-22): the six Fq2 coefficients in MyFq12 order"""
-    g = _graph()
+    g = _graph(**kw)
     (px, py), Q = g.g1_point(), g.g2_point()
     g.outputs = g.final_exp(g.miller_loop(px, py, Q))
     return g
 
 
-def build_miller(run_ahead=None):
+def build_miller(run_ahead=None, **kw):
     """miller_loop_native(q, p) (miller_loop_native.rs:320-322), the exact value"""
-    g = _graph(run_ahead=run_ahead)
+    g = _graph(run_ahead=run_ahead, **kw)
     (px, py), Q = g.g1_point(), g.g2_point()
     g.outputs = g.miller_loop(px, py, Q, exact=True)
     return g
 
 
-def build_final_exp():
+def build_final_exp(**kw):
     """final_exp_native(f) (final_exp_native.rs:209-213)"""
-    g = _graph()
+    g = _graph(**kw)
     g.outputs = g.final_exp(g.fq12_input())
     return g
 
 
-def build_multi(k, final_exp=True, run_ahead=None, pow_window=None):
+def build_multi(k, final_exp=True, run_ahead=None, pow_window=None, **kw):
     """multi_miller_loop_native over k pairs (miller_loop_native.rs:324-326), then final_exp_native (the Groth16-style product of
     pairings, final_exp_native.rs:245-263) or -- final_exp=False -- the exact Miller value"""
-    g = _graph(run_ahead=run_ahead, pow_window=pow_window)
+    g = _graph(run_ahead=run_ahead, pow_window=pow_window, **kw)
     pairs = [(g.g1_point(j), g.g2_point(j)) for j in range(k)]
     f = g.multi_miller_loop(pairs, exact=not final_exp)
     g.outputs = g.final_exp(f) if final_exp else f

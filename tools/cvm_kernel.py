@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """cvm_kernel.py -- the interpreter kernel of the lane-cooperative pairing (tools/cvm.py has the design and the program).
 
-One wave per workgroup, GROUPS = 4 pairings per wave, NR = 16 lanes per pairing.  Every lane executes the same instruction stream;
+One wave per workgroup; NR = 16 lanes per item and four items per wave, or -- the builds for the smallest launches -- NR = 32 and two.  Every lane executes the same instruction stream;
 what differs per lane is its table row (which LDS slots it reads and writes).  Per round:
 
     wait for the row / kind prefetched during the previous round, start the loads of the next ones
@@ -70,8 +70,11 @@ V_LTOP, V_DST_T, V_TWIN_T, V_T1_T = 204, 205, 206, 207          # split36: base 
 
 
 class VMKernel:
-    def __init__(self, layout="aos48"):
-        assert layout in LAYOUTS and ROW_DEPTH == 1
+    def __init__(self, layout="aos48", nr=NR):
+        assert layout in LAYOUTS and ROW_DEPTH == 1 and nr in (16, 32)
+        self.nr = nr
+        self.lg = nr.bit_length() - 1             # log2(lanes per item)
+        self.groups = 64 // nr
         self.e = Emitter()
         self.sizes = {}
         self.layout = layout
@@ -149,7 +152,7 @@ class VMKernel:
         b = ROWB[buf]
         e.emit(f"global_load_dwordx4 v[{b}:{b + 3}], v{V_ROWOFF}, {S_ROWS}", kind="vmem", vw=list(range(b, b + 4)))
         e.emit(f"global_load_dwordx4 v[{b + 4}:{b + 7}], v{V_ROWOFF}, {S_ROWS} offset:16", kind="vmem", vw=list(range(b + 4, b + 8)))
-        e.emit(f"v_add_u32_e32 v{V_ROWOFF}, {NR * ROW_DW * 4}, v{V_ROWOFF}", vw=[V_ROWOFF])
+        e.emit(f"v_add_u32_e32 v{V_ROWOFF}, {self.nr * ROW_DW * 4}, v{V_ROWOFF}", vw=[V_ROWOFF])
 
     def next_row(self):
         if ROW_DEPTH == 1:
@@ -185,10 +188,10 @@ class VMKernel:
         e.salu(f"s_mov_b32 s{S_M30}, -30")
         e.salu(f"s_lshl_b32 s{S_NSTRIDE}, s{S_N}, 3")               # bytes between the planes of the output (n items)
         e.salu(f"s_mul_i32 s{S_PITCH_IN}, s{S_NSTRIDE}, s{S_K}")      # ... of the inputs (n k elements: pair j of item g is element g k + j)
-        e.emit(f"v_and_b32_e32 v{V_ROLE}, {NR - 1}, %9", vw=[V_ROLE])
-        e.emit(f"v_lshrrev_b32_e32 v{V_T0}, 4, %9", vw=[V_T0])                             # group of the lane
-        e.salu(f"s_lshl_b32 s{S_TMP}, s{S_TMP}, 2")
-        e.emit(f"v_add_u32_e32 v{V_ITEM8}, s{S_TMP}, v{V_T0}", vw=[V_ITEM8])                # item = block * 4 + group
+        e.emit(f"v_and_b32_e32 v{V_ROLE}, {self.nr - 1}, %9", vw=[V_ROLE])
+        e.emit(f"v_lshrrev_b32_e32 v{V_T0}, {self.lg}, %9", vw=[V_T0])                     # group of the lane
+        e.salu(f"s_lshl_b32 s{S_TMP}, s{S_TMP}, {6 - self.lg}")
+        e.emit(f"v_add_u32_e32 v{V_ITEM8}, s{S_TMP}, v{V_T0}", vw=[V_ITEM8])                # item = block * (items per wave) + group
         e.emit(f"v_cmp_gt_u32_e32 vcc, s{S_N}, v{V_ITEM8}", w=["vcc"])
         e.emit(f"v_cndmask_b32_e64 v{V_VALID}, 0, 1, vcc", r=["vcc"], vw=[V_VALID])
         e.salu(f"s_sub_u32 s{S_TMP}, s{S_N}, 1")
@@ -199,9 +202,9 @@ class VMKernel:
         if self.split:
             e.salu(f"s_lshl_b32 s{S_TMP}, s{S_NSLOTS}, 5")                                  # a group's 32-byte slots
             e.emit(f"v_mul_lo_u32 v{V_LBASE}, v{V_T0}, s{S_TMP}", vw=[V_LBASE])
-            e.salu(f"s_lshl_b32 s{S_TMP}, s{S_NSLOTS}, 2")                                  # its limb-8 dwords, behind the four groups' slots
+            e.salu(f"s_lshl_b32 s{S_TMP}, s{S_NSLOTS}, 2")                                  # its limb-8 dwords, behind all the groups' slots
             e.emit(f"v_mul_lo_u32 v{V_LTOP}, v{V_T0}, s{S_TMP}", vw=[V_LTOP])
-            e.salu(f"s_lshl_b32 s{S_TMP}, s{S_NSLOTS}, {5 + 2}")
+            e.salu(f"s_lshl_b32 s{S_TMP}, s{S_NSLOTS}, {5 + 6 - self.lg}")
             e.emit(f"v_add_u32_e32 v{V_LTOP}, s{S_TMP}, v{V_LTOP}", vw=[V_LTOP])
         else:
             e.salu(f"s_mul_i32 s{S_TMP}, s{S_NSLOTS}, {SLOT_BYTES}")
@@ -218,8 +221,8 @@ class VMKernel:
         e.salu("s_addc_u32 s93, s49, 0")
         # ---- constant pool -> the group's slots [0, n_const): lane r copies constants r, r + 16, ... (clamped: the last one again)
         e.emit(f"v_mov_b32_e32 v{V_T1}, v{V_ROLE}", vw=[V_T1])
-        e.salu(f"s_add_u32 s{S_CNT}, s{S_NCONST}, {NR - 1}")
-        e.salu(f"s_lshr_b32 s{S_CNT}, s{S_CNT}, 4")
+        e.salu(f"s_add_u32 s{S_CNT}, s{S_NCONST}, {self.nr - 1}")
+        e.salu(f"s_lshr_b32 s{S_CNT}, s{S_CNT}, {self.lg}")
         e.salu(f"s_sub_u32 s{S_TMP}, s{S_NCONST}, 1")
         e.label("LC_const_%=")
         e.emit(f"v_min_u32_e32 v{V_T0}, s{S_TMP}, v{V_T1}", vw=[V_T0])
@@ -230,7 +233,7 @@ class VMKernel:
         self.addr_of_slot(self.fixed(V_TWIN), V_T0)
         e.raw("s_waitcnt vmcnt(0)")
         self.lds_store(self.fixed(V_TWIN), 0)
-        e.emit(f"v_add_u32_e32 v{V_T1}, {NR}, v{V_T1}", vw=[V_T1])
+        e.emit(f"v_add_u32_e32 v{V_T1}, {self.nr}, v{V_T1}", vw=[V_T1])
         e.salu(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
         e.salu(f"s_cmp_lg_u32 s{S_CNT}, 0")
         e.salu("s_cbranch_scc1 LC_const_%=")
@@ -266,7 +269,7 @@ class VMKernel:
         e.emit(f"v_and_b32_e32 v{V_T0}, 0xffff, v{V_DESC}", vw=[V_T0])
         self.addr_of_slot(self.fixed(V_DST), V_T0)
         self.lds_store(self.fixed(V_DST), 0)
-        e.emit(f"v_add_u32_e32 v{V_T1}, {4 * NR}, v{V_T1}", vw=[V_T1])
+        e.emit(f"v_add_u32_e32 v{V_T1}, {4 * self.nr}, v{V_T1}", vw=[V_T1])
         e.salu(f"s_sub_u32 s{S_NCHUNK}, s{S_NCHUNK}, 1")
         e.salu(f"s_cmp_lg_u32 s{S_NCHUNK}, 0")
         e.salu("s_cbranch_scc1 LC_in_%=")
@@ -435,7 +438,8 @@ class VMKernel:
         Fq number (r & 1) * 6 + (r >> 1) of the MyFq12 output; the zero-divisor flag goes to the status word"""
         e = self.e
         e.label("LC_end_%=")
-        e.emit(f"v_lshlrev_b32_e32 v{V_T1}, 2, v{V_ROLE}", vw=[V_T1])
+        e.emit(f"v_min_u32_e32 v{V_T1}, 15, v{V_ROLE}", vw=[V_T1])                          # (sixteen entries; lanes 12.. store nothing)
+        e.emit(f"v_lshlrev_b32_e32 v{V_T1}, 2, v{V_T1}", vw=[V_T1])
         e.emit(f"global_load_dword v{V_DST}, v{V_T1}, {S_BLOB} offset:32", kind="vmem", vw=[V_DST])       # the lane's output slot
         e.raw("s_waitcnt vmcnt(0)")
         e.emit(f"v_mov_b32_e32 v{V_T0}, v{V_DST}", vw=[V_T0])
@@ -486,7 +490,8 @@ class VMKernel:
 def make_blob(enc):
     """the program blob as a list of dwords: header, input descriptors, rows (one END row more than rounds, + the look-ahead's reach),
     constants (internal form: nine balanced 29-bit limbs of c R' mod p, + a pad dword)"""
-    assert enc["nr"] == NR
+    NR = enc["nr"]
+    assert NR in (16, 32)
     n_rounds = len(enc["rows"])
     trash = enc["n_slots"] - 1
     ins = [slot | fq << 16 | arr << 20 | pair << 22 for slot, arr, fq, pair in enc["inputs"]]

@@ -24,10 +24,12 @@ def concretize(lines):
     return out
 
 
-def simulate(lines, blob, g1_words=(), g2_words=(), n=1, block=0, tids=range(CK.NR), k=1, fin_words=None):
+def simulate(lines, blob, g1_words=(), g2_words=(), n=1, block=0, tids=None, k=1, fin_words=None):
     """One group of lanes on the program `blob`; g1 / g2 / f_in: the SoA u64 words of the batch (n items of k pairs; a missing
     array is a null pointer, as at the C boundary) -> (global memory, machines, rounds run)"""
     lines = concretize(lines) + ["s_endpgm"]
+    if tids is None:
+        tids = range(CK.NR)
     lds, gmem = {}, {}
     for i, w in enumerate(blob):
         gmem[BLOBB + 4 * i] = w & 0xFFFFFFFF
