@@ -92,8 +92,8 @@ int bn254_reserve(int device, void* stream, size_t n, size_t k);
  * The throughput kernels put one item on one lane: 3.6 M dependent instructions for a pairing, 6.5 ms however small the batch.
  * Behind the same entry points -- bn254_pairing_batch, bn254_miller_loop_batch, bn254_final_exp_batch, bn254_multi_pairing_batch
  * with k <= 4 pairs (both values of do_final_exp), bn254_multi_pairing_check_batch, their `_dev` and `_elems` forms -- sits a second,
- * lane-cooperative kernel: one item on sixteen lanes, four items per wave (pairing: 0.49 M instructions deep, 1.01 ms; a four-pair
- * product check 1.8 ms instead of 13.4), the same values bit for bit.  Batches of at most `n` items take it (per function scaled by
+ * lane-cooperative kernel: one item on sixteen lanes, four items per wave (pairing: 0.49 M instructions deep, 1.01 ms -- 0.83 ms on
+ * thirty-two lanes, below; a four-pair product check 1.2 ms instead of 13.4), the same values bit for bit.  Batches of at most `n` items take it (per function scaled by
  * its measured crossover against the throughput kernel: x1 pairing / Miller loop / final exponentiation / two pairs, x1.5 three
  * pairs, x2 four pairs, x0.5 the exact multi-pair Miller values); 0 turns it off.  Process-wide; default 8192. */
 void bn254_set_latency_threshold(size_t n);

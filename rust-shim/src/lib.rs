@@ -20,6 +20,8 @@ extern "C" {
     fn bn254_reserve(device: c_int, stream: *mut c_void, n: usize, k: usize) -> c_int;
     fn bn254_set_latency_threshold(n: usize);
     fn bn254_get_latency_threshold() -> usize;
+    fn bn254_set_latency_lanes(lanes: c_int);
+    fn bn254_get_latency_lanes() -> c_int;
     fn bn254_check_points(g1: *const u64, g2: *const u64, n: usize, device: c_int, stream: *mut c_void) -> c_int;
     fn bn254_pairing_sharded(g1: *const u64, g2: *const u64, out: *mut u64, n: usize, n_devices: c_int) -> c_int;
     // device pointers on devices[0] (NULL: devices 0..n_devices-1); shard i runs on devices[i]; synchronous
@@ -137,6 +139,9 @@ pub fn reserve(n: usize, k: usize) { ok(unsafe { bn254_reserve(0, core::ptr::nul
 /// `miller_loop_native`, `multi_miller_loop_native`, `final_exp_native`: one element per call) get by default; 0 turns it off.
 pub fn set_latency_threshold(n: usize) { unsafe { bn254_set_latency_threshold(n) } }
 pub fn latency_threshold() -> usize { unsafe { bn254_get_latency_threshold() } }
+/// 0 (default): thirty-two lanes per item for launches of at most one wave per SIMD, sixteen beyond; 16 / 32: fixed.
+pub fn set_latency_lanes(lanes: i32) { unsafe { bn254_set_latency_lanes(lanes) } }
+pub fn latency_lanes() -> i32 { unsafe { bn254_get_latency_lanes() } }
 
 /// The reference never looks at `infinity` (its line functions read raw x / y, miller_loop_native.rs:10-44): an infinite input is outside
 /// its contract.  Callers that want it REPORTED use this: the flags of the structs first (no device work), then the engine's check of the
