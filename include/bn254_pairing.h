@@ -99,8 +99,7 @@ int bn254_reserve(int device, void* stream, size_t n, size_t k);
 void bn254_set_latency_threshold(size_t n);
 size_t bn254_get_latency_threshold(void);
 /* The lane-cooperative programs exist for sixteen lanes per item (four items per wave; every function) and for thirty-two (two items
- * per wave; pairing, miller_loop_native, final_exp_native, the four-pair product: fewer, fuller rounds -- pairing 0.83 ms instead of
- * 1.01 -- for twice the lanes).  0 (default): thirty-two while the launch is at most one wave per SIMD (2048 items on MI355X), sixteen
+ * per wave: fewer, fuller rounds -- pairing 0.83 ms instead of 1.01 -- for twice the lanes).  0 (default): thirty-two while the launch is at most one wave per SIMD (2048 items on MI355X), sixteen
  * beyond; 16 / 32: that family whatever the size (measurements, tests). */
 void bn254_set_latency_lanes(int lanes);
 int bn254_get_latency_lanes(void);

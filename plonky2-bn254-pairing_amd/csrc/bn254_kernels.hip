@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <zlib.h>
 #include <string.h>
 #include <atomic>
 #include <map>
@@ -204,7 +205,7 @@ struct DeviceCtx {
     int n_cu = 0;
     std::mutex table_mu;       // the generator table upload (138 KB, blocking) has its own lock
     int32_t* gen_table = nullptr;
-    uint32_t* cvm_blob[13] = {};    // the latency path's round programs (0.3 - 1.4 MB each, uploaded on first use, same lock)
+    uint32_t* cvm_blob[18] = {};    // the latency path's round programs (0.3 - 1.4 MB each, uploaded on first use, same lock)
     bool cvm_init = false;
     std::map<hipStream_t, std::shared_ptr<StreamCtx>> streams;   // shared: a call keeps its context alive across a concurrent release
     std::mutex pipe_mu;        // one host-pointer pipeline at a time per device (its two workers fill the chip anyway)
@@ -332,19 +333,22 @@ std::atomic<size_t> g_latency_threshold{BN254_LATENCY_THRESHOLD_DEFAULT};
 std::atomic<int> g_latency_lanes{0};       // bn254_set_latency_lanes: 0 = by launch size, 16 / 32 = that program family whatever the size
 
 struct CvmProgram {
-    const uint32_t* blob;
-    size_t bytes;
+    const char* b64;          // the program blob, deflated and base64-encoded (cvm_asm_gen.h)
+    size_t z_bytes;           // deflated
+    size_t bytes;             // inflated
     uint32_t slots;
     uint32_t per_mille;       // share of the threshold this program takes batches up to (its own crossover against the throughput kernel)
     int wide;                 // index of the same function's thirty-two-lane program, or -1
 };
-#define CVM_PROGRAM(NAME, PM, WIDE) {BN254_CVM_##NAME##_BLOB, sizeof(BN254_CVM_##NAME##_BLOB), BN254_CVM_##NAME##_SLOTS, PM, WIDE}
-constexpr int CVM_N_PROGRAMS = 13;
+#define CVM_PROGRAM(NAME, PM, WIDE) {BN254_CVM_##NAME##_B64, BN254_CVM_##NAME##_Z_BYTES, BN254_CVM_##NAME##_BYTES, BN254_CVM_##NAME##_SLOTS, PM, WIDE}
+constexpr int CVM_N_PROGRAMS = 18;
 const CvmProgram CVM_PROGRAMS[CVM_N_PROGRAMS] = {
     CVM_PROGRAM(PAIRING, 1000, 9), CVM_PROGRAM(MILLER, BN254_CVM_PM_MILLER, 10), CVM_PROGRAM(FEXP, BN254_CVM_PM_FEXP, 11),
-    CVM_PROGRAM(MULTI2, 1000, -1), CVM_PROGRAM(MULTI3, 1500, -1), CVM_PROGRAM(MULTI4, 2000, 12),
-    CVM_PROGRAM(MMILLER2, BN254_CVM_PM_MMILLER, -1), CVM_PROGRAM(MMILLER3, BN254_CVM_PM_MMILLER, -1), CVM_PROGRAM(MMILLER4, BN254_CVM_PM_MMILLER, -1),
-    CVM_PROGRAM(PAIRING_W, 0, -1), CVM_PROGRAM(MILLER_W, 0, -1), CVM_PROGRAM(FEXP_W, 0, -1), CVM_PROGRAM(MULTI4_W, 0, -1)};
+    CVM_PROGRAM(MULTI2, 1000, 12), CVM_PROGRAM(MULTI3, 1500, 13), CVM_PROGRAM(MULTI4, 2000, 14),
+    CVM_PROGRAM(MMILLER2, BN254_CVM_PM_MMILLER, 15), CVM_PROGRAM(MMILLER3, BN254_CVM_PM_MMILLER, 16), CVM_PROGRAM(MMILLER4, BN254_CVM_PM_MMILLER, 17),
+    CVM_PROGRAM(PAIRING_W, 0, -1), CVM_PROGRAM(MILLER_W, 0, -1), CVM_PROGRAM(FEXP_W, 0, -1),
+    CVM_PROGRAM(MULTI2_W, 0, -1), CVM_PROGRAM(MULTI3_W, 0, -1), CVM_PROGRAM(MULTI4_W, 0, -1),
+    CVM_PROGRAM(MMILLER2_W, 0, -1), CVM_PROGRAM(MMILLER3_W, 0, -1), CVM_PROGRAM(MMILLER4_W, 0, -1)};
 
 // which program serves (Miller loop?, final exponentiation?, k pairs); -1: none
 template <bool M, bool F>
@@ -354,8 +358,8 @@ int cvm_program(size_t k) {
     return k == 1 ? 2 : -1;
 }
 
-// The program's blob on the device: uploaded once (a blocking copy of 0.3 - 1.1 MB on the first call that needs it; bn254_reserve does it
-// for every program up front).
+// The program's blob on the device: inflated (zlib) and uploaded once -- a blocking copy of 0.3 - 1.4 MB on the first call that needs it;
+// bn254_reserve does it for every program up front.
 int cvm_upload(int device, int prog) {
     DeviceCtx& d = g_ctx[device];
     const CvmProgram& p = CVM_PROGRAMS[prog];
@@ -367,9 +371,23 @@ int cvm_upload(int device, int prog) {
         d.cvm_init = true;
     }
     if (!d.cvm_blob[prog]) {
+        std::vector<unsigned char> z(p.z_bytes + 3), raw(p.bytes);
+        {   // base64 -> deflate stream
+            auto val = [](char ch) -> uint32_t {
+                return ch >= 'A' && ch <= 'Z' ? ch - 'A' : ch >= 'a' && ch <= 'z' ? ch - 'a' + 26 : ch >= '0' && ch <= '9' ? ch - '0' + 52 : ch == '+' ? 62 : ch == '/' ? 63 : 0;
+            };
+            size_t o = 0;
+            for (const char* q = p.b64; q[0] && q[1] && q[2] && q[3] && o + 3 <= z.size(); q += 4) {
+                uint32_t v = val(q[0]) << 18 | val(q[1]) << 12 | val(q[2]) << 6 | val(q[3]);
+                z[o++] = (unsigned char)(v >> 16); z[o++] = (unsigned char)(v >> 8); z[o++] = (unsigned char)v;
+            }
+            if (o < p.z_bytes) return BN254_ERR_HIP;
+        }
+        uLongf got = (uLongf)p.bytes;
+        if (uncompress(raw.data(), &got, z.data(), (uLong)p.z_bytes) != Z_OK || got != p.bytes) return BN254_ERR_HIP;
         uint32_t* t = nullptr;
         if (hipMalloc(&t, p.bytes) != hipSuccess) { (void)hipGetLastError(); return BN254_ERR_ALLOC; }
-        if (hipMemcpy(t, p.blob, p.bytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(t); return BN254_ERR_HIP; }
+        if (hipMemcpy(t, raw.data(), p.bytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(t); return BN254_ERR_HIP; }
         d.cvm_blob[prog] = t;
     }
     return BN254_OK;

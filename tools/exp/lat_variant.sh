@@ -17,7 +17,7 @@ print("$tag", {k: v for k, v in stats.items() if k != "by_kind"})
 PY
 sed -i 's#"../../include/bn254_pairing.h"#"'$PWD'/include/bn254_pairing.h"#' build/variants/$tag/bn254_kernels.hip
 rm -f build/variants/lib_$tag.so
-if ! hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared ${HIPCC_EXTRA:-} build/variants/$tag/bn254_kernels.hip -o build/variants/lib_$tag.so.tmp > build/variants/$tag.log 2>&1; then
+if ! hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -lz ${HIPCC_EXTRA:-} build/variants/$tag/bn254_kernels.hip -o build/variants/lib_$tag.so.tmp > build/variants/$tag.log 2>&1; then
     grep -E "error" build/variants/$tag.log | head -20 >&2 || true
     echo "build of variant $tag FAILED (log: build/variants/$tag.log)" >&2
     rm -f build/variants/lib_$tag.so.tmp
