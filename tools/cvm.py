@@ -29,11 +29,9 @@ from asmcore import P_INT, BN_X, SIX_U_PLUS_2_NAF  # noqa: E402
 
 P = P_INT
 XI = (9, 1)
-NR = 8                      # lanes (roles) per pairing
 ARR_G1, ARR_G2, ARR_F, ARR_NONE = 0, 1, 2, 3
 COST = {"m1": 950, "m3": 2000, "lin": 420, "inv": 46000}     # instructions per round (scheduling weights; tools/cvm_kernel.py prints the real ones)
 MAX_LIN_SRC = 6             # sources of an Fq2-level combination (the Fq operation it lowers to takes eight terms)
-SLOT_STRIDE = 80            # bytes per LDS slot (72 used: 2 x 9 limbs)
 
 
 # ------------------------------------------------------------------ Fq2 on integers (the emulator's arithmetic)
@@ -984,16 +982,6 @@ def build_multi(k, final_exp=True, run_ahead=None, pow_window=None, **kw):
     return g
 
 
-def build_fq12_mul():
-    g = Graph()
-    g.const((0, 0))
-    g.const((1, 0))
-    a = [g.inp(f"a{i}") for i in range(6)]
-    b = [g.inp(f"b{i}") for i in range(6)]
-    g.outputs = g.fq12_mul(a, b)
-    return g
-
-
 def build_synth(kind, count):
     """DIAGNOSTIC program (tools/exp/lat_variant.sh, CVM_SYNTH): `count` rounds in which all sixteen lanes do one operation of
     `kind` (m2 / m6 / l4 / l8) on the previous round's values -- the per-round cost of the interpreter, kind by kind"""
@@ -1019,10 +1007,6 @@ def build_synth(kind, count):
 
 
 if __name__ == "__main__":
-    import time
-    for name, fn in (("fq12_mul", build_fq12_mul), ("final_exp", build_final_exp), ("pairing", build_pairing)):
-        for nr in (16, 32):
-            for gf in (True, False):
-                t0 = time.time()
-                pr = Program(Lowered(fn()), nr=nr, greedy_fill=gf)
-                print(name, nr, gf, pr.stats(), f"{time.time() - t0:.1f} s")
+    for name, g, nr in (("pairing", build_pairing(), 16), ("pairing, 32 lanes", build_pairing(wide=True, pow_window=4), 32),
+                        ("4-pair product", build_multi(4, True, pow_window=2), 16), ("4-pair product, 32 lanes", build_multi(4, True, pow_window=4, wide=True), 32)):
+        print(name, Program(Lowered(g), nr=nr).stats())

@@ -42,18 +42,15 @@ def OP(i):
 
 OUT0, NEG0 = 130, 140
 POOL_FIRST, POOL_LAST = 150, 203
-# Row look-ahead.  1: the next row is fetched into the row registers as soon as the current one has been decoded (shipped).
-# 3: three row buffers in flight, the round's own copied to the executing row -- measured SLOWER (1.336 ms against 1.277 ms for one
-# pairing, profiles/r04_latency_ab.txt): the rows come from L2 within a round; what a round waits for is the LDS (operand fetch).
-ROW_DEPTH = int(os.environ.get("CVM_ROW_DEPTH", "1"))
+# The row of the NEXT round is fetched into these registers as soon as the current one has been decoded.  (Rows fetched three rounds
+# ahead through rotating buffers were measured SLOWER -- 1.336 ms against 1.277 ms for one pairing at that stage: the rows come from L2
+# within a round, the copies cost more than the wait; what a round waits for is the LDS, the operand fetch.)
+ROWN = 228
 INV_SAFEGCD = bool(int(os.environ.get("CVM_INV_SAFEGCD", "1")))  # the inversion by divsteps instead of the Fermat chain
 OVERLAP = bool(int(os.environ.get("CVM_OVERLAP", "1")))      # operand limbs that a pass needs late are fetched inside it
-ROWN = 204 if ROW_DEPTH > 1 else 228
-ROWB = [212, 220, 228]
 V_LBASE, V_ROWOFF, V_ROLE, V_ITEM8, V_FLAG, V_T0, V_DST, V_TWIN, V_VALID, V_T1 = 236, 237, 238, 239, 240, 241, 242, 243, 244, 245
 V_ELEM, V_DESC = 246, 247
-S_BLOB, S_ROWS, S_NROUNDS, S_KIND, S_KINDS, S_KNEXT, S_NCONST, S_NSLOTS, S_TMP = "s[48:49]", "s[50:51]", 52, 53, "s[62:63]", 64, 65, 66, 67
-S_PHASE = 89
+S_BLOB, S_ROWS, S_NROUNDS, S_KIND, S_NCONST, S_NSLOTS, S_TMP = "s[48:49]", "s[50:51]", 52, 53, 65, 66, 67
 S_CONSTS, S_G1, S_G2, S_OUT, S_N, S_NSTRIDE, S_STATUS = "s[68:69]", "s[70:71]", "s[72:73]", "s[74:75]", 76, 77, "s[78:79]"
 S_FIN, S_INS, S_K, S_PITCH_IN, S_NCHUNK = "s[90:91]", "s[92:93]", 94, 95, 96
 S_H = 80               # s80..s87: header words / scratch
@@ -71,7 +68,7 @@ V_LTOP, V_DST_T, V_TWIN_T, V_T1_T = 204, 205, 206, 207          # split36: base 
 
 class VMKernel:
     def __init__(self, layout="aos48", nr=NR):
-        assert layout in LAYOUTS and ROW_DEPTH == 1 and nr in (16, 32)
+        assert layout in LAYOUTS and nr in (16, 32)
         self.nr = nr
         self.lg = nr.bit_length() - 1             # log2(lanes per item)
         self.groups = 64 // nr
@@ -146,17 +143,13 @@ class VMKernel:
                     self.e.emit(pts[k][0], kind="lds", vw=pts[k][1])
         return out
 
-    def prefetch_row(self, buf):
-        """the row three rounds ahead into row buffer `buf` (whose previous content has been copied to the executing row)"""
+    def next_row(self):
+        """the next round's row into the row registers (everything that reads the current row has been issued)"""
         e = self.e
-        b = ROWB[buf]
+        b = ROWN
         e.emit(f"global_load_dwordx4 v[{b}:{b + 3}], v{V_ROWOFF}, {S_ROWS}", kind="vmem", vw=list(range(b, b + 4)))
         e.emit(f"global_load_dwordx4 v[{b + 4}:{b + 7}], v{V_ROWOFF}, {S_ROWS} offset:16", kind="vmem", vw=list(range(b + 4, b + 8)))
         e.emit(f"v_add_u32_e32 v{V_ROWOFF}, {self.nr * ROW_DW * 4}, v{V_ROWOFF}", vw=[V_ROWOFF])
-
-    def next_row(self):
-        if ROW_DEPTH == 1:
-            self.prefetch_row(2)
 
     def finish(self, dst, twin):
         """result in OUT -> dst slot, its negation -> twin slot; next round"""
@@ -274,31 +267,13 @@ class VMKernel:
         e.salu(f"s_cmp_lg_u32 s{S_NCHUNK}, 0")
         e.salu("s_cbranch_scc1 LC_in_%=")
         # ---- the first rows (the round's kind travels in the row: dword 7, high half)
-        for b in range(ROW_DEPTH):
-            self.prefetch_row(b if ROW_DEPTH > 1 else 2)
-        e.salu(f"s_mov_b32 s{S_PHASE}, 0")
+        self.next_row()
 
     # -------------------------------------------------------------- the round loop
     def round_loop(self):
-        """Rows are fetched ROW_DEPTH rounds ahead (a short round is over before an L2 hit returns): three row buffers take the
-        loads in turn; the round's own buffer is copied to the executing row and refilled at once."""
         e = self.e
         e.label("LC_round_%=")
-        if ROW_DEPTH == 1:
-            e.raw("s_waitcnt vmcnt(0)")
-        for b in range(ROW_DEPTH if ROW_DEPTH > 1 else 0):
-            if b < ROW_DEPTH - 1:
-                e.salu(f"s_cmp_eq_u32 s{S_PHASE}, {b}")
-                e.salu(f"s_cbranch_scc0 LC_ph{b + 1}_%=")
-            e.raw(f"s_waitcnt vmcnt({2 * (ROW_DEPTH - 1)})")
-            for i in range(ROW_DW):
-                e.emit(f"v_mov_b32_e32 v{ROWN + i}, v{ROWB[b] + i}", vw=[ROWN + i])
-            self.prefetch_row(b)
-            e.salu(f"s_mov_b32 s{S_PHASE}, {(b + 1) % ROW_DEPTH}")
-            if b < ROW_DEPTH - 1:
-                e.salu("s_branch LC_go_%=")
-                e.label(f"LC_ph{b + 1}_%=")
-        e.label("LC_go_%=")
+        e.raw("s_waitcnt vmcnt(0)")
         e.emit(f"v_readfirstlane_b32 s{S_KIND}, v{ROWN + 7}", kind="valu")
         e.salu(f"s_lshr_b32 s{S_KIND}, s{S_KIND}, 16")
         for kind in (cvm.K_L4, cvm.K_M6, cvm.K_M2, cvm.K_M4, cvm.K_L8, cvm.K_INV):      # by frequency in the pairing program
@@ -502,7 +477,7 @@ def make_blob(enc):
     for row in enc["rows"]:
         for dw in row:
             rows += dw
-    rows += [0] * (NR * ROW_DW * (1 + ROW_DEPTH))          # the END row, and what the look-ahead reads behind it
+    rows += [0] * (NR * ROW_DW * 2)                        # the END row, and the row the look-ahead reads behind it
     consts = []
     for c in enc["consts"]:
         consts += [w & 0xFFFFFFFF for w in bal_limbs(c * K4.RP % P_INT)] + [0]
