@@ -193,7 +193,7 @@ def test_other_programs_equal_the_reference_functions():
 def test_wide_programs_equal_the_reference_functions():
     """the thirty-two-lane programs (monomial cyclotomic squarings, four-bit windows): pairing and the four-pair product"""
     want = [c for x in R.fq12_to_fp2s(R.pairing_myfq12(P_PT, Q_PT)) for c in x]
-    low = cvm.Lowered(cvm.build_pairing(wide=True, pow_window=4))
+    low = cvm.Lowered(cvm.build_pairing(wide=True, pow_window="fixed"))
     pr = cvm.Program(low, nr=32)
     assert low.evaluate(FLAT) == want and pr.run(FLAT) == want
     assert len(pr.rounds) < 1000 and max(v.bound for v in low.fv) <= cvm.Lowered.V_MAX
@@ -204,7 +204,7 @@ def test_wide_programs_equal_the_reference_functions():
     Q = [R.g2_mul(R.G2_GEN, 5 + 3 * j) for j in range(4)]
     flat = [c for j in range(4) for c in (P[j][0], P[j][1], Q[j][0][0], Q[j][0][1], Q[j][1][0], Q[j][1][1])]
     m = R.final_exp_native(R.multi_miller_loop_native([(P[j], Q[j]) for j in range(4)]))
-    low = cvm.Lowered(cvm.build_multi(4, True, pow_window=4, wide=True))
+    low = cvm.Lowered(cvm.build_multi(4, True, pow_window="fixed", wide=True))
     pr = cvm.Program(low, nr=32)
     assert pr.run(flat) == [c for x in R.fq12_to_fp2s(m) for c in x]
 

@@ -427,26 +427,39 @@ class Graph:
         the odd powers a, a^3, ... -- window 3: 17 multiplications and one for the table instead of the NAF's 23; a multiplication is
         two rounds on the critical path, a squaring three."""
         w = self.pow_window
-        digits = []
-        e = BN_X
-        while e:
-            d = 0
-            if e & 1:
-                d = e % (1 << w)
-                if d >= 1 << (w - 1):
-                    d -= 1 << w
-                e -= d
-            digits.append(d)
-            e >>= 1
-        top = len(digits) - 1
-        assert digits[top] > 0
-        odd = {1: a}
-        need = max(abs(d) for d in digits)
-        if need > 1:
-            a2 = self.cyc_sqr(a)
-            a2x = self.fq12_mul_pre(a2)
-            for k in range(3, need + 1, 2):
-                odd[k] = self.fq12_mul(odd[k - 2], a2, a2x)
+        if w == "fixed":
+            # the throughput kernels' signed fixed-set recoding (tools/kgen4_prog.py X_DIGITS, found by tools/exp/xchain.py): digits in
+            # {0, +-1, +-5, +-9, +-13}, 59 squarings + 12 multiplications in the loop, b^4, b^5, b^9, b^13 from 2 squarings + 3 multiplications
+            from kgen4_prog import X_DIGITS
+            digits = list(X_DIGITS)
+            top = len(digits) - 1
+            b4 = self.cyc_sqr(self.cyc_sqr(a))
+            b4x = self.fq12_mul_pre(b4)
+            odd = {1: a}
+            odd[5] = self.fq12_mul(a, b4, b4x)
+            odd[9] = self.fq12_mul(odd[5], b4, b4x)
+            odd[13] = self.fq12_mul(odd[9], b4, b4x)
+        else:
+            digits = []
+            e = BN_X
+            while e:
+                d = 0
+                if e & 1:
+                    d = e % (1 << w)
+                    if d >= 1 << (w - 1):
+                        d -= 1 << w
+                    e -= d
+                digits.append(d)
+                e >>= 1
+            top = len(digits) - 1
+            assert digits[top] > 0
+            odd = {1: a}
+            need = max(abs(d) for d in digits)
+            if need > 1:
+                a2 = self.cyc_sqr(a)
+                a2x = self.fq12_mul_pre(a2)
+                for k in range(3, need + 1, 2):
+                    odd[k] = self.fq12_mul(odd[k - 2], a2, a2x)
         pre = {}
         for k, v in odd.items():
             vc = self.fq12_conj(v)
