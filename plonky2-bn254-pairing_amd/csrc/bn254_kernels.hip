@@ -29,10 +29,10 @@ constexpr size_t LDS_BYTES = BN254_LDS_BYTES;           // 8 slots x 72 B x 256 
 constexpr size_t SLOT_BYTES = BN254_SLOT_BYTES;         // one Fq2: 2 x 9 balanced 29-bit limbs
 constexpr size_t MAX_K = 64;                            // pairs per group of the multi-pairing kernels
 #ifndef BN254_LATENCY_THRESHOLD_DEFAULT
-#define BN254_CVM_PM_MILLER 1000      // per mille of the threshold each program takes batches up to: its own measured crossover (profiles/r04_latency.json)
+#define BN254_CVM_PM_MILLER 800      // per mille of the threshold each program takes batches up to: its own measured crossover (profiles/r04_latency.json)
 #define BN254_CVM_PM_FEXP 1000
 #define BN254_CVM_PM_MMILLER 500
-#define BN254_LATENCY_THRESHOLD_DEFAULT 8192            // the measured crossover (profiles/r04_latency.json): 4.9 ms against 6.5 ms at 8192, 8.8 against 6.5 at 16384
+#define BN254_LATENCY_THRESHOLD_DEFAULT 16384           // below the measured crossover (profiles/r04_latency.json): pairing 4.45 ms against 6.45 at 16384, 8.9 against 6.5 at 32768
 #endif
 
 // ------------------------------------------------------------------ kernels
@@ -344,7 +344,7 @@ struct CvmProgram {
 constexpr int CVM_N_PROGRAMS = 18;
 const CvmProgram CVM_PROGRAMS[CVM_N_PROGRAMS] = {
     CVM_PROGRAM(PAIRING, 1000, 9), CVM_PROGRAM(MILLER, BN254_CVM_PM_MILLER, 10), CVM_PROGRAM(FEXP, BN254_CVM_PM_FEXP, 11),
-    CVM_PROGRAM(MULTI2, 1000, 12), CVM_PROGRAM(MULTI3, 1500, 13), CVM_PROGRAM(MULTI4, 2000, 14),
+    CVM_PROGRAM(MULTI2, 1000, 12), CVM_PROGRAM(MULTI3, 1250, 13), CVM_PROGRAM(MULTI4, 1500, 14),
     CVM_PROGRAM(MMILLER2, BN254_CVM_PM_MMILLER, 15), CVM_PROGRAM(MMILLER3, BN254_CVM_PM_MMILLER, 16), CVM_PROGRAM(MMILLER4, BN254_CVM_PM_MMILLER, 17),
     CVM_PROGRAM(PAIRING_W, 0, -1), CVM_PROGRAM(MILLER_W, 0, -1), CVM_PROGRAM(FEXP_W, 0, -1),
     CVM_PROGRAM(MULTI2_W, 0, -1), CVM_PROGRAM(MULTI3_W, 0, -1), CVM_PROGRAM(MULTI4_W, 0, -1),
@@ -393,6 +393,12 @@ int cvm_upload(int device, int prog) {
     return BN254_OK;
 }
 
+// waves of the interpreter that a CU holds at `lds` bytes each (160 KB of LDS; 248 registers: two waves per SIMD)
+size_t resident_waves(size_t lds) {
+    size_t w = lds ? (160 * 1024) / lds : 8;
+    return w > 8 ? 8 : (w ? w : 1);
+}
+
 int launch_cvm(int prog, const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in, uint64_t* out, size_t n, size_t k, int device, void* stream) {
     LaunchCtx c;
     int rc = ctx_get(device, stream, 1, 1, &c);          // the status word and the stream context; the kernel needs no scratch
@@ -405,24 +411,25 @@ int launch_cvm(int prog, const uint64_t* g1, const uint64_t* g2, const uint64_t*
         int w = CVM_PROGRAMS[prog].wide;
         if ((rc = cvm_upload(device, w))) return rc;
         const CvmProgram& pw = CVM_PROGRAMS[w];
-        hipLaunchKernelGGL(k_cvm_wide, dim3((uint32_t)((n + 1) / 2)), dim3(64), (size_t)2 * pw.slots * BN254_CVM_SLOT_BYTES, (hipStream_t)stream, g1, g2, f_in,
+        size_t lds_w = (size_t)2 * pw.slots * BN254_CVM_SLOT_BYTES, cap = resident_waves(lds_w) * (size_t)c.n_cu, need = (n + 1) / 2;
+        hipLaunchKernelGGL(k_cvm_wide, dim3((uint32_t)(need < cap ? need : cap)), dim3(64), lds_w, (hipStream_t)stream, g1, g2, f_in,
                            out, (uint32_t)n, (uint32_t)k, (uint4*)d.cvm_blob[w], 0u, c.status);
         HIPCHK(hipGetLastError());
         return BN254_OK;
     }
     const CvmProgram& p = CVM_PROGRAMS[prog];
     if ((rc = cvm_upload(device, prog))) return rc;
-    // One wave per workgroup.  The contiguous slot layout is the faster one (one address computation less per operand); the split
-    // layout needs 3/4 of the LDS, so more waves fit a CU: taken when the launch has more waves than the contiguous layout can hold
-    // resident AND the split layout holds more.
-    uint32_t grid = (uint32_t)((n + BN254_CVM_GROUPS - 1) / BN254_CVM_GROUPS);
+    // One wave per workgroup; the grid is what is RESIDENT (LDS-limited, at most two waves per SIMD), every wave walks its items: the
+    // hardware's own distribution of more workgroups than fit left CUs a whole pass behind the others.  The contiguous slot layout
+    // is the faster one (one address computation less per operand); the split layout needs 3/4 of the LDS, so more waves fit a CU:
+    // taken when the launch has more waves than the contiguous layout holds resident AND the split layout holds more.
+    size_t need = (n + BN254_CVM_GROUPS - 1) / BN254_CVM_GROUPS;
     size_t lds = (size_t)BN254_CVM_GROUPS * p.slots * BN254_CVM_SLOT_BYTES, lds_split = (size_t)BN254_CVM_GROUPS * p.slots * BN254_CVM_SLOT_BYTES_SPLIT;
-    size_t per_cu = (160 * 1024) / lds, per_cu_split = (160 * 1024) / lds_split;
-    if (per_cu > 8) per_cu = 8;                           // (two waves per SIMD: 248 registers each)
-    if (per_cu_split > 8) per_cu_split = 8;
-    bool split = per_cu_split > per_cu && (size_t)grid > per_cu * (size_t)c.n_cu;
-    hipLaunchKernelGGL(split ? k_cvm_split : k_cvm, dim3(grid), dim3(64), split ? lds_split : lds, (hipStream_t)stream, g1, g2, f_in, out,
-                       (uint32_t)n, (uint32_t)k, (uint4*)d.cvm_blob[prog], 0u, c.status);
+    size_t per_cu = resident_waves(lds), per_cu_split = resident_waves(lds_split);
+    bool split = per_cu_split > per_cu && need > per_cu * (size_t)c.n_cu;
+    size_t cap = (split ? per_cu_split : per_cu) * (size_t)c.n_cu;
+    hipLaunchKernelGGL(split ? k_cvm_split : k_cvm, dim3((uint32_t)(need < cap ? need : cap)), dim3(64), split ? lds_split : lds, (hipStream_t)stream,
+                       g1, g2, f_in, out, (uint32_t)n, (uint32_t)k, (uint4*)d.cvm_blob[prog], 0u, c.status);
     HIPCHK(hipGetLastError());
     return BN254_OK;
 }

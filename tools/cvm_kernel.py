@@ -53,6 +53,8 @@ V_ELEM, V_DESC = 246, 247
 S_BLOB, S_ROWS, S_NROUNDS, S_KIND, S_NCONST, S_NSLOTS, S_TMP = "s[48:49]", "s[50:51]", 52, 53, 65, 66, 67
 S_CONSTS, S_G1, S_G2, S_OUT, S_N, S_NSTRIDE, S_STATUS = "s[68:69]", "s[70:71]", "s[72:73]", "s[74:75]", 76, 77, "s[78:79]"
 S_FIN, S_INS, S_K, S_PITCH_IN, S_NCHUNK = "s[90:91]", "s[92:93]", 94, 95, 96
+S_ITEM0, S_GSTEP, S_NCHUNK0 = 97, 98, 99      # first item of the wave's current pass, items per pass of the whole grid, input chunks per item
+V_GRP = 208
 S_H = 80               # s80..s87: header words / scratch
 S_CNT = 88
 S_SAVE = "s[60:61]"
@@ -182,15 +184,10 @@ class VMKernel:
         e.salu(f"s_lshl_b32 s{S_NSTRIDE}, s{S_N}, 3")               # bytes between the planes of the output (n items)
         e.salu(f"s_mul_i32 s{S_PITCH_IN}, s{S_NSTRIDE}, s{S_K}")      # ... of the inputs (n k elements: pair j of item g is element g k + j)
         e.emit(f"v_and_b32_e32 v{V_ROLE}, {self.nr - 1}, %9", vw=[V_ROLE])
-        e.emit(f"v_lshrrev_b32_e32 v{V_T0}, {self.lg}, %9", vw=[V_T0])                     # group of the lane
-        e.salu(f"s_lshl_b32 s{S_TMP}, s{S_TMP}, {6 - self.lg}")
-        e.emit(f"v_add_u32_e32 v{V_ITEM8}, s{S_TMP}, v{V_T0}", vw=[V_ITEM8])                # item = block * (items per wave) + group
-        e.emit(f"v_cmp_gt_u32_e32 vcc, s{S_N}, v{V_ITEM8}", w=["vcc"])
-        e.emit(f"v_cndmask_b32_e64 v{V_VALID}, 0, 1, vcc", r=["vcc"], vw=[V_VALID])
-        e.salu(f"s_sub_u32 s{S_TMP}, s{S_N}, 1")
-        e.emit(f"v_min_u32_e32 v{V_ITEM8}, s{S_TMP}, v{V_ITEM8}", vw=[V_ITEM8])             # lanes past the end redo the last item (they never store)
-        e.emit(f"v_mul_lo_u32 v{V_ELEM}, v{V_ITEM8}, s{S_K}", vw=[V_ELEM])                  # first input element of the item
-        e.emit(f"v_lshlrev_b32_e32 v{V_ITEM8}, 3, v{V_ITEM8}", vw=[V_ITEM8])
+        e.emit(f"v_lshrrev_b32_e32 v{V_GRP}, {self.lg}, %9", vw=[V_GRP])                   # group of the lane
+        e.emit(f"v_mov_b32_e32 v{V_T0}, v{V_GRP}", vw=[V_T0])
+        e.salu(f"s_lshl_b32 s{S_ITEM0}, s{S_TMP}, {6 - self.lg}")                          # the wave walks items block * G + group, + grid * G, ...
+        e.salu(f"s_lshl_b32 s{S_GSTEP}, %11, {6 - self.lg}")
         e.raw("s_waitcnt lgkmcnt(0)")
         if self.split:
             e.salu(f"s_lshl_b32 s{S_TMP}, s{S_NSLOTS}, 5")                                  # a group's 32-byte slots
@@ -202,8 +199,7 @@ class VMKernel:
         else:
             e.salu(f"s_mul_i32 s{S_TMP}, s{S_NSLOTS}, {SLOT_BYTES}")
             e.emit(f"v_mul_lo_u32 v{V_LBASE}, v{V_T0}, s{S_TMP}", vw=[V_LBASE])
-        e.emit(f"v_lshlrev_b32_e32 v{V_ROWOFF}, 5, v{V_ROLE}", vw=[V_ROWOFF])
-        e.emit(f"v_mov_b32_e32 v{V_FLAG}, 0", vw=[V_FLAG])
+        e.salu(f"s_mov_b32 s{S_NCHUNK0}, s{S_NCHUNK}")
         for r in (OUT0 + 9, NEG0 + 9):
             e.emit(f"v_mov_b32_e32 v{r}, 0", vw=[r])
         e.salu(f"s_add_u32 s50, s48, s{S_H + 1}")            # rows
@@ -230,6 +226,18 @@ class VMKernel:
         e.salu(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
         e.salu(f"s_cmp_lg_u32 s{S_CNT}, 0")
         e.salu("s_cbranch_scc1 LC_const_%=")
+        # ---- one item per group and pass (the grid is sized to what is resident: a wave walks its items)
+        e.label("LC_item_%=")
+        e.emit(f"v_add_u32_e32 v{V_ITEM8}, s{S_ITEM0}, v{V_GRP}", vw=[V_ITEM8])
+        e.emit(f"v_cmp_gt_u32_e32 vcc, s{S_N}, v{V_ITEM8}", w=["vcc"])
+        e.emit(f"v_cndmask_b32_e64 v{V_VALID}, 0, 1, vcc", r=["vcc"], vw=[V_VALID])
+        e.salu(f"s_sub_u32 s{S_TMP}, s{S_N}, 1")
+        e.emit(f"v_min_u32_e32 v{V_ITEM8}, s{S_TMP}, v{V_ITEM8}", vw=[V_ITEM8])             # lanes past the end redo the last item (they never store)
+        e.emit(f"v_mul_lo_u32 v{V_ELEM}, v{V_ITEM8}, s{S_K}", vw=[V_ELEM])                  # first input element of the item
+        e.emit(f"v_lshlrev_b32_e32 v{V_ITEM8}, 3, v{V_ITEM8}", vw=[V_ITEM8])
+        e.emit(f"v_lshlrev_b32_e32 v{V_ROWOFF}, 5, v{V_ROLE}", vw=[V_ROWOFF])
+        e.emit(f"v_mov_b32_e32 v{V_FLAG}, 0", vw=[V_FLAG])
+        e.salu(f"s_mov_b32 s{S_NCHUNK}, s{S_NCHUNK0}")
         # ---- inputs: sixteen descriptors per chunk, one per lane: slot | Fq number << 16 | array << 20 | pair << 22.  The lane reads the
         # four words of that Fq from its array (the section of another array is skipped under EXEC: its pointer may be null), converts,
         # stores to the slot (padding descriptors: array 3, the trash slot).
@@ -446,6 +454,9 @@ class VMKernel:
         e.emit(f"global_store_dword v{V_T1}, v{V_T0}, {S_STATUS}", kind="vmem")
         e.salu(f"s_mov_b64 exec, {S_SAVE}")
         e.raw("s_waitcnt vmcnt(0)")
+        e.salu(f"s_add_u32 s{S_ITEM0}, s{S_ITEM0}, s{S_GSTEP}")
+        e.salu(f"s_cmp_lt_u32 s{S_ITEM0}, s{S_N}")
+        e.salu("s_cbranch_scc1 LC_item_%=")
 
     def build(self):
         self.prologue()
