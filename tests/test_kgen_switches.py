@@ -45,7 +45,8 @@ def _run(which, env_extra):
 def test_split_miller_loop_builds_and_is_exact():
     n_split = _run("single", {"KGEN_FISSION": "1"})
     assert 3_480_000 < n_split < 3_600_000                 # the shipped kernel's work (3.52 M instructions), plus the line stores / loads
-    _run("multi", {"KGEN_FISSION": "1"})
+    # (the k-pair kernel of the same switch was exact too when the experiment was run -- profiles/r04_ab.txt; the variant is not shipped
+    # and its second simulation, 45 s, is no longer part of the suite: KGEN_FISSION=1 python tests/test_kgen_switches.py multi)
 
 
 def test_round3_baseline_switches():
