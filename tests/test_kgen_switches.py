@@ -1,8 +1,8 @@
 """Generator switches that are NOT the shipped default still build, certify and compute the right values (one lane, simulator):
 
   KGEN_FISSION=1   the split Miller loop (built, verified, measured, not adopted -- its line traffic costs more clock
-                   than its cycles save).  Kept as a reproducible experiment: one pairing of k_pairing and a k = 2 group of k_mpairing against
-                   the golden fixtures, with the call sequence the bound certification walked.
+                   than its cycles save).  Kept as a reproducible experiment: one pairing of k_pairing against the golden fixtures, with
+                   the call sequence the bound certification walked (a k = 2 group of k_mpairing: `_run("multi", ...)` by hand).
   all round-4 switches off: the generator still emits round 3's kernels (the A/B baseline `lib_base.so` of profiles/r04_ab.txt).
 The switches are read at import time, so each case runs in a fresh interpreter."""
 import os
@@ -46,7 +46,7 @@ def test_split_miller_loop_builds_and_is_exact():
     n_split = _run("single", {"KGEN_FISSION": "1"})
     assert 3_480_000 < n_split < 3_600_000                 # the shipped kernel's work (3.52 M instructions), plus the line stores / loads
     # (the k-pair kernel of the same switch was exact too when the experiment was run -- profiles/r04_ab.txt; the variant is not shipped
-    # and its second simulation, 45 s, is no longer part of the suite: KGEN_FISSION=1 python tests/test_kgen_switches.py multi)
+    # and its second simulation, 45 s, is no longer part of the suite: _run("multi", {"KGEN_FISSION": "1"}))
 
 
 def test_round3_baseline_switches():
