@@ -91,8 +91,9 @@ class V:
 class Graph:
     """SSA builder over Fq2 values (lowered to Fq operations, where the value bounds are tracked, by `Lowered`)."""
 
-    def __init__(self, run_ahead=None, pow_window=None, wide=False):
+    def __init__(self, run_ahead=None, pow_window=None, wide=False, flat_sqr=None):
         self.wide = wide                  # the program is scheduled for thirty-two lanes: formulations that trade operations for depth
+        self.flat_sqr = wide if flat_sqr is None else flat_sqr     # f^2 of the Miller loop as a schoolbook square (one pair: the lanes are there)
         self.pow_window = pow_window or self.POW_X_WINDOW          # signed window of the hard part's x-powers (pow_x)
         self.vals = []
         self.consts = {}
@@ -193,6 +194,22 @@ class Graph:
     def fq12_sqr(self, f):
         """complex squaring over Fq6 (tests/sched_model.py fq12_sqr): t = A0 A1, u = (A0 + A1)(A0 + v A1);
         f^2 = (u - t - v t) + 2 t w: six three-term sums between two layers of linear combinations"""
+        if self.flat_sqr:
+            # thirty-two lanes: the schoolbook square without sums in front -- the 21 distinct products a_i a_j in fifteen sums of at
+            # most three (by weight and by wrap: c_k = lo_k + xi hi_k), ONE round of thirty operations, then the recombination:
+            # two rounds on f's chain instead of three
+            a = f
+            m = self.mul
+            X = {1: m((a[0], a[1])), 2: m((a[0], a[2])), 3: m((a[0], a[3]), (a[1], a[2])), 4: m((a[0], a[4]), (a[1], a[3])),
+                 5: m((a[0], a[5]), (a[1], a[4]), (a[2], a[3]))}
+            Y = {0: m((a[1], a[5]), (a[2], a[4])), 1: m((a[2], a[5]), (a[3], a[4])), 2: m((a[3], a[5])), 3: m((a[4], a[5]))}
+            S = [m((a[i], a[i])) for i in range(6)]
+            return [self.lin((S[0], ID), (S[3], mxi()), (Y[0], mxi(2))),
+                    self.lin((X[1], mk(2)), (Y[1], mxi(2))),
+                    self.lin((S[1], ID), (X[2], mk(2)), (S[4], mxi()), (Y[2], mxi(2))),
+                    self.lin((X[3], mk(2)), (Y[3], mxi(2))),
+                    self.lin((S[2], ID), (X[4], mk(2)), (S[5], mxi())),
+                    self.lin((X[5], mk(2)))]
         A0, A1 = (f[0], f[2], f[4]), (f[1], f[3], f[5])
         ax0 = (self.xi(A0[1]), self.xi(A0[2]))
         t = self.fq6_mul(A0, A1, ax0)
