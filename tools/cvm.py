@@ -177,6 +177,17 @@ class Graph:
 
     def fq12_mul(self, a, b, bx=None):
         """dense product: c_k = sum_i a_i B(k - i), B(j) = b_j (j >= 0) or xi b_(j+6); two chained three-term sums per coefficient"""
+        if self.wide:
+            # thirty-two lanes: the wrapped and the unwrapped part of every coefficient as sums of at most three products of their own --
+            # sixteen sums, ONE round of thirty-two operations -- and c_k = lo_k + xi hi_k in the recombination: a product round and a
+            # (five times cheaper) combination round instead of two product rounds, and no xi-multiples of b to keep
+            out = []
+            for k in range(6):
+                lo = [(a[i], b[k - i]) for i in range(k + 1)]
+                hi = [(a[i], b[k - i + 6]) for i in range(k + 1, 6)]
+                srcs = [(self.mul(*lo[j:j + 3]), ID) for j in range(0, len(lo), 3)] + [(self.mul(*hi[j:j + 3]), mxi()) for j in range(0, len(hi), 3)]
+                out.append(self.lin(*srcs))
+            return out
         if bx is None:
             bx = [None] + [self.xi(b[j]) for j in range(1, 6)]
 
@@ -189,6 +200,8 @@ class Graph:
         return out
 
     def fq12_mul_pre(self, b):
+        if self.wide:
+            return None
         return [None] + [self.xi(b[j]) for j in range(1, 6)]
 
     def fq12_sqr(self, f):
@@ -482,7 +495,7 @@ class Graph:
             vc = self.fq12_conj(v)
             vx = self.fq12_mul_pre(v)
             pre[k] = (v, vx)
-            pre[-k] = (vc, [None] + [vx[j] if j % 2 == 0 else self.neg(vx[j]) for j in range(1, 6)])     # xi conj(v)_j = +- xi v_j: the twins
+            pre[-k] = (vc, None if vx is None else [None] + [vx[j] if j % 2 == 0 else self.neg(vx[j]) for j in range(1, 6)])     # xi conj(v)_j = +- xi v_j: the twins
         res = odd[digits[top]]
         for i in range(top - 1, -1, -1):
             res = self.cyc_sqr(res)
