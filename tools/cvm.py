@@ -214,15 +214,15 @@ class Graph:
             a = f
             m = self.mul
             X = {1: m((a[0], a[1])), 2: m((a[0], a[2])), 3: m((a[0], a[3]), (a[1], a[2])), 4: m((a[0], a[4]), (a[1], a[3])),
-                 5: m((a[0], a[5]), (a[1], a[4]), (a[2], a[3]))}
-            Y = {0: m((a[1], a[5]), (a[2], a[4])), 1: m((a[2], a[5]), (a[3], a[4])), 2: m((a[3], a[5])), 3: m((a[4], a[5]))}
+                 5: m((a[0], a[5]), (a[1], a[4])), 6: m((a[2], a[3]))}          # (X5 in two: no sum of the round has more than two
+            Y = {0: m((a[1], a[5]), (a[2], a[4])), 1: m((a[2], a[5]), (a[3], a[4])), 2: m((a[3], a[5])), 3: m((a[4], a[5]))}   # products -- a four-product round)
             S = [m((a[i], a[i])) for i in range(6)]
             return [self.lin((S[0], ID), (S[3], mxi()), (Y[0], mxi(2))),
                     self.lin((X[1], mk(2)), (Y[1], mxi(2))),
                     self.lin((S[1], ID), (X[2], mk(2)), (S[4], mxi()), (Y[2], mxi(2))),
                     self.lin((X[3], mk(2)), (Y[3], mxi(2))),
                     self.lin((S[2], ID), (X[4], mk(2)), (S[5], mxi())),
-                    self.lin((X[5], mk(2)))]
+                    self.lin((X[5], mk(2)), (X[6], mk(2)))]
         A0, A1 = (f[0], f[2], f[4]), (f[1], f[3], f[5])
         ax0 = (self.xi(A0[1]), self.xi(A0[2]))
         t = self.fq6_mul(A0, A1, ax0)
