@@ -98,9 +98,12 @@ int bn254_reserve(int device, void* stream, size_t n, size_t k);
  * pairs, x1.5 four pairs, x0.5 the exact multi-pair Miller values); 0 turns it off.  Process-wide; default 16384. */
 void bn254_set_latency_threshold(size_t n);
 size_t bn254_get_latency_threshold(void);
-/* The lane-cooperative programs exist for sixteen lanes per item (four items per wave; every function) and for thirty-two (two items
- * per wave: fewer, fuller rounds -- pairing 0.70 ms instead of 1.01 -- for twice the lanes).  0 (default): thirty-two while the launch is at most one wave per SIMD (2048 items on MI355X), sixteen
- * beyond; 16 / 32: that family whatever the size (measurements, tests). */
+/* The lane-cooperative programs exist for sixteen lanes per item (four items per wave; every function), for thirty-two (two items per
+ * wave: fewer, fuller rounds -- pairing 0.70 ms instead of 1.01 -- for twice the lanes) and, for the products of three and four pairings,
+ * for sixty-four (one item per wave: the lines of a step are then multiplied with each other off the accumulator's chain).
+ * 0 (default): sixty-four / thirty-two while the launch is at most one wave per SIMD (1024 / 2048 items on MI355X), sixteen beyond;
+ * 16 / 32 / 64: that family whatever the size (measurements, tests; a function without a program of the family takes the next
+ * smaller one). */
 void bn254_set_latency_lanes(int lanes);
 int bn254_get_latency_lanes(void);
 /* Scratch and the status word are kept per (device, stream), so calls on different streams are independent;

@@ -452,7 +452,7 @@ def get_latency_threshold():
 
 
 def set_latency_lanes(lanes):
-    """0: the lane-cooperative program family by launch size (thirty-two lanes per item for the smallest launches); 16 / 32: fixed."""
+    """0: the lane-cooperative program family by launch size (sixty-four / thirty-two lanes per item for the smallest launches); 16 / 32 / 64: fixed."""
     load_library().bn254_set_latency_lanes(lanes)
 
 

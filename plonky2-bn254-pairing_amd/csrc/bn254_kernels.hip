@@ -87,6 +87,7 @@ BN254_ASM_KERNEL(k_generate, BN254_ASM_GENERATE)    // synthetic subgroup points
 BN254_CVM_KERNEL(k_cvm, BN254_ASM_CVM)               // LDS slots of 48 contiguous bytes: the fastest round (launches of up to three waves per CU)
 BN254_CVM_KERNEL(k_cvm_split, BN254_ASM_CVM_SPLIT)   // 36 bytes per slot: four waves of the pairing program per CU (larger launches)
 BN254_CVM_KERNEL(k_cvm_wide, BN254_ASM_CVM_WIDE)     // thirty-two lanes per item, two items per wave (launches of at most one wave per SIMD)
+BN254_CVM_KERNEL(k_cvm_full, BN254_ASM_CVM_FULL)     // sixty-four lanes per item: products of three and four pairings, at most one wave per SIMD
 
 // verdict[i] = 1 iff Fq12 element i equals MyFq12::one (coeffs[0] = R mod p in ark's Montgomery limbs, the rest 0):
 // the check pattern of final_exp_native.rs:245-263 (a Groth16-style product of pairings == 1), one byte per group.
@@ -205,7 +206,7 @@ struct DeviceCtx {
     int n_cu = 0;
     std::mutex table_mu;       // the generator table upload (138 KB, blocking) has its own lock
     int32_t* gen_table = nullptr;
-    uint32_t* cvm_blob[18] = {};    // the latency path's round programs (0.3 - 1.4 MB each, uploaded on first use, same lock)
+    uint32_t* cvm_blob[22] = {};    // the latency path's round programs (0.3 - 1.4 MB each, uploaded on first use, same lock)
     bool cvm_init = false;
     std::map<hipStream_t, std::shared_ptr<StreamCtx>> streams;   // shared: a call keeps its context alive across a concurrent release
     std::mutex pipe_mu;        // one host-pointer pipeline at a time per device (its two workers fill the chip anyway)
@@ -339,16 +340,18 @@ struct CvmProgram {
     uint32_t slots;
     uint32_t per_mille;       // share of the threshold this program takes batches up to (its own crossover against the throughput kernel)
     int wide;                 // index of the same function's thirty-two-lane program, or -1
+    int full;                 // ... of its sixty-four-lane program, or -1
 };
-#define CVM_PROGRAM(NAME, PM, WIDE) {BN254_CVM_##NAME##_B64, BN254_CVM_##NAME##_Z_BYTES, BN254_CVM_##NAME##_BYTES, BN254_CVM_##NAME##_SLOTS, PM, WIDE}
-constexpr int CVM_N_PROGRAMS = 18;
+#define CVM_PROGRAM(NAME, PM, WIDE, FULL) {BN254_CVM_##NAME##_B64, BN254_CVM_##NAME##_Z_BYTES, BN254_CVM_##NAME##_BYTES, BN254_CVM_##NAME##_SLOTS, PM, WIDE, FULL}
+constexpr int CVM_N_PROGRAMS = 22;
 const CvmProgram CVM_PROGRAMS[CVM_N_PROGRAMS] = {
-    CVM_PROGRAM(PAIRING, 1000, 9), CVM_PROGRAM(MILLER, BN254_CVM_PM_MILLER, 10), CVM_PROGRAM(FEXP, BN254_CVM_PM_FEXP, 11),
-    CVM_PROGRAM(MULTI2, 1000, 12), CVM_PROGRAM(MULTI3, 1250, 13), CVM_PROGRAM(MULTI4, 1500, 14),
-    CVM_PROGRAM(MMILLER2, BN254_CVM_PM_MMILLER, 15), CVM_PROGRAM(MMILLER3, BN254_CVM_PM_MMILLER, 16), CVM_PROGRAM(MMILLER4, BN254_CVM_PM_MMILLER, 17),
-    CVM_PROGRAM(PAIRING_W, 0, -1), CVM_PROGRAM(MILLER_W, 0, -1), CVM_PROGRAM(FEXP_W, 0, -1),
-    CVM_PROGRAM(MULTI2_W, 0, -1), CVM_PROGRAM(MULTI3_W, 0, -1), CVM_PROGRAM(MULTI4_W, 0, -1),
-    CVM_PROGRAM(MMILLER2_W, 0, -1), CVM_PROGRAM(MMILLER3_W, 0, -1), CVM_PROGRAM(MMILLER4_W, 0, -1)};
+    CVM_PROGRAM(PAIRING, 1000, 9, -1), CVM_PROGRAM(MILLER, BN254_CVM_PM_MILLER, 10, -1), CVM_PROGRAM(FEXP, BN254_CVM_PM_FEXP, 11, -1),
+    CVM_PROGRAM(MULTI2, 1000, 12, -1), CVM_PROGRAM(MULTI3, 1250, 13, 18), CVM_PROGRAM(MULTI4, 1500, 14, 19),
+    CVM_PROGRAM(MMILLER2, BN254_CVM_PM_MMILLER, 15, -1), CVM_PROGRAM(MMILLER3, BN254_CVM_PM_MMILLER, 16, 20), CVM_PROGRAM(MMILLER4, BN254_CVM_PM_MMILLER, 17, 21),
+    CVM_PROGRAM(PAIRING_W, 0, -1, -1), CVM_PROGRAM(MILLER_W, 0, -1, -1), CVM_PROGRAM(FEXP_W, 0, -1, -1),
+    CVM_PROGRAM(MULTI2_W, 0, -1, -1), CVM_PROGRAM(MULTI3_W, 0, -1, -1), CVM_PROGRAM(MULTI4_W, 0, -1, -1),
+    CVM_PROGRAM(MMILLER2_W, 0, -1, -1), CVM_PROGRAM(MMILLER3_W, 0, -1, -1), CVM_PROGRAM(MMILLER4_W, 0, -1, -1),
+    CVM_PROGRAM(MULTI3_X, 0, -1, -1), CVM_PROGRAM(MULTI4_X, 0, -1, -1), CVM_PROGRAM(MMILLER3_X, 0, -1, -1), CVM_PROGRAM(MMILLER4_X, 0, -1, -1)};
 
 // which program serves (Miller loop?, final exponentiation?, k pairs); -1: none
 template <bool M, bool F>
@@ -368,6 +371,7 @@ int cvm_upload(int device, int prog) {
         HIPCHK(hipFuncSetAttribute((const void*)k_cvm, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)k_cvm_split, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)k_cvm_wide, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)k_cvm_full, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         d.cvm_init = true;
     }
     if (!d.cvm_blob[prog]) {
@@ -407,7 +411,22 @@ int launch_cvm(int prog, const uint64_t* g1, const uint64_t* g2, const uint64_t*
     // The smallest launches -- at most one wave per SIMD with two items per wave -- take the function's thirty-two-lane program where
     // there is one: fewer, fuller rounds (pairing: 979 instead of 1 326).
     int lanes = g_latency_lanes.load();
-    if (CVM_PROGRAMS[prog].wide >= 0 && (lanes == 32 || (lanes == 0 && n <= (size_t)2 * 4 * (size_t)c.n_cu))) {
+    // ... and products of three and four pairings, while the launch is at most one wave per SIMD with ONE item per wave, the sixty-four-lane
+    // program: the lines of a step multiplied with each other off f's chain (four-pair product: 1 008 rounds instead of 1 297)
+    if (CVM_PROGRAMS[prog].full >= 0) {
+        int x = CVM_PROGRAMS[prog].full;
+        const CvmProgram& px = CVM_PROGRAMS[x];
+        size_t lds_x = (size_t)px.slots * BN254_CVM_SLOT_BYTES, cap = resident_waves(lds_x) * (size_t)c.n_cu;
+        size_t once = cap < (size_t)4 * (size_t)c.n_cu ? cap : (size_t)4 * (size_t)c.n_cu;       // one pass, one wave per SIMD at most
+        if (lanes == 64 || (lanes == 0 && n <= once)) {
+            if ((rc = cvm_upload(device, x))) return rc;
+            hipLaunchKernelGGL(k_cvm_full, dim3((uint32_t)(n < cap ? n : cap)), dim3(64), lds_x, (hipStream_t)stream, g1, g2, f_in, out, (uint32_t)n,
+                               (uint32_t)k, (uint4*)d.cvm_blob[x], 0u, c.status);
+            HIPCHK(hipGetLastError());
+            return BN254_OK;
+        }
+    }
+    if (CVM_PROGRAMS[prog].wide >= 0 && (lanes == 32 || lanes == 64 || (lanes == 0 && n <= (size_t)2 * 4 * (size_t)c.n_cu))) {
         int w = CVM_PROGRAMS[prog].wide;
         if ((rc = cvm_upload(device, w))) return rc;
         const CvmProgram& pw = CVM_PROGRAMS[w];
@@ -687,7 +706,7 @@ size_t bn254_scratch_bytes(size_t n, size_t k) {
     return BN254_SCRATCH_WG_CONTIGUOUS ? scratch_pitch(kk, grid) * grid : scratch_pitch(kk, grid) * scratch_slots(kk);
 }
 
-void bn254_set_latency_lanes(int lanes) { g_latency_lanes.store(lanes == 16 || lanes == 32 ? lanes : 0); }
+void bn254_set_latency_lanes(int lanes) { g_latency_lanes.store(lanes == 16 || lanes == 32 || lanes == 64 ? lanes : 0); }
 int bn254_get_latency_lanes(void) { return g_latency_lanes.load(); }
 void bn254_set_latency_threshold(size_t n) { g_latency_threshold.store(n); }
 size_t bn254_get_latency_threshold(void) { return g_latency_threshold.load(); }

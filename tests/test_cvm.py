@@ -103,7 +103,7 @@ def _sim(pr, want_flat, layout="aos48"):
     return ms, rounds
 
 
-@pytest.mark.parametrize("layout,nr", [("aos48", 16), ("split36", 16), ("aos48", 32)])
+@pytest.mark.parametrize("layout,nr", [("aos48", 16), ("split36", 16), ("aos48", 32), ("aos48", 64)])
 def test_interpreter_kernel_every_round_kind_on_the_simulator(layout, nr):
     low = cvm.Lowered(_mini())
     pr = cvm.Program(low, nr=nr)
@@ -207,6 +207,16 @@ def test_wide_programs_equal_the_reference_functions():
     low = cvm.Lowered(cvm.build_multi(4, True, pow_window="fixed", wide=True))
     pr = cvm.Program(low, nr=32)
     assert pr.run(flat) == [c for x in R.fq12_to_fp2s(m) for c in x]
+    # sixty-four lanes: the lines of a step multiplied with each other first, one dense product per step for f (three and four pairs,
+    # the product of pairings and the exact Miller value)
+    for k in (3, 4):
+        mm = R.multi_miller_loop_native([(P[j], Q[j]) for j in range(k)])
+        for fe in (True, False):
+            low = cvm.Lowered(cvm.build_multi(k, fe, pow_window="fixed", wide=True, line_tree=True))
+            pr = cvm.Program(low, nr=64)
+            want_k = [c for x in R.fq12_to_fp2s(R.final_exp_native(mm) if fe else mm) for c in x]
+            assert low.evaluate(flat[:6 * k]) == want_k and pr.run(flat[:6 * k]) == want_k, (k, fe)
+            assert max(v.bound for v in low.fv) <= cvm.Lowered.V_MAX
 
 
 def test_whole_pairing_on_the_simulator():

@@ -11,10 +11,10 @@ pytestmark = pytest.mark.gpu
 HX = lambda xs: [int(x, 16) for x in xs]
 
 
-@pytest.fixture(params=[16, 32], ids=["16-lanes", "32-lanes"])
+@pytest.fixture(params=[16, 32, 64], ids=["16-lanes", "32-lanes", "64-lanes"])
 def pk(request):
     """the package with the lane-cooperative program family pinned (sixteen / thirty-two lanes per item; functions without a
-    thirty-two-lane program take their sixteen-lane one); threshold and family are restored afterwards"""
+    program of the family take the next smaller one); threshold and family are restored afterwards"""
     p = H.pkg()
     old = p.get_latency_threshold()
     p.set_latency_lanes(request.param)
@@ -28,7 +28,7 @@ def test_threshold_is_settable(pk):
     assert pk.get_latency_threshold() == 12345
     pk.set_latency_threshold(0)
     assert pk.get_latency_threshold() == 0
-    for lanes, want in ((16, 16), (32, 32), (0, 0), (7, 0)):
+    for lanes, want in ((16, 16), (32, 32), (64, 64), (0, 0), (7, 0)):
         pk.set_latency_lanes(lanes)
         assert pk.get_latency_lanes() == want
 

@@ -91,7 +91,8 @@ class V:
 class Graph:
     """SSA builder over Fq2 values (lowered to Fq operations, where the value bounds are tracked, by `Lowered`)."""
 
-    def __init__(self, run_ahead=None, pow_window=None, wide=False, flat_sqr=None):
+    def __init__(self, run_ahead=None, pow_window=None, wide=False, flat_sqr=None, line_tree=False):
+        self.line_tree = line_tree        # several pairs: the lines of a step are multiplied with each other first (a tree, off f's chain), f takes ONE dense product
         self.wide = wide                  # the program is scheduled for thirty-two lanes: formulations that trade operations for depth
         self.flat_sqr = wide if flat_sqr is None else flat_sqr     # f^2 of the Miller loop as a schoolbook square (one pair: the lanes are there)
         self.pow_window = pow_window or self.POW_X_WINDOW          # signed window of the hard part's x-powers (pow_x)
@@ -197,6 +198,17 @@ class Graph:
         for k in range(6):
             t = self.mul(*[(a[i], B(k, i)) for i in range(3)])
             out.append(self.mul(*[(a[i], B(k, i)) for i in range(3, 6)], add=t))
+        return out
+
+    def fq12_mul_gen(self, a, b):
+        """product of two Fq12 elements whose zero coefficients are None (lines, products of lines): the wide formulation of fq12_mul
+        over the non-zero terms only"""
+        out = []
+        for k in range(6):
+            lo = [(a[i], b[k - i]) for i in range(k + 1) if a[i] is not None and b[k - i] is not None]
+            hi = [(a[i], b[k - i + 6]) for i in range(k + 1, 6) if a[i] is not None and b[k - i + 6] is not None]
+            srcs = [(self.mul(*lo[j:j + 3]), ID) for j in range(0, len(lo), 3)] + [(self.mul(*hi[j:j + 3]), mxi()) for j in range(0, len(hi), 3)]
+            out.append(self.lin(*srcs) if srcs else None)
         return out
 
     def fq12_mul_pre(self, b):
@@ -398,13 +410,37 @@ class Graph:
         f = None
         hist = []                                     # f at the start of every iteration (run_ahead)
 
+        pend = []                                     # line_tree: the lines of the current step that f has not taken yet
+
+        def take(L6):
+            nonlocal f
+            if self.line_tree and f is not None:
+                pend.append(L6)
+            elif f is None:
+                f = [c if c is not None else zero for c in L6]
+            elif L6[0] is not None:
+                f = self.mul_by_034(f, (L6[0], L6[3], L6[4]))
+            else:
+                f = self.mul_by_235(f, (L6[2], L6[3], L6[5]))
+
+        def flush():
+            nonlocal f
+            while len(pend) > 1:                      # pairwise products of the pending lines, level by level
+                nxt = [self.fq12_mul_gen(pend[i], pend[i + 1]) for i in range(0, len(pend) - 1, 2)]
+                if len(pend) % 2:
+                    nxt.append(pend[-1])
+                pend[:] = nxt
+            if pend:
+                T = pend.pop()
+                f = self.fq12_mul_gen(f, T)
+
         def dbl(j):
             nonlocal f, scale
             (px, py), _ = pairs[j]
             lam = Rs[j][2]
             ra = self.run_ahead
             Rs[j], L = self.dbl_step(Rs[j], px, py, after=hist[-ra][0] if ra is not None and len(hist) >= ra else None)
-            f = [L[0], zero, zero, L[1], L[2], zero] if f is None else self.mul_by_034(f, L)
+            take([L[0], None, None, L[1], L[2], None])
             if exact and lam is not one:
                 # the factor is lam = Z^2 and the scale is squared right after the iteration's doublings: (scale Z)^2 = scale^2 lam --
                 # two dependent products per doubling instead of three, as many as f's own chain has rounds for
@@ -415,18 +451,20 @@ class Graph:
             (px, py), _ = pairs[j]
             lam = Rs[j][2]
             Rs[j], L = self.add_step(Rs[j], Qs, px, py, nQy=nQsy)
-            f = self.mul_by_235(f, L)
+            take([None, None, L[0], L[1], None, L[2]])
             if exact:
                 scale = lam if scale is None else self.mul((scale, lam))
 
         for j in range(len(pairs)):
             dbl(j)
+        flush()
         for i in range(63, -1, -1):
             if i != 63:
                 hist.append(f)
                 f = self.fq12_sqr(f)
                 for j in range(len(pairs)):
                     dbl(j)
+                flush()
                 if exact and scale is not None:           # scale <- (scale * prod Z_j)^2 = scale^2 * prod lam_j
                     scale = self.mul((scale, scale))
             if enc[i] != 0:
@@ -435,12 +473,14 @@ class Graph:
                         add(j, (Q[0], Q[1]), nQy[j])
                     else:
                         add(j, (Q[0], nQy[j]), Q[1])
+                flush()
         c2, c3 = end_constants()
         for j, (_, Q) in enumerate(pairs):
             Q1 = (self.mul((self.conj(Q[0]), self.const(c2))), self.mul((self.conj(Q[1]), self.const(c3))))
             nQ2 = (self.mul((self.conj(Q1[0]), self.const(c2))), self.mul((self.lin((Q1[1], NCONJ)), self.const(c3))))
             add(j, Q1, None)
             add(j, nQ2, None)
+        flush()
         if exact:
             si = self.fq2_inv(scale)
             f = [self.mul((c, si)) for c in f]

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """cvm_kernel.py -- the interpreter kernel of the lane-cooperative pairing (tools/cvm.py has the design and the program).
 
-One wave per workgroup; NR = 16 lanes per item and four items per wave, or -- the builds for the smallest launches -- NR = 32 and two.  Every lane executes the same instruction stream;
+One wave per workgroup; NR = 16 lanes per item and four items per wave, or -- the builds for the smallest launches -- NR = 32 and two,
+NR = 64 and one (the products of three and four pairings).  Every lane executes the same instruction stream;
 what differs per lane is its table row (which LDS slots it reads and writes).  Per round:
 
     wait for the row / kind prefetched during the previous round, start the loads of the next ones
@@ -70,7 +71,7 @@ V_LTOP, V_DST_T, V_TWIN_T, V_T1_T = 204, 205, 206, 207          # split36: base 
 
 class VMKernel:
     def __init__(self, layout="aos48", nr=NR):
-        assert layout in LAYOUTS and nr in (16, 32)
+        assert layout in LAYOUTS and nr in (16, 32, 64)
         self.nr = nr
         self.lg = nr.bit_length() - 1             # log2(lanes per item)
         self.groups = 64 // nr
@@ -477,7 +478,7 @@ def make_blob(enc):
     """the program blob as a list of dwords: header, input descriptors, rows (one END row more than rounds, + the look-ahead's reach),
     constants (internal form: nine balanced 29-bit limbs of c R' mod p, + a pad dword)"""
     NR = enc["nr"]
-    assert NR in (16, 32)
+    assert NR in (16, 32, 64)
     n_rounds = len(enc["rows"])
     trash = enc["n_slots"] - 1
     ins = [slot | fq << 16 | arr << 20 | pair << 22 for slot, arr, fq, pair in enc["inputs"]]
