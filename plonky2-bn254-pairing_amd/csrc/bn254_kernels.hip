@@ -901,7 +901,7 @@ int bn254_reserve(int device, void* stream, size_t n, size_t k) {
         sc->naf_ring.push_back(ns);
     }
     if (!sc->status_host && hipHostMalloc((void**)&sc->status_host, sizeof(int), hipHostMallocDefault) != hipSuccess) return BN254_ERR_ALLOC;
-    if (g_latency_threshold.load())                    // the latency path's round programs (6 MB in all): small calls upload nothing later
+    if (g_latency_threshold.load())                    // the latency path's round programs (20 MB in all): small calls upload nothing later
         for (int prog = 0; prog < CVM_N_PROGRAMS; prog++)
             if ((rc = cvm_upload(device, prog))) return rc;
     return BN254_OK;
