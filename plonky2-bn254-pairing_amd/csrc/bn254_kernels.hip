@@ -206,7 +206,7 @@ struct DeviceCtx {
     int n_cu = 0;
     std::mutex table_mu;       // the generator table upload (138 KB, blocking) has its own lock
     int32_t* gen_table = nullptr;
-    uint32_t* cvm_blob[24] = {};    // the latency path's round programs (0.3 - 1.4 MB each, uploaded on first use, same lock)
+    uint32_t* cvm_blob[26] = {};    // the latency path's round programs (0.3 - 1.4 MB each, uploaded on first use, same lock)
     bool cvm_init = false;
     std::map<hipStream_t, std::shared_ptr<StreamCtx>> streams;   // shared: a call keeps its context alive across a concurrent release
     std::mutex pipe_mu;        // one host-pointer pipeline at a time per device (its two workers fill the chip anyway)
@@ -343,15 +343,16 @@ struct CvmProgram {
     int full;                 // ... of its sixty-four-lane program, or -1
 };
 #define CVM_PROGRAM(NAME, PM, WIDE, FULL) {BN254_CVM_##NAME##_B64, BN254_CVM_##NAME##_Z_BYTES, BN254_CVM_##NAME##_BYTES, BN254_CVM_##NAME##_SLOTS, PM, WIDE, FULL}
-constexpr int CVM_N_PROGRAMS = 24;
+constexpr int CVM_N_PROGRAMS = 26;
 const CvmProgram CVM_PROGRAMS[CVM_N_PROGRAMS] = {
-    CVM_PROGRAM(PAIRING, 1000, 9, 18), CVM_PROGRAM(MILLER, BN254_CVM_PM_MILLER, 10, -1), CVM_PROGRAM(FEXP, BN254_CVM_PM_FEXP, 11, -1),
+    CVM_PROGRAM(PAIRING, 1000, 9, 18), CVM_PROGRAM(MILLER, BN254_CVM_PM_MILLER, 10, 22), CVM_PROGRAM(FEXP, BN254_CVM_PM_FEXP, 11, -1),
     CVM_PROGRAM(MULTI2, 1000, 12, 19), CVM_PROGRAM(MULTI3, 1250, 13, 20), CVM_PROGRAM(MULTI4, 1500, 14, 21),
-    CVM_PROGRAM(MMILLER2, BN254_CVM_PM_MMILLER, 15, -1), CVM_PROGRAM(MMILLER3, BN254_CVM_PM_MMILLER, 16, 22), CVM_PROGRAM(MMILLER4, BN254_CVM_PM_MMILLER, 17, 23),
+    CVM_PROGRAM(MMILLER2, BN254_CVM_PM_MMILLER, 15, 23), CVM_PROGRAM(MMILLER3, BN254_CVM_PM_MMILLER, 16, 24), CVM_PROGRAM(MMILLER4, BN254_CVM_PM_MMILLER, 17, 25),
     CVM_PROGRAM(PAIRING_W, 0, -1, -1), CVM_PROGRAM(MILLER_W, 0, -1, -1), CVM_PROGRAM(FEXP_W, 0, -1, -1),
     CVM_PROGRAM(MULTI2_W, 0, -1, -1), CVM_PROGRAM(MULTI3_W, 0, -1, -1), CVM_PROGRAM(MULTI4_W, 0, -1, -1),
     CVM_PROGRAM(MMILLER2_W, 0, -1, -1), CVM_PROGRAM(MMILLER3_W, 0, -1, -1), CVM_PROGRAM(MMILLER4_W, 0, -1, -1),
-    CVM_PROGRAM(PAIRING_X, 0, -1, -1), CVM_PROGRAM(MULTI2_X, 0, -1, -1), CVM_PROGRAM(MULTI3_X, 0, -1, -1), CVM_PROGRAM(MULTI4_X, 0, -1, -1), CVM_PROGRAM(MMILLER3_X, 0, -1, -1), CVM_PROGRAM(MMILLER4_X, 0, -1, -1)};
+    CVM_PROGRAM(PAIRING_X, 0, -1, -1), CVM_PROGRAM(MULTI2_X, 0, -1, -1), CVM_PROGRAM(MULTI3_X, 0, -1, -1), CVM_PROGRAM(MULTI4_X, 0, -1, -1),
+    CVM_PROGRAM(MILLER_X, 0, -1, -1), CVM_PROGRAM(MMILLER2_X, 0, -1, -1), CVM_PROGRAM(MMILLER3_X, 0, -1, -1), CVM_PROGRAM(MMILLER4_X, 0, -1, -1)};
 
 // which program serves (Miller loop?, final exponentiation?, k pairs); -1: none
 template <bool M, bool F>
@@ -901,7 +902,7 @@ int bn254_reserve(int device, void* stream, size_t n, size_t k) {
         sc->naf_ring.push_back(ns);
     }
     if (!sc->status_host && hipHostMalloc((void**)&sc->status_host, sizeof(int), hipHostMallocDefault) != hipSuccess) return BN254_ERR_ALLOC;
-    if (g_latency_threshold.load())                    // the latency path's round programs (20 MB in all): small calls upload nothing later
+    if (g_latency_threshold.load())                    // the latency path's round programs (25 MB in all): small calls upload nothing later
         for (int prog = 0; prog < CVM_N_PROGRAMS; prog++)
             if ((rc = cvm_upload(device, prog))) return rc;
     return BN254_OK;
