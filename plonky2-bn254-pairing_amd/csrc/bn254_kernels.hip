@@ -29,7 +29,7 @@ constexpr size_t LDS_BYTES = BN254_LDS_BYTES;           // 8 slots x 72 B x 256 
 constexpr size_t SLOT_BYTES = BN254_SLOT_BYTES;         // one Fq2: 2 x 9 balanced 29-bit limbs
 constexpr size_t MAX_K = 64;                            // pairs per group of the multi-pairing kernels
 #ifndef BN254_LATENCY_THRESHOLD_DEFAULT
-#define BN254_CVM_PM_MILLER 800      // per mille of the threshold each program takes batches up to: its own measured crossover (profiles/r04_latency.json)
+#define BN254_CVM_PM_MILLER 1000      // per mille of the threshold each program takes batches up to: its own measured crossover (profiles/r04_latency.json)
 #define BN254_CVM_PM_FEXP 1000
 #define BN254_CVM_PM_MMILLER 500
 #define BN254_LATENCY_THRESHOLD_DEFAULT 16384           // below the measured crossover (profiles/r04_latency.json): pairing 4.45 ms against 6.45 at 16384, 8.9 against 6.5 at 32768
@@ -347,7 +347,7 @@ constexpr int CVM_N_PROGRAMS = 26;
 const CvmProgram CVM_PROGRAMS[CVM_N_PROGRAMS] = {
     CVM_PROGRAM(PAIRING, 1000, 9, 18), CVM_PROGRAM(MILLER, BN254_CVM_PM_MILLER, 10, 22), CVM_PROGRAM(FEXP, BN254_CVM_PM_FEXP, 11, -1),
     CVM_PROGRAM(MULTI2, 1000, 12, 19), CVM_PROGRAM(MULTI3, 1250, 13, 20), CVM_PROGRAM(MULTI4, 1500, 14, 21),
-    CVM_PROGRAM(MMILLER2, BN254_CVM_PM_MMILLER, 15, 23), CVM_PROGRAM(MMILLER3, BN254_CVM_PM_MMILLER, 16, 24), CVM_PROGRAM(MMILLER4, BN254_CVM_PM_MMILLER, 17, 25),
+    CVM_PROGRAM(MMILLER2, 1000, 15, 23), CVM_PROGRAM(MMILLER3, BN254_CVM_PM_MMILLER, 16, 24), CVM_PROGRAM(MMILLER4, BN254_CVM_PM_MMILLER, 17, 25),
     CVM_PROGRAM(PAIRING_W, 0, -1, -1), CVM_PROGRAM(MILLER_W, 0, -1, -1), CVM_PROGRAM(FEXP_W, 0, -1, -1),
     CVM_PROGRAM(MULTI2_W, 0, -1, -1), CVM_PROGRAM(MULTI3_W, 0, -1, -1), CVM_PROGRAM(MULTI4_W, 0, -1, -1),
     CVM_PROGRAM(MMILLER2_W, 0, -1, -1), CVM_PROGRAM(MMILLER3_W, 0, -1, -1), CVM_PROGRAM(MMILLER4_W, 0, -1, -1),

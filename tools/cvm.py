@@ -1,25 +1,30 @@
 #!/usr/bin/env python3
-"""cvm.py -- the lane-cooperative ("latency") pairing: one pairing on EIGHT lanes instead of one.
+"""cvm.py -- the lane-cooperative ("latency") path: ONE item (a pairing, a Miller loop, a final exponentiation, a product of up to four
+pairings) on sixteen, thirty-two or sixty-four lanes instead of one.
 
-The throughput kernels (tools/kgen4_prog.py) put one pairing on one lane: 3.6 M dependent instructions, 6.3 ms however few
-pairings there are.  A single signature check wants the opposite trade: this file spreads ONE pairing over a group of eight
-lanes (eight groups per wave) and runs it as a table-driven sequence of ROUNDS.  In a round every lane of the group does one
-operation of the same kind on Fq2 values that live in an LDS slot array shared by the group:
+The throughput kernels (tools/kgen4_prog.py) put one pairing on one lane: 3.55 M dependent instructions, 6.4 ms however few pairings
+there are.  A single call of one of the reference's scalar functions wants the opposite trade: this file spreads ONE item over a group
+of lanes and runs it as a table-driven sequence of ROUNDS.  In a round every lane of the group does one operation of the same family
+on Fq values that live in an LDS slot array shared by the group:
 
-    MUL   dst <- x0 y0 [+ x1 y1 + x2 y2] [+ addend]        (one dual Karatsuba column pass, L1v4.kfips)
-    LIN   dst <- sum over up to four sources of a 2x2 small-integer matrix applied to (c0, c1), reduced to (-0.51 p, 0.51 p)
-    INV   dst <- (1 / src.c0, 0)                            (Fermat chain; sets the zero-divisor flag)
+    mul   dst <- up to six products x y (+ an addend)                    one Montgomery column pass (L1v4.fips)
+    lin   dst <- up to eight small-integer multiples of sources          one reducing 64-bit chain (L1v4.lincomb)
+    inv   dst <- 1 / src                                                 Bernstein-Yang divsteps (L1v4.fq_inv_safegcd)
 
 Which slots and coefficients: a per-round, per-lane table row (32 bytes) in global memory.  The kernel is a small interpreter
-(tools/cvm_kernel.py); the PROGRAM -- the reference's pairing, miller_loop_native.rs:320-322 followed by final_exp_native.rs:209-213,
-in the schedule of tests/sched_model.py -- is data, produced here:
+(tools/cvm_kernel.py); the PROGRAMS -- the reference's pairing (src/pairing.rs:20-22), miller_loop_native / multi_miller_loop_native
+(miller_loop_native.rs:320-326) with the exact value, final_exp_native (final_exp_native.rs:209-213), in the schedule of
+tests/sched_model.py -- are data, produced here:
 
-    Graph      SSA builder over Fq2 values (the field tower, G2 steps, sparse products, cyclotomic squaring, Frobenius, inversion)
-    schedule   list scheduling of the DAG into rounds (critical path first), slot allocation by liveness
-    Program    rounds + constant pool; `run` executes it on big integers (the check of scheduling and allocation);
-               `encode` packs the table the kernel reads
+    Graph      SSA builder over Fq2 values: the field tower, G2 steps, sparse products, cyclotomic squarings, Frobenius, inversion, the
+               Miller loop over k pairs with the shared f, the final exponentiation; `wide` / `line_tree` select the formulations that
+               trade operations for depth when thirty-two / sixty-four lanes are there to take them
+    Lowered    the same as Fq operations (one lane each): real values never multiply a zero component, negations are twins written by
+               the producing lane, value bounds are checked
+    Program    list scheduling into rounds (critical path first), LDS slots by liveness; `run` executes the scheduled program on big
+               integers; `encode` packs the table the kernel reads
 
-Nothing here is on the throughput path; tools/gen_kernels.py calls `build_tables()` and writes csrc/cvm_tables_gen.h.
+Nothing here is on the throughput path; tools/gen_kernels.py builds the programs and writes csrc/cvm_asm_gen.h.
 """
 import os
 import sys
@@ -30,7 +35,6 @@ from asmcore import P_INT, BN_X, SIX_U_PLUS_2_NAF  # noqa: E402
 P = P_INT
 XI = (9, 1)
 ARR_G1, ARR_G2, ARR_F, ARR_NONE = 0, 1, 2, 3
-COST = {"m1": 950, "m3": 2000, "lin": 420, "inv": 46000}     # instructions per round (scheduling weights; tools/cvm_kernel.py prints the real ones)
 MAX_LIN_SRC = 6             # sources of an Fq2-level combination (the Fq operation it lowers to takes eight terms)
 
 
@@ -795,7 +799,7 @@ class Lowered:
 # ------------------------------------------------------------------ scheduling
 K_END, K_M2, K_M4, K_M6, K_L4, K_L8, K_INV = 0, 1, 2, 3, 4, 5, 6
 KIND_NAME = {K_M2: "m2", K_M4: "m4", K_M6: "m6", K_L4: "l4", K_L8: "l8", K_INV: "inv"}
-COST = {K_M2: 385, K_M4: 565, K_M6: 750, K_L4: 160, K_L8: 225, K_INV: 61000}       # instructions per round (tools/cvm_kernel.py prints the real ones)
+COST = {K_M2: 385, K_M4: 565, K_M6: 750, K_L4: 160, K_L8: 225, K_INV: 17600}       # instructions per round incl. the loop's own (scheduling weights; tools/cvm_kernel.py prints the handlers' sizes)
 FAMILY = {K_M2: "m", K_M4: "m", K_M6: "m", K_L4: "l", K_L8: "l", K_INV: "i"}
 
 
