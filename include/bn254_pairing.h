@@ -93,7 +93,7 @@ int bn254_reserve(int device, void* stream, size_t n, size_t k);
  * Behind the same entry points -- bn254_pairing_batch, bn254_miller_loop_batch, bn254_final_exp_batch, bn254_multi_pairing_batch
  * with k <= 4 pairs (both values of do_final_exp), bn254_multi_pairing_check_batch, their `_dev` and `_elems` forms -- sits a second,
  * lane-cooperative kernel: one item on sixteen lanes, four items per wave (pairing: 0.49 M instructions deep, 1.01 ms -- 0.66 ms on
- * more lanes, below; a four-pair product check 0.83 ms instead of 13.4), the same values bit for bit.  Batches of at most `n` items take it (per function scaled by
+ * more lanes, below; a four-pair product check 0.79 ms instead of 13.4), the same values bit for bit.  Batches of at most `n` items take it (per function scaled by
  * its measured crossover against the throughput kernel: x1 pairing / Miller loop / final exponentiation / two pairs (both values), x1.25 three
  * pairs, x1.5 four pairs, x0.5 the exact three- and four-pair Miller values); 0 turns it off.  Process-wide; default 16384. */
 void bn254_set_latency_threshold(size_t n);

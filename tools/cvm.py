@@ -815,11 +815,12 @@ def op_kind(v):
 class Program:
     """rounds: [(kind, [FV] (one per lane, at most nr))] + slot numbers"""
 
-    def __init__(self, low, nr=16, greedy_fill=True, inv_weight=None):
+    def __init__(self, low, nr=16, greedy_fill=True, inv_weight=None, m_weight=1.0):
         """inv_weight: the inversion's weight in the critical-path heights, if not its cost.  The exact Miller programs end with the
         inversion of the scale, which needs the whole point chain: a larger weight lets that chain (and its lines, in LDS) run further
         ahead of f -- fewer rounds, more slots."""
         self.low = low
+        self.m_weight = m_weight          # factor on the two- and four-product passes' weight in the heights (1.5: the sixty-four-lane multi-pair programs)
         self.inv_weight = inv_weight
         self.nr = nr
         self.greedy_fill = greedy_fill
@@ -860,7 +861,8 @@ class Program:
         for v in reversed(self.low.fv):
             if v.id not in self.live or v.kind not in ("mul", "lin", "inv"):
                 continue
-            v.height = (self.inv_weight if self.inv_weight is not None and v.cost == K_INV else COST[v.cost]) + max((u.height for u in self._consumers(v)), default=0)
+            own = self.inv_weight if self.inv_weight is not None and v.cost == K_INV else COST[v.cost] * (self.m_weight if v.cost in (K_M2, K_M4) else 1)
+            v.height = own + max((u.height for u in self._consumers(v)), default=0)
 
     @staticmethod
     def _producer(s):
