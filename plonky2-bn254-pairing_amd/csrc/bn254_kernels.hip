@@ -31,7 +31,7 @@ constexpr size_t MAX_K = 64;                            // pairs per group of th
 #ifndef BN254_LATENCY_THRESHOLD_DEFAULT
 #define BN254_CVM_PM_MILLER 1000      // per mille of the threshold each program takes batches up to: its own measured crossover (profiles/r04_latency.json)
 #define BN254_CVM_PM_FEXP 1000
-#define BN254_CVM_PM_MMILLER 500
+#define BN254_CVM_PM_MMILLER 1000
 #define BN254_LATENCY_THRESHOLD_DEFAULT 16384           // below the measured crossover (profiles/r04_latency.json): pairing 4.45 ms against 6.45 at 16384, 8.9 against 6.5 at 32768
 #endif
 
