@@ -52,6 +52,10 @@ inline MyFq12 unpack_fq12(const uint64_t* buf, size_t n, size_t i) { MyFq12 r; f
 // Sizes what the library keeps for (device, NULL stream) -- the stream every function of this header uses -- for calls of up to n units x k
 // pairs: no later call of that size allocates device memory (bn254_reserve).
 inline void reserve(size_t n, size_t k = 1, int device = 0) { check(bn254_reserve(device, nullptr, n, k)); }
+// The scalar functions below (one element per call) run on the lane-cooperative kernels by default (bn254_pairing.h: LATENCY PATH);
+// batches of at most `n` items do, 0 turns that off.
+inline void set_latency_threshold(size_t n) { bn254_set_latency_threshold(n); }
+inline size_t latency_threshold() { return bn254_get_latency_threshold(); }
 
 inline MyFq12 miller_loop_native(const G2Affine& Q, const G1Affine& P, int device = 0) {
     uint64_t g1[8], g2[16], out[48];
