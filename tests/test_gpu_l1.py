@@ -66,6 +66,7 @@ def _simulate(name, regs):
     for i in range(K4.NL):
         m.s[K4.S_P + i] = K4.P_L[i] & 0xFFFFFFFF
     m.s[K4.S_N0], m.s[K4.S_REDN], m.s[K4.S_M30] = K4.N0P, K4.REDN_C, (-30) & 0xFFFFFFFF
+    m.s[K4.S_HALF], m.s[K4.S_HALF + 1] = 1 << 28, 0
     for r, x in enumerate(regs):
         m.v[r] = x
     S.run_block(_body(name), m)
@@ -84,6 +85,7 @@ def _source(cases):
         stores = "".join(f'"global_store_dword v247, v{r}, %0 offset:{4 * k}\\n"' for k, r in enumerate(OUT[name]))
         consts = "".join(f'"s_mov_b32 s{K4.S_P + i}, 0x{K4.P_L[i] & 0xffffffff:x}\\n"' for i in range(K4.NL))
         consts += f'"s_mov_b32 s{K4.S_N0}, 0x{K4.N0P:x}\\n" "s_mov_b32 s{K4.S_REDN}, 0x{K4.REDN_C & 0xffffffff:x}\\n" "s_mov_b32 s{K4.S_M30}, 0x{(-30) & 0xffffffff:x}\\n"'
+        consts += f'"s_mov_b32 s{K4.S_HALF}, 0x10000000\\n" "s_mov_b32 s{K4.S_HALF + 1}, 0\\n"'
         src.append(f'''__global__ void __launch_bounds__(64) k_{name}(uint32_t* out, const uint32_t* in) {{
     uint32_t* o = out + (size_t)blockIdx.x * {n_out};
     const uint32_t* i_ = in + (size_t)blockIdx.x * {NV};

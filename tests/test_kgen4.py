@@ -50,6 +50,7 @@ def _m4(vals, rng, slack):
         m.s[K4.S_P + i] = K4.P_L[i] & 0xFFFFFFFF
     m.s[K4.S_N0] = K4.N0P
     m.s[K4.S_REDN] = K4.REDN_C
+    m.s[K4.S_HALF], m.s[K4.S_HALF + 1] = 1 << 28, 0          # the digit extraction's rounding constant (kgen4.DIGIT_ADD)
     m.s[K4.S_M30] = (-30) & 0xFFFFFFFF
     for j, x in enumerate(vals):
         for i, w in enumerate(_redundant(x, rng, slack)):

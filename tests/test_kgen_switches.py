@@ -51,6 +51,6 @@ def test_split_miller_loop_builds_and_is_exact():
 
 def test_round3_baseline_switches():
     off = {k: "0" for k in ("KGEN_MUL6_KEEP_DIFFS", "KGEN_DBL_LAZY_Y3", "KGEN_CYC_WIDE_M", "KGEN_FQINV_WIDE_M", "KGEN_MUL3_KEEP_DY", "KGEN_ADD_INJECT",
-                            "KGEN_BOUSTRO", "KGEN_INV_FUSED", "KGEN_INV_SAFEGCD")}
+                            "KGEN_BOUSTRO", "KGEN_INV_FUSED", "KGEN_INV_SAFEGCD", "KGEN_DIGIT_ADD")}
     n_r3 = _run("single", off)
     assert 3_660_000 < n_r3 < 3_680_000                    # round 3: 3.672 M instructions per pairing (profiles/r03_instr_histogram.json)

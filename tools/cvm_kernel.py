@@ -84,6 +84,8 @@ class VMKernel:
     def l1(self):
         g = L1v4(self.e)
         g.pool = Pool(POOL_FIRST, POOL_LAST)
+        if g.half is not None:
+            g.half = "s[62:63]"          # (this kernel's scalar register map)
         return g
 
     # -------------------------------------------------------------- small helpers
@@ -182,6 +184,8 @@ class VMKernel:
         e.salu(f"s_mov_b32 s{S_N0}, 0x{N0P:x}")
         e.salu(f"s_mov_b32 s{S_REDN}, 0x{REDN_C:x}")
         e.salu(f"s_mov_b32 s{S_M30}, -30")
+        e.salu(f"s_mov_b32 s62, 0x{1 << 28:x}")                      # s[62:63] = 2^28: the digit extraction's rounding constant (L1v4.half)
+        e.salu("s_mov_b32 s63, 0")
         e.salu(f"s_lshl_b32 s{S_NSTRIDE}, s{S_N}, 3")               # bytes between the planes of the output (n items)
         e.salu(f"s_mul_i32 s{S_PITCH_IN}, s{S_NSTRIDE}, s{S_K}")      # ... of the inputs (n k elements: pair j of item g is element g k + j)
         e.emit(f"v_and_b32_e32 v{V_ROLE}, {self.nr - 1}, %9", vw=[V_ROLE])

@@ -44,7 +44,7 @@ def main():
         bd, K4 = bodies(env)
         init = [f"v_mov_b32 v{i}, 0x{(0x00234567 * (i + 3)) & 0x0fffffff:x}" for i in range(248)]
         init += [f"s_mov_b32 s{K4.S_P + i}, 0x{K4.P_L[i] & 0xffffffff:x}" for i in range(K4.NL)]
-        init += [f"s_mov_b32 s{K4.S_N0}, 0x{K4.N0P:x}", f"s_mov_b32 s{K4.S_REDN}, 0x{K4.REDN_C & 0xffffffff:x}", f"s_mov_b32 s{K4.S_M30}, 0x{(-30) & 0xffffffff:x}"]
+        init += [f"s_mov_b32 s{K4.S_N0}, 0x{K4.N0P:x}", f"s_mov_b32 s{K4.S_REDN}, 0x{K4.REDN_C & 0xffffffff:x}", f"s_mov_b32 s{K4.S_HALF}, 0x10000000", f"s_mov_b32 s{K4.S_HALF + 1}, 0", f"s_mov_b32 s{K4.S_M30}, 0x{(-30) & 0xffffffff:x}"]
         for n in ROUTINES:
             kid = f"k_{vname}_{n}"
             body = " \\\n".join('"%s\\n"' % l for l in [".p2align 3"] + bd[n])

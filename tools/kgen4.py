@@ -48,6 +48,11 @@ DBL_LAZY_Y3 = bool(int(os.environ.get("KGEN_DBL_LAZY_Y3", "1")))                
 ADD_INJECT = bool(int(os.environ.get("KGEN_ADD_INJECT", "1")))                     # A/B switch: theta / mu of the addition step as pass outputs
 MUL3_KEEP_DY = bool(int(os.environ.get("KGEN_MUL3_KEEP_DY", "1")))                 # A/B switch: line-side Karatsuba differences of the sparse multiplications kept across passes
 MUL6_KEEP_DIFFS = bool(int(os.environ.get("KGEN_MUL6_KEEP_DIFFS", "1")))      # A/B switch (tools/exp/build_variant.sh)
+# A/B switch: the balanced digit of a column sum is taken off by ROUNDING -- (S - d) >> 29 == (S + 2^28) >> 29 -- i.e. a 64-bit add of a
+# scalar constant (v_lshl_add_u64) instead of the multiply-add S += d * (-1): as many instructions, 126 k multiply-adds per pairing less.
+# The constant sits in an SGPR pair (S_HALF; the split-loop experiment needs those registers itself).
+DIGIT_ADD = bool(int(os.environ.get("KGEN_DIGIT_ADD", "1"))) and not bool(int(os.environ.get("KGEN_FISSION", "0")))
+S_HALF = 52         # s[52:53] = 2^28 (kernels with another scalar register map: L1v4.half)
 V_LDS = 76          # v76, v77: LDS byte address of the lane's 16-byte chunks (+0, +64 KiB) ; v78: of its 8-byte tail chunks
 V_LTAIL = 78
 V_GOFF = 79         # byte offset of the lane's 16-byte chunks inside a global scratch slot: wave * 4608 + lane * 16 (V_GOFF8 = 246: ... + lane * 8, the tail)
@@ -112,6 +117,7 @@ class L1v4:
         self.pool = Pool(TMP_FIRST, TMP_LAST)
         self.p = [f"s{S_P + i}" for i in range(NL)]
         self.n0 = f"s{S_N0}"
+        self.half = f"s[{S_HALF}:{S_HALF + 1}]" if DIGIT_ADD else None
 
     # ------------------------------------------------------------------ 64-bit accumulator helpers
     def _acc(self):
@@ -136,7 +142,10 @@ class L1v4:
     def _digit(self, acc, P, dst):
         """dst <- balanced low digit of the accumulator; accumulator <- (accumulator - digit) >> 29."""
         self.e.emit(f"v_bfe_i32 v{dst}, v{acc}, 0, {LB}", vw=[dst])
-        self.e.emit(f"v_mad_i64_i32 {P}, vcc, v{dst}, -1, {P}", w=["vcc"], vw=[acc, acc + 1])
+        if self.half is not None:
+            self.e.emit(f"v_lshl_add_u64 {P}, {P}, 0, {self.half}", vw=[acc, acc + 1])
+        else:
+            self.e.emit(f"v_mad_i64_i32 {P}, vcc, v{dst}, -1, {P}", w=["vcc"], vw=[acc, acc + 1])
         self.e.emit(f"v_ashrrev_i64 {P}, {LB}, {P}", vw=[acc, acc + 1])
 
     # ------------------------------------------------------------------ fused Montgomery column pass

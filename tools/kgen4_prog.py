@@ -27,6 +27,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from asmcore import Emitter, P_INT, BN_X, SIX_U_PLUS_2_NAF, max_branch_distance, place_with_islands  # noqa: E402
+from kgen4 import DIGIT_ADD as K4_DIGIT_ADD, S_HALF as K4_S_HALF  # noqa: E402
 from kgen4 import (A0, B0, HOME0, L1V4_NAMES, L1v4, LB, MUL3_KEEP_DY, N0P, N_AGPR_SLOTS, N_HOME, N_LDS_SLOTS, NL, P_L, REDN_C, S_M30, S_N0, S_P, S_REDN,  # noqa: E402
                    S_RET1, S_RET2, S_RET3, SLOT_DW, SLOT_BYTES, V_FLAG, V_GOFF, V_GOFF8, V_IDX, V_IDX8, V_LDS, V_LTAIL, V_TID, bal_limbs, hx, mont4)
 
@@ -38,7 +39,8 @@ S_GSTRIDE = 66            # bytes between consecutive global slots
 S_I = 67                  # Miller-loop digit index
 S_NAF_NZ = "s[68:69]"     # 6u+2 NAF: non-zero mask, negative mask (digits 0..63)
 S_NAF_NEG = "s[70:71]"
-# (s50..s53, s72..s75: free -- the x-power schedule is unrolled control code, its digit masks are gone)
+# (s50..s53, s72..s75 were freed when the x-power schedule became unrolled control code; since then: s50..s53 the split-loop experiment,
+#  s[52:53] the digit extraction's rounding constant when that experiment is off, s72..s74 the alternating pair passes)
 S_J = 76                  # pow_x digit index
 S_GBASE = 77              # global Fq12 register operand of fq12_mul (slot number * stride, low 32 bits)
 S_ITEM = 78
@@ -2263,6 +2265,9 @@ class KernelBuilder:
         e.salu(f"s_mov_b32 s{S_N0}, 0x{N0P:x}")
         e.salu(f"s_mov_b32 s{S_REDN}, 0x{REDN_C:x}")
         e.salu(f"s_mov_b32 s{S_M30}, -30")
+        if K4_DIGIT_ADD:
+            e.salu(f"s_mov_b32 s{K4_S_HALF}, 0x{1 << (LB - 1):x}")
+            e.salu(f"s_mov_b32 s{K4_S_HALF + 1}, 0")
         nz, neg = naf_masks(SIX_U_PLUS_2_NAF[:64])
         e.salu(f"s_mov_b32 s68, 0x{nz & 0xFFFFFFFF:x}")
         e.salu(f"s_mov_b32 s69, 0x{nz >> 32:x}")

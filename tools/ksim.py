@@ -150,6 +150,9 @@ class Machine:
                     raise SimError(f"read of uninitialised {tok}")
                 a, b = a or 0, b or 0
             return a | (b << 32)
+        if tok.startswith("s["):                       # a 64-bit scalar operand (the digit extraction's rounding constant)
+            self._hazard(tok)
+            return self.sget(tok)
         return int(tok, 0) & M64
 
     def _hazard(self, reg):
