@@ -69,6 +69,8 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-power", action="store_true", help="do not sample the package power (rocm-smi) during the timed steps")
     ap.add_argument("--no-extra", action="store_true", help="skip configs[1] and configs[3] (reported under \"extra\" at N = 1)")
+    ap.add_argument("--no-scalar-latency", action="store_true",
+                    help="skip the one-item calls of the scalar signatures in \"extra\" (profiling runs: their small launches would enter the kernel averages)")
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="wall-clock budget of the cpu_baseline legs (single thread + all cores)")
     return ap.parse_args(argv)
 
@@ -253,7 +255,7 @@ def spot_check(pkg, torch, g1, g2, out, n, positions, threads):
     return bool(np.array_equal(pkg.layout.to_aos(got, 48), want))
 
 
-def extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n, sample_power=False):
+def extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n, sample_power=False, scalar_latency=True):
     """BASELINE.json configs[1] and configs[3] on one GPU (not the headline `value`); inputs: the resident 2^20 batch."""
     out = {}
 
@@ -315,7 +317,7 @@ def extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n, sample_power=F
     out["layout kernels at 2^20 elements (roofline bound: hbm, 8 TB/s)"] = lay
     # the reference's functions are SCALAR (one pairing / one group per call): wall time of one call on one item, launch to completion,
     # on the throughput kernel (one item per lane) and on the lane-cooperative kernel that small batches take
-    if hasattr(pkg, "set_latency_threshold"):
+    if scalar_latency and hasattr(pkg, "set_latency_threshold"):
         import time as _t
         keep = pkg.get_latency_threshold()
         o4 = torch.zeros(48, dtype=torch.int64, device=dev)
@@ -560,7 +562,8 @@ def run_rank(args):
                 print("bench.py: gathered outputs differ from the whole-batch recomputation", file=sys.stderr)
                 rc = 3
         if rc == 0 and on_gpu and world == 1 and not args.no_extra and log2 == LOG2_SINGLE:
-            rec["extra"] = extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n, sample_power=power is not None)
+            rec["extra"] = extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n, sample_power=power is not None,
+                                           scalar_latency=not args.no_scalar_latency)
         if rc == 0 and on_gpu and world == 1 and not args.no_cpu_baseline:
             m = min(n, 1 << 15)
             g1h = g1.view(8, n)[:, :m].cpu().numpy().view(np.uint64).reshape(-1).copy()
