@@ -72,6 +72,9 @@ def parse(argv=None):
     ap.add_argument("--no-scalar-latency", action="store_true",
                     help="skip the one-item calls of the scalar signatures in \"extra\" (profiling runs: their small launches would enter the kernel averages)")
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="wall-clock budget of the cpu_baseline legs (single thread + all cores)")
+    ap.add_argument("--dist-at-one", action="store_true",
+                    help="run the N > 1 flow (process group, scatter, collectives, gather) with whatever world size the environment gives, "
+                         "world size 1 included: how the RCCL side of configs[4] is exercised on a one-GPU box (tests/test_rccl_one_rank.py)")
     return ap.parse_args(argv)
 
 
@@ -363,6 +366,8 @@ def run_rank(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("BENCH_TEST_FAIL_RANK") == str(rank) and os.environ.get("PYTEST_CURRENT_TEST"):
+        raise RuntimeError("injected fault (BENCH_TEST_FAIL_RANK, a pytest-only hook): this rank dies before the rendezvous")
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
     on_gpu = not test_engine
     if on_gpu:
@@ -377,15 +382,24 @@ def run_rank(args):
     else:
         dev, stream, sync = torch.device("cpu"), None, (lambda: None)
     dist = None
-    if world > 1:
+    multi = world > 1 or args.dist_at_one          # the configs[4] flow: process group, scatter, collectives, gather
+    if multi:
         import torch.distributed as dist
+        from datetime import timedelta
+        # a bounded rendezvous and bounded collectives: a rank that died (build, out of memory) must end the job with a reason in
+        # seconds, not hold its peers for the default ten minutes (the longest gap between two collectives here is the timed steps)
+        tmo = timedelta(seconds=float(os.environ.get("BENCH_DIST_TIMEOUT_S", "120")))
+        if "RANK" not in os.environ:               # --dist-at-one started by hand: a one-rank group of its own
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK=str(local_rank))
         if backend == "nccl" and on_gpu:
-            dist.init_process_group(backend="nccl", device_id=dev)
+            dist.init_process_group(backend="nccl", device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend=backend)
-    sharded = __import__("importlib").import_module("plonky2-bn254-pairing_amd.sharded") if world > 1 else None
+            dist.init_process_group(backend=backend, timeout=tmo)
+    sharded = __import__("importlib").import_module("plonky2-bn254-pairing_amd.sharded") if multi else None
 
-    log2 = args.log2_batch if args.log2_batch is not None else (LOG2_SINGLE if world == 1 else LOG2_PER_GPU_MULTI)
+    log2 = args.log2_batch if args.log2_batch is not None else (LOG2_PER_GPU_MULTI if multi else LOG2_SINGLE)
     n = 1 << log2                                   # pairings per GPU per step
     n_total = n * world
     exchange = None
@@ -393,7 +407,7 @@ def run_rank(args):
     g2 = torch.zeros(16 * n, dtype=torch.int64, device=dev)
     out = torch.zeros(48 * n, dtype=torch.int64, device=dev)
     full = None
-    if world == 1:
+    if not multi:
         pkg.generate_pairs_dev(0xB2540001, g1, g2, n, device=local_rank, stream=stream)
         pkg.last_status(local_rank, stream)
     else:
@@ -459,7 +473,7 @@ def run_rank(args):
         per_rank = [[float(x) for x in t.tolist()] for t in allr]
 
     gathered = None
-    if world > 1:
+    if multi:
         sync()
         dist.barrier()
         t0 = time.perf_counter()
@@ -484,7 +498,7 @@ def run_rank(args):
         notes, stale = pmc_summary(log2, kern_avg_ms)
         traffic = notes.get("hbm_bytes_per_launch_corrected")
         insts_per_item = notes.get("valu_wave_insts_per_work_item")        # wave-instructions per 64 pairings (one wave's lanes)
-        cfg_name = "configs[2]" if (world == 1 and log2 == 20) else ("configs[4]" if (world > 1 and log2 == 21) else "custom size")
+        cfg_name = "configs[2]" if (not multi and log2 == 20) else ("configs[4]" if (world > 1 and log2 == 21) else "custom size")
         rec = {
             "metric": "BN254 pairings/sec (whole node)", "value": value, "unit": "pairings/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -495,7 +509,7 @@ def run_rank(args):
                                    f"pairing() = final_exp_native(miller_loop_native)",
                        "pairings_per_gpu": n, "pairings_total": n_total, "layout": "SoA limb-major u64 Montgomery, inputs resident in HBM",
                        "ranks_share_one_gpu": bool(on_gpu and world > 1 and os.environ.get("BENCH_SHARE_GPU")),
-                       "sharding": None if world == 1 else "contiguous slices per rank, scattered from / gathered to rank 0 over RCCL outside the timed steps; no data-path collective"},
+                       "sharding": None if not multi else "contiguous slices per rank, scattered from / gathered to rank 0 over RCCL outside the timed steps; no data-path collective"},
             "roofline": {"bound": "valu-int32-mul", "achieved": achieved / 1e12, "peak": PEAK_MUL32_PER_S / 1e12, "unit": "T mul32/s",
                          "frac": achieved / PEAK_MUL32_PER_S, "traffic": traffic,
                          "achieved_note": "work-normalised: SURVEY.md 8(d)'s algorithmic mul32 per pairing x pairings/s (kernel time from HIP events), "
@@ -527,7 +541,7 @@ def run_rank(args):
                                  "note": "the schema's HBM view of the same kernel: algorithmic bytes (576 B/pairing) over the launch time "
                                          "against 8 TB/s -- three orders of magnitude from the bound (SURVEY.md 8d: integer-VALU bound)"}},
         }
-        if world > 1:
+        if multi:
             rec["rccl_ranks"] = dist.get_world_size()
             rec["per_rank"] = {"kernel_ms_avg": [r[0] for r in per_rank], "kernel_ms_min": [r[1] for r in per_rank],
                                "kernel_ms_max": [r[2] for r in per_rank], "peak_device_bytes": [r[3] for r in per_rank],
@@ -542,17 +556,17 @@ def run_rank(args):
             threads = min(32, usable_cores(host_cpu_info()))
             pos = sorted({0, 1, 255, 256, n // 2 + 77, n - 257, n - 1, 65535 % n, 65536 % n})
             ok = spot_check(pkg, torch, g1, g2, out, n, pos, threads)
-            if world > 1:
+            if multi:
                 # every peer's slice: its first lane, one in the middle, its last lane -- against the oracle on rank 0's copy of the inputs
                 gp = sorted({r * n + off for r in range(1, world) for off in (0, n // 2 + 5, n - 1)})
-                ok = ok and spot_check(pkg, torch, full[0], full[1], gathered, n_total, gp, threads)
+                ok = ok and (not gp or spot_check(pkg, torch, full[0], full[1], gathered, n_total, gp, threads))
                 ok = ok and bool(torch.equal(gathered.view(48, n_total)[:, :n], out.view(48, n)))
                 rec["verified_positions_in_peer_slices"] = len(gp)
             rec["verified_vs_oracle"] = ok
             if not ok:
                 print("bench.py: GPU results differ from the oracle -- no measurement reported", file=sys.stderr)
                 rc = 3
-        if not on_gpu and world > 1:
+        if not on_gpu and multi:
             # launcher tests (stand-in engine): the gathered batch must be what the engine makes of the WHOLE input on rank 0 --
             # every peer's slice, every lane (shard bounds, scatter and gather all have to be right for that)
             ref = torch.zeros(48 * n_total, dtype=torch.int64)
@@ -561,10 +575,10 @@ def run_rank(args):
             if not rec["gathered_equals_whole_batch_recomputation"]:
                 print("bench.py: gathered outputs differ from the whole-batch recomputation", file=sys.stderr)
                 rc = 3
-        if rc == 0 and on_gpu and world == 1 and not args.no_extra and log2 == LOG2_SINGLE:
+        if rc == 0 and on_gpu and not multi and not args.no_extra and log2 == LOG2_SINGLE:
             rec["extra"] = extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n, sample_power=power is not None,
                                            scalar_latency=not args.no_scalar_latency)
-        if rc == 0 and on_gpu and world == 1 and not args.no_cpu_baseline:
+        if rc == 0 and on_gpu and not multi and not args.no_cpu_baseline:
             m = min(n, 1 << 15)
             g1h = g1.view(8, n)[:, :m].cpu().numpy().view(np.uint64).reshape(-1).copy()
             g2h = g2.view(16, n)[:, :m].cpu().numpy().view(np.uint64).reshape(-1).copy()
@@ -586,7 +600,18 @@ def main(argv=None):
     args = parse(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args, argv))
-    sys.exit(run_rank(args))
+    try:
+        rc = run_rank(args)
+    except SystemExit:
+        raise
+    except BaseException as e:      # noqa: BLE001 -- a rank must not die silently: its peers wait in a collective
+        import traceback
+        traceback.print_exc()
+        print(f"bench.py: rank {os.environ.get('RANK', '0')} of {os.environ.get('WORLD_SIZE', '1')} failed -- {type(e).__name__}: {e}; "
+              f"leaving with code 1 so that the launcher ends the other ranks", file=sys.stderr, flush=True)
+        sys.stdout.flush()
+        os._exit(1)                 # no destructors: a process group in a broken state can hang in its own teardown
+    sys.exit(rc)
 
 
 if __name__ == "__main__":
