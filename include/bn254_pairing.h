@@ -71,12 +71,17 @@ extern "C" {
 #define BN254_ERR_NAF_CARRY (-5)    /* reference: get_naf assert at final_exp_native.rs:123 */
 #define BN254_ERR_ALLOC (-6)
 #define BN254_ERR_INFINITY (-7)     /* bn254_check_points: a point at infinity (ark affine form x = y = 0) in the batch */
+#define BN254_ERR_NOT_ON_CURVE (-8)    /* bn254_check_points_ex: a point is not on its curve / a coordinate is not below p */
+#define BN254_ERR_NOT_IN_SUBGROUP (-9) /* bn254_check_points_ex: a G2 point outside the r-torsion; reference: `G2Affine::new` panics
+                                        * (src/miller_loop_native.rs:303,311) */
 
 /* number of visible HIP devices (0 when none / no driver) */
 int bn254_device_count(void);
 const char* bn254_strerror(int status);
 /* Synchronises `stream` on `device` and returns the sticky status of the device-side
- * checks (zero divisor) accumulated since the last call; clears it. */
+ * checks accumulated since the last call; clears it.  Two sticky words are kept per stream: the zero-divisor flag of the
+ * compute kernels and the flags of the point checks; the point checks win (infinity, then not-on-curve, then not-in-subgroup),
+ * whatever ran in between: a pairing on an invalid point that also divides by zero still reports the invalid point. */
 int bn254_last_status(int device, void* stream);
 /* Bytes of device scratch a call over n lanes (k pairs each) will use (informational; never touches the HIP runtime:
  * the persistent grid is min(work items, CUs), CUs = those of a device the library already runs on, else 256). */
@@ -105,6 +110,15 @@ size_t bn254_get_latency_threshold(void);
  * smaller one). */
 void bn254_set_latency_lanes(int lanes);
 int bn254_get_latency_lanes(void);
+/* The two settings above are process-wide DEFAULTS.  A (device, stream) may carry its own: calls on that stream then select their
+ * kernel by `threshold` / `lanes` whatever other threads set for theirs (two host threads with different needs -- one serving scalar
+ * calls, one timing the throughput kernel -- use two streams).  threshold = BN254_LATENCY_INHERIT / lanes = -1 return the stream to
+ * the process-wide default.  Never touches the HIP runtime; the setting lives until bn254_release_stream. */
+#define BN254_LATENCY_INHERIT ((size_t)-1)
+int bn254_set_stream_latency(int device, void* stream, size_t threshold, int lanes);
+/* Which kernel the most recent pairing / Miller / final-exponentiation launch on (device, stream) took: 1 = the throughput kernel (one
+ * item per lane), 16 / 32 / 64 = the lane-cooperative kernel with that many lanes per item, 0 = none yet (diagnostic; no HIP call). */
+int bn254_last_kernel(int device, void* stream);
 /* Scratch and the status word are kept per (device, stream), so calls on different streams are independent;
  * this frees what the library holds for `stream` (call it before destroying a stream you used). */
 int bn254_release_stream(int device, void* stream);
@@ -230,6 +244,26 @@ int bn254_multi_pairing_check_batch_elems(const uint64_t* g1, const uint64_t* g2
  * inputs; nothing is computed from them.  (The Rust shim tests the `infinity` flag of the structs it is handed instead.) */
 int bn254_check_points_dev(const uint64_t* g1, const uint64_t* g2, size_t n, int device, void* stream);
 int bn254_check_points(const uint64_t* g1, const uint64_t* g2, size_t n, int device, void* stream);
+/* The rest of the reference's IMPLICIT input contract.  ark-ec's `Affine::new` asserts on-curve and in-subgroup, and the reference
+ * builds the Frobenius images of Q with it (`G2Affine::new(out_x, out_y)`, src/miller_loop_native.rs:303,311): a G2 point outside the
+ * r-torsion makes the reference PANIC at the end of its Miller loop, and `G1Affine::rand` / `G2Affine::rand` (src/pairing.rs:65-66)
+ * never produce one.  The pairing kernels do not look -- they return a value for any coordinates (and not the value a from-scratch
+ * affine computation would give for off-curve input: their projective steps use the curve equation).  A caller with untrusted points
+ * runs this check first; `flags` selects
+ *   BN254_CHECK_INFINITY   all-zero G1 or G2 coordinates (as bn254_check_points)                          -> BN254_ERR_INFINITY
+ *   BN254_CHECK_ON_CURVE   y^2 = x^3 + 3 (G1), y^2 = x^3 + 3/(9+u) (G2), every coordinate below p           -> BN254_ERR_NOT_ON_CURVE
+ *   BN254_CHECK_SUBGROUP   on-curve, and Q in the r-torsion: [x+1]Q + psi([x]Q) + psi^2([x]Q) == psi^3([2x]Q)
+ *                          (ePrint 2022/348; psi = the reference's twisted_frobenius; G1 has cofactor one) -> BN254_ERR_NOT_IN_SUBGROUP
+ * `per_point` (may be NULL): one byte per pair, the OR of 2 (infinity), 4 (not on curve), 8 (not in subgroup) -- which pair it was.
+ * The `_dev` form sets the stream's sticky point-check status (reported by the next bn254_last_status in the order above, whatever
+ * ran in between); the host-pointer form returns it.  COST: not free and not part of the hot path -- the subgroup check is a 63-bit
+ * scalar multiplication on the twist per pair (about 1.0 k Fq2 products: a sixth of a pairing's field work, in plain HIP C++);
+ * measured figures in DESIGN.md.  HBM: the 192 input bytes per pair once (+ 1 byte out). */
+#define BN254_CHECK_INFINITY 1
+#define BN254_CHECK_ON_CURVE 2
+#define BN254_CHECK_SUBGROUP 4
+int bn254_check_points_ex_dev(const uint64_t* g1, const uint64_t* g2, size_t n, int flags, uint8_t* per_point, int device, void* stream);
+int bn254_check_points_ex(const uint64_t* g1, const uint64_t* g2, size_t n, int flags, uint8_t* per_point, int device, void* stream);
 
 /* ---- synthetic inputs (bench / tests): on-device subgroup points ------------------------ */
 /* P_i = [s_i] G1, Q_i = [t_i] G2 with s_i, t_i from SplitMix64(seed, i) (non-zero, < 2^128);

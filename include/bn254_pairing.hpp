@@ -56,6 +56,9 @@ inline void reserve(size_t n, size_t k = 1, int device = 0) { check(bn254_reserv
 // batches of at most `n` items do, 0 turns that off.
 inline void set_latency_threshold(size_t n) { bn254_set_latency_threshold(n); }
 inline size_t latency_threshold() { return bn254_get_latency_threshold(); }
+// ... for the NULL stream of `device` alone (the stream every function of this header uses), whatever other users of the library set
+// process-wide; BN254_LATENCY_INHERIT / -1 return to the defaults.
+inline void set_stream_latency(size_t threshold, int lanes = -1, int device = 0) { check(bn254_set_stream_latency(device, nullptr, threshold, lanes)); }
 
 inline MyFq12 miller_loop_native(const G2Affine& Q, const G1Affine& P, int device = 0) {
     uint64_t g1[8], g2[16], out[48];
@@ -168,6 +171,20 @@ inline std::vector<MyFq12> multi_pairing_batch(const std::vector<G1Affine>& ps, 
     check(bn254_multi_pairing_batch_elems(detail::words(ps.data()), detail::words(qs.data()), detail::words(r.data()), np / k, k, do_final_exp ? 1 : 0,
                                           BN254_FQ12_MYFQ12, device, nullptr));
     return r;
+}
+
+// ark's implicit input contract for untrusted points (`G1Affine::new` / `G2Affine::new`: on the curve, G2 in the r-torsion -- the reference
+// calls the latter itself, miller_loop_native.rs:303,311, and panics there): throws Panic(BN254_ERR_INFINITY / _NOT_ON_CURVE /
+// _NOT_IN_SUBGROUP) like the reference would; per_point (optional) receives one flag byte per pair (2 | 4 | 8).
+inline void check_points_full(const std::vector<G1Affine>& ps, const std::vector<G2Affine>& qs, std::vector<uint8_t>* per_point = nullptr,
+                              int device = 0) {
+    const size_t n = ps.size();
+    if (qs.size() != n) throw Panic(BN254_ERR_INVALID_ARG);
+    std::vector<uint64_t> g1(8 * n), g2(16 * n);
+    for (size_t i = 0; i < n; i++) { detail::pack_g1(ps[i], g1.data(), n, i); detail::pack_g2(qs[i], g2.data(), n, i); }
+    if (per_point) per_point->assign(n, 0);
+    check(bn254_check_points_ex(g1.data(), g2.data(), n, BN254_CHECK_INFINITY | BN254_CHECK_ON_CURVE | BN254_CHECK_SUBGROUP,
+                                per_point ? per_point->data() : nullptr, device, nullptr));
 }
 
 // One process, several GPUs: contiguous slices per device, no exchange step (bn254_pairing_sharded_elems).

@@ -33,6 +33,11 @@ ERR_ZERO_DIVISOR = -4
 ERR_NAF_CARRY = -5
 ERR_ALLOC = -6
 ERR_INFINITY = -7
+ERR_NOT_ON_CURVE = -8
+ERR_NOT_IN_SUBGROUP = -9
+CHECK_INFINITY, CHECK_ON_CURVE, CHECK_SUBGROUP = 1, 2, 4       # bn254_check_points_ex flags
+PT_INFINITY, PT_NOT_ON_CURVE, PT_NOT_IN_SUBGROUP = 2, 4, 8     # bits of its per-point verdict byte
+LATENCY_INHERIT = (1 << (8 * ctypes.sizeof(ctypes.c_size_t))) - 1
 
 P = 21888242871839275222246405745257275088696311157297823662689037894645226208583
 R_ORDER = 21888242871839275222246405745257275088548364400416034343698204186575808495617
@@ -82,6 +87,10 @@ _PROTOS = {
     "bn254_release_stream": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p]),
     "bn254_check_points_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "bn254_check_points": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_check_points_ex_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_check_points_ex": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_set_stream_latency": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]),
+    "bn254_last_kernel": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p]),
     "bn254_reserve": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t]),
     "bn254_set_latency_threshold": (None, [ctypes.c_size_t]),
     "bn254_get_latency_threshold": (ctypes.c_size_t, []),
@@ -435,6 +444,35 @@ def check_points(g1, g2, n, device=0):
 def check_points_dev(g1, g2, n, device=0, stream=None):
     """device batches: sets the stream's sticky status (last_status then raises ERR_INFINITY)"""
     _check(load_library().bn254_check_points_dev(_dev(g1), _dev(g2), n, device, _stream(stream)), "check_points")
+
+
+def check_points_ex(g1, g2, n, flags=CHECK_INFINITY | CHECK_SUBGROUP, device=0, want_per_point=False):
+    """The reference's implicit input contract on limb-major host batches (ark's `Affine::new`: on the curve and, for G2, in the
+    r-torsion -- /root/reference/src/miller_loop_native.rs:303,311).  Raises Bn254Error with ERR_INFINITY / ERR_NOT_ON_CURVE /
+    ERR_NOT_IN_SUBGROUP; with want_per_point returns (status, uint8 verdicts) instead of raising."""
+    g1, g2 = _np_in(g1, G1_WORDS, n), _np_in(g2, G2_WORDS, n)
+    per = np.zeros(n, dtype=np.uint8) if want_per_point else None
+    rc = load_library().bn254_check_points_ex(_ptr(g1), _ptr(g2), n, flags, _ptr(per) if want_per_point else None, device, None)
+    if want_per_point:
+        return rc, per
+    _check(rc, "check_points_ex")
+
+
+def check_points_ex_dev(g1, g2, n, flags=CHECK_INFINITY | CHECK_SUBGROUP, per_point=None, device=0, stream=None):
+    """device batches: sets the stream's sticky point-check status (last_status then raises); per_point: optional uint8 device tensor"""
+    _check(load_library().bn254_check_points_ex_dev(_dev(g1), _dev(g2), n, flags, _dev(per_point) if per_point is not None else None, device,
+                                                    _stream(stream)), "check_points_ex")
+
+
+def set_stream_latency(threshold=LATENCY_INHERIT, lanes=-1, device=0, stream=None):
+    """This (device, stream)'s own kernel selection: batches of at most `threshold` items take the lane-cooperative kernel (0: never),
+    `lanes` = 0 / 16 / 32 / 64 picks its program family; LATENCY_INHERIT / -1 return to the process-wide defaults."""
+    _check(load_library().bn254_set_stream_latency(device, _stream(stream), threshold, lanes), "set_stream_latency")
+
+
+def last_kernel(device=0, stream=None):
+    """1 = the throughput kernel, 16 / 32 / 64 = lanes per item of the lane-cooperative kernel, 0 = no compute launch on this stream yet"""
+    return load_library().bn254_last_kernel(device, _stream(stream))
 
 
 def reserve(n, k=1, device=0, stream=None):

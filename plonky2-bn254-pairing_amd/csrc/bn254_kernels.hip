@@ -21,6 +21,7 @@
 #include "gen_table_gen.h"
 #include "pairing_asm_gen.h"
 #include "cvm_asm_gen.h"
+#include "bn254_point_checks.h"
 #include "../../include/bn254_pairing.h"
 
 namespace {
@@ -113,7 +114,7 @@ __global__ void __launch_bounds__(256) k_subgroup(const uint64_t* __restrict__ s
     }
 }
 
-// status |= 2 when a point of the batch is the point at infinity in ark's affine form (x = y = 0, all limbs zero): the reference reads
+// status[1] |= 2 when a point of the batch is the point at infinity in ark's affine form (x = y = 0, all limbs zero): the reference reads
 // raw x / y and never looks at the `infinity` flag, so such an input is outside its contract; callers that want
 // the distinct status SURVEY 8(b) asks for run this check (HBM-bound: every input word is read once).
 __global__ void __launch_bounds__(256) k_check_points(const uint64_t* __restrict__ g1, const uint64_t* __restrict__ g2, size_t n, int* status) {
@@ -121,7 +122,7 @@ __global__ void __launch_bounds__(256) k_check_points(const uint64_t* __restrict
         uint64_t a = 0, b = 0;
         for (int w = 0; w < 8; w++) a |= g1[(size_t)w * n + i];
         for (int w = 0; w < 16; w++) b |= g2[(size_t)w * n + i];
-        if (a == 0 || b == 0) atomicOr(status, 2);
+        if (a == 0 || b == 0) atomicOr(status, 2);      // `status` = the stream's point-check word (not the kernels' zero-divisor word)
     }
 }
 
@@ -186,8 +187,13 @@ struct StreamCtx {
     std::vector<void*> retired;   // buffers that were outgrown while work on them may still be queued: freed once the stream has been
                                   // synchronised (bn254_last_status, bn254_release_stream) -- growing never waits for the stream
     std::vector<NafSlot> naf_ring;
-    int* status = nullptr;
-    int* status_host = nullptr;   // pinned: the status word is read back on the caller's stream
+    int* status = nullptr;        // TWO words: [0] the zero-divisor flag (the generated kernels store a plain 1), [1] the point-check
+                                  // flags (atomicOr: 2 infinity, 4 not on the curve, 8 G2 not in the subgroup) -- separate words, so a
+                                  // pairing kernel that trips over the all-zero point cannot overwrite the more specific verdict
+    int* status_host = nullptr;   // pinned: the status words are read back on the caller's stream
+    size_t lat_threshold = (size_t)-1;   // bn254_set_stream_latency: this stream's own kernel selection; (size_t)-1 / -1 = the process-wide
+    int lat_lanes = -1;                  // defaults (bn254_set_latency_threshold / _lanes)
+    int last_kernel = 0;                 // bn254_last_kernel: 1 = throughput kernel (one item per lane), 16 / 32 / 64 = lanes per item
     size_t last_pitch = 0;        // scratch geometry of the most recent launch (diagnostic builds read their clock stamps back from it)
     uint32_t last_grid = 0;
     ~StreamCtx() {                // the last holder (bn254_release_stream, after the stream has been synchronised) frees everything
@@ -303,9 +309,10 @@ int ctx_get(int device, void* stream, size_t k, size_t n_items, LaunchCtx* out, 
     }
     std::shared_ptr<StreamCtx> sc = stream_ctx(device, stream);
     out->lock = std::unique_lock<std::recursive_mutex>(sc->mu);
+    out->s = sc;            // before anything can fail: the lock above must never outlive the last reference to its mutex
     if (!sc->status) {
-        if (hipMalloc(&sc->status, sizeof(int)) != hipSuccess) { sc->status = nullptr; return BN254_ERR_ALLOC; }
-        HIPCHK(hipMemsetAsync(sc->status, 0, sizeof(int), (hipStream_t)stream));
+        if (hipMalloc(&sc->status, 2 * sizeof(int)) != hipSuccess) { sc->status = nullptr; return BN254_ERR_ALLOC; }
+        HIPCHK(hipMemsetAsync(sc->status, 0, 2 * sizeof(int), (hipStream_t)stream));
     }
     uint32_t grid = (uint32_t)(n_items < (size_t)c.n_cu ? n_items : (size_t)c.n_cu);
     if (grid == 0) grid = 1;
@@ -314,7 +321,6 @@ int ctx_get(int device, void* stream, size_t k, size_t n_items, LaunchCtx* out, 
     // slots inside a block with 32-bit byte offsets
     if (pitch >= (1ull << 32)) return BN254_ERR_INVALID_ARG;
     if ((rc = ensure(sc.get(), sc->scratch, BN254_SCRATCH_WG_CONTIGUOUS ? pitch * grid : pitch * scratch_slots(k)))) return rc;
-    out->s = sc;
     out->n_cu = c.n_cu;
     out->scratch = (uint4*)sc->scratch.p;
     out->status = sc->status;
@@ -332,6 +338,20 @@ int launch_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_
 // Batches of at most this many items take the lane-cooperative kernel where a program exists (bn254_set_latency_threshold; 0: never).
 std::atomic<size_t> g_latency_threshold{BN254_LATENCY_THRESHOLD_DEFAULT};
 std::atomic<int> g_latency_lanes{0};       // bn254_set_latency_lanes: 0 = by launch size, 16 / 32 = that program family whatever the size
+
+// the kernel selection of a call: the stream's own setting where it has one (bn254_set_stream_latency), else the process-wide default
+void latency_cfg(int device, void* stream, size_t* threshold, int* lanes) {
+    size_t t = (size_t)-1;
+    int l = -1;
+    if (device >= 0 && device < 64) {
+        DeviceCtx& c = g_ctx[device];
+        std::lock_guard<std::mutex> lk(c.mu);
+        auto it = c.streams.find((hipStream_t)stream);
+        if (it != c.streams.end()) { t = it->second->lat_threshold; l = it->second->lat_lanes; }
+    }
+    *threshold = t == (size_t)-1 ? g_latency_threshold.load() : t;
+    *lanes = l < 0 ? g_latency_lanes.load() : l;
+}
 
 struct CvmProgram {
     const char* b64;          // the program blob, deflated and base64-encoded (cvm_asm_gen.h)
@@ -404,14 +424,13 @@ size_t resident_waves(size_t lds) {
     return w > 8 ? 8 : (w ? w : 1);
 }
 
-int launch_cvm(int prog, const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in, uint64_t* out, size_t n, size_t k, int device, void* stream) {
+int launch_cvm(int prog, int lanes, const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in, uint64_t* out, size_t n, size_t k, int device, void* stream) {
     LaunchCtx c;
     int rc = ctx_get(device, stream, 1, 1, &c);          // the status word and the stream context; the kernel needs no scratch
     if (rc) return rc;
     DeviceCtx& d = g_ctx[device];
     // The smallest launches -- at most one wave per SIMD with two items per wave -- take the function's thirty-two-lane program where
     // there is one: fewer, fuller rounds (pairing: 979 instead of 1 326).
-    int lanes = g_latency_lanes.load();
     // ... and products of three and four pairings, while the launch is at most one wave per SIMD with ONE item per wave, the sixty-four-lane
     // program: the lines of a step multiplied with each other off f's chain (four-pair product: 1 008 rounds instead of 1 297)
     if (CVM_PROGRAMS[prog].full >= 0) {
@@ -424,6 +443,7 @@ int launch_cvm(int prog, const uint64_t* g1, const uint64_t* g2, const uint64_t*
             hipLaunchKernelGGL(k_cvm_full, dim3((uint32_t)(n < cap ? n : cap)), dim3(64), lds_x, (hipStream_t)stream, g1, g2, f_in, out, (uint32_t)n,
                                (uint32_t)k, (uint4*)d.cvm_blob[x], 0u, c.status);
             HIPCHK(hipGetLastError());
+            c.s->last_kernel = 64;
             return BN254_OK;
         }
     }
@@ -435,6 +455,7 @@ int launch_cvm(int prog, const uint64_t* g1, const uint64_t* g2, const uint64_t*
         hipLaunchKernelGGL(k_cvm_wide, dim3((uint32_t)(need < cap ? need : cap)), dim3(64), lds_w, (hipStream_t)stream, g1, g2, f_in,
                            out, (uint32_t)n, (uint32_t)k, (uint4*)d.cvm_blob[w], 0u, c.status);
         HIPCHK(hipGetLastError());
+        c.s->last_kernel = 32;
         return BN254_OK;
     }
     const CvmProgram& p = CVM_PROGRAMS[prog];
@@ -451,6 +472,7 @@ int launch_cvm(int prog, const uint64_t* g1, const uint64_t* g2, const uint64_t*
     hipLaunchKernelGGL(split ? k_cvm_split : k_cvm, dim3((uint32_t)(need < cap ? need : cap)), dim3(64), split ? lds_split : lds, (hipStream_t)stream,
                        g1, g2, f_in, out, (uint32_t)n, (uint32_t)k, (uint4*)d.cvm_blob[prog], 0u, c.status);
     HIPCHK(hipGetLastError());
+    c.s->last_kernel = 16;
     return BN254_OK;
 }
 
@@ -492,8 +514,13 @@ int launch_pairing(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in,
     }
     {
         int prog = cvm_program<M, F>(k);
-        if (prog >= 0 && n_groups * 1000 <= g_latency_threshold.load() * CVM_PROGRAMS[prog].per_mille && n_groups * k < (1u << 22))
-            return launch_cvm(prog, g1, g2, f_in, out, n_groups, k, device, stream);
+        if (prog >= 0 && n_groups * k < (1u << 22)) {
+            size_t thr; int lanes;
+            latency_cfg(device, stream, &thr, &lanes);
+            // n_groups * 1000 <= thr * per_mille without the overflow of a huge threshold ("always": SIZE_MAX)
+            unsigned __int128 lhs = (unsigned __int128)n_groups * 1000u, rhs = (unsigned __int128)thr * CVM_PROGRAMS[prog].per_mille;
+            if (lhs <= rhs) return launch_cvm(prog, lanes, g1, g2, f_in, out, n_groups, k, device, stream);
+        }
     }
     LaunchCtx c;
     int rc = ctx_get(device, stream, k, (n_groups + BLOCK - 1) / BLOCK, &c);
@@ -511,6 +538,7 @@ int launch_pairing(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in,
         else go(k_mmiller);
     }
     HIPCHK(hipGetLastError());
+    c.s->last_kernel = 1;
     return BN254_OK;
 }
 
@@ -659,6 +687,8 @@ const char* bn254_strerror(int status) {
         case BN254_ERR_NAF_CARRY: return "get_naf: carry out of the top limb (the reference panics here)";
         case BN254_ERR_ALLOC: return "device allocation failed";
         case BN254_ERR_INFINITY: return "a point at infinity in the batch (outside the reference's contract: it reads raw x / y)";
+        case BN254_ERR_NOT_ON_CURVE: return "a point of the batch is not on its curve, or a coordinate is not below p (ark's G1Affine::new / G2Affine::new panic here)";
+        case BN254_ERR_NOT_IN_SUBGROUP: return "a G2 point of the batch is not in the r-torsion (ark's G2Affine::new panics here: miller_loop_native.rs:303,311)";
         default: return "unknown status";
     }
 }
@@ -678,15 +708,20 @@ int bn254_last_status(int device, void* stream) {
     std::lock_guard<std::recursive_mutex> lk(sc->mu);
     if (!sc->status) { HIPCHK(hipStreamSynchronize(st)); free_retired(sc.get()); return BN254_OK; }
     // the read-back (and the clearing store) are enqueued on the caller's stream: other streams are not touched
-    if (!sc->status_host && hipHostMalloc((void**)&sc->status_host, sizeof(int), hipHostMallocDefault) != hipSuccess) return BN254_ERR_ALLOC;
-    HIPCHK(hipMemcpyAsync(sc->status_host, sc->status, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (!sc->status_host && hipHostMalloc((void**)&sc->status_host, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) return BN254_ERR_ALLOC;
+    HIPCHK(hipMemcpyAsync(sc->status_host, sc->status, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     free_retired(sc.get());
-    if (*sc->status_host) {
-        int v = *sc->status_host;
-        HIPCHK(hipMemsetAsync(sc->status, 0, sizeof(int), st));
+    if (sc->status_host[0] | sc->status_host[1]) {
+        int zero_div = sc->status_host[0], pts = sc->status_host[1];
+        HIPCHK(hipMemsetAsync(sc->status, 0, 2 * sizeof(int), st));
         HIPCHK(hipStreamSynchronize(st));
-        return (v & 2) ? BN254_ERR_INFINITY : BN254_ERR_ZERO_DIVISOR;      // (an infinite input makes everything behind it meaningless)
+        // the most specific verdict first: an invalid input makes everything computed from it meaningless (an all-zero point also
+        // trips the zero-divisor flag of the pairing kernels behind the check)
+        if (pts & bn254_chk::PT_INFINITY) return BN254_ERR_INFINITY;
+        if (pts & bn254_chk::PT_NOT_ON_CURVE) return BN254_ERR_NOT_ON_CURVE;
+        if (pts & bn254_chk::PT_NOT_IN_SUBGROUP) return BN254_ERR_NOT_IN_SUBGROUP;
+        return zero_div ? BN254_ERR_ZERO_DIVISOR : BN254_ERR_HIP;
     }
     return BN254_OK;
 }
@@ -710,6 +745,22 @@ size_t bn254_scratch_bytes(size_t n, size_t k) {
 void bn254_set_latency_lanes(int lanes) { g_latency_lanes.store(lanes == 16 || lanes == 32 || lanes == 64 ? lanes : 0); }
 int bn254_get_latency_lanes(void) { return g_latency_lanes.load(); }
 void bn254_set_latency_threshold(size_t n) { g_latency_threshold.store(n); }
+int bn254_last_kernel(int device, void* stream) {
+    if (device < 0 || device >= 64) return BN254_ERR_INVALID_ARG;
+    DeviceCtx& c = g_ctx[device];
+    std::lock_guard<std::mutex> lk(c.mu);
+    auto it = c.streams.find((hipStream_t)stream);
+    return it == c.streams.end() ? 0 : it->second->last_kernel;
+}
+int bn254_set_stream_latency(int device, void* stream, size_t threshold, int lanes) {
+    if (device < 0 || device >= 64 || !(lanes == -1 || lanes == 0 || lanes == 16 || lanes == 32 || lanes == 64)) return BN254_ERR_INVALID_ARG;
+    std::shared_ptr<StreamCtx> sc = stream_ctx(device, stream);      // (no HIP call: the setting may precede the first launch)
+    DeviceCtx& c = g_ctx[device];
+    std::lock_guard<std::mutex> lk(c.mu);
+    sc->lat_threshold = threshold;
+    sc->lat_lanes = lanes;
+    return BN254_OK;
+}
 size_t bn254_get_latency_threshold(void) { return g_latency_threshold.load(); }
 
 int bn254_pairing_batch_dev(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n, int device, void* stream) {
@@ -790,9 +841,31 @@ int bn254_check_points_dev(const uint64_t* g1, const uint64_t* g2, size_t n, int
     if (rc) return rc;
     size_t blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_check_points, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, g1, g2, n, c.status);
+    hipLaunchKernelGGL(k_check_points, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, g1, g2, n, c.status + 1);
     HIPCHK(hipGetLastError());
     return BN254_OK;
+}
+int bn254_check_points_ex_dev(const uint64_t* g1, const uint64_t* g2, size_t n, int flags, uint8_t* per_point, int device, void* stream) {
+    if (n == 0) return BN254_OK;
+    if (!g1 || !g2 || n >= (1ull << 29) || (flags & ~7) || !flags) return BN254_ERR_INVALID_ARG;
+    LaunchCtx c;
+    int rc = ctx_get(device, stream, 1, 1, &c);
+    if (rc) return rc;
+    static const bn254_chk::Consts K = BN254_CHK_CONSTS;
+    size_t blocks = (n + 63) / 64, cap = (size_t)c.n_cu * 32;       // one point per thread; wave-sized workgroups spread small batches over the CUs
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(bn254_chk::k_check_points_ex, dim3((uint32_t)blocks), dim3(64), 0, (hipStream_t)stream, g1, g2, n, flags, K, per_point, c.status + 1);
+    HIPCHK(hipGetLastError());
+    return BN254_OK;
+}
+int bn254_check_points_ex(const uint64_t* g1, const uint64_t* g2, size_t n, int flags, uint8_t* per_point, int device, void* stream) {
+    if (n == 0) return BN254_OK;
+    if (!g1 || !g2) return BN254_ERR_INVALID_ARG;
+    Stage s; uint64_t *d1, *d2, *d3 = nullptr; int rc;
+    if ((rc = s.init(device, stream)) || (rc = s.up(g1, 64 * n, &d1)) || (rc = s.up(g2, 128 * n, &d2)) || (per_point && (rc = s.up(nullptr, n, &d3)))) return rc;
+    if ((rc = bn254_check_points_ex_dev(d1, d2, n, flags, (uint8_t*)d3, device, stream))) return rc;
+    if (per_point && hipMemcpyAsync(per_point, d3, n, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return BN254_ERR_HIP;
+    return bn254_last_status(device, stream);
 }
 int bn254_check_points(const uint64_t* g1, const uint64_t* g2, size_t n, int device, void* stream) {
     if (n == 0) return BN254_OK;
@@ -901,8 +974,8 @@ int bn254_reserve(int device, void* stream, size_t n, size_t k) {
         if (hipEventCreateWithFlags(&ns.done, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(ns.host); return BN254_ERR_HIP; }
         sc->naf_ring.push_back(ns);
     }
-    if (!sc->status_host && hipHostMalloc((void**)&sc->status_host, sizeof(int), hipHostMallocDefault) != hipSuccess) return BN254_ERR_ALLOC;
-    if (g_latency_threshold.load())                    // the latency path's round programs (25 MB in all): small calls upload nothing later
+    if (!sc->status_host && hipHostMalloc((void**)&sc->status_host, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) return BN254_ERR_ALLOC;
+    if ((sc->lat_threshold == (size_t)-1 ? g_latency_threshold.load() : sc->lat_threshold) != 0)                    // the latency path's round programs (25 MB in all): small calls upload nothing later
         for (int prog = 0; prog < CVM_N_PROGRAMS; prog++)
             if ((rc = cvm_upload(device, prog))) return rc;
     return BN254_OK;

@@ -23,6 +23,8 @@ extern "C" {
     fn bn254_set_latency_lanes(lanes: c_int);
     fn bn254_get_latency_lanes() -> c_int;
     fn bn254_check_points(g1: *const u64, g2: *const u64, n: usize, device: c_int, stream: *mut c_void) -> c_int;
+    fn bn254_check_points_ex(g1: *const u64, g2: *const u64, n: usize, flags: c_int, per_point: *mut u8, device: c_int, stream: *mut c_void) -> c_int;
+    fn bn254_set_stream_latency(device: c_int, stream: *mut c_void, threshold: usize, lanes: c_int) -> c_int;
     fn bn254_pairing_sharded(g1: *const u64, g2: *const u64, out: *mut u64, n: usize, n_devices: c_int) -> c_int;
     // device pointers on devices[0] (NULL: devices 0..n_devices-1); shard i runs on devices[i]; synchronous
     #[allow(dead_code)]
@@ -130,7 +132,6 @@ fn fq12_from_ark_words(w: &[u64]) -> Fq12 {
     let f2 = |j: usize| Fq2::new(f(2 * j), f(2 * j + 1));
     Fq12::new(ark_bn254::Fq6::new(f2(0), f2(1), f2(2)), ark_bn254::Fq6::new(f2(3), f2(4), f2(5)))
 }
-/// New: whole batches in one launch (what the engine is for).  Output: MyFq12 per pairing.
 /// Sizes the library's per-(device, stream) buffers for calls of up to `n` lanes x `k` pairs on device 0 / the NULL stream
 /// (the ones every function of this shim uses): no later call of that size allocates device memory.
 pub fn reserve(n: usize, k: usize) { ok(unsafe { bn254_reserve(0, core::ptr::null_mut(), n, k) }) }
@@ -139,7 +140,7 @@ pub fn reserve(n: usize, k: usize) { ok(unsafe { bn254_reserve(0, core::ptr::nul
 /// `miller_loop_native`, `multi_miller_loop_native`, `final_exp_native`: one element per call) get by default; 0 turns it off.
 pub fn set_latency_threshold(n: usize) { unsafe { bn254_set_latency_threshold(n) } }
 pub fn latency_threshold() -> usize { unsafe { bn254_get_latency_threshold() } }
-/// 0 (default): thirty-two lanes per item for launches of at most one wave per SIMD, sixteen beyond; 16 / 32: fixed.
+/// 0 (default): sixty-four / thirty-two lanes per item while the launch is at most one wave per SIMD, sixteen beyond; 16 / 32 / 64: fixed.
 pub fn set_latency_lanes(lanes: i32) { unsafe { bn254_set_latency_lanes(lanes) } }
 pub fn latency_lanes() -> i32 { unsafe { bn254_get_latency_lanes() } }
 
@@ -152,6 +153,20 @@ pub fn check_points(ps: &[G1Affine], qs: &[G2Affine]) -> Result<(), i32> {
     match unsafe { bn254_check_points(g1.as_ptr(), g2.as_ptr(), ps.len(), 0, core::ptr::null_mut()) } { 0 => Ok(()), rc => Err(rc) }
 }
 
+/// The rest of ark's implicit contract, for untrusted points: `G2Affine::new` -- which the reference itself calls on the Frobenius images
+/// of Q (miller_loop_native.rs:303,311) -- panics unless the point is on the curve and in the r-torsion.  The engine computes a value for
+/// any coordinates; this runs its optional check (flags 1 | 2 | 4: infinity, on-curve, G2 subgroup) and panics like the reference would:
+/// `Err(-7 / -8 / -9)` = infinity / not on the curve / G2 not in the subgroup.
+pub fn check_points_full(ps: &[G1Affine], qs: &[G2Affine]) -> Result<(), i32> {
+    if ps.iter().any(|p| p.infinity) || qs.iter().any(|q| q.infinity) { return Err(-7); }
+    let (g1, g2) = (pack_g1(ps), pack_g2(qs));
+    match unsafe { bn254_check_points_ex(g1.as_ptr(), g2.as_ptr(), ps.len(), 7, core::ptr::null_mut(), 0, core::ptr::null_mut()) } { 0 => Ok(()), rc => Err(rc) }
+}
+/// Kernel selection of the NULL stream of device 0 (the stream this shim uses) alone, whatever other users of the library set
+/// process-wide: `threshold = usize::MAX` / `lanes = -1` return to the defaults.
+pub fn set_stream_latency(threshold: usize, lanes: i32) { ok(unsafe { bn254_set_stream_latency(0, core::ptr::null_mut(), threshold, lanes) }) }
+
+/// New: whole batches in one launch (what the engine is for).  Output: MyFq12 per pairing.
 pub fn pairing_batch(ps: &[G1Affine], qs: &[G2Affine]) -> Vec<MyFq12> {
     assert_eq!(ps.len(), qs.len()); let n = ps.len();
     let (g1, g2) = (elems_g1(ps), elems_g2(qs)); let mut out = vec![0u64; 48 * n];

@@ -1013,6 +1013,9 @@ class Program:
                     dw[5] = sum((co[4 + j] & 0xFF) << (8 * j) for j in range(4))
                     dw[6] = dst << 16
                 else:
+                    # the kernel writes the zero-divisor status under the mask of its output stores (role < 12: cvm_kernel.epilogue);
+                    # an inversion on a higher lane would lose its flag
+                    assert v is None or r < 12, "inv operation scheduled on a lane that cannot report a zero divisor"
                     dw[0] = v.args.slot if v is not None else one
                     dw[6] = dst << 16
                 row.append(dw)
