@@ -23,9 +23,10 @@ with the child's code; under the driver's own torch.distributed.run launch it re
 WORLD_SIZE / MASTER_* from the environment.
 
 The JSON line also carries
-  roofline     -- integer-VALU bound (2,286,160 mul32 of algorithmic work per pairing)
-                  against the calibrated v_mad_u64_u32 issue peak of gfx950 (tools/valu_calib.hip,
-                  profiles/valu_calib_r01.txt); kernel time from HIP events on the launch stream
+  roofline     -- integer-VALU bound (2,286,160 mul32 of algorithmic work per pairing):
+                  `frac` against the NOMINAL issue peak (1024 SIMDs x 2.4 GHz / 4 cycles x 64 lanes = 39.3 T mul32/s), and
+                  beside it the fraction of the v_mad_u64_u32 issue rate CALIBRATED ON THIS LEASE (tools/valu_calib --mad-only,
+                  a child process of this run); kernel time from HIP events on the launch stream
   cpu_baseline -- the C oracle (a port of the reference's schedule) timed on the host cores on a
                   bounded sample (single thread and all cores), rank 0, N = 1 only.
 The process exits non-zero (and prints no headline line) when the GPU results do not match the oracle.
@@ -54,8 +55,9 @@ NOMINAL_PEAK_MUL32_PER_S = 9.83e12
 NOMINAL_ISSUE_PEAK_MUL32_PER_S = 1024 * 2.4e9 / 4 * 64
 LOG2_SINGLE = 20                         # configs[2]
 LOG2_PER_GPU_MULTI = 21                  # configs[4]: 2^24 over 8 GPUs
-PMC_SUMMARY = os.environ.get("BENCH_PMC_SUMMARY", os.path.join(ROOT, "profiles", "r04_pmc.json"))
-PMC_SUMMARY_GROTH16 = os.environ.get("BENCH_PMC_SUMMARY_GROTH16", os.path.join(ROOT, "profiles", "r04_groth16_pmc.json"))
+PMC_SUMMARY = os.environ.get("BENCH_PMC_SUMMARY", os.path.join(ROOT, "profiles", "r05_pmc.json"))
+PMC_SUMMARY_GROTH16 = os.environ.get("BENCH_PMC_SUMMARY_GROTH16", os.path.join(ROOT, "profiles", "r05_groth16_pmc.json"))
+CALIB_R01_MUL32_PER_S = PEAK_MUL32_PER_S   # profiles/valu_calib_r01.txt (one box, round 1): kept for comparison with earlier rounds only
 KERNEL_HEADER = os.path.join(ROOT, "plonky2-bn254-pairing_amd", "csrc", "pairing_asm_gen.h")
 
 
@@ -187,6 +189,43 @@ def pmc_summary(log2, kern_avg_ms, path=None):
     return notes, None
 
 
+def calibrate_this_lease():
+    """The calibrated peak, re-taken on the lease this run has (round 5): tools/valu_calib --mad-only as a CHILD process (a pure
+    v_mad_u64_u32 stream at eight waves per SIMD, half a second, wall time from HIP events).  None (with the reason) when the binary
+    is missing or fails: the fraction of the nominal issue peak does not depend on it."""
+    exe = os.path.join(ROOT, "tools", "valu_calib")
+    if not os.path.exists(exe):
+        return None, "tools/valu_calib not built"
+    try:
+        p = subprocess.run([exe, "--mad-only", "--json"], capture_output=True, text=True, timeout=120)
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        if p.returncode != 0 or not line:
+            return None, f"tools/valu_calib failed (rc {p.returncode}): {(p.stdout + p.stderr)[-200:]}"
+        rec = json.loads(line[0])
+        rec["when"] = time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime())
+        rec["host"] = os.uname().nodename
+        return rec, None
+    except Exception as e:      # noqa: BLE001
+        return None, f"tools/valu_calib: {type(e).__name__}: {e}"
+
+
+def box_id():
+    """What identifies the box a line was measured on (the pool's boxes differ by a few per cent in the clock they hold)."""
+    info = {"host": os.uname().nodename}
+    try:
+        txt = subprocess.run(["rocm-smi", "--showuniqueid", "--showserial"], capture_output=True, text=True, timeout=10).stdout
+        import re
+        m = re.search(r"Unique ID:\s*(\S+)", txt)
+        if m:
+            info["gpu_unique_id"] = m.group(1)
+        m = re.search(r"Serial Number:\s*(\S+)", txt)
+        if m:
+            info["gpu_serial"] = m.group(1)
+    except Exception:           # noqa: BLE001
+        pass
+    return info
+
+
 # ------------------------------------------------------------------------------------------------ one rank
 def load_engine():
     """The HIP engine, or -- for the CPU launcher tests only -- an injected stand-in (BENCH_TEST_ENGINE=module:attr under tests/).
@@ -258,7 +297,7 @@ def spot_check(pkg, torch, g1, g2, out, n, positions, threads):
     return bool(np.array_equal(pkg.layout.to_aos(got, 48), want))
 
 
-def extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n, sample_power=False, scalar_latency=True):
+def extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n, sample_power=False, scalar_latency=True, calib_peak=None):
     """BASELINE.json configs[1] and configs[3] on one GPU (not the headline `value`); inputs: the resident 2^20 batch."""
     out = {}
 
@@ -279,8 +318,9 @@ def extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n, sample_power=F
     o = torch.zeros(48 * m, dtype=torch.int64, device=dev)
     ms = timed(lambda: pkg.pairing_batch_dev(s1, s2, o, m, device=local_rank, stream=stream), 10)
     out["configs[1]: 2^16 independent pairings"] = {"ms": ms, "pairings_per_s": m / (ms * 1e-3),
-                                                    "roofline_frac": m / (ms * 1e-3) * W_MUL32_PER_PAIRING / PEAK_MUL32_PER_S,
-                                                    "roofline_frac_of_nominal_issue_peak": m / (ms * 1e-3) * W_MUL32_PER_PAIRING / NOMINAL_ISSUE_PEAK_MUL32_PER_S}
+                                                    "roofline_frac": m / (ms * 1e-3) * W_MUL32_PER_PAIRING / NOMINAL_ISSUE_PEAK_MUL32_PER_S,
+                                                    "roofline_frac_of_calibrated_peak": (m / (ms * 1e-3) * W_MUL32_PER_PAIRING / calib_peak) if calib_peak else None,
+                                                    "roofline_frac_of_calibrated_peak_r01": m / (ms * 1e-3) * W_MUL32_PER_PAIRING / CALIB_R01_MUL32_PER_S}
     groups, k = 1 << 18, 4
     assert groups * k <= n
     o2 = torch.zeros(48 * groups, dtype=torch.int64, device=dev)
@@ -289,9 +329,11 @@ def extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n, sample_power=F
     notes, stale = pmc_summary(18, ms, PMC_SUMMARY_GROTH16)
     ipi = notes.get("valu_wave_insts_per_work_item")
     g16 = {"ms": ms, "groups_per_s": groups / (ms * 1e-3), "pairs_per_s": groups * k / (ms * 1e-3),
-           "roofline_frac": ach / PEAK_MUL32_PER_S, "kernel": "k_mpairing",
-           "roofline": {"bound": "valu-int32-mul", "achieved": ach / 1e12, "peak": PEAK_MUL32_PER_S / 1e12, "unit": "T mul32/s", "frac": ach / PEAK_MUL32_PER_S,
-                        "frac_of_nominal_issue_peak": ach / NOMINAL_ISSUE_PEAK_MUL32_PER_S, "nominal_issue_peak": NOMINAL_ISSUE_PEAK_MUL32_PER_S / 1e12,
+           "roofline_frac": ach / NOMINAL_ISSUE_PEAK_MUL32_PER_S, "kernel": "k_mpairing",
+           "roofline": {"bound": "valu-int32-mul", "achieved": ach / 1e12, "peak": NOMINAL_ISSUE_PEAK_MUL32_PER_S / 1e12, "unit": "T mul32/s",
+                        "frac": ach / NOMINAL_ISSUE_PEAK_MUL32_PER_S, "frac_of_nominal_issue_peak": ach / NOMINAL_ISSUE_PEAK_MUL32_PER_S,
+                        "frac_of_calibrated_peak": (ach / calib_peak) if calib_peak else None, "calibrated_peak_this_lease": (calib_peak / 1e12) if calib_peak else None,
+                        "frac_of_calibrated_peak_r01": ach / CALIB_R01_MUL32_PER_S,
                         "traffic": notes.get("hbm_bytes_per_launch_corrected"), "algorithmic_bytes_per_launch": (192 * k + 384) * groups,
                         "work_per_unit": f"{W_MUL32_PER_GROTH16_GROUP} mul32 per 4-pair group (SURVEY.md 8d)", "kernel": "k_mpairing", "kernel_ms_avg": ms,
                         "pmc_summary": os.path.relpath(PMC_SUMMARY_GROTH16, ROOT), "pmc_summary_kernel_ms": notes.get("kernel_ms_avg_rocprof"),
@@ -320,14 +362,14 @@ def extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n, sample_power=F
     out["layout kernels at 2^20 elements (roofline bound: hbm, 8 TB/s)"] = lay
     # the reference's functions are SCALAR (one pairing / one group per call): wall time of one call on one item, launch to completion,
     # on the throughput kernel (one item per lane) and on the lane-cooperative kernel that small batches take
-    if scalar_latency and hasattr(pkg, "set_latency_threshold"):
+    if scalar_latency and hasattr(pkg, "set_stream_latency"):
         import time as _t
-        keep = pkg.get_latency_threshold()
+        # the kernel selection of THIS stream only (bn254_set_stream_latency): the process-wide defaults are not touched
         o4 = torch.zeros(48, dtype=torch.int64, device=dev)
         f4 = torch.zeros(48, dtype=torch.int64, device=dev)
         one = lambda t, planes, cnt: t.view(planes, n)[:, :cnt].contiguous().view(-1)
         p1, q1, p4, q4 = one(g1, 8, 1), one(g2, 16, 1), one(g1, 8, 4), one(g2, 16, 4)
-        pkg.set_latency_threshold(0)
+        pkg.set_stream_latency(0, -1, local_rank, stream)
         pkg.miller_loop_batch_dev(p1, q1, f4, 1, device=local_rank, stream=stream)
         calls = {"pairing(p, q)": lambda: pkg.pairing_batch_dev(p1, q1, o4, 1, device=local_rank, stream=stream),
                  "miller_loop_native(q, p)": lambda: pkg.miller_loop_batch_dev(p1, q1, o4, 1, device=local_rank, stream=stream),
@@ -337,7 +379,7 @@ def extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n, sample_power=F
         for name, fn in calls.items():
             row = {}
             for kern, thr in (("throughput_kernel_ms", 0), ("lane_cooperative_kernel_ms", 1 << 20)):
-                pkg.set_latency_threshold(thr)
+                pkg.set_stream_latency(thr, -1, local_rank, stream)
                 ts = []
                 for _ in range(7):
                     torch.cuda.synchronize(dev)
@@ -350,7 +392,7 @@ def extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n, sample_power=F
                 row["same_limbs"] = bool(torch.equal(row["_ref"], o4))
             del row["_ref"]
             lat[name] = row
-        pkg.set_latency_threshold(keep)
+        pkg.set_stream_latency(pkg.LATENCY_INHERIT, -1, local_rank, stream)
         out["scalar signatures: one item per call, wall ms (launch to completion, inputs resident)"] = lat
     pkg.last_status(local_rank, stream)
     return out
@@ -497,6 +539,8 @@ def run_rank(args):
         achieved = per_gpu_rate * W_MUL32_PER_PAIRING
         notes, stale = pmc_summary(log2, kern_avg_ms)
         traffic = notes.get("hbm_bytes_per_launch_corrected")
+        calib, calib_err = calibrate_this_lease() if (on_gpu and not os.environ.get("BENCH_NO_CALIB")) else (None, "not measured (test engine or BENCH_NO_CALIB)")
+        calib_peak = calib["mul32_per_s"] if calib else None
         insts_per_item = notes.get("valu_wave_insts_per_work_item")        # wave-instructions per 64 pairings (one wave's lanes)
         cfg_name = "configs[2]" if (not multi and log2 == 20) else ("configs[4]" if (world > 1 and log2 == 21) else "custom size")
         rec = {
@@ -505,13 +549,19 @@ def run_rank(args):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "i32 limbs (254-bit Montgomery field, signed reduced-radix limbs, 32x32->64 integer multiply-add on the VALU)",
             "data": "synthetic: on-device [s]G1, [t]G2 subgroup points, SplitMix64 scalars, seed 0xB2540001" + (" [TEST ENGINE, not a measurement]" if test_engine else ""),
+            "box": box_id() if on_gpu else None,
             "config": {"workload": f"2^{log2} independent pairings per GPU per step, {world} GPU(s): BASELINE.json {cfg_name}; "
                                    f"pairing() = final_exp_native(miller_loop_native)",
                        "pairings_per_gpu": n, "pairings_total": n_total, "layout": "SoA limb-major u64 Montgomery, inputs resident in HBM",
                        "ranks_share_one_gpu": bool(on_gpu and world > 1 and os.environ.get("BENCH_SHARE_GPU")),
                        "sharding": None if not multi else "contiguous slices per rank, scattered from / gathered to rank 0 over RCCL outside the timed steps; no data-path collective"},
-            "roofline": {"bound": "valu-int32-mul", "achieved": achieved / 1e12, "peak": PEAK_MUL32_PER_S / 1e12, "unit": "T mul32/s",
-                         "frac": achieved / PEAK_MUL32_PER_S, "traffic": traffic,
+            "roofline": {"bound": "valu-int32-mul", "achieved": achieved / 1e12, "peak": NOMINAL_ISSUE_PEAK_MUL32_PER_S / 1e12, "unit": "T mul32/s",
+                         "frac": achieved / NOMINAL_ISSUE_PEAK_MUL32_PER_S, "traffic": traffic,
+                         "peak_note": "the NOMINAL integer multiply-add issue peak: 1024 SIMDs x 2.4 GHz / 4 cycles x 64 lanes = 39.3 T mul32/s (the MI355X guide has "
+                                      "no integer-VALU figure); the peak a pure multiply-add stream actually reaches on THIS lease is measured beside it "
+                                      "(peaks.calibrated_this_lease, frac_of_calibrated_peak)",
+                         "frac_of_calibrated_peak": (achieved / calib_peak) if calib_peak else None,
+                         "frac_of_calibrated_peak_r01": achieved / CALIB_R01_MUL32_PER_S,
                          "achieved_note": "work-normalised: SURVEY.md 8(d)'s algorithmic mul32 per pairing x pairings/s (kernel time from HIP events), "
                                           "not the multiply-adds the kernel executes",
                          "traffic_note": f"HBM bytes per launch from the committed PMC summary {os.path.relpath(PMC_SUMMARY, ROOT)} (separate --pmc passes of this "
@@ -523,8 +573,11 @@ def run_rank(args):
                          "work_per_unit": f"{W_MUL32_PER_PAIRING} mul32 = {W_FQMUL_PER_PAIRING} fqmul x 136 per pairing (SURVEY.md 8d)",
                          "frac_of_nominal_quarter_rate_peak": achieved / NOMINAL_PEAK_MUL32_PER_S,
                          "frac_of_nominal_issue_peak": achieved / NOMINAL_ISSUE_PEAK_MUL32_PER_S,
-                         "peaks": {"calibrated": {"value": PEAK_MUL32_PER_S / 1e12, "frac": achieved / PEAK_MUL32_PER_S,
-                                                  "what": "measured v_mad_u64_u32 issue rate, 8 waves/SIMD, at the clock the package holds under that load (profiles/valu_calib_r01.txt)"},
+                         "peaks": {"calibrated_this_lease": None if not calib else dict(calib, value=calib_peak / 1e12, frac=achieved / calib_peak),
+                                   "calibrated_this_lease_missing": calib_err,
+                                   "calibrated_r01": {"value": CALIB_R01_MUL32_PER_S / 1e12, "frac": achieved / CALIB_R01_MUL32_PER_S,
+                                                      "what": "round 1's single measurement on another box (profiles/valu_calib_r01.txt): the denominator of the fractions "
+                                                              "quoted in rounds 1-4, kept for comparison only"},
                                    "nominal_issue": {"value": NOMINAL_ISSUE_PEAK_MUL32_PER_S / 1e12, "frac": achieved / NOMINAL_ISSUE_PEAK_MUL32_PER_S,
                                                      "what": "1024 SIMDs x 2.4 GHz / 4 cycles x 64 lanes"}, "unit": "T mul32/s"},
                          "valu_issue": None if not insts_per_item else {
@@ -577,7 +630,7 @@ def run_rank(args):
                 rc = 3
         if rc == 0 and on_gpu and not multi and not args.no_extra and log2 == LOG2_SINGLE:
             rec["extra"] = extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n, sample_power=power is not None,
-                                           scalar_latency=not args.no_scalar_latency)
+                                           scalar_latency=not args.no_scalar_latency, calib_peak=calib_peak)
         if rc == 0 and on_gpu and not multi and not args.no_cpu_baseline:
             m = min(n, 1 << 15)
             g1h = g1.view(8, n)[:, :m].cpu().numpy().view(np.uint64).reshape(-1).copy()

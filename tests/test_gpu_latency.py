@@ -1,6 +1,7 @@
 """The lane-cooperative (latency) kernel of pairing() -- sixteen lanes per pairing, tools/cvm.py -- against the golden vectors,
 the C oracle and the throughput kernel: identical limbs on every lane, for batch sizes around the group / wave / grid edges.
-Which kernel a call takes is the library's threshold (bn254_set_latency_threshold): the tests pin it per call."""
+Which kernel a call takes is the stream's own setting (bn254_set_stream_latency) where it has one, else the process-wide default
+(bn254_set_latency_threshold / _lanes): the tests pin the NULL stream's setting per call and never touch the defaults."""
 import numpy as np
 import pytest
 
@@ -11,47 +12,72 @@ pytestmark = pytest.mark.gpu
 HX = lambda xs: [int(x, 16) for x in xs]
 
 
+class _Pinned:
+    """The package with the kernel selection of ONE stream -- the NULL stream of device 0, which every call of this file uses -- in the
+    test's hands (bn254_set_stream_latency): `set_latency_threshold` here pins that stream's threshold and the fixture's program family;
+    the process-wide defaults are never touched (round 4 flipped them around every call)."""
+
+    def __init__(self, p, lanes):
+        self._p, self._lanes = p, lanes
+
+    def __getattr__(self, k):
+        return getattr(self._p, k)
+
+    def set_latency_threshold(self, thr):
+        self._p.set_stream_latency(thr, self._lanes, 0, None)
+
+
 @pytest.fixture(params=[16, 32, 64], ids=["16-lanes", "32-lanes", "64-lanes"])
 def pk(request):
-    """the package with the lane-cooperative program family pinned (sixteen / thirty-two lanes per item; functions without a
-    program of the family take the next smaller one); threshold and family are restored afterwards"""
+    """the package with the lane-cooperative program family pinned on the NULL stream (sixteen / thirty-two / sixty-four lanes per
+    item; functions without a program of the family take the next smaller one); the stream returns to the defaults afterwards"""
     p = H.pkg()
-    old = p.get_latency_threshold()
-    p.set_latency_lanes(request.param)
-    yield p
-    p.set_latency_threshold(old)
-    p.set_latency_lanes(0)
+    keep = (p.get_latency_threshold(), p.get_latency_lanes())
+    yield _Pinned(p, request.param)
+    p.set_stream_latency(p.LATENCY_INHERIT, -1, 0, None)
+    assert (p.get_latency_threshold(), p.get_latency_lanes()) == keep
 
 
-def test_threshold_is_settable(pk):
-    pk.set_latency_threshold(12345)
-    assert pk.get_latency_threshold() == 12345
-    pk.set_latency_threshold(0)
-    assert pk.get_latency_threshold() == 0
-    for lanes, want in ((16, 16), (32, 32), (64, 64), (0, 0), (7, 0)):
-        pk.set_latency_lanes(lanes)
-        assert pk.get_latency_lanes() == want
+def test_threshold_is_settable():
+    """the process-wide DEFAULTS (what a stream without a setting of its own follows)"""
+    pk = H.pkg()
+    keep = (pk.get_latency_threshold(), pk.get_latency_lanes())
+    try:
+        pk.set_latency_threshold(12345)
+        assert pk.get_latency_threshold() == 12345
+        pk.set_latency_threshold(0)
+        assert pk.get_latency_threshold() == 0
+        for lanes, want in ((16, 16), (32, 32), (64, 64), (0, 0), (7, 0)):
+            pk.set_latency_lanes(lanes)
+            assert pk.get_latency_lanes() == want
+    finally:
+        pk.set_latency_threshold(keep[0])
+        pk.set_latency_lanes(keep[1])
 
 
 def test_program_family_follows_the_launch_size():
-    """default (0): thirty-two lanes per item up to one wave per SIMD, sixteen beyond -- same limbs either way, on both sides of the edge"""
+    """lanes = 0: sixty-four / thirty-two lanes per item up to one wave per SIMD, sixteen beyond -- same limbs either way, on both sides of the edge"""
     import torch
     pk = H.pkg()
     assert pk.get_latency_lanes() == 0
-    old = pk.get_latency_threshold()
     try:
-        for n in (2047, 2048, 2049, 3000):
+        seen = {}
+        for n in (1024, 1025, 2047, 2048, 2049, 3000):
             g1, g2 = _dev_pairs(pk, n, 0x5EED + n)
             outs = []
             for thr in (0, 1 << 20):
                 o = torch.empty(48 * n, dtype=torch.int64, device=torch.device("cuda:0"))
-                pk.set_latency_threshold(thr)
+                pk.set_stream_latency(thr, 0, 0, None)
                 pk.pairing_batch_dev(g1, g2, o, n)
                 outs.append(o)
+                seen[(n, thr)] = pk.last_kernel(0, None)
             pk.last_status()
             assert torch.equal(outs[0], outs[1]), n
+        assert all(seen[(n, 0)] == 1 for n in (1024, 2048, 3000))
+        assert seen[(1024, 1 << 20)] == 64 and seen[(1025, 1 << 20)] == 32 and seen[(2048, 1 << 20)] == 32
+        assert seen[(2049, 1 << 20)] == 16 and seen[(3000, 1 << 20)] == 16
     finally:
-        pk.set_latency_threshold(old)
+        pk.set_stream_latency(pk.LATENCY_INHERIT, -1, 0, None)
 
 
 def test_golden_vectors_on_the_latency_kernel(pk):

@@ -155,7 +155,54 @@ template <int K> static int run(const Kind& kd, uint64_t* dbuf, int iters) {
     return 0;
 }
 
-int main() {
+// --mad-only [--json]: the one figure bench.py's roofline needs, re-taken on THIS lease -- the chip-wide issue rate of a pure
+// v_mad_u64_u32 stream (the 32 x 32 + 64 multiply-add every limb product of the pairing kernels is; the signed form v_mad_i64_i32
+// issues at the same rate) at eight waves per SIMD, held for about half a second so that the package settles at the clock its power
+// limit allows under that load; the mean of the second half of the launches counts.
+static int mad_only(bool json) {
+    hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+    const int threads = 1024, lds = 72 * 1024, blocks = 256 * 2 * 4, iters = 8192, launches = 16;
+    size_t nthreads = (size_t)blocks * threads;
+    uint64_t* dbuf; CK(hipMalloc(&dbuf, nthreads * 2 * 8));
+    CK(hipFuncSetAttribute((const void*)k_calib<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(k_calib<0>, dim3(blocks), dim3(threads), lds, 0, dbuf, iters / 4);
+    CK(hipDeviceSynchronize());
+    std::vector<hipEvent_t> ev(launches + 1);
+    for (auto& evt : ev) CK(hipEventCreate(&evt));
+    CK(hipEventRecord(ev[0]));
+    for (int l = 0; l < launches; l++) {
+        hipLaunchKernelGGL(k_calib<0>, dim3(blocks), dim3(threads), lds, 0, dbuf, iters);
+        CK(hipEventRecord(ev[l + 1]));
+    }
+    CK(hipDeviceSynchronize());
+    std::vector<uint64_t> h(nthreads * 2);
+    CK(hipMemcpy(h.data(), dbuf, h.size() * 8, hipMemcpyDeviceToHost));      // stamps of the LAST launch
+    std::vector<double> clk;
+    for (size_t w = 0; w < nthreads / 64; ++w) clk.push_back((double)h[2 * (w * 64)] / ((double)h[2 * (w * 64) + 1] * 10.0));
+    std::sort(clk.begin(), clk.end());
+    double n_inst = (double)iters * 64, waves = (double)(nthreads / 64), sum = 0, best = 0, worst = 1e30;
+    for (int l = launches / 2; l < launches; l++) {
+        float ms = 0; CK(hipEventElapsedTime(&ms, ev[l], ev[l + 1]));
+        double g = n_inst * waves / (ms * 1e-3);
+        sum += g; best = std::max(best, g); worst = std::min(worst, g);
+    }
+    double rate = sum / (launches - launches / 2);
+    if (json)
+        printf("{\"what\": \"v_mad_u64_u32 x8 independent chains, 8 waves/SIMD, %d launches of %d x 64 instructions per wave, mean of the second half (wall, HIP events)\", "
+               "\"wave_inst_per_s\": %.6e, \"mul32_per_s\": %.6e, \"best\": %.6e, \"worst\": %.6e, \"in_kernel_clock_ghz_median\": %.4f, "
+               "\"device\": \"%s\", \"cus\": %d, \"nominal_clock_khz\": %d}\n",
+               launches, iters, rate, rate * 64, best, worst, clk[clk.size() / 2], prop.name, prop.multiProcessorCount, prop.clockRate);
+    else
+        printf("v_mad_u64_u32 x8 indep  w/SIMD=8  wall Gwave-inst/s=%8.2f (best %8.2f, worst %8.2f)  clk(GHz)=%5.3f\n", rate / 1e9, best / 1e9, worst / 1e9,
+               clk[clk.size() / 2]);
+    CK(hipFree(dbuf));
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    bool only = false, json = false;
+    for (int i = 1; i < argc; i++) { only |= std::string(argv[i]) == "--mad-only"; json |= std::string(argv[i]) == "--json"; }
+    if (only) return mad_only(json);
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     printf("device: %s  CUs=%d  clock=%d kHz\n", prop.name, prop.multiProcessorCount, prop.clockRate);
     uint64_t* dbuf; CK(hipMalloc(&dbuf, (size_t)256 * 2 * 4 * 1024 * 2 * 8));
