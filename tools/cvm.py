@@ -35,6 +35,9 @@ from asmcore import P_INT, BN_X, SIX_U_PLUS_2_NAF  # noqa: E402
 P = P_INT
 XI = (9, 1)
 ARR_G1, ARR_G2, ARR_F, ARR_NONE = 0, 1, 2, 3
+BANK_AWARE = bool(int(os.environ.get("CVM_BANKS", "1")))       # LDS slots by liveness and bank class (Program._allocate_banked)
+BANK_SLACK = int(os.environ.get("CVM_BANK_SLACK", "0"))        # slots the class-aware assignment may use beyond the liveness-only count
+N_TRASH = int(os.environ.get("CVM_TRASH", "1"))      # trash slots per item (Program.encode)
 MAX_LIN_SRC = 6             # sources of an Fq2-level combination (the Fq operation it lowers to takes eight terms)
 
 
@@ -913,7 +916,144 @@ class Program:
                         ready.append(u)
         self.rounds = rounds
 
+    # -------------------------------------------------------------- LDS slots by liveness AND bank (round 5)
+    # A round's operand fetch is one ds_read per operand part, executed by all lanes, each with its own slot address.  Measured
+    # (tools/lds_bank_calib.hip, profiles/r05_lds_bank_calib.txt): with ONE wave on the CU a read whose lanes name random slots costs
+    # 22.5 cycles against 19.5 for sixteen consecutive slots -- nothing to gain -- but the LDS pipe is shared by the waves of a CU, and
+    # with FOUR waves (every launch of more than 768 waves) the same random pattern costs 44 cycles per read per wave against 21 for the
+    # conflict-free one: the pipe, not the issue slots, then bounds the chain rounds (eight reads and six writes for 160 instructions).
+    # So slots are assigned by liveness and by CLASS = slot mod 16: the values that the sixteen lanes of a group fetch in ONE read
+    # (same round, same operand position) should sit in sixteen different classes -- 48-byte slots of different classes lie in
+    # different 16-byte bank groups (3 is odd), 32-byte slots (the split layout) two per bank group, which is free.
+    N_CLASS = 16
+
+    def _operand_positions(self, v):
+        """[(position in the row, FV)] of the slots operation v reads (Program.encode's layout)"""
+        if v.kind == "mul":
+            t, add = v.args
+            out = []
+            for i, (x, y) in enumerate(t):
+                out += [(2 * i, x), (2 * i + 1, y)]
+            if add is not None:
+                out.append((12, add))
+            return out
+        if v.kind == "lin":
+            return [(i, s_) for i, (s_, _) in enumerate(v.args)]
+        return [(0, v.args)]
+
+    def _access_sets(self):
+        """{key: [FV]}: the values (distinct ones: lanes naming the same slot are served together) that the lanes of one sixteen-lane
+        block touch with one LDS instruction -- an operand position of a round, or the round's result / twin stores"""
+        sets = {}
+        for rnd, (kind, take) in enumerate(self.rounds):
+            for r, v in enumerate(take):
+                blk = r // 16
+                for pos, s_ in self._operand_positions(v):
+                    sets.setdefault((rnd, pos, blk), {})[s_.id] = s_
+                sets.setdefault((rnd, "w", blk), {})[v.id] = v
+                if v.twin is not None:
+                    sets.setdefault((rnd, "t", blk), {})[v.twin.id] = v.twin
+        return {k: list(d.values()) for k, d in sets.items()}
+
+    def conflict_stats(self):
+        """(accesses, lanes beyond the first in a class) over all access sets: what the assignment leaves"""
+        n = extra = 0
+        for mem in self._access_sets().values():
+            per = {}
+            for v in mem:
+                per[v.slot % self.N_CLASS] = per.get(v.slot % self.N_CLASS, 0) + 1
+            n += len(mem)
+            extra += sum(c - 1 for c in per.values())
+        return n, extra
+
+    def _allocate_banked(self, cap):
+        """slots by liveness and class; at most `cap` slots (rows of sixteen are opened while the total stays below it)"""
+        low, NC = self.low, self.N_CLASS
+        n_rounds = len(self.rounds)
+        sets = self._access_sets()
+        keys_of = {}
+        for k, mem in sets.items():
+            for v in mem:
+                keys_of.setdefault(v.id, []).append(k)
+        cls = {}
+
+        def cost(v, c):
+            return sum(1 for k in keys_of.get(v.id, ()) for m in sets[k] if m.id != v.id and cls.get(m.id) == c)
+
+        for v in low.fv:
+            if v.id in self.live:
+                v.last = max((u.rnd for u in v.users if u.kind != "negof"), default=-1)
+        for o in low.outputs:
+            o.last = n_rounds
+        # constants: the kernel copies them to slots [0, n_const): a permutation inside that range, most-read first
+        consts = [v for v in low.fv if v.kind == "const" and v.id in self.live]
+        self.n_const = len(consts)
+        free_c = list(range(self.n_const))
+        for v in sorted(consts, key=lambda v: -len(keys_of.get(v.id, ()))):
+            best = min(free_c, key=lambda s_: (cost(v, s_ % NC), s_))
+            free_c.remove(best)
+            v.slot = best
+            cls[v.id] = best % NC
+        nxt = self.n_const
+        free = {c: [] for c in range(NC)}           # free slots by class
+        top = [self.n_const]                        # slots [0, top) exist
+
+        def take_slot(v):
+            ranked = sorted(range(NC), key=lambda c: (cost(v, c), c))
+            c0 = cost(v, ranked[0])
+            for c in ranked:
+                if free[c]:
+                    # a free slot of a class that is as good as the best one, or (when the best classes are full) the best free one
+                    if cost(v, c) == c0 or top[0] >= cap:
+                        s_ = min(free[c])
+                        free[c].remove(s_)
+                        return s_
+            # the best classes have no free slot and there is room: open slots up to the next one of the best class
+            want = ranked[0]
+            while top[0] < cap:
+                s_ = top[0]
+                top[0] += 1
+                if s_ % NC == want:
+                    return s_
+                free[s_ % NC].append(s_)
+            for c in ranked:
+                if free[c]:
+                    s_ = min(free[c])
+                    free[c].remove(s_)
+                    return s_
+            s_ = top[0]                              # over the cap: the program needs more slots than that
+            top[0] += 1
+            return s_
+
+        for v in low.inputs:
+            v.slot = take_slot(v)
+            cls[v.id] = v.slot % NC
+        self.first_dyn = top[0]
+        expire = {}
+        for rnd, (kind, take) in enumerate(self.rounds):
+            for s_ in expire.pop(rnd, []):
+                free[s_ % NC].append(s_)
+            for v in take:
+                for w in (v, v.twin):
+                    if w is None:
+                        continue
+                    if w.last <= rnd and w.last < n_rounds:
+                        assert w is v and v.twin is not None, (w.kind, w.id)
+                    w.slot = take_slot(w)
+                    cls[w.id] = w.slot % NC
+                    if w.last < n_rounds:
+                        expire.setdefault(max(w.last, rnd) + 1, []).append(w.slot)
+        self.n_slots = top[0]
+
     def _allocate(self):
+        if BANK_AWARE:
+            self._allocate_plain()
+            base = self.n_slots
+            self._allocate_banked(base + BANK_SLACK)
+            return
+        self._allocate_plain()
+
+    def _allocate_plain(self):
         low = self.low
         nxt = 0
         for v in low.fv:                        # constants first, then inputs: fixed slots
@@ -985,7 +1125,9 @@ class Program:
         zero = self.low.zero.slot
         one = self.low.const(1).slot
         assert one is not None
-        trash = self.n_slots
+        # lanes without work and results without a twin write a TRASH slot; N_TRASH of them, lane r takes number r mod N_TRASH (sixteen lanes
+        # storing to ONE address are a sixteen-way conflict in the LDS: CVM_TRASH, measured in profiles/r05_latency_ab.txt)
+        trash0 = self.n_slots
         kinds, rows = [], []
         for kind, take in self.rounds:
             kinds.append(kind)
@@ -993,6 +1135,7 @@ class Program:
             for r in range(self.nr):
                 dw = [0] * 8
                 v = take[r] if r < len(take) else None
+                trash = trash0 + r % N_TRASH
                 dst = v.slot if v is not None else trash
                 twin = v.twin.slot if v is not None and v.twin is not None else trash
                 dw[7] = twin | kind << 16
@@ -1026,14 +1169,14 @@ class Program:
             if v.kind == "const" and v.id in self.live:
                 consts[v.slot] = v.args
         return {"kinds": kinds, "rows": rows, "consts": consts, "inputs": [(v.slot,) + tuple(v.args[1:]) for v in self.low.inputs],
-                "outputs": [v.slot for v in self.low.outputs], "n_slots": self.n_slots + 1, "nr": self.nr}
+                "outputs": [v.slot for v in self.low.outputs], "n_slots": self.n_slots + N_TRASH, "trash": trash0, "nr": self.nr}
 
     def stats(self):
         from collections import Counter
         c = Counter(KIND_NAME[k] for k, _ in self.rounds)
         instr = sum(COST[k] for k, _ in self.rounds)
         fill = sum(len(t) for _, t in self.rounds) / (self.nr * len(self.rounds))
-        return {"rounds": len(self.rounds), "by_kind": dict(c), "instr_est": instr, "fill": round(fill, 3), "slots": self.n_slots + 1,
+        return {"rounds": len(self.rounds), "by_kind": dict(c), "instr_est": instr, "fill": round(fill, 3), "slots": self.n_slots + N_TRASH,
                 "consts": self.n_const, "ops": len(self.ops)}
 
 

@@ -49,6 +49,7 @@ POOL_FIRST, POOL_LAST = 150, 203
 ROWN = 228
 INV_SAFEGCD = bool(int(os.environ.get("CVM_INV_SAFEGCD", "1")))  # the inversion by divsteps instead of the Fermat chain
 OVERLAP = bool(int(os.environ.get("CVM_OVERLAP", "1")))      # operand limbs that a pass needs late are fetched inside it
+ADDR16 = bool(int(os.environ.get("CVM_ADDR16", "1")))        # slot addresses by v_mad_u32_u16 with op_sel straight from the packed row (one instruction instead of two / three)
 V_LBASE, V_ROWOFF, V_ROLE, V_ITEM8, V_FLAG, V_T0, V_DST, V_TWIN, V_VALID, V_T1 = 236, 237, 238, 239, 240, 241, 242, 243, 244, 245
 V_ELEM, V_DESC = 246, 247
 S_BLOB, S_ROWS, S_NROUNDS, S_KIND, S_NCONST, S_NSLOTS, S_TMP = "s[48:49]", "s[50:51]", 52, 53, 65, 66, 67
@@ -101,6 +102,15 @@ class VMKernel:
 
     def slot_addr(self, dst, row_reg, hi):
         e = self.e
+        if ADDR16:
+            # one instruction per address: slot number (a 16-bit half of the row dword, picked by op_sel) x slot bytes + the group's base
+            h = 1 if hi else 0
+            if self.split:
+                e.emit(f"v_mad_u32_u16 v{dst[0]}, v{row_reg}, 32, v{V_LBASE} op_sel:[{h},0,0,0]", vw=[dst[0]])
+                e.emit(f"v_mad_u32_u16 v{dst[1]}, v{row_reg}, 4, v{V_LTOP} op_sel:[{h},0,0,0]", vw=[dst[1]])
+            else:
+                e.emit(f"v_mad_u32_u16 v{dst[0]}, v{row_reg}, {SLOT_BYTES}, v{V_LBASE} op_sel:[{h},0,0,0]", vw=[dst[0]])
+            return
         if hi:
             e.emit(f"v_lshrrev_b32_e32 v{V_T0}, 16, v{row_reg}", vw=[V_T0])
         else:
@@ -484,7 +494,7 @@ def make_blob(enc):
     NR = enc["nr"]
     assert NR in (16, 32, 64)
     n_rounds = len(enc["rows"])
-    trash = enc["n_slots"] - 1
+    trash = enc.get("trash", enc["n_slots"] - 1)
     ins = [slot | fq << 16 | arr << 20 | pair << 22 for slot, arr, fq, pair in enc["inputs"]]
     assert all(fq < 16 and pair < 64 for _, _, fq, pair in enc["inputs"])
     while len(ins) % NR:

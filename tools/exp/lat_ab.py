@@ -24,19 +24,26 @@ def main():
     libs = [("shipped", pk.load_library())] + [(os.path.basename(p), pk.load_library(p)) for p in sys.argv[1:]]
     for n in sizes:
         pk.generate_pairs_dev(0xB2540001, g1, g2, n)
-        for name, lib in libs:
-            lib.bn254_set_latency_threshold(1 << 30)
-            dst = ref if name == "shipped" else out
-            ts = []
-            for i in range(8):
-                t0 = time.perf_counter()
-                rc = lib.bn254_pairing_batch_dev(g1.data_ptr(), g2.data_ptr(), dst.data_ptr(), n, 0, st)
-                torch.cuda.synchronize()
-                ts.append(time.perf_counter() - t0)
-                assert rc == 0
-            lib.bn254_last_status(0, st)
-            same = bool(torch.equal(out[:48 * n], ref[:48 * n])) if name != "shipped" else True
-            print(f"n={n:6d} {name:28s} {min(ts[2:]) * 1e3:9.4f} ms  same={same}", flush=True)
+        best = {name: 1e9 for name, _ in libs}
+        same = {name: True for name, _ in libs}
+        for rnd in range(4):                    # the libraries take turns (and the order rotates): no library is always the first after an idle gap
+            order = libs[rnd % len(libs):] + libs[:rnd % len(libs)]
+            for name, lib in order:
+                lib.bn254_set_latency_threshold(1 << 30)
+                dst = ref if name == "shipped" else out
+                ts = []
+                for i in range(6):
+                    t0 = time.perf_counter()
+                    rc = lib.bn254_pairing_batch_dev(g1.data_ptr(), g2.data_ptr(), dst.data_ptr(), n, 0, st)
+                    torch.cuda.synchronize()
+                    ts.append(time.perf_counter() - t0)
+                    assert rc == 0
+                lib.bn254_last_status(0, st)
+                if name != "shipped" and rnd > 0:
+                    same[name] = same[name] and bool(torch.equal(out[:48 * n], ref[:48 * n]))
+                best[name] = min(best[name], min(ts[2:]))
+        for name, _ in libs:
+            print(f"n={n:6d} {name:28s} {best[name] * 1e3:9.4f} ms  same={same[name]}", flush=True)
 
 
 if __name__ == "__main__":

@@ -378,6 +378,16 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None, start_pc=None, 
             elif op == "v_mad_u32_u24":
                 m.vset(a[0], (m.vsrc(a[1]) & 0xFFFFFF) * (m.vsrc(a[2]) & 0xFFFFFF) + m.vsrc(a[3]))
                 m.count_valu += 1
+            elif op == "v_mad_u32_u16":            # D = S0.u16 * S1.u16 + S2.u32; op_sel:[h0,h1,0,0] takes the HIGH halves of S0 / S1
+                last, _, mod = a[3].partition(" ")
+                sel = [int(x) for x in re.search(r"op_sel:\[([0-9,]+)\]", mod).group(1).split(",")] if "op_sel" in mod else [0, 0, 0, 0]
+                if sel[2] or sel[3]:
+                    raise SimError("v_mad_u32_u16: op_sel on the 32-bit operands")
+                x, y = m.vsrc(a[1]), m.vsrc(a[2])
+                x = (x >> 16) & 0xFFFF if sel[0] else x & 0xFFFF
+                y = (y >> 16) & 0xFFFF if sel[1] else y & 0xFFFF
+                m.vset(a[0], x * y + m.vsrc(last))
+                m.count_valu += 1
             elif op == "v_lshrrev_b64":
                 r = m.vsrc64(a[2]) >> (m.vsrc(a[1]) & 63)
                 lo = int(re.match(r"v\[(\d+):", a[0]).group(1))
