@@ -338,6 +338,20 @@ def test_multi_pairing_kernel_resident_points(vec):
     assert out == HX(g["miller"])
 
 
+def test_multi_pairing_kernel_untracked_with_final_exp(vec):
+    """k_mpairing itself (k = 4, untracked, final exponentiation on the shared f): the kernel whose streamed loop keeps pair 0's R and
+    -- round 5 -- pair 1's X and Y on chip (LDS slots 2 and 7; pair 3's packed evaluation point moves into the LDS behind the eight
+    slots and two VGPRs).  Expected value: final_exp_native of the golden multi_miller_loop_native value."""
+    g = vec["groups"][3]
+    k, idx = g["k"], g["idx"]
+    assert k == 4
+    kb = K4P.KernelBuilder(do_miller=True, do_fexp=True, track=False, multi=True)
+    assert len(kb.r1_slots()) == 2 and kb.p3_moved()
+    g1, g2 = _soa([HX(vec["g1"][i]) for i in idx]), _soa([HX(vec["g2"][i]) for i in idx])
+    out, m = run_kernel(kb, g1, g2, k=k)
+    assert out == R.final_exp_native(HX(g["miller"])) and STAT not in m.gmem
+
+
 def test_multi_pairing_kernel_streamed_points(vec):
     """k = 5: more pairs than stay on chip -- P travels with R through the prefetch buffer, Q is fetched in the addition steps.
     Expected value: the product of the single Miller values (the reference's own T1, miller_loop_native.rs:336-348)."""

@@ -177,6 +177,9 @@ EXP_NO_PREFETCH = bool(int(os.environ.get("KGEN_EXP_NO_PREFETCH", "0")))
 SCRATCH_LD_MOD = os.environ.get("KGEN_SCRATCH_LD_MOD", "")
 SCRATCH_ST_MOD = os.environ.get("KGEN_SCRATCH_ST_MOD", "sc0 sc1")
 EXP_NO_SCRATCH = bool(int(os.environ.get("KGEN_EXP_NO_SCRATCH", "0")))      # TIMING ONLY: no scratch load / store is emitted at all
+# TIMING ONLY (results of groups of two and more pairs are WRONG): pair 1's X and Y (KGEN_EXP_R1=2) or X alone (=1) are neither prefetched
+# nor stored in the streamed loop -- what a partly resident second pair could gain at most (round 5, profiles/r05_ab.txt)
+EXP_R1 = int(os.environ.get("KGEN_EXP_R1", "0"))
 # The line coefficients go from the fused point step to the sparse multiplication in registers (home blocks 7, 4, 5; the xi-multiplied
 # copies are formed straight in the operand blocks) instead of through three AGPR slots and two temporaries: -180 moves per sparse
 # multiplication, no LDS temporary left in it, and the freed slots take the result temporaries.
@@ -1243,17 +1246,28 @@ class Prog:
         vs = []
         if alt is not None:
             cond, other, lab = alt[:3]
+            part = alt[4] if len(alt) > 4 else None          # (condition emitter, slots): pair 1's first coordinates live on chip as well
             l_alt, l_done = lab("L_si_alt"), lab("L_si_done")
-            for s_ in list(slots[:3]) + list(other):
+            for s_ in list(slots[:3]) + list(other) + (list(part[1]) if part else []):
                 self._need(mag(self.r_of(s_)) <= 1.0, f"fused step operand {s_} is not normalised")
                 vs.append(self.v_of(s_))
             self.wait()
             cond(self.e)
             self.e.salu(f"s_cbranch_scc1 {l_alt}")
+            if part:
+                l_part = lab("L_si_part")
+                part[0](self.e)
+                self.e.salu(f"s_cbranch_scc1 {l_part}")
             for k in range(3):
                 self.load(HOME0 + SLOT_DW * k, slots[k])
             self.wait()
             self.e.salu(f"s_branch {l_done}")
+            if part:
+                self.e.label(l_part)
+                for k in range(3):
+                    self.load(HOME0 + SLOT_DW * k, part[1][k] if k < len(part[1]) else slots[k])
+                self.wait()
+                self.e.salu(f"s_branch {l_done}")
             self.e.label(l_alt)
             for k in range(3):
                 self.load(HOME0 + SLOT_DW * k, other[k])
@@ -1278,16 +1292,32 @@ class Prog:
             return
         cond, other, lab = alt[:3]
         turn = alt[3] if len(alt) > 3 else None          # (condition emitter, slots): the pair that opens the next pass as well keeps its R on chip
+        part = alt[4] if len(alt) > 4 else None          # (condition emitter, slots): pair 1's first coordinates stay on chip, the rest streams
         l_alt, l_done = lab("L_so_alt"), lab("L_so_done")
         self.wait()
         cond(self.e)
         self.e.salu(f"s_cbranch_scc1 {l_alt}")
+        if part is not None:
+            l_part = lab("L_so_part")
+            part[0](self.e)
+            self.e.salu(f"s_cbranch_scc1 {l_part}")
         if turn is not None:
             l_turn = lab("L_so_turn")
             turn[0](self.e)
             self.e.salu(f"s_cbranch_scc1 {l_turn}")
+        if EXP_R1:
+            l_r1, l_r1d = lab("L_so_r1"), lab("L_so_r1d")
+            self.e.salu(f"s_cmp_eq_u32 s{S_JP}, 1")
+            self.e.salu(f"s_cbranch_scc1 {l_r1}")
         for k, dst, v in zip(blocks, R, vs):
             self._step_out(k, dst, v)
+        if EXP_R1:
+            self.wait()
+            self.e.salu(f"s_branch {l_r1d}")
+            self.e.label(l_r1)
+            for k, dst, v in list(zip(blocks, R, vs))[EXP_R1:]:
+                self._step_out(k, dst, v)
+            self.e.label(l_r1d)
         self.wait()
         self.e.salu(f"s_branch {l_done}")
         if turn is not None:
@@ -1296,6 +1326,25 @@ class Prog:
                 self._step_out(k, dst, v)
             self.wait()
             self.e.salu(f"s_branch {l_done}")
+        if part is not None:
+            n1 = len(part[1])
+            self.e.label(l_part)
+            for k, dst, v in list(zip(blocks, part[1], vs))[:n1]:
+                self._step_out(k, dst, v)
+            if turn is not None:                          # (k = 2: pair 1 is also the pair that turns)
+                l_pt = lab("L_so_part_turn")
+                turn[0](self.e)
+                self.e.salu(f"s_cbranch_scc1 {l_pt}")
+            for k, dst, v in list(zip(blocks, R, vs))[n1:]:
+                self._step_out(k, dst, v)
+            self.wait()
+            self.e.salu(f"s_branch {l_done}")
+            if turn is not None:
+                self.e.label(l_pt)
+                for k, dst, v in list(zip(blocks, turn[1], vs))[n1:]:
+                    self._step_out(k, dst, v)
+                self.wait()
+                self.e.salu(f"s_branch {l_done}")
         self.e.label(l_alt)
         for k, dst, v in zip(blocks, other, vs):
             self._step_out(k, dst, v)
@@ -1742,7 +1791,7 @@ class KernelBuilder:
             keys += [Prog.key(s_) for s_ in (*self.R, self.QX, self.QY, self.PX, self.PY, self.SX, self.SY)]
             keys += [("globdyn", i) for i in range(7)]
             if self.multi and self.r0_resident():
-                keys += [Prog.key(s_) for s_ in self.R0_LDS]
+                keys += [Prog.key(s_) for s_ in self.R0_LDS] + [Prog.key(s_) for s_ in self.r1_slots()]
             if self.fission:
                 keys += [Prog.key(s_) for s_ in self.LINE_BUF] + ([] if self.multi else [Prog.key(s_) for s_ in self.FIS_PARK])
         return frozenset(keys)
@@ -1780,7 +1829,7 @@ class KernelBuilder:
         self.l2_maxv[name] = p.max_v
         return p
 
-    def miller_temps(self, extra=(), no_homes=False):
+    def miller_temps(self, extra=(), no_homes=False, in_loop=False):
         """Fast temporaries of the Miller-loop routines: the home registers (only block 8 in routines built on the fused
         Fq6 multiplication, whose workspace is blocks 0..7), the free AGPR slots, routine-specific dead slots; global
         scratch slots only as overflow."""
@@ -1788,6 +1837,9 @@ class KernelBuilder:
         fa, fl = self.MILLER_FREE
         if self.fission and not self.multi:      # LDS 3..5 hold RZ, PX, PY during phase 2 of the split loop
             fl = []
+        if in_loop and self.multi and self.r0_resident():    # (f^2 of the streamed loop) LDS 3..5 hold pair 0's R, LDS 2 pair 1's X there: never temporaries
+            return (homes + fa + list(extra) + ([] if self.track or self.SCALE.kind == "agpr" or self.r1_slots() else [self.SCALE])
+                    + [GLOB(GLOB_TMP0 + i) for i in range(8)])
         return (homes + fa + ([] if self.track else ([self.SCALE] if self.SCALE.kind == "agpr" else [])) + list(extra) + fl
                 + ([] if self.track or self.SCALE.kind == "agpr" else [self.SCALE]) + [GLOB(GLOB_TMP0 + i) for i in range(8)])
 
@@ -1831,7 +1883,7 @@ class KernelBuilder:
             # during f^2 the line (AGPR 6..8) and the addition point (AGPR 4, 5) are dead
             # during f^2 the line and the addition point are dead (in the multi kernels the S slots hold the prefetched pair)
             self.l2_routine("L2_sqr", lambda p: p.fq12_sqr(self.F),
-                            self.miller_temps(extra=(tuple(self.LINE) if self.multi else (self.SX, self.SY, *self.LINE)), no_homes=True))
+                            self.miller_temps(extra=(tuple(self.LINE) if self.multi else (self.SX, self.SY, *self.LINE)), no_homes=True, in_loop=True))
             # (routines that run the fused steps hand the line over in registers: the LINE slots are then ordinary temporaries)
             hot = lambda name: LINE_IN_REGS and Prog.FUSED_STEPS and name not in self.COLD
             line_tmp = lambda name: tuple(self.LINE) if hot(name) else ()
@@ -3048,6 +3100,14 @@ class KernelBuilder:
                 p.A(GlobDyn(k_)).to(dst)
             p.wait()
             p.reset_tags()
+        if self.r1_slots():                                           # ... and pair 1's resident coordinates (every group has a pair 1)
+            e.salu(f"s_mov_b32 s{S_JP}, 1")
+            self.pair_select(e)
+            p.reset_tags()
+            for k_, dst in zip((4, 5, 6), self.r1_slots()):
+                p.A(GlobDyn(k_)).to(dst)
+            p.wait()
+            p.reset_tags()
         e.salu(f"s_mul_i32 s{self.S_GNEXT}, s{S_GSTRIDE}, {self.PAIR_SLOT0}")      # prime the stream: pair 0
         if self.boustrophedon():
             e.salu(f"s_mov_b32 s{self.S_DIR}, 1")
@@ -3103,6 +3163,15 @@ class KernelBuilder:
                 p.A(src).to(GlobDyn(k_))
             p.wait()
             e.raw("s_waitcnt vmcnt(0)")                               # acknowledged before the end steps read the block back
+            p.reset_tags()
+        if self.r1_slots():
+            e.salu(f"s_mov_b32 s{S_JP}, 1")
+            self.pair_select(e)
+            p.reset_tags()
+            for k_, src in zip((4, 5, 6), self.r1_slots()):
+                p.A(src).to(GlobDyn(k_))
+            p.wait()
+            e.raw("s_waitcnt vmcnt(0)")
             p.reset_tags()
 
         if self.fission:
@@ -3291,6 +3360,26 @@ class KernelBuilder:
     def r0_resident(self):
         return bool(int(os.environ.get("KGEN_R0_LDS", "1"))) and LINE_IN_REGS and Prog.FUSED_STEPS and SPREAD_PREFETCH
 
+    # Round 5 -- pair 1 PARTLY resident.  The untracked kernels (k_mpairing) have one LDS slot left in the streamed loop (slot 2, the line
+    # scale of the exact-value kernels): pair 1's X lives there for the whole loop and only Y, Z stream -- 4 of the 30 slot moves of two
+    # passes over four pairs (-13 % of the R stream).  A timing-only build that drops those moves altogether measured +0.52 % (X alone)
+    # and +1.14 % (X and Y) on the Groth16 shape (profiles/r05_ab.txt): what residency can gain at most.  A second coordinate needs a
+    # second slot: every other slot is taken.
+    R1_LDS = [LDS(2, "R1X"), LDS(7, "R1Y")]
+    # The second slot (7) is the home of pair 3's packed evaluation point in resident-P mode: that point moves into the 16 KB of LDS the
+    # eight slots leave (sixteen dwords per lane: four 16-byte chunk planes behind the tails, at byte P3_LDS_BASE) and its last two limbs
+    # into two VGPRs that nothing else uses (V_P3T) -- no repacking, one scalar branch where a pair's P is written or read.
+    P3_LDS_BASE = N_LDS_SLOTS * (Prog.N_B128 * 4096 + 2048)
+    V_P3T = 252
+
+    def r1_slots(self):
+        """the LDS slots of pair 1's resident coordinates (X first), or [] (exact-value kernels: slot 2 holds the line scale)"""
+        n = int(os.environ.get("KGEN_R1_LDS", "2"))
+        return self.R1_LDS[:n] if (self.multi and not self.track and self.boustrophedon()) else []
+
+    def p3_moved(self):
+        return len(self.r1_slots()) >= 2
+
     S_GNEXT = 49               # byte offset of the NEXT pair's scratch block
     S_DIR, S_CNT, S_NEXTP = 72, 73, 74       # boustrophedon passes: direction (+1 / -1), pairs left in the pass, index of the pair of the NEXT step
 
@@ -3331,6 +3420,9 @@ class KernelBuilder:
                 e.salu(f"s_cbranch_scc1 {L(f'L_pf_r0_{u}')}")
                 e.salu(f"s_cmp_eq_u32 s{self.S_NEXTP}, s{S_JP}")
                 e.salu(f"s_cbranch_scc1 {L(f'L_pf_r0_{u}')}")
+                if (EXP_R1 and part < EXP_R1) or part < len(self.r1_slots()):     # pair 1's resident coordinates are on chip
+                    e.salu(f"s_cmp_eq_u32 s{self.S_NEXTP}, 1")
+                    e.salu(f"s_cbranch_scc1 {L(f'L_pf_r0_{u}')}")
             elif self.r0_resident():                      # the next pair is pair 0 (the index wraps): its R is on chip
                 u = self.uid()
                 e.salu(f"s_add_u32 s{S_TMP0}, s{S_JP}, 1")
@@ -3402,10 +3494,24 @@ class KernelBuilder:
         for i in range(NL):
             e.emit(f"v_mov_b32_e32 v{A0 + NL + i}, v{B0 + i}", vw=[A0 + NL + i])
         va, vt = B0, B0 + 1                                   # (block B is dead now)
+        L = self.lab
+        u = self.uid()
+        if self.p3_moved():                                   # pair 3: the chunk planes behind the slots, the tail in two VGPRs (slot 7 holds pair 1's Y)
+            e.salu(f"s_cmp_eq_u32 s{S_JP}, 3")
+            e.salu(f"s_cbranch_scc1 {L(f'L_pk_p3_{u}')}")
         self._res_p_addr(e, va, vt)
         for c in range(Prog.N_B128):
             e.emit(f"ds_write_b128 v{va}, v[{A0 + 4 * c}:{A0 + 4 * c + 3}] offset:{4096 * c}", kind="lds")
         e.emit(f"ds_write_b64 v{vt}, v[{A0 + 16}:{A0 + 17}]", kind="lds")
+        if self.p3_moved():
+            e.salu(f"s_branch {L(f'L_pk_done_{u}')}")
+            e.label(L(f"L_pk_p3_{u}"))
+            e.emit(f"v_add_u32_e32 v{va}, 0x{self.P3_LDS_BASE:x}, v{V_LDS}", vw=[va])
+            for c in range(Prog.N_B128):
+                e.emit(f"ds_write_b128 v{va}, v[{A0 + 4 * c}:{A0 + 4 * c + 3}] offset:{4096 * c}", kind="lds")
+            e.emit(f"v_mov_b32_e32 v{self.V_P3T}, v{A0 + 16}", vw=[self.V_P3T])
+            e.emit(f"v_mov_b32_e32 v{self.V_P3T + 1}, v{A0 + 17}", vw=[self.V_P3T + 1])
+            e.label(L(f"L_pk_done_{u}"))
         p.reset_tags()
 
     def _stream_routines(self, sc):
@@ -3421,6 +3527,8 @@ class KernelBuilder:
         alt = (lambda e_: e_.salu(f"s_cmp_eq_u32 s{S_JP}, 0"), self.R0_LDS, lambda n: L(f"{n}_{self.uid()}")) if res0 else None
         if self.boustrophedon():                   # the pair that also opens the next pass: R straight into the prefetch buffer
             alt = alt + ((lambda e_: e_.salu(f"s_cmp_eq_u32 s{self.S_NEXTP}, s{S_JP}"), Rb),)
+        if self.r1_slots():                        # pair 1: its first coordinates from / to their LDS slots, the others stream
+            alt = alt + ((lambda e_: e_.salu(f"s_cmp_eq_u32 s{S_JP}, 1"), self.r1_slots()),)
 
         def load_p(p):
             """block B <- (Px, Py): from the buffer, or -- resident-P mode -- from the pair's packed LDS slot"""
@@ -3433,11 +3541,23 @@ class KernelBuilder:
             e.salu(f"s_branch {L(f'L_lp_done_{u}')}")
             e.label(L(f"L_lp_res_{u}"))
             va, vt = A0, A0 + 1                               # block A is free until the step itself
+            if self.p3_moved():
+                e.salu(f"s_cmp_eq_u32 s{S_JP}, 3")
+                e.salu(f"s_cbranch_scc1 {L(f'L_lp_p3_{u}')}")
             self._res_p_addr(e, va, vt)
             for c in range(Prog.N_B128):
                 e.emit(f"ds_read_b128 v[{B0 + 4 * c}:{B0 + 4 * c + 3}], v{va} offset:{4096 * c}", kind="lds", vw=range(B0 + 4 * c, B0 + 4 * c + 4))
             e.emit(f"ds_read_b64 v[{B0 + 16}:{B0 + 17}], v{vt}", kind="lds", vw=[B0 + 16, B0 + 17])
             e.raw("s_waitcnt lgkmcnt(0)")
+            if self.p3_moved():
+                e.salu(f"s_branch {L(f'L_lp_done_{u}')}")
+                e.label(L(f"L_lp_p3_{u}"))
+                e.emit(f"v_add_u32_e32 v{va}, 0x{self.P3_LDS_BASE:x}, v{V_LDS}", vw=[va])
+                for c in range(Prog.N_B128):
+                    e.emit(f"ds_read_b128 v[{B0 + 4 * c}:{B0 + 4 * c + 3}], v{va} offset:{4096 * c}", kind="lds", vw=range(B0 + 4 * c, B0 + 4 * c + 4))
+                e.emit(f"v_mov_b32_e32 v{B0 + 16}, v{self.V_P3T}", vw=[B0 + 16])
+                e.emit(f"v_mov_b32_e32 v{B0 + 17}, v{self.V_P3T + 1}", vw=[B0 + 17])
+                e.raw("s_waitcnt lgkmcnt(0)")
             e.label(L(f"L_lp_done_{u}"))
 
         def load_q(p):
