@@ -30,10 +30,16 @@ constexpr size_t LDS_BYTES = BN254_LDS_BYTES;           // 8 slots x 72 B x 256 
 constexpr size_t SLOT_BYTES = BN254_SLOT_BYTES;         // one Fq2: 2 x 9 balanced 29-bit limbs
 constexpr size_t MAX_K = 64;                            // pairs per group of the multi-pairing kernels
 #ifndef BN254_LATENCY_THRESHOLD_DEFAULT
-#define BN254_CVM_PM_MILLER 1000      // per mille of the threshold each program takes batches up to: its own measured crossover (profiles/r04_latency.json)
-#define BN254_CVM_PM_FEXP 1000
+// per mille of the threshold each program takes batches up to: its own measured crossover against the throughput kernel, re-measured in
+// round 5 on the bank-aware programs (profiles/r05_latency.json; the sixteen-lane programs run in passes of 4 096 items, four waves per CU):
+// pairing 5.41 ms at 20 480 against 6.45, 6.51 at 24 576; miller_loop_native 3.31 at 24 576 against 3.75; final_exp_native 2.80 at 20 480
+// against 3.09; 2-pair product 8.32 at 24 576 against 8.85; 4-pair product 11.8 at 24 576 against 13.5; exact 2-pair value 6.12 at 28 672
+// against 6.32; exact 4-pair value 9.89 at 20 480 against 11.5 (11.39 / 11.49 at 24 576)
+#define BN254_CVM_PM_PAIRING 1250
+#define BN254_CVM_PM_MILLER 1500
+#define BN254_CVM_PM_FEXP 1250
 #define BN254_CVM_PM_MMILLER 1000
-#define BN254_LATENCY_THRESHOLD_DEFAULT 16384           // below the measured crossover (profiles/r04_latency.json): pairing 4.45 ms against 6.45 at 16384, 8.9 against 6.5 at 32768
+#define BN254_LATENCY_THRESHOLD_DEFAULT 16384
 #endif
 
 // ------------------------------------------------------------------ kernels
@@ -365,9 +371,9 @@ struct CvmProgram {
 #define CVM_PROGRAM(NAME, PM, WIDE, FULL) {BN254_CVM_##NAME##_B64, BN254_CVM_##NAME##_Z_BYTES, BN254_CVM_##NAME##_BYTES, BN254_CVM_##NAME##_SLOTS, PM, WIDE, FULL}
 constexpr int CVM_N_PROGRAMS = 26;
 const CvmProgram CVM_PROGRAMS[CVM_N_PROGRAMS] = {
-    CVM_PROGRAM(PAIRING, 1000, 9, 18), CVM_PROGRAM(MILLER, BN254_CVM_PM_MILLER, 10, 22), CVM_PROGRAM(FEXP, BN254_CVM_PM_FEXP, 11, -1),
-    CVM_PROGRAM(MULTI2, 1000, 12, 19), CVM_PROGRAM(MULTI3, 1250, 13, 20), CVM_PROGRAM(MULTI4, 1500, 14, 21),
-    CVM_PROGRAM(MMILLER2, 1000, 15, 23), CVM_PROGRAM(MMILLER3, BN254_CVM_PM_MMILLER, 16, 24), CVM_PROGRAM(MMILLER4, BN254_CVM_PM_MMILLER, 17, 25),
+    CVM_PROGRAM(PAIRING, BN254_CVM_PM_PAIRING, 9, 18), CVM_PROGRAM(MILLER, BN254_CVM_PM_MILLER, 10, 22), CVM_PROGRAM(FEXP, BN254_CVM_PM_FEXP, 11, -1),
+    CVM_PROGRAM(MULTI2, 1500, 12, 19), CVM_PROGRAM(MULTI3, 1500, 13, 20), CVM_PROGRAM(MULTI4, 1500, 14, 21),
+    CVM_PROGRAM(MMILLER2, 1750, 15, 23), CVM_PROGRAM(MMILLER3, BN254_CVM_PM_MMILLER, 16, 24), CVM_PROGRAM(MMILLER4, 1250, 17, 25),
     CVM_PROGRAM(PAIRING_W, 0, -1, -1), CVM_PROGRAM(MILLER_W, 0, -1, -1), CVM_PROGRAM(FEXP_W, 0, -1, -1),
     CVM_PROGRAM(MULTI2_W, 0, -1, -1), CVM_PROGRAM(MULTI3_W, 0, -1, -1), CVM_PROGRAM(MULTI4_W, 0, -1, -1),
     CVM_PROGRAM(MMILLER2_W, 0, -1, -1), CVM_PROGRAM(MMILLER3_W, 0, -1, -1), CVM_PROGRAM(MMILLER4_W, 0, -1, -1),

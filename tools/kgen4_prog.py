@@ -199,6 +199,17 @@ LINE_IN_REGS = bool(int(os.environ.get("KGEN_LINE_REGS", "1")))
 # k_pairing (tools/clock_stamp.py, same box), so the launches got 2 .. 4 % slower.  HBM traffic costs package power, and the package is close
 # enough to its limit that power is taken from the shader clock.
 FISSION = bool(int(os.environ.get("KGEN_FISSION", "0")))
+# Round 5 -- TWO DOUBLING ITERATIONS PER CHUNK, the lines kept on chip (the untracked one-pair kernel, k_pairing).  The cure for the
+# instruction supply that costs no memory traffic: where digit i of the loop is zero, iterations i and i - 1 run as
+#     dbl step (i), dbl step (i - 1)  |  f^2, f * line (i), f^2, f * line (i - 1)        (then iteration i - 1's addition step, if any)
+# -- the second doubling step finds the 47 KB of the first one in the instruction cache, the second f^2 + sparse multiplication (56 KB)
+# those of the first -- instead of [f^2, dbl step, sparse multiplication] twice (103 KB each through a 64 KB cache).  The point steps do
+# not depend on f; the two lines wait in six slots that nothing in the loop touches (LDS 2 .. 5, which the Miller phase of this kernel
+# never used, and the two AGPR slots of the addition point, free outside addition steps).  Iterations with a non-zero digit keep the
+# round-4 sequence.  ONE copy of each code: the park set is picked by a scalar register (S_PARK).
+CHUNK2 = bool(int(os.environ.get("KGEN_CHUNK2", "1")))
+CHUNK_LAYOUT = bool(int(os.environ.get("KGEN_CHUNK_LAYOUT", "0")))     # measured: the contiguous f half LOSES the chunking's +0.24 % again (profiles/r05_ab.txt)
+S_PARK = 50                                    # (s50 / s51: the split-loop experiment's cursors, free without it)
 FIS_MAX_K = 4                                  # larger groups keep the streamed loop (the line area is 3 x FIS_STEPS slots per pair)
 FIS_STEPS = 63 + sum(1 for d in SIX_U_PLUS_2_NAF[:64] if d)       # point steps of the main loop: 63 doublings + 26 additions
 S_LOFF, S_LSTEP, S_LOFF2 = 50, 51, 52         # byte offsets (inside the workgroup's scratch block): phase-1 line cursor, its step, phase-2 cursor
@@ -1664,6 +1675,68 @@ class KernelBuilder:
         return f"{name}_%="
 
     @property
+    def chunk2(self):
+        """two doubling iterations per chunk with both lines parked on chip: the untracked one-pair kernels (k_pairing)"""
+        return (CHUNK2 and self.do_miller and not self.track and not self.multi and not self.helper and not self.generate and LINE_IN_REGS
+                and Prog.FUSED_STEPS and not FISSION and self.F_IN_AGPR)
+
+    def chunk_park(self):
+        return [[LDS(3, "parkA0"), LDS(4, "parkA1"), LDS(5, "parkA2")], [LDS(2, "parkB0"), self.SX, self.SY]]
+
+    def _chunk_routines(self):
+        """L2_dbl_p: the fused doubling step on the resident R, its line -> park set S_PARK.  L2_sp034_c: park set S_PARK -> the line
+        registers (home blocks 7, 4, 5), then the sparse multiplication."""
+        park = self.chunk_park()
+        bounds = {}
+        temps = [HOME(i) for i in range(N_HOME)] + list(self.LINE) + [GLOB(GLOB_TMP0 + i) for i in range(8)]
+        pkeys = frozenset(Prog.key(s_) for set_ in park for s_ in set_)
+        L = self.lab
+
+        def dbl_p(p):
+            e = p.e
+            p.temp_keys = p.temp_keys | pkeys            # the parked lines have their own contract (recorded below), not V_STORE
+            p.dbl_step(self.R, (self.PX, self.PY), self.LINE)
+            p.wait()
+            u = self.uid()
+            e.salu(f"s_cmp_eq_u32 s{S_PARK}, 0")
+            e.salu(f"s_cbranch_scc0 {L(f'L_pk1_{u}')}")
+            p._store_line(park[0])
+            p.wait()
+            e.salu(f"s_branch {L(f'L_pkd_{u}')}")
+            e.label(L(f"L_pk1_{u}"))
+            p._store_line(park[1])
+            p.wait()
+            e.label(L(f"L_pkd_{u}"))
+            for i, src in enumerate(Prog.LINE_REGS):
+                bounds[i] = (mag(p.r_of(src)), p.v_of(src))
+        flat = [s_ for set_ in park for s_ in set_]
+        self.l2_routine("L2_dbl_p", dbl_p, temps, local=list(self.LINE) + flat)      # (the parked lines travel to L2_sp034_c with the bounds recorded above)
+
+        def sp_c(p):
+            e = p.e
+            p.reset_tags()
+            p.temp_keys = p.temp_keys | pkeys
+            u = self.uid()
+            e.salu(f"s_cmp_eq_u32 s{S_PARK}, 0")
+            e.salu(f"s_cbranch_scc0 {L(f'L_up1_{u}')}")
+            for dst, src in zip(Prog.LINE_REGS, park[0]):
+                p.load(HOME0 + SLOT_DW * dst.idx, src)
+            p.wait()
+            e.salu(f"s_branch {L(f'L_upd_{u}')}")
+            e.label(L(f"L_up1_{u}"))
+            for dst, src in zip(Prog.LINE_REGS, park[1]):
+                p.load(HOME0 + SLOT_DW * dst.idx, src)
+            p.wait()
+            e.label(L(f"L_upd_{u}"))
+            for i, dst in enumerate(Prog.LINE_REGS):
+                m_, v_ = bounds[i]
+                p._need(v_ <= V_CAP, f"line coefficient of {v_} p")
+                p.slot_r[p.key(dst)] = (-m_, m_) if m_ > 1.0 else p.r_norm(v_)
+                p.slot_v[p.key(dst)] = v_
+            p.mul_by_034(self.F, *Prog.LINE_REGS)
+        self.l2_routine("L2_sp034_c", sp_c, temps, local=list(self.LINE) + flat)
+
+    @property
     def fission(self):
         """split Miller loop (see FISSION): the untracked kernels -- k_pairing, k_mpairing (groups of up to FIS_MAX_K pairs)"""
         return FISSION and self.do_miller and not self.track and LINE_IN_REGS and Prog.FUSED_STEPS
@@ -1819,6 +1892,9 @@ class KernelBuilder:
         p.wait()
         e.salu(f"s_setpc_b64 {S_RET2}")
         self.sections.append(e)
+        if not hasattr(self, "l2_section"):
+            self.l2_section = {}
+        self.l2_section[name] = e
         self._cold = False
         tk = {Prog.key(t) for t in temps} | {Prog.key(s_) for s_ in local}
         self.l2_bodies[name] = (body, temps)
@@ -1882,8 +1958,11 @@ class KernelBuilder:
             sc = self.SCALE if self.track else None
             # during f^2 the line (AGPR 6..8) and the addition point (AGPR 4, 5) are dead
             # during f^2 the line and the addition point are dead (in the multi kernels the S slots hold the prefetched pair)
-            self.l2_routine("L2_sqr", lambda p: p.fq12_sqr(self.F),
-                            self.miller_temps(extra=(tuple(self.LINE) if self.multi else (self.SX, self.SY, *self.LINE)), no_homes=True, in_loop=True))
+            if self.chunk2:      # (the addition point's slots and LDS 2..5 hold parked lines while f^2 runs)
+                sqr_temps = [HOME(8)] + list(self.LINE) + [GLOB(GLOB_TMP0 + i) for i in range(8)]
+            else:
+                sqr_temps = self.miller_temps(extra=(tuple(self.LINE) if self.multi else (self.SX, self.SY, *self.LINE)), no_homes=True, in_loop=True)
+            self.l2_routine("L2_sqr", lambda p: p.fq12_sqr(self.F), sqr_temps)
             # (routines that run the fused steps hand the line over in registers: the LINE slots are then ordinary temporaries)
             hot = lambda name: LINE_IN_REGS and Prog.FUSED_STEPS and name not in self.COLD
             line_tmp = lambda name: tuple(self.LINE) if hot(name) else ()
@@ -1903,6 +1982,8 @@ class KernelBuilder:
             self.l2_routine("L2_addmul_last", lambda p: addmul(p, False), self.miller_temps(), local=self.LINE)
             if self.fission:
                 self._fission_routines()
+            if self.chunk2:
+                self._chunk_routines()
             if self.multi:
                 self._stream_routines(sc)
             if self.track:
@@ -1950,6 +2031,17 @@ class KernelBuilder:
             first.insert(0, second.pop())
         while first and tot(first) - tot(second) > size[id(first[0])]:
             second.append(first.pop(0))
+        hot_l1 = ()
+        if self.chunk2 and CHUNK_LAYOUT:
+            # the f half of a chunk -- f^2 glue, sparse-multiplication glue, mul3, mul6 and the small routines they call: 56 KB -- as ONE
+            # contiguous stretch of the image (it is what has to survive in the 64 KB instruction cache from the first f^2 to the second)
+            for name in ("L2_sqr", "L2_sp034_c"):
+                sec = self.l2_section[name]
+                for lst in (first, second):
+                    if any(x is sec for x in lst):
+                        lst[:] = [x for x in lst if x is not sec]
+                first.append(sec)
+            hot_l1 = ("mul3", "mul6", "norm", "redn", "mulxi", "mulxir")
         main.salu(f"s_branch {self.lab('L_exit')}")
         tail = Emitter()
         tail.label(self.lab("L_exit"))
@@ -1965,7 +2057,11 @@ class KernelBuilder:
             if nf + nb:
                 order.append((nb / (nf + nb), -len(e_.ins) if nb <= nf else len(e_.ins), n))
         order.sort()
-        secs = [self._pro] + first + [main] + self.control_sections + [l1[n] for _, _, n in order] + second + [tail]
+        if hot_l1:
+            order = [o for n_ in hot_l1 for o in order if o[2] == n_] + [o for o in order if o[2] not in hot_l1]
+            secs = [self._pro] + first + [l1[n] for _, _, n in order if n in hot_l1] + [main] + self.control_sections + [l1[n] for _, _, n in order if n not in hot_l1] + second + [tail]
+        else:
+            secs = [self._pro] + first + [main] + self.control_sections + [l1[n] for _, _, n in order] + second + [tail]
         # transfers that cannot reach their target (+-128 KB) go through one-instruction trampolines between the sections
         out, self.n_trampolines = place_with_islands([e.finalize() for e in secs], 131072 - 1024, self.lab)
         assert max_branch_distance(out) < 131072 - 512
@@ -2034,16 +2130,23 @@ class KernelBuilder:
             dn, an = ("L2_dblmul_s", "L2_addmul_s") if self.multi else ("L2_dblmul", "L2_addmul")
             if self.multi:
                 run("L2_prefetch")
-            for i in range(63, -1, -1):
+            i = 63
+            while i >= 0:
                 if i != 63:
-                    run("L2_sqr")
-                    if self.track:
-                        run("L2_sqscale")
-                    for _ in range(k_pairs):
-                        run(dn)
+                    if self.chunk2 and SIX_U_PLUS_2_NAF[i] == 0 and i > 0:
+                        for name in ("L2_dbl_p", "L2_dbl_p", "L2_sqr", "L2_sp034_c", "L2_sqr", "L2_sp034_c"):
+                            run(name)
+                        i -= 1
+                    else:
+                        run("L2_sqr")
+                        if self.track:
+                            run("L2_sqscale")
+                        for _ in range(k_pairs):
+                            run(dn)
                 if SIX_U_PLUS_2_NAF[i] != 0:
                     for _ in range(k_pairs):
                         run(an)
+                i -= 1
             for _ in range(k_pairs):                                    # per pair: + Q1, then - Q2
                 run("L2_addmul")
                 run("L2_addmul_last")
@@ -2952,6 +3055,23 @@ class KernelBuilder:
         e.label(L("L_mloop"))
         e.salu(f"s_cmp_eq_u32 s{S_I}, 63")
         e.salu(f"s_cbranch_scc1 {L('L_mskip')}")
+        if self.chunk2:
+            # digit i zero and an iteration i - 1 exists: the two doubling steps first (lines parked), then the two f^2 + sparse
+            # multiplications; iteration i - 1's addition step (if its digit is not zero) follows below
+            e.salu(f"s_bitcmp1_b64 {S_NAF_NZ}, s{S_I}")
+            e.salu(f"s_cbranch_scc1 {L('L_msingle')}")
+            e.salu(f"s_cmp_eq_u32 s{S_I}, 0")
+            e.salu(f"s_cbranch_scc1 {L('L_msingle')}")
+            for j in (0, 1):
+                e.salu(f"s_mov_b32 s{S_PARK}, {j}")
+                self.call2(e, "L2_dbl_p")
+            for j in (0, 1):
+                self.call2(e, "L2_sqr")
+                e.salu(f"s_mov_b32 s{S_PARK}, {j}")
+                self.call2(e, "L2_sp034_c")
+            e.salu(f"s_sub_u32 s{S_I}, s{S_I}, 1")
+            e.salu(f"s_branch {L('L_mskip')}")
+            e.label(L("L_msingle"))
         self.call2(e, "L2_sqr")
         if self.track:
             self.call2(e, "L2_sqscale")
