@@ -69,6 +69,27 @@ def test_pairing_program_equals_the_reference_pairing():
         assert not (written & read), rnd
 
 
+def test_miller_half_program_of_the_two_launch_pairing():
+    """MILLER_U (round 5): the Miller loop of pairing() without the line scale, scheduled for sixteen lanes in at most 142 slots (eight
+    waves per CU in the 36-byte layout).  Its value differs from miller_loop_native's by an Fq2 factor only -- final_exp_native of it IS
+    pairing(P, Q), limb for limb -- and the scheduled program obeys the no-write-while-read rule of every program."""
+    g = cvm.build_miller_u()
+    low = cvm.Lowered(g)
+    pr = cvm.Program(low, nr=CK.NR)
+    flat = pr.run(FLAT)
+    f = [(flat[2 * i], flat[2 * i + 1]) for i in range(6)]
+    assert R.fq12_to_fp2s(R.final_exp_native(R.fq12_from_fp2s(f))) == R.fq12_to_fp2s(R.pairing_myfq12(P_PT, Q_PT))
+    exact = R.fq12_to_fp2s(R.miller_loop_native(Q_PT, P_PT))
+    ratio = R.fq2_mul(f[0], R.fq2_inv(exact[0]))                       # one Fq2 factor for all six coefficients
+    assert all(R.fq2_mul(exact[i], ratio) == f[i] for i in range(6))
+    st = pr.stats()
+    assert st["slots"] <= 142 and st["rounds"] < 640, st
+    for rnd, (kind, take) in enumerate(pr.rounds):
+        written = {w.slot for v in take for w in (v, v.twin) if w is not None}
+        read = {s.slot for v in take for s in v.srcs()}
+        assert not (written & read), rnd
+
+
 def _mini():
     g = cvm.Graph()
     g.const((0, 0))

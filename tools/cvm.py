@@ -1204,6 +1204,17 @@ def build_miller(run_ahead=None, **kw):
     return g
 
 
+def build_miller_u(**kw):
+    """The Miller loop of pairing() WITHOUT the scale: miller_loop_native's value up to the Fq2 factor that the easy part of the final
+    exponentiation kills -- what `pairing` = final_exp_native(miller_loop_native(..)) needs of it (src/pairing.rs:20-22).  The first half
+    of the two-launch form of pairing for mid-size batches: 136 slots, so that EIGHT waves of it fit a CU (two per SIMD: one wave's
+    operand fetch runs under the other's arithmetic), where the whole pairing program holds 271 slots and four."""
+    g = _graph(**kw)
+    (px, py), Q = g.g1_point(), g.g2_point()
+    g.outputs = g.miller_loop(px, py, Q)
+    return g
+
+
 def build_final_exp(**kw):
     """final_exp_native(f) (final_exp_native.rs:209-213)"""
     g = _graph(**kw)
