@@ -32,12 +32,12 @@ constexpr size_t MAX_K = 64;                            // pairs per group of th
 #ifndef BN254_LATENCY_THRESHOLD_DEFAULT
 // per mille of the threshold each program takes batches up to: its own measured crossover against the throughput kernel, re-measured in
 // round 5 on the bank-aware programs (profiles/r05_latency.json; the sixteen-lane programs run in passes of 4 096 items, four waves per CU):
-// pairing (two launches above 4 096 items) 6.23 ms at 24 576 against 6.39, 7.17 at 28 672; miller_loop_native 3.31 at 24 576 against 3.75; final_exp_native 2.80 at 20 480
-// against 3.09; 2-pair product 8.32 at 24 576 against 8.85; 4-pair product 11.8 at 24 576 against 13.5; exact 2-pair value 6.12 at 28 672
+// pairing (seven launches above 4 096 items) 5.88 ms at 24 576 against 6.40, 6.73 at 28 672; miller_loop_native 3.31 at 24 576 against 3.75; final_exp_native (six
+// launches) 3.00 at 24 576 against 3.07; 2-pair product 8.32 at 24 576 against 8.85; 4-pair product 11.8 at 24 576 against 13.5; exact 2-pair value 6.12 at 28 672
 // against 6.32; exact 4-pair value 9.89 at 20 480 against 11.5 (11.39 / 11.49 at 24 576)
 #define BN254_CVM_PM_PAIRING 1500
 #define BN254_CVM_PM_MILLER 1500
-#define BN254_CVM_PM_FEXP 1250
+#define BN254_CVM_PM_FEXP 1500
 #define BN254_CVM_PM_MMILLER 1000
 #ifndef BN254_CVM_SPLIT_MIN
 #define BN254_CVM_SPLIT_MIN 4096        // pairing() on the lane-cooperative kernel in two launches above this many items (one wave per SIMD of the fused program)
@@ -191,7 +191,8 @@ constexpr size_t NAF_RING_MAX = 64;
 struct StreamCtx {
     std::recursive_mutex mu;
     Buf scratch, naf, tmp;
-    Buf mid;                   // pairing() in two launches (mid-size batches on the lane-cooperative kernel): the Miller values in between
+    Buf mid;                   // pairing() in several launches (mid-size batches on the lane-cooperative kernel): the Miller values in between
+    Buf fx[5];                 // ... and final_exp_native's: m, m^x, m^(x^2), m^(x^3), the y-chain's first part
     Buf sub[4];                // groups of more than MAX_K pairs: sub-group inputs (G1, G2) and the two Miller values in flight
     Buf stage[8];              // device staging of the host-pointer entry points (inputs / outputs), grown on demand
     std::vector<void*> retired;   // buffers that were outgrown while work on them may still be queued: freed once the stream has been
@@ -208,6 +209,7 @@ struct StreamCtx {
     uint32_t last_grid = 0;
     ~StreamCtx() {                // the last holder (bn254_release_stream, after the stream has been synchronised) frees everything
         for (Buf* b : {&scratch, &naf, &tmp, &mid}) if (b->p) (void)hipFree(b->p);
+        for (Buf& b : fx) if (b.p) (void)hipFree(b.p);
         for (Buf& b : stage) if (b.p) (void)hipFree(b.p);
         for (Buf& b : sub) if (b.p) (void)hipFree(b.p);
         for (void* q : retired) (void)hipFree(q);
@@ -222,7 +224,7 @@ struct DeviceCtx {
     int n_cu = 0;
     std::mutex table_mu;       // the generator table upload (138 KB, blocking) has its own lock
     int32_t* gen_table = nullptr;
-    uint32_t* cvm_blob[27] = {};    // the latency path's round programs (0.3 - 1.4 MB each, uploaded on first use, same lock)
+    uint32_t* cvm_blob[31] = {};    // the latency path's round programs (0.3 - 1.4 MB each, uploaded on first use, same lock)
     bool cvm_init = false;
     std::map<hipStream_t, std::shared_ptr<StreamCtx>> streams;   // shared: a call keeps its context alive across a concurrent release
     std::mutex pipe_mu;        // one host-pointer pipeline at a time per device (its two workers fill the chip anyway)
@@ -373,8 +375,9 @@ struct CvmProgram {
     int full;                 // ... of its sixty-four-lane program, or -1
 };
 #define CVM_PROGRAM(NAME, PM, WIDE, FULL) {BN254_CVM_##NAME##_B64, BN254_CVM_##NAME##_Z_BYTES, BN254_CVM_##NAME##_BYTES, BN254_CVM_##NAME##_SLOTS, PM, WIDE, FULL}
-constexpr int CVM_N_PROGRAMS = 27;
-constexpr int CVM_MILLER_U = 26;      // the Miller half of pairing() (two-launch form for mid-size batches)
+constexpr int CVM_N_PROGRAMS = 31;
+constexpr int CVM_MILLER_U = 26;      // the Miller half of pairing() (separate launch for mid-size batches)
+constexpr int CVM_EASY = 27, CVM_POWX = 28, CVM_YCH1 = 29, CVM_YCH2 = 30;      // final_exp_native in six launches (mid-size batches)
 const CvmProgram CVM_PROGRAMS[CVM_N_PROGRAMS] = {
     CVM_PROGRAM(PAIRING, BN254_CVM_PM_PAIRING, 9, 18), CVM_PROGRAM(MILLER, BN254_CVM_PM_MILLER, 10, 22), CVM_PROGRAM(FEXP, BN254_CVM_PM_FEXP, 11, -1),
     CVM_PROGRAM(MULTI2, 1500, 12, 19), CVM_PROGRAM(MULTI3, 1500, 13, 20), CVM_PROGRAM(MULTI4, 1500, 14, 21),
@@ -384,7 +387,7 @@ const CvmProgram CVM_PROGRAMS[CVM_N_PROGRAMS] = {
     CVM_PROGRAM(MMILLER2_W, 0, -1, -1), CVM_PROGRAM(MMILLER3_W, 0, -1, -1), CVM_PROGRAM(MMILLER4_W, 0, -1, -1),
     CVM_PROGRAM(PAIRING_X, 0, -1, -1), CVM_PROGRAM(MULTI2_X, 0, -1, -1), CVM_PROGRAM(MULTI3_X, 0, -1, -1), CVM_PROGRAM(MULTI4_X, 0, -1, -1),
     CVM_PROGRAM(MILLER_X, 0, -1, -1), CVM_PROGRAM(MMILLER2_X, 0, -1, -1), CVM_PROGRAM(MMILLER3_X, 0, -1, -1), CVM_PROGRAM(MMILLER4_X, 0, -1, -1),
-    CVM_PROGRAM(MILLER_U, 0, -1, -1)};
+    CVM_PROGRAM(MILLER_U, 0, -1, -1), CVM_PROGRAM(EASY, 0, -1, -1), CVM_PROGRAM(POWX, 0, -1, -1), CVM_PROGRAM(YCH1, 0, -1, -1), CVM_PROGRAM(YCH2, 0, -1, -1)};
 
 // which program serves (Miller loop?, final exponentiation?, k pairs); -1: none
 template <bool M, bool F>
@@ -488,6 +491,27 @@ int launch_cvm(int prog, int lanes, const uint64_t* g1, const uint64_t* g2, cons
     return BN254_OK;
 }
 
+// final_exp_native on a mid-size batch as SIX launches of the lane-cooperative kernel -- easy part, the three x-powers (one program,
+// three times), the y-chain in two parts (the first takes three Fq12 batches through the g1 / g2 / f_in arguments, the second two) --
+// through per-stream buffers.  The whole program holds 277 slots per item (four waves per CU); its pieces 70 / 117 / 146 / 143 (eight,
+// eight, seven, seven): two waves per SIMD, one's operand fetch under the other's arithmetic.  Same values: the same operations in the
+// same order on the same limbs (tests/test_cvm.py composes the pieces on integers; tests/test_gpu_latency.py on the GPU).
+int launch_fexp_pieces(const uint64_t* f_in, uint64_t* out, size_t n, int device, void* stream) {
+    LaunchCtx hold;
+    int rc = ctx_get(device, stream, 1, 1, &hold);
+    if (rc) return rc;
+    StreamCtx* sc = hold.s.get();
+    for (Buf& b : sc->fx)
+        if ((rc = ensure(sc, b, 384 * n))) return rc;
+    uint64_t *m = (uint64_t*)sc->fx[0].p, *mx = (uint64_t*)sc->fx[1].p, *mx2 = (uint64_t*)sc->fx[2].p, *mx3 = (uint64_t*)sc->fx[3].p, *t1 = (uint64_t*)sc->fx[4].p;
+    if ((rc = launch_cvm(CVM_EASY, 16, nullptr, nullptr, f_in, m, n, 1, device, stream))) return rc;
+    if ((rc = launch_cvm(CVM_POWX, 16, nullptr, nullptr, m, mx, n, 1, device, stream))) return rc;
+    if ((rc = launch_cvm(CVM_POWX, 16, nullptr, nullptr, mx, mx2, n, 1, device, stream))) return rc;
+    if ((rc = launch_cvm(CVM_POWX, 16, nullptr, nullptr, mx2, mx3, n, 1, device, stream))) return rc;
+    if ((rc = launch_cvm(CVM_YCH1, 16, mx, mx2, mx3, t1, n, 1, device, stream))) return rc;
+    return launch_cvm(CVM_YCH2, 16, m, nullptr, t1, out, n, 1, device, stream);
+}
+
 template <bool M, bool F>
 int launch_pairing(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in, uint64_t* out, size_t n_groups, size_t k, int device, void* stream) {
     if (n_groups == 0) return BN254_OK;
@@ -532,9 +556,9 @@ int launch_pairing(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in,
             // n_groups * 1000 <= thr * per_mille without the overflow of a huge threshold ("always": SIZE_MAX)
             unsigned __int128 lhs = (unsigned __int128)n_groups * 1000u, rhs = (unsigned __int128)thr * CVM_PROGRAMS[prog].per_mille;
             if (lhs <= rhs) {
-                // pairing(), mid-size batch: TWO launches -- the Miller loop without the line scale (136 slots per item: eight waves per
-                // CU, two per SIMD, one wave's operand fetch under the other's arithmetic), then final_exp_native on its values (277 slots:
-                // four waves per CU, as the fused program) -- while the launch has more waves than one per SIMD (below that nothing overlaps).
+                // pairing(), mid-size batch: SEVEN launches -- the Miller loop without the line scale (136 slots per item: eight waves per
+                // CU, two per SIMD, one wave's operand fetch under the other's arithmetic), then final_exp_native on its values in six
+                // pieces (launch_fexp_pieces) -- while the launch has more waves than one per SIMD (below that nothing overlaps).
                 if (M && F && k == 1 && lanes == 0 && n_groups > (size_t)BN254_CVM_SPLIT_MIN) {
                     LaunchCtx hold;
                     int rc = ctx_get(device, stream, 1, 1, &hold);
@@ -542,8 +566,10 @@ int launch_pairing(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in,
                     if ((rc = ensure(hold.s.get(), hold.s->mid, 384 * n_groups))) return rc;
                     uint64_t* mid = (uint64_t*)hold.s->mid.p;
                     if ((rc = launch_cvm(CVM_MILLER_U, 16, g1, g2, nullptr, mid, n_groups, 1, device, stream))) return rc;
-                    return launch_cvm(cvm_program<false, true>(1), 16, nullptr, nullptr, mid, out, n_groups, 1, device, stream);
+                    return launch_fexp_pieces(mid, out, n_groups, device, stream);
                 }
+                if (!M && F && lanes == 0 && n_groups > (size_t)BN254_CVM_SPLIT_MIN)          // final_exp_native alone, mid-size batch: the same six launches
+                    return launch_fexp_pieces(f_in, out, n_groups, device, stream);
                 return launch_cvm(prog, lanes, g1, g2, f_in, out, n_groups, k, device, stream);
             }
         }
@@ -989,7 +1015,9 @@ int bn254_reserve(int device, void* stream, size_t n, size_t k) {
         if ((rc = ensure(sc, sc->scratch, need))) return rc;
     }
     if ((rc = ensure(sc, sc->tmp, 384 * (n ? n : 1)))) return rc;                                   // the `== one` verdict's Fq12 values
-    if ((rc = ensure(sc, sc->mid, 384 * (n ? n : 1)))) return rc;                                   // pairing() in two launches: the Miller values
+    if (n <= ((size_t)1 << 17) && (rc = ensure(sc, sc->mid, 384 * (n ? n : 1)))) return rc;         // pairing() / final_exp_native in several launches (mid-size
+    for (Buf& b : sc->fx)                                                                           // batches on the lane-cooperative kernel): the values in between
+        if (n <= ((size_t)1 << 17) && (rc = ensure(sc, b, 384 * (n ? n : 1)))) return rc;
     if ((rc = ensure(sc, sc->naf, 65536 + 64))) return rc;                                          // pow_native digits (16-bit length field)
     if (k > MAX_K && ((rc = ensure(sc, sc->sub[0], 64 * n * MAX_K)) || (rc = ensure(sc, sc->sub[1], 128 * n * MAX_K)) ||
                       (rc = ensure(sc, sc->sub[2], 384 * n)) || (rc = ensure(sc, sc->sub[3], 384 * n))))

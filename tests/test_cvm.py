@@ -90,6 +90,32 @@ def test_miller_half_program_of_the_two_launch_pairing():
         assert not (written & read), rnd
 
 
+def test_final_exp_pieces_compose_to_final_exp_native():
+    """EASY, POWX (three times), YCH1, YCH2 (round 5: final_exp_native as six launches for mid-size batches): the scheduled sixteen-lane
+    programs, run on integers one after the other with each piece's outputs as the next one's inputs, give final_exp_native(f) for a
+    non-unitary f (a Miller value times a scale) -- and every piece fits seven or eight waves per CU (at most 146 slots)."""
+    f = [R.fq2_mul(c, (7, 3)) for c in R.fq12_to_fp2s(R.miller_loop_native(Q_PT, P_PT))]
+    want = R.fq12_to_fp2s(R.final_exp_native(R.fq12_from_fp2s(f)))
+    flat = lambda x: [c for v in x for c in v]
+    unflat = lambda w: [(w[2 * i], w[2 * i + 1]) for i in range(6)]
+    progs = {}
+    for piece in ("easy", "powx", "ych1", "ych2"):
+        pr = cvm.Program(cvm.Lowered(cvm.build_fexp_piece(piece)), nr=CK.NR)
+        assert pr.stats()["slots"] <= 146, (piece, pr.stats())
+        for rnd, (kind, take) in enumerate(pr.rounds):
+            written = {w.slot for v in take for w in (v, v.twin) if w is not None}
+            assert not (written & {s.slot for v in take for s in v.srcs()}), (piece, rnd)
+        progs[piece] = pr
+    m = unflat(progs["easy"].run(flat(f)))
+    assert m == R.fq12_to_fp2s(R.easy_part(R.fq12_from_fp2s(f)))
+    mx = unflat(progs["powx"].run(flat(m)))
+    assert R.fq12_from_fp2s(mx) == R.pow_native(R.fq12_from_fp2s(m), [R.BN_X])
+    mx2 = unflat(progs["powx"].run(flat(mx)))
+    mx3 = unflat(progs["powx"].run(flat(mx2)))
+    t1 = unflat(progs["ych1"].run(flat(mx) + flat(mx2) + flat(mx3)))          # inputs in the order g1, g2, f_in
+    assert unflat(progs["ych2"].run(flat(m) + flat(t1))) == want
+
+
 def _mini():
     g = cvm.Graph()
     g.const((0, 0))

@@ -195,6 +195,40 @@ def test_miller_loop_and_final_exp_on_the_latency_kernel(pk, n):
     assert torch.equal(e, f) and torch.equal(c, e)                 # pairing = final_exp(miller)
 
 
+@pytest.mark.parametrize("n", [4097, 9000])
+def test_mid_size_batches_take_the_multi_launch_form(n):
+    """Above 4 096 items (lanes left to the launch size) `pairing` runs as seven launches of the lane-cooperative kernel -- the Miller loop
+    without the line scale, then final_exp_native in six pieces -- and `final_exp_native` alone as those six: every lane equals the
+    throughput kernels (round 5)."""
+    import torch
+    p = H.pkg()
+    g1, g2 = _dev_pairs(p, n, 0xB25400AA + n)
+    try:
+        outs = {}
+        for thr in (0, 1 << 20):
+            p.set_stream_latency(thr, 0, 0, None)
+            mil = torch.empty(48 * n, dtype=torch.int64, device=torch.device("cuda:0"))
+            fe = torch.empty_like(mil)
+            pa = torch.empty_like(mil)
+            p.miller_loop_batch_dev(g1, g2, mil, n)
+            p.final_exp_batch_dev(mil, fe, n)
+            p.pairing_batch_dev(g1, g2, pa, n)
+            p.last_status()
+            assert p.last_kernel(0, None) == (1 if thr == 0 else 16)
+            outs[thr] = (mil, fe, pa)
+        a, b = outs[0], outs[1 << 20]
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(b[1], b[2])
+        # a zero input among them: the easy part's inversion raises the status word from its own launch
+        z = a[0].clone()
+        z.view(48, n)[:, 5] = 0
+        p.final_exp_batch_dev(z, torch.empty_like(z), n)
+        with pytest.raises(p.Bn254Error) as e:
+            p.last_status()
+        assert e.value.status == p.ERR_ZERO_DIVISOR
+    finally:
+        p.set_stream_latency(p.LATENCY_INHERIT, -1, 0, None)
+
+
 def test_golden_miller_and_final_exp_on_the_latency_kernel(pk):
     vec = H.load_golden("bn254_vectors.json")
     P = [tuple(HX(p)) for p in vec["g1"]]

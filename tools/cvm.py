@@ -37,6 +37,7 @@ XI = (9, 1)
 ARR_G1, ARR_G2, ARR_F, ARR_NONE = 0, 1, 2, 3
 BANK_AWARE = bool(int(os.environ.get("CVM_BANKS", "1")))       # LDS slots by liveness and bank class (Program._allocate_banked)
 BANK_SLACK = int(os.environ.get("CVM_BANK_SLACK", "0"))        # slots the class-aware assignment may use beyond the liveness-only count
+INPUT_SLOTS_EXPIRE = bool(int(os.environ.get("CVM_INPUT_EXPIRE", "1")))      # an input's slot is reused once its last reader has run (YCH1 takes 36 input values: 146 -> 141 slots)
 N_TRASH = int(os.environ.get("CVM_TRASH", "1"))      # trash slots per item (Program.encode)
 MAX_LIN_SRC = 6             # sources of an Fq2-level combination (the Fq operation it lowers to takes eight terms)
 
@@ -132,8 +133,10 @@ class Graph:
     def g2_point(self, j=0):
         return self.inp(f"q{j}x", src=(ARR_G2, 0, 1, j)), self.inp(f"q{j}y", src=(ARR_G2, 2, 3, j))
 
-    def fq12_input(self):
-        return [self.inp(f"f{i}", src=(ARR_F, i, i + 6, 0)) for i in range(6)]
+    def fq12_input(self, arr=ARR_F):
+        """an Fq12 (MyFq12 order) read from array `arr`: f_in, or -- the pieces of the final exponentiation that take two or three Fq12
+        values -- the g1 / g2 arrays, which are then Fq12 batches too (the kernel reads any array the same way)"""
+        return [self.inp(f"f{arr}_{i}", src=(arr, i, i + 6, 0)) for i in range(6)]
 
     def const(self, c):
         c = (c[0] % P, c[1] % P)
@@ -183,8 +186,10 @@ class Graph:
                 self.mul((a[0], b[1]), (a[1], b[0]), (a2x, b[2])),
                 self.mul((a[0], b[2]), (a[1], b[1]), (a[2], b[0])))
 
-    def fq12_mul(self, a, b, bx=None):
-        """dense product: c_k = sum_i a_i B(k - i), B(j) = b_j (j >= 0) or xi b_(j+6); two chained three-term sums per coefficient"""
+    def fq12_mul(self, a, b, bx=None, after=None):
+        """dense product: c_k = sum_i a_i B(k - i), B(j) = b_j (j >= 0) or xi b_(j+6); two chained three-term sums per coefficient.
+        after: a value the product's first sums must not be scheduled before (no data flows: keeps a product that is only needed
+        later from being computed early and waiting in LDS)"""
         if self.wide:
             # thirty-two lanes: the wrapped and the unwrapped part of every coefficient as sums of at most three products of their own --
             # sixteen sums, ONE round of thirty-two operations -- and c_k = lo_k + xi hi_k in the recombination: a product round and a
@@ -203,7 +208,7 @@ class Graph:
             return b[k - i] if i <= k else bx[k - i + 6]
         out = []
         for k in range(6):
-            t = self.mul(*[(a[i], B(k, i)) for i in range(3)])
+            t = self.mul(*[(a[i], B(k, i)) for i in range(3)], after=after)
             out.append(self.mul(*[(a[i], B(k, i)) for i in range(3, 6)], add=t))
         return out
 
@@ -554,18 +559,26 @@ class Graph:
     def final_exp(self, f):
         """final_exp_native (final_exp_native.rs:209-213): easy part, then hard_part_BN_native (:130-169) in the kernels' schedule
         (tests/sched_model.py final_exp_gpu)"""
-        f2 = self.fq12_mul(self.fq12_conj(f), self.fq12_inv(f))
-        m = self.fq12_mul(self.frobenius(f2, 2), f2)
-        mp, mp2, mp3 = self.frobenius(m, 1), self.frobenius(m, 2), self.frobenius(m, 3)
-        y0 = self.fq12_mul(mp, self.fq12_mul(mp2, mp3))
-        y1 = self.fq12_conj(m)
+        m = self.easy_part(f)
         mx = self.pow_x(m)
-        mxp = self.frobenius(mx, 1)
         mx2 = self.pow_x(mx)
+        mx3 = self.pow_x(mx2)
+        return self.hard_tail_2(m, self.hard_tail_1(mx, mx2, mx3))
+
+    # the pieces of final_exp_native, as the one-launch programs use them in sequence and the mid-size batches as separate launches
+    # (EASY, POWX three times, YCH1, YCH2: each piece holds at most ~146 slots where the whole holds 277)
+    def easy_part(self, f):
+        """easy_part (final_exp_native.rs:195-206): f^((p^6 - 1)(p^2 + 1))"""
+        f2 = self.fq12_mul(self.fq12_conj(f), self.fq12_inv(f))
+        return self.fq12_mul(self.frobenius(f2, 2), f2)
+
+    def hard_tail_1(self, mx, mx2, mx3, serial=False):
+        """the part of hard_part_BN_native's y-chain (final_exp_native.rs:130-169) that needs m^x, m^(x^2), m^(x^3) only: ((y3 y5 T0)^2 (y2 T0))^2
+        with T0 = y6^2 y4 y5"""
+        mxp = self.frobenius(mx, 1)
         mx2p = self.frobenius(mx2, 1)
         y2 = self.frobenius(mx2, 2)
         y5 = self.fq12_conj(mx2)
-        mx3 = self.pow_x(mx2)
         mx3p = self.frobenius(mx3, 1)
         y3 = self.fq12_conj(mxp)
         y4 = self.fq12_conj(self.fq12_mul(mx, mx2p))
@@ -573,12 +586,19 @@ class Graph:
         T0 = self.cyc_sqr(y6)
         T0 = self.fq12_mul(T0, y4)
         T0 = self.fq12_mul(T0, y5)
-        T1 = self.fq12_mul(y3, y5)
+        # serial (the stand-alone piece YCH1): y3 y5 is needed behind T0 only -- computed early it waits in twelve slots (+ twins)
+        T1 = self.fq12_mul(y3, y5, after=T0[0] if serial else None)
         T1 = self.fq12_mul(T1, T0)
         T0 = self.fq12_mul(y2, T0)
         T1 = self.cyc_sqr(T1)
         T1 = self.fq12_mul(T1, T0)
-        T1 = self.cyc_sqr(T1)
+        return self.cyc_sqr(T1)
+
+    def hard_tail_2(self, m, T1):
+        """... and the rest: (T1 y1)^2 (T1 y0) with y0 = m^p m^(p^2) m^(p^3), y1 = conj(m)"""
+        mp, mp2, mp3 = self.frobenius(m, 1), self.frobenius(m, 2), self.frobenius(m, 3)
+        y0 = self.fq12_mul(mp, self.fq12_mul(mp2, mp3))
+        y1 = self.fq12_conj(m)
         T0 = self.fq12_mul(T1, y1)
         T1 = self.fq12_mul(T1, y0)
         T0 = self.cyc_sqr(T0)
@@ -1025,11 +1045,13 @@ class Program:
             top[0] += 1
             return s_
 
+        expire = {}
         for v in low.inputs:
             v.slot = take_slot(v)
             cls[v.id] = v.slot % NC
+            if INPUT_SLOTS_EXPIRE and 0 <= v.last < n_rounds and not any(o is v for o in low.outputs):
+                expire.setdefault(v.last + 1, []).append(v.slot)       # an input's slot serves other values once its last reader has run
         self.first_dyn = top[0]
-        expire = {}
         for rnd, (kind, take) in enumerate(self.rounds):
             for s_ in expire.pop(rnd, []):
                 free[s_ % NC].append(s_)
@@ -1072,6 +1094,10 @@ class Program:
         for o in low.outputs:
             o.last = n_rounds
         free, expire = [], {}
+        if INPUT_SLOTS_EXPIRE:
+            for v in low.inputs:
+                if 0 <= v.last < n_rounds and not any(o is v for o in low.outputs):
+                    expire.setdefault(v.last + 1, []).append(v.slot)
         for rnd, (kind, take) in enumerate(self.rounds):
             free += expire.pop(rnd, [])
             free.sort(reverse=True)
@@ -1212,6 +1238,22 @@ def build_miller_u(**kw):
     g = _graph(**kw)
     (px, py), Q = g.g1_point(), g.g2_point()
     g.outputs = g.miller_loop(px, py, Q)
+    return g
+
+
+def build_fexp_piece(piece, **kw):
+    """the launches of final_exp_native for mid-size batches: "easy" f_in -> m; "powx" f_in -> f_in^x (cyclotomic input); "ych1" (g1, g2, f_in) =
+    (m^x, m^(x^2), m^(x^3)) -> T1; "ych2" (g1, f_in) = (m, T1) -> final_exp_native's value"""
+    g = _graph(**kw)
+    if piece == "easy":
+        g.outputs = g.easy_part(g.fq12_input())
+    elif piece == "powx":
+        g.outputs = g.pow_x(g.fq12_input())
+    elif piece == "ych1":
+        g.outputs = g.hard_tail_1(g.fq12_input(ARR_G1), g.fq12_input(ARR_G2), g.fq12_input(), serial=True)
+    else:
+        assert piece == "ych2"
+        g.outputs = g.hard_tail_2(g.fq12_input(ARR_G1), g.fq12_input())
     return g
 
 
