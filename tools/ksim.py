@@ -9,6 +9,7 @@ s_call_b64 / s_setpc_b64.  Besides computing, it re-checks what the generator mu
   * every register read was written before (catches allocation bugs)
 It is test infrastructure (tests/test_kgen.py), not part of the product.
 """
+import functools
 import re
 
 M32 = 0xFFFFFFFF
@@ -17,6 +18,31 @@ M64 = 0xFFFFFFFFFFFFFFFF
 
 class SimError(Exception):
     pass
+
+
+@functools.lru_cache(maxsize=None)
+def _vpair(tok):
+    """low register of a v[lo:hi] operand, or None (cached: the simulator parses every operand of every executed instruction)"""
+    m = re.match(r"v\[(\d+):", tok)
+    return int(m.group(1)) if m else None
+
+
+@functools.lru_cache(maxsize=None)
+def _vreg(tok):
+    """n of a plain vN operand, or None"""
+    return int(tok[1:]) if tok[0] == "v" and tok[1:].isdigit() else None
+
+
+@functools.lru_cache(maxsize=None)
+def _spair(tok):
+    m = re.match(r"s\[(\d+):(\d+)\]", tok)
+    return int(m.group(1)) if m else None
+
+
+@functools.lru_cache(maxsize=None)
+def _sreg(tok):
+    m = re.match(r"s(\d+)$", tok)
+    return int(m.group(1)) if m else None
 
 
 def _split_args(rest):
@@ -54,16 +80,15 @@ class Machine:
             return self.vcc
         if name == "exec":
             return self.exec
-        m = re.match(r"s\[(\d+):(\d+)\]", name)
-        if m:
-            lo = int(m.group(1))
+        lo = _spair(name)
+        if lo is not None:
             a, b = self.s.get(lo), self.s.get(lo + 1)
             if a is None or b is None:
                 raise SimError(f"uninitialised {name}")
             return a | (b << 32)
-        m = re.match(r"s(\d+)$", name)
-        if m:
-            x = self.s.get(int(m.group(1)))
+        r_ = _sreg(name)
+        if r_ is not None:
+            x = self.s.get(r_)
             if x is None:
                 raise SimError(f"uninitialised {name}")
             return x
@@ -76,15 +101,14 @@ class Machine:
         if name == "exec":
             self.exec = val & M64
             return
-        m = re.match(r"s\[(\d+):(\d+)\]", name)
-        if m:
-            lo = int(m.group(1))
+        lo = _spair(name)
+        if lo is not None:
             self.s[lo] = val & M32
             self.s[lo + 1] = (val >> 32) & M32
             return
-        m = re.match(r"s(\d+)$", name)
-        if m:
-            self.s[int(m.group(1))] = val & M32
+        r_ = _sreg(name)
+        if r_ is not None:
+            self.s[r_] = val & M32
             return
         raise SimError("bad sgpr " + name)
 
@@ -94,10 +118,10 @@ class Machine:
     # register of a pair whose true value does not fit 64 signed bits is an error.
     def exact_of(self, tok):
         """true value of a 64-bit accumulator operand (falls back to the signed register content)"""
-        m = re.match(r"v\[(\d+):(\d+)\]", tok)
+        lo = _vpair(tok)
         c = self.vsrc64(tok, check=False)
-        if m:
-            ex = self.exact.get(int(m.group(1)))
+        if lo is not None:
+            ex = self.exact.get(lo)
             if ex is not None and (ex - c) % (1 << 64) == 0:
                 return ex
         return c - (1 << 64) if c >> 63 else c
@@ -120,9 +144,11 @@ class Machine:
 
     def vsrc(self, tok, valu=True):
         """32-bit source operand of a VALU instruction."""
-        if tok[0] == "v" and tok[1].isdigit():
-            self._consume(int(tok[1:]))
-            x = self.v[int(tok[1:])]
+        r = _vreg(tok)
+        if r is not None:
+            if self.exact:
+                self._consume(r)
+            x = self.v[r]
             if x is None:
                 if self.check_uninit:
                     raise SimError(f"read of uninitialised {tok}")
@@ -137,9 +163,8 @@ class Machine:
         return int(tok, 0) & M32
 
     def vsrc64(self, tok, check=True):
-        m = re.match(r"v\[(\d+):(\d+)\]", tok)
-        if m:
-            lo = int(m.group(1))
+        lo = _vpair(tok)
+        if lo is not None:
             if lo % 2:
                 raise SimError("odd-aligned 64-bit VGPR operand " + tok)
             if check:
@@ -169,9 +194,10 @@ class Machine:
         self.valu_w[reg] = self.count
 
     def vset(self, tok, val):
-        r = int(tok[1:])
+        r = _vreg(tok)
         self.v[r] = val & M32
-        self.exact.pop(r & ~1, None)
+        if self.exact:
+            self.exact.pop(r & ~1, None)
 
 
 _PARSED = {}
@@ -254,7 +280,7 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None, start_pc=None, 
         try:
             if op == "v_mad_u64_u32":
                 r = m.vsrc(a[2]) * m.vsrc(a[3]) + m.vsrc64(a[4])
-                lo = int(re.match(r"v\[(\d+):", a[0]).group(1))
+                lo = _vpair(a[0])
                 if lo % 2:
                     raise SimError("odd-aligned 64-bit VGPR dest")
                 v[lo] = r & M32
@@ -266,7 +292,7 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None, start_pc=None, 
                 x = x - (1 << 32) if x >> 31 else x
                 y = y - (1 << 32) if y >> 31 else y
                 r = x * y + m.exact_of(a[4])
-                lo = int(re.match(r"v\[(\d+):", a[0]).group(1))
+                lo = _vpair(a[0])
                 if lo % 2:
                     raise SimError("odd-aligned 64-bit VGPR dest")
                 m.set_exact(lo, r)
@@ -274,7 +300,7 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None, start_pc=None, 
                 m.count_valu += 1
             elif op == "v_lshl_add_u64":
                 r = (m.exact_of(a[1]) << (m.vsrc(a[2]) & 7)) + m.exact_of(a[3])
-                lo = int(re.match(r"v\[(\d+):", a[0]).group(1))
+                lo = _vpair(a[0])
                 m.set_exact(lo, r)
                 m.count_valu += 1
             elif op == "v_ashrrev_i64":
@@ -282,7 +308,7 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None, start_pc=None, 
                 c = m.vsrc64(a[2])
                 c = c - (1 << 64) if c >> 63 else c
                 r = c >> sh
-                lo = int(re.match(r"v\[(\d+):", a[0]).group(1))
+                lo = _vpair(a[0])
                 v[lo] = r & M32
                 v[lo + 1] = (r >> 32) & M32
                 m.count_valu += 1
@@ -390,7 +416,7 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None, start_pc=None, 
                 m.count_valu += 1
             elif op == "v_lshrrev_b64":
                 r = m.vsrc64(a[2]) >> (m.vsrc(a[1]) & 63)
-                lo = int(re.match(r"v\[(\d+):", a[0]).group(1))
+                lo = _vpair(a[0])
                 if lo % 2:
                     raise SimError("odd-aligned 64-bit VGPR dest")
                 v[lo] = r & M32
