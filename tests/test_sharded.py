@@ -306,3 +306,12 @@ def test_bench_power_sampler_reads_rocm_smi(tmp_path, monkeypatch):
     with bench.PowerSampler() as ps:
         time.sleep(0.1)
     assert ps.summary() is None
+
+
+@pytest.mark.gpu
+def test_rank0_generates_the_whole_configs4_batch_in_one_call():
+    """What rank 0 of the 8-GPU run does before the scatter (bench.py, BASELINE.json configs[4]): 2^24 pairs from ONE bn254_generate_pairs_dev call
+    (3.2 GB; the plane offsets reach 2^31 bytes) -- points at the ends and in the middle equal [s]G1, [t]G2 for the generator's stated scalars, and
+    the pairings of the LAST rank's 2^21-lane slice equal the oracle."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "exp", "gen_2_24.py")], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "ok: 2^24 pairs" in p.stdout, (p.stdout[-500:], p.stderr[-1500:])
