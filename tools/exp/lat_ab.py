@@ -22,6 +22,8 @@ def main():
     out = torch.empty(48 * nmax, dtype=torch.int64, device=dev)
     st = torch.cuda.current_stream(dev).cuda_stream
     libs = [("shipped", pk.load_library())] + [(os.path.basename(p), pk.load_library(p)) for p in sys.argv[1:]]
+    if os.environ.get("LAT_ONLY"):              # counter runs (tools/exp/lat_pmc2.sh): the named libraries alone (the package's own library only generates the inputs)
+        libs = libs[1:]
     for n in sizes:
         pk.generate_pairs_dev(0xB2540001, g1, g2, n)
         best = {name: 1e9 for name, _ in libs}
