@@ -202,9 +202,10 @@ struct StreamCtx {
                                   // flags (atomicOr: 2 infinity, 4 not on the curve, 8 G2 not in the subgroup) -- separate words, so a
                                   // pairing kernel that trips over the all-zero point cannot overwrite the more specific verdict
     int* status_host = nullptr;   // pinned: the status words are read back on the caller's stream
-    size_t lat_threshold = (size_t)-1;   // bn254_set_stream_latency: this stream's own kernel selection; (size_t)-1 / -1 = the process-wide
-    int lat_lanes = -1;                  // defaults (bn254_set_latency_threshold / _lanes)
-    int last_kernel = 0;                 // bn254_last_kernel: 1 = throughput kernel (one item per lane), 16 / 32 / 64 = lanes per item
+    std::atomic<size_t> lat_threshold{(size_t)-1};   // bn254_set_stream_latency: this stream's own kernel selection; (size_t)-1 / -1 = the process-wide
+    std::atomic<int> lat_lanes{-1};                  // defaults (bn254_set_latency_threshold / _lanes)
+    std::atomic<int> last_kernel{0};     // bn254_last_kernel: 1 = throughput kernel (one item per lane), 16 / 32 / 64 = lanes per item (written under the
+                                         // context's mutex, read by the diagnostic without it)
     size_t last_pitch = 0;        // scratch geometry of the most recent launch (diagnostic builds read their clock stamps back from it)
     uint32_t last_grid = 0;
     ~StreamCtx() {                // the last holder (bn254_release_stream, after the stream has been synchronised) frees everything
@@ -359,7 +360,7 @@ void latency_cfg(int device, void* stream, size_t* threshold, int* lanes) {
         DeviceCtx& c = g_ctx[device];
         std::lock_guard<std::mutex> lk(c.mu);
         auto it = c.streams.find((hipStream_t)stream);
-        if (it != c.streams.end()) { t = it->second->lat_threshold; l = it->second->lat_lanes; }
+        if (it != c.streams.end()) { t = it->second->lat_threshold.load(); l = it->second->lat_lanes.load(); }
     }
     *threshold = t == (size_t)-1 ? g_latency_threshold.load() : t;
     *lanes = l < 0 ? g_latency_lanes.load() : l;
@@ -802,15 +803,15 @@ int bn254_last_kernel(int device, void* stream) {
     DeviceCtx& c = g_ctx[device];
     std::lock_guard<std::mutex> lk(c.mu);
     auto it = c.streams.find((hipStream_t)stream);
-    return it == c.streams.end() ? 0 : it->second->last_kernel;
+    return it == c.streams.end() ? 0 : it->second->last_kernel.load();
 }
 int bn254_set_stream_latency(int device, void* stream, size_t threshold, int lanes) {
     if (device < 0 || device >= 64 || !(lanes == -1 || lanes == 0 || lanes == 16 || lanes == 32 || lanes == 64)) return BN254_ERR_INVALID_ARG;
     std::shared_ptr<StreamCtx> sc = stream_ctx(device, stream);      // (no HIP call: the setting may precede the first launch)
     DeviceCtx& c = g_ctx[device];
     std::lock_guard<std::mutex> lk(c.mu);
-    sc->lat_threshold = threshold;
-    sc->lat_lanes = lanes;
+    sc->lat_threshold.store(threshold);
+    sc->lat_lanes.store(lanes);
     return BN254_OK;
 }
 size_t bn254_get_latency_threshold(void) { return g_latency_threshold.load(); }
@@ -1030,7 +1031,7 @@ int bn254_reserve(int device, void* stream, size_t n, size_t k) {
         sc->naf_ring.push_back(ns);
     }
     if (!sc->status_host && hipHostMalloc((void**)&sc->status_host, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) return BN254_ERR_ALLOC;
-    if ((sc->lat_threshold == (size_t)-1 ? g_latency_threshold.load() : sc->lat_threshold) != 0)                    // the latency path's round programs (25 MB in all): small calls upload nothing later
+    if ((sc->lat_threshold.load() == (size_t)-1 ? g_latency_threshold.load() : sc->lat_threshold.load()) != 0)                    // the latency path's round programs (25 MB in all): small calls upload nothing later
         for (int prog = 0; prog < CVM_N_PROGRAMS; prog++)
             if ((rc = cvm_upload(device, prog))) return rc;
     return BN254_OK;
