@@ -374,7 +374,7 @@ def test_dev_calls_are_capturable_into_a_hip_graph_after_reserve():
     pk = H.pkg()
     dev = torch.device("cuda:0")
     side = torch.cuda.Stream(dev)
-    n_big, n_small, k = 1 << 16, 300, 4
+    n_big, n_small, k, n_mid = 1 << 16, 300, 4, 5000
     with torch.cuda.stream(side):
         g1 = torch.zeros(8 * n_big, dtype=torch.int64, device=dev)
         g2 = torch.zeros(16 * n_big, dtype=torch.int64, device=dev)
@@ -383,6 +383,9 @@ def test_dev_calls_are_capturable_into_a_hip_graph_after_reserve():
         s2 = torch.zeros(16 * n_small * k, dtype=torch.int64, device=dev)
         out_small = torch.zeros(48 * n_small * k, dtype=torch.int64, device=dev)
         verdict = torch.zeros(n_small, dtype=torch.uint8, device=dev)
+        out_mid = torch.zeros(48 * n_mid, dtype=torch.int64, device=dev)
+        m1 = torch.zeros(8 * n_mid, dtype=torch.int64, device=dev)
+        m2 = torch.zeros(16 * n_mid, dtype=torch.int64, device=dev)
         pk.generate_pairs_dev(0x6A01, g1, g2, n_big, 0, side)
         pk.generate_pairs_dev(0x6A02, s1, s2, n_small * k, 0, side)
         pk.reserve(n_big, k, 0, side)                       # scratch, status words, verdict buffer, every round program: nothing left to do at launch
@@ -392,20 +395,25 @@ def test_dev_calls_are_capturable_into_a_hip_graph_after_reserve():
             pk.pairing_batch_dev(g1, g2, out_big, n_big, 0, side)                         # throughput kernel
             pk.pairing_batch_dev(s1, s2, out_small, n_small * k, 0, side)                 # lane-cooperative kernel
             pk.multi_pairing_check_batch_dev(s1, s2, verdict, n_small, k, 0, side)        # k_cvm + k_is_one
+            pk.pairing_batch_dev(m1, m2, out_mid, n_mid, 0, side)                         # mid-size: SEVEN launches through per-stream buffers
         want = []
         for seed in (0x6A11, 0x6A12):
             pk.generate_pairs_dev(seed, g1, g2, n_big, 0, side)
             pk.generate_pairs_dev(seed + 0x100, s1, s2, n_small * k, 0, side)
-            out_big.zero_(); out_small.zero_(); verdict.fill_(7)
+            pk.generate_pairs_dev(seed + 0x200, m1, m2, n_mid, 0, side)
+            out_big.zero_(); out_small.zero_(); verdict.fill_(7); out_mid.zero_()
             graph.replay()
             side.synchronize()
-            got = (out_big.clone(), out_small.clone(), verdict.clone())
+            got = (out_big.clone(), out_small.clone(), verdict.clone(), out_mid.clone())
             out_big.zero_(); out_small.zero_(); verdict.fill_(7)
             pk.pairing_batch_dev(g1, g2, out_big, n_big, 0, side)
             pk.pairing_batch_dev(s1, s2, out_small, n_small * k, 0, side)
             pk.multi_pairing_check_batch_dev(s1, s2, verdict, n_small, k, 0, side)
             pk.last_status(0, side)
             assert torch.equal(got[0], out_big) and torch.equal(got[1], out_small) and torch.equal(got[2], verdict)
+            pk.pairing_batch_dev(m1, m2, out_mid, n_mid, 0, side)
+            pk.last_status(0, side)
+            assert torch.equal(got[3], out_mid) and int(out_mid.abs().sum()) != 0
             assert int(out_big.abs().sum()) != 0 and int(verdict.max()) <= 1
             want.append(got[0][:48].clone())
         assert not torch.equal(want[0], want[1])            # the replays really ran on new inputs
