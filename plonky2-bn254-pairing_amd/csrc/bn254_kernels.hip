@@ -225,7 +225,7 @@ struct DeviceCtx {
     int n_cu = 0;
     std::mutex table_mu;       // the generator table upload (138 KB, blocking) has its own lock
     int32_t* gen_table = nullptr;
-    uint32_t* cvm_blob[31] = {};    // the latency path's round programs (0.3 - 1.4 MB each, uploaded on first use, same lock)
+    uint32_t* cvm_blob[34] = {};    // the latency path's round programs (0.3 - 1.4 MB each, uploaded on first use, same lock)
     bool cvm_init = false;
     std::map<hipStream_t, std::shared_ptr<StreamCtx>> streams;   // shared: a call keeps its context alive across a concurrent release
     std::mutex pipe_mu;        // one host-pointer pipeline at a time per device (its two workers fill the chip anyway)
@@ -376,9 +376,10 @@ struct CvmProgram {
     int full;                 // ... of its sixty-four-lane program, or -1
 };
 #define CVM_PROGRAM(NAME, PM, WIDE, FULL) {BN254_CVM_##NAME##_B64, BN254_CVM_##NAME##_Z_BYTES, BN254_CVM_##NAME##_BYTES, BN254_CVM_##NAME##_SLOTS, PM, WIDE, FULL}
-constexpr int CVM_N_PROGRAMS = 31;
+constexpr int CVM_N_PROGRAMS = 34;
 constexpr int CVM_MILLER_U = 26;      // the Miller half of pairing() (separate launch for mid-size batches)
 constexpr int CVM_EASY = 27, CVM_POWX = 28, CVM_YCH1 = 29, CVM_YCH2 = 30;      // final_exp_native in six launches (mid-size batches)
+constexpr int CVM_MMILLER_U = 29;    // + k (2, 3, 4): the Miller halves of the k-pair products
 const CvmProgram CVM_PROGRAMS[CVM_N_PROGRAMS] = {
     CVM_PROGRAM(PAIRING, BN254_CVM_PM_PAIRING, 9, 18), CVM_PROGRAM(MILLER, BN254_CVM_PM_MILLER, 10, 22), CVM_PROGRAM(FEXP, BN254_CVM_PM_FEXP, 11, -1),
     CVM_PROGRAM(MULTI2, 1500, 12, 19), CVM_PROGRAM(MULTI3, 1500, 13, 20), CVM_PROGRAM(MULTI4, 1500, 14, 21),
@@ -388,7 +389,8 @@ const CvmProgram CVM_PROGRAMS[CVM_N_PROGRAMS] = {
     CVM_PROGRAM(MMILLER2_W, 0, -1, -1), CVM_PROGRAM(MMILLER3_W, 0, -1, -1), CVM_PROGRAM(MMILLER4_W, 0, -1, -1),
     CVM_PROGRAM(PAIRING_X, 0, -1, -1), CVM_PROGRAM(MULTI2_X, 0, -1, -1), CVM_PROGRAM(MULTI3_X, 0, -1, -1), CVM_PROGRAM(MULTI4_X, 0, -1, -1),
     CVM_PROGRAM(MILLER_X, 0, -1, -1), CVM_PROGRAM(MMILLER2_X, 0, -1, -1), CVM_PROGRAM(MMILLER3_X, 0, -1, -1), CVM_PROGRAM(MMILLER4_X, 0, -1, -1),
-    CVM_PROGRAM(MILLER_U, 0, -1, -1), CVM_PROGRAM(EASY, 0, -1, -1), CVM_PROGRAM(POWX, 0, -1, -1), CVM_PROGRAM(YCH1, 0, -1, -1), CVM_PROGRAM(YCH2, 0, -1, -1)};
+    CVM_PROGRAM(MILLER_U, 0, -1, -1), CVM_PROGRAM(EASY, 0, -1, -1), CVM_PROGRAM(POWX, 0, -1, -1), CVM_PROGRAM(YCH1, 0, -1, -1), CVM_PROGRAM(YCH2, 0, -1, -1),
+    CVM_PROGRAM(MMILLER2_U, 0, -1, -1), CVM_PROGRAM(MMILLER3_U, 0, -1, -1), CVM_PROGRAM(MMILLER4_U, 0, -1, -1)};
 
 // which program serves (Miller loop?, final exponentiation?, k pairs); -1: none
 template <bool M, bool F>
@@ -437,6 +439,8 @@ int cvm_upload(int device, int prog) {
 // waves of the interpreter that a CU holds at `lds` bytes each (160 KB of LDS; 248 registers: two waves per SIMD)
 size_t resident_waves(size_t lds) {
     size_t w = lds ? (160 * 1024) / lds : 8;
+    if (w > 4 && w < 8) w = 4;       // five to seven waves leave one or two SIMDs with two waves and the others with one: the launch then takes as long as
+                                     // the two-wave SIMDs need (1.6 .. 1.8 single-wave times for 1.25 .. 1.75 x the waves) -- one per SIMD is faster
     return w > 8 ? 8 : (w ? w : 1);
 }
 
@@ -560,13 +564,15 @@ int launch_pairing(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in,
                 // pairing(), mid-size batch: SEVEN launches -- the Miller loop without the line scale (136 slots per item: eight waves per
                 // CU, two per SIMD, one wave's operand fetch under the other's arithmetic), then final_exp_native on its values in six
                 // pieces (launch_fexp_pieces) -- while the launch has more waves than one per SIMD (below that nothing overlaps).
-                if (M && F && k == 1 && lanes == 0 && n_groups > (size_t)BN254_CVM_SPLIT_MIN) {
+                // (the k-pair products likewise: their Miller halves keep four waves per CU -- 163 .. 242 slots -- but the final exponentiation's pieces
+                // run with eight)
+                if (M && F && k <= 4 && lanes == 0 && n_groups > (size_t)BN254_CVM_SPLIT_MIN) {
                     LaunchCtx hold;
                     int rc = ctx_get(device, stream, 1, 1, &hold);
                     if (rc) return rc;
                     if ((rc = ensure(hold.s.get(), hold.s->mid, 384 * n_groups))) return rc;
                     uint64_t* mid = (uint64_t*)hold.s->mid.p;
-                    if ((rc = launch_cvm(CVM_MILLER_U, 16, g1, g2, nullptr, mid, n_groups, 1, device, stream))) return rc;
+                    if ((rc = launch_cvm(k == 1 ? CVM_MILLER_U : CVM_MMILLER_U + (int)k, 16, g1, g2, nullptr, mid, n_groups, k, device, stream))) return rc;
                     return launch_fexp_pieces(mid, out, n_groups, device, stream);
                 }
                 if (!M && F && lanes == 0 && n_groups > (size_t)BN254_CVM_SPLIT_MIN)          // final_exp_native alone, mid-size batch: the same six launches

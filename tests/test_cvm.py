@@ -90,6 +90,22 @@ def test_miller_half_program_of_the_two_launch_pairing():
         assert not (written & read), rnd
 
 
+def test_multi_miller_half_programs():
+    """MMILLER2_U / 3_U / 4_U: multi_miller_loop_native without the line scale -- final_exp_native of the scheduled program's value is the
+    product of the pairings (the first launch of the mid-size form of the k-pair products)."""
+    base = [(R.g1_mul(R.G1_GEN, 11 + 7 * j), R.g2_mul(R.G2_GEN, 5 + 3 * j)) for j in range(4)]
+    for k in (2, 3, 4):
+        pairs = base[:k]
+        pr = cvm.Program(cvm.Lowered(cvm.build_multi_miller_u(k)), nr=CK.NR)
+        flat_in = []
+        for Pp, Qq in pairs:
+            flat_in += [Pp[0], Pp[1], Qq[0][0], Qq[0][1], Qq[1][0], Qq[1][1]]
+        w = pr.run(flat_in)
+        f = [(w[2 * i], w[2 * i + 1]) for i in range(6)]
+        want = R.final_exp_native(R.multi_miller_loop_native(pairs))
+        assert R.final_exp_native(R.fq12_from_fp2s(f)) == want, k
+
+
 def test_final_exp_pieces_compose_to_final_exp_native():
     """EASY, POWX (three times), YCH1, YCH2 (round 5: final_exp_native as six launches for mid-size batches): the scheduled sixteen-lane
     programs, run on integers one after the other with each piece's outputs as the next one's inputs, give final_exp_native(f) for a

@@ -229,6 +229,31 @@ def test_mid_size_batches_take_the_multi_launch_form(n):
         p.set_stream_latency(p.LATENCY_INHERIT, -1, 0, None)
 
 
+@pytest.mark.parametrize("k", [2, 3, 4])
+def test_mid_size_products_take_the_multi_launch_form(k):
+    """k-pair products with the final exponentiation above 4 096 groups: the Miller half in one launch, final_exp_native in six pieces -- every
+    group equals the throughput kernel's value, the `== one` verdicts likewise"""
+    import torch
+    p = H.pkg()
+    n = 4200
+    g1, g2 = _dev_pairs(p, n * k, 0xB25400CC + k)
+    dev = torch.device("cuda:0")
+    try:
+        outs = {}
+        for thr in (0, 1 << 20):
+            p.set_stream_latency(thr, 0, 0, None)
+            o = torch.empty(48 * n, dtype=torch.int64, device=dev)
+            v = torch.empty(n, dtype=torch.uint8, device=dev)
+            p.multi_pairing_batch_dev(g1, g2, o, n, k, do_final_exp=True)
+            p.multi_pairing_check_batch_dev(g1, g2, v, n, k)
+            p.last_status()
+            assert p.last_kernel(0, None) == (1 if thr == 0 else 16)
+            outs[thr] = (o, v)
+        assert torch.equal(outs[0][0], outs[1 << 20][0]) and torch.equal(outs[0][1], outs[1 << 20][1])
+    finally:
+        p.set_stream_latency(p.LATENCY_INHERIT, -1, 0, None)
+
+
 def test_golden_miller_and_final_exp_on_the_latency_kernel(pk):
     vec = H.load_golden("bn254_vectors.json")
     P = [tuple(HX(p)) for p in vec["g1"]]

@@ -1241,6 +1241,15 @@ def build_miller_u(**kw):
     return g
 
 
+def build_multi_miller_u(k, **kw):
+    """multi_miller_loop_native over k pairs WITHOUT the line scale (as build_miller_u): the first launch of the mid-size form of the k-pair
+    products, whose final exponentiation then runs as the six pieces"""
+    g = _graph(**kw)
+    pairs = [(g.g1_point(j), g.g2_point(j)) for j in range(k)]
+    g.outputs = g.multi_miller_loop(pairs, exact=False)
+    return g
+
+
 def build_fexp_piece(piece, **kw):
     """the launches of final_exp_native for mid-size batches: "easy" f_in -> m; "powx" f_in -> f_in^x (cyclotomic input); "ych1" (g1, g2, f_in) =
     (m^x, m^(x^2), m^(x^3)) -> T1; "ych2" (g1, f_in) = (m, T1) -> final_exp_native's value"""
