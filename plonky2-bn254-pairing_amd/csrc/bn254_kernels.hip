@@ -32,9 +32,9 @@ constexpr size_t MAX_K = 64;                            // pairs per group of th
 #ifndef BN254_LATENCY_THRESHOLD_DEFAULT
 // per mille of the threshold each program takes batches up to: its own measured crossover against the throughput kernel, re-measured in
 // round 5 on the bank-aware programs (profiles/r05_latency.json; the sixteen-lane programs run in passes of 4 096 items, four waves per CU):
-// pairing (seven launches above 4 096 items) 5.88 ms at 24 576 against 6.40, 6.73 at 28 672; miller_loop_native 3.31 at 24 576 against 3.75; final_exp_native (six
-// launches) 3.00 at 24 576 against 3.07; 2-pair product 8.32 at 24 576 against 8.85; 4-pair product 11.8 at 24 576 against 13.5; exact 2-pair value 6.12 at 28 672
-// against 6.32; exact 4-pair value 9.89 at 20 480 against 11.5 (11.39 / 11.49 at 24 576)
+// pairing (seven launches above 4 096 items) 5.88 ms at 24 576 against 6.37, 6.70 at 28 672 against 6.41; miller_loop_native 3.30 at 24 576 against 3.69; final_exp_native
+// (six launches) 2.99 at 24 576 against 3.06; 2-pair product (Miller half + six pieces above 4 096 groups, as the others) 7.86 at 24 576 against 8.86, 9.08 at 28 672 against
+// 8.81; 4-pair product 13.02 at 28 672 against 13.54; exact 2-pair value 6.09 at 28 672 against 6.31; exact 4-pair value 11.26 at 24 576 against 11.44
 #define BN254_CVM_PM_PAIRING 1500
 #define BN254_CVM_PM_MILLER 1500
 #define BN254_CVM_PM_FEXP 1500
@@ -382,8 +382,8 @@ constexpr int CVM_EASY = 27, CVM_POWX = 28, CVM_YCH1 = 29, CVM_YCH2 = 30;      /
 constexpr int CVM_MMILLER_U = 29;    // + k (2, 3, 4): the Miller halves of the k-pair products
 const CvmProgram CVM_PROGRAMS[CVM_N_PROGRAMS] = {
     CVM_PROGRAM(PAIRING, BN254_CVM_PM_PAIRING, 9, 18), CVM_PROGRAM(MILLER, BN254_CVM_PM_MILLER, 10, 22), CVM_PROGRAM(FEXP, BN254_CVM_PM_FEXP, 11, -1),
-    CVM_PROGRAM(MULTI2, 1500, 12, 19), CVM_PROGRAM(MULTI3, 1500, 13, 20), CVM_PROGRAM(MULTI4, 1500, 14, 21),
-    CVM_PROGRAM(MMILLER2, 1750, 15, 23), CVM_PROGRAM(MMILLER3, BN254_CVM_PM_MMILLER, 16, 24), CVM_PROGRAM(MMILLER4, 1250, 17, 25),
+    CVM_PROGRAM(MULTI2, 1500, 12, 19), CVM_PROGRAM(MULTI3, 1500, 13, 20), CVM_PROGRAM(MULTI4, 1750, 14, 21),
+    CVM_PROGRAM(MMILLER2, 1750, 15, 23), CVM_PROGRAM(MMILLER3, BN254_CVM_PM_MMILLER, 16, 24), CVM_PROGRAM(MMILLER4, 1500, 17, 25),
     CVM_PROGRAM(PAIRING_W, 0, -1, -1), CVM_PROGRAM(MILLER_W, 0, -1, -1), CVM_PROGRAM(FEXP_W, 0, -1, -1),
     CVM_PROGRAM(MULTI2_W, 0, -1, -1), CVM_PROGRAM(MULTI3_W, 0, -1, -1), CVM_PROGRAM(MULTI4_W, 0, -1, -1),
     CVM_PROGRAM(MMILLER2_W, 0, -1, -1), CVM_PROGRAM(MMILLER3_W, 0, -1, -1), CVM_PROGRAM(MMILLER4_W, 0, -1, -1),

@@ -282,6 +282,37 @@ def test_wide_programs_equal_the_reference_functions():
             assert max(v.bound for v in low.fv) <= cvm.Lowered.V_MAX
 
 
+def test_sixty_four_lane_programs_equal_the_reference_functions():
+    """the sixty-four-lane programs as shipped (tools/gen_kernels.py CVM_FULL_PROGRAMS: single products on f's chain, four-term
+    combinations): graph, Fq lowering and schedule on big integers against the reference's functions; no slot is written in the round
+    that reads it"""
+    import gen_kernels as G
+    P = [R.g1_mul(R.G1_GEN, 11 + 7 * j) for j in range(4)]
+    Q = [R.g2_mul(R.G2_GEN, 5 + 3 * j) for j in range(4)]
+    flat = [c for j in range(4) for c in (P[j][0], P[j][1], Q[j][0][0], Q[j][0][1], Q[j][1][0], Q[j][1][1])]
+    mm = {k: R.multi_miller_loop_native([(P[j], Q[j]) for j in range(k)]) for k in (1, 2, 3, 4)}
+    want = {"PAIRING_X": (1, R.final_exp_native(mm[1])), "MILLER_X": (1, mm[1])}
+    for k in (2, 3, 4):
+        want[f"MULTI{k}_X"] = (k, R.final_exp_native(mm[k]))
+        want[f"MMILLER{k}_X"] = (k, mm[k])
+    assert mm[1] == R.miller_loop_native(Q[0], P[0])
+    for name, _, build in G.CVM_FULL_PROGRAMS:
+        k, w12 = want[name]
+        w = [c for x in R.fq12_to_fp2s(w12) for c in x]
+        low = cvm.Lowered(build(cvm))
+        pr = cvm.Program(low, nr=64, inv_weight=G.CVM_INV_WEIGHT.get(name), m_weight=G.CVM_M_WEIGHT.get(name, 1.0))
+        assert low.evaluate(flat[:6 * k]) == w and pr.run(flat[:6 * k]) == w, name
+        assert max(v.bound for v in low.fv) <= cvm.Lowered.V_MAX
+        for rnd, (kind, take) in enumerate(pr.rounds):
+            assert len(take) <= 64
+            written = {x.slot for v in take for x in (v, v.twin) if x is not None}
+            assert not (written & {s.slot for v in take for s in v.srcs()}), (name, rnd)
+    # the pairing program is what the review's one-item target is about: single products -> no six-product round on f's chain
+    pr = cvm.Program(cvm.Lowered(G.CVM_FULL_PROGRAMS[0][2](cvm)), nr=64)
+    st = pr.stats()
+    assert st["by_kind"].get("m6", 0) <= 4 and st["by_kind"].get("l8", 0) == 0 and st["instr_est"] < 290_000
+
+
 def test_whole_pairing_on_the_simulator():
     """the shipped program (csrc/cvm_asm_gen.h) on sixteen simulated lanes: pairing(P, Q), bit for bit"""
     low = cvm.Lowered(cvm.build_pairing())

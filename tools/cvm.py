@@ -67,6 +67,7 @@ def f2pow(a, e):
 
 
 ID, NEG, CONJ, NCONJ = (1, 0, 0, 1), (-1, 0, 0, -1), (1, 0, 0, -1), (-1, 0, 0, 1)
+XI2 = (80, -18, 18, 80)          # matrix of multiplication by xi^2 = 80 + 18 u
 
 
 def mxi(k=1):
@@ -79,11 +80,11 @@ def mk(k):
 
 
 class V:
-    __slots__ = ("id", "kind", "args", "bound", "users", "name", "real", "src", "early", "after")
+    __slots__ = ("id", "kind", "args", "bound", "users", "name", "real", "src", "early", "after", "pt")
 
     def __init__(self, id_, kind, args, bound):
         self.id, self.kind, self.args, self.bound = id_, kind, args, bound
-        self.users, self.name, self.real, self.src, self.early, self.after = [], None, False, None, False, None
+        self.users, self.name, self.real, self.src, self.early, self.after, self.pt = [], None, False, None, False, None, False
 
     def srcs(self):
         if self.kind in ("m1", "m3"):
@@ -99,7 +100,12 @@ class V:
 class Graph:
     """SSA builder over Fq2 values (lowered to Fq operations, where the value bounds are tracked, by `Lowered`)."""
 
-    def __init__(self, run_ahead=None, pow_window=None, wide=False, flat_sqr=None, line_tree=False):
+    def __init__(self, run_ahead=None, pow_window=None, wide=False, flat_sqr=None, line_tree=False, full=False):
+        # sixty-four lanes: f's chain as SINGLE products (two-product rounds instead of four- and six-product ones) whose sums are taken by the
+        # combination that follows them -- a doubling iteration of one pair is [21 products of f's coefficients | f^2 | 18 products with the
+        # line | f] = 385 + 225 + 385 + 225 instructions instead of [15 sums of two | f^2 | 6 sums of three] = 565 + 225 + 750; the dense
+        # product 31 operations of at most two products
+        self.full = full
         self.line_tree = line_tree        # several pairs: the lines of a step are multiplied with each other first (a tree, off f's chain), f takes ONE dense product
         self.wide = wide                  # the program is scheduled for thirty-two lanes: formulations that trade operations for depth
         self.flat_sqr = wide if flat_sqr is None else flat_sqr     # f^2 of the Miller loop as a schoolbook square (one pair: the lanes are there)
@@ -108,10 +114,13 @@ class Graph:
         self.consts = {}
         self.inputs = []
         self.outputs = []
+        self._in_point_step = False
+        self._xi_of = {}                  # full: value id -> xi times the value, where a sparse multiplication produced it beside the value
         self.run_ahead = run_ahead        # iterations the Miller loop's point chain may run ahead of f's (None: as far as lanes are free)
 
     def _new(self, kind, args, bound):
         v = V(len(self.vals), kind, args, bound)
+        v.pt = self._in_point_step              # an operation of a point step (Program: pt_weight)
         self.vals.append(v)
         for s in v.srcs():
             s.users.append(v)
@@ -190,6 +199,19 @@ class Graph:
         """dense product: c_k = sum_i a_i B(k - i), B(j) = b_j (j >= 0) or xi b_(j+6); two chained three-term sums per coefficient.
         after: a value the product's first sums must not be scheduled before (no data flows: keeps a product that is only needed
         later from being computed early and waiting in LDS)"""
+        if self.full:
+            # sixty-four lanes: c_k = its six products in FOUR sources (two sums of two, two single products; the wrapped ones against
+            # xi b_j, which the caller holds for a table entry or a combination off the chain makes): 24 operations of at most two
+            # products and a four-term combination -- a four-product round and a cheap combination instead of a six-product round and
+            # an eight-term one
+            if bx is None:
+                bx = [None] + [self.xi(b[j]) for j in range(1, 6)]
+            out = []
+            for k in range(6):
+                t = [(a[i], b[k - i] if i <= k else bx[k - i + 6]) for i in range(6)]
+                out.append(self.lin((self.mul(t[0], t[1], after=after), ID), (self.mul(t[2], t[3], after=after), ID),
+                                    (self.mul(t[4], after=after), ID), (self.mul(t[5], after=after), ID)))
+            return out
         if self.wide:
             # thirty-two lanes: the wrapped and the unwrapped part of every coefficient as sums of at most three products of their own --
             # sixteen sums, ONE round of thirty-two operations -- and c_k = lo_k + xi hi_k in the recombination: a product round and a
@@ -224,13 +246,34 @@ class Graph:
         return out
 
     def fq12_mul_pre(self, b):
-        if self.wide:
+        if self.wide and not self.full:
             return None
         return [None] + [self.xi(b[j]) for j in range(1, 6)]
 
     def fq12_sqr(self, f):
         """complex squaring over Fq6 (tests/sched_model.py fq12_sqr): t = A0 A1, u = (A0 + A1)(A0 + v A1);
         f^2 = (u - t - v t) + 2 t w: six three-term sums between two layers of linear combinations"""
+        if self.full:
+            # sixty-four lanes: the 21 distinct products a_i a_j one by one (42 operations, a two-product round), the sums in the recombination
+            a = f
+            X2 = mk(2)
+            if all(a[j].id in self._xi_of for j in (3, 4, 5)):
+                # ... whose wrapped ones take xi a_3, xi a_4, xi a_5 (the sparse multiplication in front made them): four terms at most
+                xa = {j: self._xi_of[a[j].id] for j in (3, 4, 5)}
+                m = lambda i, j: self.mul((a[i], a[j] if i + j < 6 else xa[j]))
+                return [self.lin((m(0, 0), ID), (m(3, 3), ID), (m(1, 5), X2), (m(2, 4), X2)),
+                        self.lin((m(0, 1), X2), (m(2, 5), X2), (m(3, 4), X2)),
+                        self.lin((m(1, 1), ID), (m(0, 2), X2), (m(4, 4), ID), (m(3, 5), X2)),
+                        self.lin((m(0, 3), X2), (m(1, 2), X2), (m(4, 5), X2)),
+                        self.lin((m(2, 2), ID), (m(0, 4), X2), (m(1, 3), X2), (m(5, 5), ID)),
+                        self.lin((m(0, 5), X2), (m(1, 4), X2), (m(2, 3), X2))]
+            m = lambda i, j: self.mul((a[i], a[j]))
+            return [self.lin((m(0, 0), ID), (m(3, 3), mxi()), (m(1, 5), mxi(2)), (m(2, 4), mxi(2))),
+                    self.lin((m(0, 1), X2), (m(2, 5), mxi(2)), (m(3, 4), mxi(2))),
+                    self.lin((m(1, 1), ID), (m(0, 2), X2), (m(4, 4), mxi()), (m(3, 5), mxi(2))),
+                    self.lin((m(0, 3), X2), (m(1, 2), X2), (m(4, 5), mxi(2))),
+                    self.lin((m(2, 2), ID), (m(0, 4), X2), (m(1, 3), X2), (m(5, 5), mxi())),
+                    self.lin((m(0, 5), X2), (m(1, 4), X2), (m(2, 3), X2))]
         if self.flat_sqr:
             # thirty-two lanes: the schoolbook square without sums in front -- the 21 distinct products a_i a_j in fifteen sums of at
             # most three (by weight and by wrap: c_k = lo_k + xi hi_k), ONE round of thirty operations, then the recombination:
@@ -340,6 +383,7 @@ class Graph:
         """homogeneous projective doubling, the point scaled by xi^2 (L1v4.r_dblstep); line (L0, L3, L4) (miller_loop_native.rs:30-44).
         px, py: the G1 point's coordinates as Fq2 values (c1 = 0)."""
         X, Y, Z = Rp
+        self._in_point_step = True
         B = self.mul((Y, Y), after=after)
         C = self.mul((Z, Z), after=after)
         XX = self.mul((X, X), after=after)
@@ -354,24 +398,28 @@ class Graph:
         xH4 = self.lin((YZ, mxi(8)))                 # 4 xi H
         XYx2 = self.lin((XY, mxi(2)))
         X3 = self.mul((XYx2, T))
-        Y3 = self.mul((S, S), (N, N12))
+        # (sixty-four lanes: the two products of Y3 one by one, summed in the combination round that f's chain has anyway -- the round of
+        # the second-level products stays a two-product round)
+        Y3 = self.lin((self.mul((S, S)), ID), (self.mul((N, N12)), ID)) if self.full else self.mul((S, S), (N, N12))
         Z3 = self.mul((xB, xH4))
         L0 = self.lin((B, mxi()), (C, mk(-9)))
         H = self.lin((YZ, mk(2)))
         L3 = self.mul((H, py))
         XX3n = self.lin((XX, mk(-3)))
         L4 = self.mul((XX3n, px))
+        self._in_point_step = False
         return (X3, Y3, Z3), (L0, L3, L4)
 
     def add_step(self, Rp, Q, px, py, nQy=None):
         """mixed addition R + Q, line (L2, L3, L5) (miller_loop_native.rs:10-28)"""
         X, Y, Z = Rp
         x2, y2 = Q
+        self._in_point_step = True
         ny2 = nQy if nQy is not None else self.neg(y2)
         nx2 = self.neg(x2)
         theta = self.mul((ny2, Z), add=Y)
         mu = self.mul((nx2, Z), add=X)
-        L5 = self.mul((X, y2), (nx2, Y))
+        L5 = self.lin((self.mul((X, y2)), ID), (self.mul((nx2, Y)), ID)) if self.full else self.mul((X, y2), (nx2, Y))
         nmu = self.neg(mu)
         L2 = self.mul((nmu, py))
         L3 = self.mul((theta, px))
@@ -381,15 +429,36 @@ class Graph:
         F = self.mul((Z, C))
         G = self.mul((X, D))
         H = self.lin((E, ID), (F, ID), (G, mk(-2)))
-        GH = self.lin((G, ID), (H, NEG))
+        GH = self.lin((G, mk(3)), (E, NEG), (F, NEG)) if self.full else self.lin((G, ID), (H, NEG))       # (G - H beside H, not behind it)
         nE = self.neg(E)
         X3 = self.mul((mu, H))
         Y3 = self.mul((theta, GH), (nE, Y))
         Z3 = self.mul((Z, E))
+        self._in_point_step = False
         return (X3, Y3, Z3), (L2, L3, L5)
 
-    def mul_by_034(self, a, L):
+    def _sparse_full(self, a, terms, want_x=False):
+        """sixty-four lanes: the eighteen products of a sparse multiplication one by one, the sums in a combination of at most four
+        terms (the line's coefficients times xi where the product wraps: on the line's path, which leads).  want_x: the result is squared
+        next -- xi c_3, xi c_4, xi c_5 as nine more products with the coefficients times xi once more, so that the square's combinations
+        keep to four terms too (Graph.fq12_sqr)"""
+        bx = {}
+
+        def X(b, n):
+            if n and (b.id, n) not in bx:
+                bx[b.id, n] = self.lin((b, mxi() if n == 1 else XI2))
+            return bx[b.id, n] if n else b
+        out = [self.lin(*[(self.mul((a[i], X(b, wrapped))), ID) for i, b, wrapped in row]) for row in terms]
+        if want_x:
+            for k in (3, 4, 5):
+                self._xi_of[out[k].id] = self.lin(*[(self.mul((a[i], X(b, wrapped + 1))), ID) for i, b, wrapped in terms[k]])
+        return out
+
+    def mul_by_034(self, a, L, want_x=False):
         b0, b3, b4 = L
+        if self.full:
+            return self._sparse_full(a, want_x=want_x, terms=[[(0, b0, 0), (3, b3, 1), (2, b4, 1)], [(1, b0, 0), (4, b3, 1), (3, b4, 1)], [(2, b0, 0), (5, b3, 1), (4, b4, 1)],
+                                         [(3, b0, 0), (0, b3, 0), (5, b4, 1)], [(4, b0, 0), (1, b3, 0), (0, b4, 0)], [(5, b0, 0), (2, b3, 0), (1, b4, 0)]])
         b3x, b4x = self.xi(b3), self.xi(b4)
         return [self.mul((a[0], b0), (a[3], b3x), (a[2], b4x)),
                 self.mul((a[1], b0), (a[4], b3x), (a[3], b4x)),
@@ -398,8 +467,11 @@ class Graph:
                 self.mul((a[4], b0), (a[1], b3), (a[0], b4)),
                 self.mul((a[5], b0), (a[2], b3), (a[1], b4))]
 
-    def mul_by_235(self, a, L):
+    def mul_by_235(self, a, L, want_x=False):
         b2, b3, b5 = L
+        if self.full:
+            return self._sparse_full(a, want_x=want_x, terms=[[(4, b2, 1), (3, b3, 1), (1, b5, 1)], [(5, b2, 1), (4, b3, 1), (2, b5, 1)], [(0, b2, 0), (5, b3, 1), (3, b5, 1)],
+                                         [(1, b2, 0), (0, b3, 0), (4, b5, 1)], [(2, b2, 0), (1, b3, 0), (5, b5, 1)], [(3, b2, 0), (2, b3, 0), (0, b5, 0)]])
         b2x, b3x, b5x = self.xi(b2), self.xi(b3), self.xi(b5)
         return [self.mul((a[4], b2x), (a[3], b3x), (a[1], b5x)),
                 self.mul((a[5], b2x), (a[4], b3x), (a[2], b5x)),
@@ -424,16 +496,17 @@ class Graph:
 
         pend = []                                     # line_tree: the lines of the current step that f has not taken yet
 
-        def take(L6):
+        def take(L6, last=False):
+            """last: the iteration's last line -- f is squared next"""
             nonlocal f
             if self.line_tree and f is not None:
                 pend.append(L6)
             elif f is None:
                 f = [c if c is not None else zero for c in L6]
             elif L6[0] is not None:
-                f = self.mul_by_034(f, (L6[0], L6[3], L6[4]))
+                f = self.mul_by_034(f, (L6[0], L6[3], L6[4]), want_x=last)
             else:
-                f = self.mul_by_235(f, (L6[2], L6[3], L6[5]))
+                f = self.mul_by_235(f, (L6[2], L6[3], L6[5]), want_x=last)
 
         def flush():
             nonlocal f
@@ -444,26 +517,26 @@ class Graph:
                 pend[:] = nxt
             if pend:
                 T = pend.pop()
-                f = self.fq12_mul_gen(f, T)
+                f = self.fq12_mul(f, T) if self.full and all(c is not None for c in T) else self.fq12_mul_gen(f, T)
 
-        def dbl(j):
+        def dbl(j, last=False):
             nonlocal f, scale
             (px, py), _ = pairs[j]
             lam = Rs[j][2]
             ra = self.run_ahead
             Rs[j], L = self.dbl_step(Rs[j], px, py, after=hist[-ra][0] if ra is not None and len(hist) >= ra else None)
-            take([L[0], None, None, L[1], L[2], None])
+            take([L[0], None, None, L[1], L[2], None], last)
             if exact and lam is not one:
                 # the factor is lam = Z^2 and the scale is squared right after the iteration's doublings: (scale Z)^2 = scale^2 lam --
                 # two dependent products per doubling instead of three, as many as f's own chain has rounds for
                 scale = lam if scale is None else self.mul((scale, lam))
 
-        def add(j, Qs, nQsy):
+        def add(j, Qs, nQsy, last=False):
             nonlocal f, scale
             (px, py), _ = pairs[j]
             lam = Rs[j][2]
             Rs[j], L = self.add_step(Rs[j], Qs, px, py, nQy=nQsy)
-            take([None, None, L[0], L[1], None, L[2]])
+            take([None, None, L[0], L[1], None, L[2]], last)
             if exact:
                 scale = lam if scale is None else self.mul((scale, lam))
 
@@ -475,16 +548,17 @@ class Graph:
                 hist.append(f)
                 f = self.fq12_sqr(f)
                 for j in range(len(pairs)):
-                    dbl(j)
+                    dbl(j, last=self.full and enc[i] == 0 and i > 0 and j == len(pairs) - 1)
                 flush()
                 if exact and scale is not None:           # scale <- (scale * prod Z_j)^2 = scale^2 * prod lam_j
                     scale = self.mul((scale, scale))
             if enc[i] != 0:
                 for j, (_, Q) in enumerate(pairs):
+                    last = self.full and i > 0 and j == len(pairs) - 1
                     if enc[i] == 1:
-                        add(j, (Q[0], Q[1]), nQy[j])
+                        add(j, (Q[0], Q[1]), nQy[j], last)
                     else:
-                        add(j, (Q[0], nQy[j]), Q[1])
+                        add(j, (Q[0], nQy[j]), Q[1], last)
                 flush()
         c2, c3 = end_constants()
         for j, (_, Q) in enumerate(pairs):
@@ -649,11 +723,11 @@ def end_constants():
 # ------------------------------------------------------------------ lowering to Fq operations
 class FV:
     """one Fq value: kind in / const / mul / lin / inv, or `negof` (the negated twin its producer's lane writes beside the result)"""
-    __slots__ = ("id", "kind", "args", "bound", "users", "rnd", "slot", "height", "last", "twin", "cost", "after")
+    __slots__ = ("id", "kind", "args", "bound", "users", "rnd", "slot", "height", "last", "twin", "cost", "after", "pt")
 
     def __init__(self, id_, kind, args, bound):
         self.id, self.kind, self.args, self.bound = id_, kind, args, bound
-        self.users, self.rnd, self.slot, self.height, self.last, self.twin, self.cost, self.after = [], None, None, 0, -1, None, None, None
+        self.users, self.rnd, self.slot, self.height, self.last, self.twin, self.cost, self.after, self.pt = [], None, None, 0, -1, None, None, None, False
 
     def srcs(self):
         if self.kind == "mul":
@@ -688,7 +762,11 @@ class Lowered:
         self.map = {}            # Fq2 value id -> (c0 FV, c1 FV | None)
         self.zero = self.const(0)
         for v in g.vals:
+            n0 = len(self.fv)
             self.map[v.id] = self._lower(v)
+            if v.pt:
+                for r in self.fv[n0:]:
+                    r.pt = True
         self.outputs = []
         for o in g.outputs:
             c0, c1 = self.map[o.id]
@@ -838,11 +916,12 @@ def op_kind(v):
 class Program:
     """rounds: [(kind, [FV] (one per lane, at most nr))] + slot numbers"""
 
-    def __init__(self, low, nr=16, greedy_fill=True, inv_weight=None, m_weight=1.0):
+    def __init__(self, low, nr=16, greedy_fill=True, inv_weight=None, m_weight=1.0, pt_weight=1.0):
         """inv_weight: the inversion's weight in the critical-path heights, if not its cost.  The exact Miller programs end with the
         inversion of the scale, which needs the whole point chain: a larger weight lets that chain (and its lines, in LDS) run further
         ahead of f -- fewer rounds, more slots."""
         self.low = low
+        self.pt_weight = pt_weight        # factor on the weight of the point steps' operations in the heights (< 1: f's chain leads the choice of a round's family)
         self.m_weight = m_weight          # factor on the two- and four-product passes' weight in the heights (1.5: the sixty-four-lane multi-pair programs)
         self.inv_weight = inv_weight
         self.nr = nr
@@ -885,6 +964,8 @@ class Program:
             if v.id not in self.live or v.kind not in ("mul", "lin", "inv"):
                 continue
             own = self.inv_weight if self.inv_weight is not None and v.cost == K_INV else COST[v.cost] * (self.m_weight if v.cost in (K_M2, K_M4) else 1)
+            if v.pt:
+                own *= self.pt_weight
             v.height = own + max((u.height for u in self._consumers(v)), default=0)
 
     @staticmethod
@@ -1276,9 +1357,11 @@ def build_final_exp(**kw):
 def build_multi(k, final_exp=True, run_ahead=None, pow_window=None, **kw):
     """multi_miller_loop_native over k pairs (miller_loop_native.rs:324-326), then final_exp_native (the Groth16-style product of
     pairings, final_exp_native.rs:245-263) or -- final_exp=False -- the exact Miller value"""
-    g = _graph(run_ahead=run_ahead, pow_window=pow_window, **kw)
+    full = kw.pop("full", False)            # "fexp": the sixty-four-lane formulations in the final exponentiation only (four pairs: the Miller loop's rounds are full of lanes as they are)
+    g = _graph(run_ahead=run_ahead, pow_window=pow_window, full=full is True, **kw)
     pairs = [(g.g1_point(j), g.g2_point(j)) for j in range(k)]
     f = g.multi_miller_loop(pairs, exact=not final_exp)
+    g.full = bool(full)
     g.outputs = g.final_exp(f) if final_exp else f
     return g
 

@@ -97,7 +97,7 @@ def gpu(lib_path, sim_json):
         res["routines"][name] = {"calls": k, "cycles": c, "instructions_sim": ins, "cycles_per_instruction": (c / ins if ins else None)}
         print(f"{name:16s} {k:7.0f} {c:12.0f} {ins or 0:10d} {(c / ins if ins else 0):9.3f}   {100 * c / (float(np.median(tot)) / items):5.1f} %")
     print("wave cycles per item", res["wave_cycles_per_item"], "inside L2 routines", covered)
-    json.dump(res, open(os.path.join(ROOT, "gpurun_out", "r04_l2_profile.json"), "w"), indent=1)
+    json.dump(res, open(os.path.join(ROOT, "gpurun_out", os.environ.get("L2_PROFILE_OUT", "r05_l2_profile.json")), "w"), indent=1)
 
 
 if __name__ == "__main__":
