@@ -225,7 +225,7 @@ struct DeviceCtx {
     int n_cu = 0;
     std::mutex table_mu;       // the generator table upload (138 KB, blocking) has its own lock
     int32_t* gen_table = nullptr;
-    uint32_t* cvm_blob[34] = {};    // the latency path's round programs (0.3 - 1.4 MB each, uploaded on first use, same lock)
+    uint32_t* cvm_blob[40] = {};    // the latency path's round programs (0.3 - 1.4 MB each, uploaded on first use, same lock)
     bool cvm_init = false;
     std::map<hipStream_t, std::shared_ptr<StreamCtx>> streams;   // shared: a call keeps its context alive across a concurrent release
     std::mutex pipe_mu;        // one host-pointer pipeline at a time per device (its two workers fill the chip anyway)
@@ -376,12 +376,13 @@ struct CvmProgram {
     int full;                 // ... of its sixty-four-lane program, or -1
 };
 #define CVM_PROGRAM(NAME, PM, WIDE, FULL) {BN254_CVM_##NAME##_B64, BN254_CVM_##NAME##_Z_BYTES, BN254_CVM_##NAME##_BYTES, BN254_CVM_##NAME##_SLOTS, PM, WIDE, FULL}
-constexpr int CVM_N_PROGRAMS = 34;
+constexpr int CVM_N_PROGRAMS = 35;
+static_assert(CVM_N_PROGRAMS <= 40, "DeviceCtx::cvm_blob");
 constexpr int CVM_MILLER_U = 26;      // the Miller half of pairing() (separate launch for mid-size batches)
 constexpr int CVM_EASY = 27, CVM_POWX = 28, CVM_YCH1 = 29, CVM_YCH2 = 30;      // final_exp_native in six launches (mid-size batches)
 constexpr int CVM_MMILLER_U = 29;    // + k (2, 3, 4): the Miller halves of the k-pair products
 const CvmProgram CVM_PROGRAMS[CVM_N_PROGRAMS] = {
-    CVM_PROGRAM(PAIRING, BN254_CVM_PM_PAIRING, 9, 18), CVM_PROGRAM(MILLER, BN254_CVM_PM_MILLER, 10, 22), CVM_PROGRAM(FEXP, BN254_CVM_PM_FEXP, 11, -1),
+    CVM_PROGRAM(PAIRING, BN254_CVM_PM_PAIRING, 9, 18), CVM_PROGRAM(MILLER, BN254_CVM_PM_MILLER, 10, 22), CVM_PROGRAM(FEXP, BN254_CVM_PM_FEXP, 11, 34),
     CVM_PROGRAM(MULTI2, 1500, 12, 19), CVM_PROGRAM(MULTI3, 1500, 13, 20), CVM_PROGRAM(MULTI4, 1750, 14, 21),
     CVM_PROGRAM(MMILLER2, 1750, 15, 23), CVM_PROGRAM(MMILLER3, BN254_CVM_PM_MMILLER, 16, 24), CVM_PROGRAM(MMILLER4, 1500, 17, 25),
     CVM_PROGRAM(PAIRING_W, 0, -1, -1), CVM_PROGRAM(MILLER_W, 0, -1, -1), CVM_PROGRAM(FEXP_W, 0, -1, -1),
@@ -390,7 +391,8 @@ const CvmProgram CVM_PROGRAMS[CVM_N_PROGRAMS] = {
     CVM_PROGRAM(PAIRING_X, 0, -1, -1), CVM_PROGRAM(MULTI2_X, 0, -1, -1), CVM_PROGRAM(MULTI3_X, 0, -1, -1), CVM_PROGRAM(MULTI4_X, 0, -1, -1),
     CVM_PROGRAM(MILLER_X, 0, -1, -1), CVM_PROGRAM(MMILLER2_X, 0, -1, -1), CVM_PROGRAM(MMILLER3_X, 0, -1, -1), CVM_PROGRAM(MMILLER4_X, 0, -1, -1),
     CVM_PROGRAM(MILLER_U, 0, -1, -1), CVM_PROGRAM(EASY, 0, -1, -1), CVM_PROGRAM(POWX, 0, -1, -1), CVM_PROGRAM(YCH1, 0, -1, -1), CVM_PROGRAM(YCH2, 0, -1, -1),
-    CVM_PROGRAM(MMILLER2_U, 0, -1, -1), CVM_PROGRAM(MMILLER3_U, 0, -1, -1), CVM_PROGRAM(MMILLER4_U, 0, -1, -1)};
+    CVM_PROGRAM(MMILLER2_U, 0, -1, -1), CVM_PROGRAM(MMILLER3_U, 0, -1, -1), CVM_PROGRAM(MMILLER4_U, 0, -1, -1),
+    CVM_PROGRAM(FEXP_X, 0, -1, -1)};
 
 // which program serves (Miller loop?, final exponentiation?, k pairs); -1: none
 template <bool M, bool F>

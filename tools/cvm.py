@@ -39,6 +39,7 @@ BANK_AWARE = bool(int(os.environ.get("CVM_BANKS", "1")))       # LDS slots by li
 BANK_SLACK = int(os.environ.get("CVM_BANK_SLACK", "0"))        # slots the class-aware assignment may use beyond the liveness-only count
 INPUT_SLOTS_EXPIRE = bool(int(os.environ.get("CVM_INPUT_EXPIRE", "1")))      # an input's slot is reused once its last reader has run (YCH1 takes 36 input values: 146 -> 141 slots)
 N_TRASH = int(os.environ.get("CVM_TRASH", "1"))      # trash slots per item (Program.encode)
+GH_SHORT = bool(int(os.environ.get("CVM_GH_SHORT", "0")))      # add_step: G - H = 3 G - E - F beside H instead of behind it
 MAX_LIN_SRC = 6             # sources of an Fq2-level combination (the Fq operation it lowers to takes eight terms)
 
 
@@ -429,7 +430,7 @@ class Graph:
         F = self.mul((Z, C))
         G = self.mul((X, D))
         H = self.lin((E, ID), (F, ID), (G, mk(-2)))
-        GH = self.lin((G, mk(3)), (E, NEG), (F, NEG)) if self.full else self.lin((G, ID), (H, NEG))       # (G - H beside H, not behind it)
+        GH = self.lin((G, mk(3)), (E, NEG), (F, NEG)) if (self.full or GH_SHORT) else self.lin((G, ID), (H, NEG))       # (G - H beside H, not behind it)
         nE = self.neg(E)
         X3 = self.mul((mu, H))
         Y3 = self.mul((theta, GH), (nE, Y))

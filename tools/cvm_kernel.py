@@ -299,7 +299,8 @@ class VMKernel:
         e.raw("s_waitcnt vmcnt(0)")
         e.emit(f"v_readfirstlane_b32 s{S_KIND}, v{ROWN + 7}", kind="valu")
         e.salu(f"s_lshr_b32 s{S_KIND}, s{S_KIND}, 16")
-        for kind in (cvm.K_L4, cvm.K_M6, cvm.K_M2, cvm.K_M4, cvm.K_L8, cvm.K_INV):      # by frequency in the pairing program
+        # by frequency in the pairing program (the sixty-four-lane programs: two-product rounds and four-term combinations, tools/cvm.py Graph.full)
+        for kind in ((cvm.K_L4, cvm.K_M2, cvm.K_M4, cvm.K_L8, cvm.K_M6, cvm.K_INV) if self.nr == 64 else (cvm.K_L4, cvm.K_M6, cvm.K_M2, cvm.K_M4, cvm.K_L8, cvm.K_INV)):
             e.salu(f"s_cmp_eq_u32 s{S_KIND}, {kind}")
             e.salu(f"s_cbranch_scc1 LC_k{kind}_%=")
         e.salu("s_branch LC_end_%=")
