@@ -307,6 +307,13 @@ def test_sixty_four_lane_programs_equal_the_reference_functions():
             assert len(take) <= 64
             written = {x.slot for v in take for x in (v, v.twin) if x is not None}
             assert not (written & {s.slot for v in take for s in v.srcs()}), (name, rnd)
+    name, _, build = G.CVM_EXTRA_PROGRAMS[-1]
+    assert name == "FEXP_X"
+    low = cvm.Lowered(build(cvm))
+    pr = cvm.Program(low, nr=64)
+    w = [c for x in R.fq12_to_fp2s(R.final_exp_native(mm[2])) for c in x]
+    fin = [c for x in R.fq12_to_fp2s(mm[2]) for c in x]
+    assert low.evaluate(fin) == w and pr.run(fin) == w
     # the pairing program is what the review's one-item target is about: single products -> no six-product round on f's chain
     pr = cvm.Program(cvm.Lowered(G.CVM_FULL_PROGRAMS[0][2](cvm)), nr=64)
     st = pr.stats()
