@@ -76,6 +76,21 @@ def test_program_family_follows_the_launch_size():
         assert all(seen[(n, 0)] == 1 for n in (1024, 2048, 3000))
         assert seen[(1024, 1 << 20)] == 64 and seen[(1025, 1 << 20)] == 32 and seen[(2048, 1 << 20)] == 32
         assert seen[(2049, 1 << 20)] == 16 and seen[(3000, 1 << 20)] == 16
+        # final_exp_native has a sixty-four-lane program of its own since round 5 (single products: its chain is shorter there too)
+        n = 700
+        g1, g2 = _dev_pairs(pk, n, 0xFE70)
+        f = torch.empty(48 * n, dtype=torch.int64, device=torch.device("cuda:0"))
+        pk.set_stream_latency(0, 0, 0, None)
+        pk.miller_loop_batch_dev(g1, g2, f, n)
+        outs = []
+        for thr, want in ((0, 1), (1 << 20, 64)):
+            o = torch.empty(48 * n, dtype=torch.int64, device=torch.device("cuda:0"))
+            pk.set_stream_latency(thr, 0, 0, None)
+            pk.final_exp_batch_dev(f, o, n)
+            assert pk.last_kernel(0, None) == want
+            outs.append(o)
+        pk.last_status()
+        assert torch.equal(outs[0], outs[1])
     finally:
         pk.set_stream_latency(pk.LATENCY_INHERIT, -1, 0, None)
 
