@@ -209,9 +209,17 @@ def calibrate_this_lease():
         return None, f"tools/valu_calib: {type(e).__name__}: {e}"
 
 
+def under_profiler():
+    """rocprofv3's preloaded library rides into child processes and initialises the GPU there: no rocm-smi (an `env python3` script, i.e. an
+    exec after that initialisation) from a profiled run"""
+    return any(k.startswith(("ROCP", "ROCPROF")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+
+
 def box_id():
     """What identifies the box a line was measured on (the pool's boxes differ by a few per cent in the clock they hold)."""
     info = {"host": os.uname().nodename}
+    if under_profiler():
+        return info
     try:
         txt = subprocess.run(["rocm-smi", "--showuniqueid", "--showserial"], capture_output=True, text=True, timeout=10).stdout
         import re
@@ -480,7 +488,7 @@ def run_rank(args):
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)] if on_gpu else []
     import contextlib
     # (not under a profiler: its preloaded library would ride into the rocm-smi child processes)
-    profiled = any(k.startswith(("ROCP", "ROCPROF")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    profiled = under_profiler()
     power = PowerSampler() if (on_gpu and rank == 0 and not args.no_power and not profiled) else None
     with (power or contextlib.nullcontext()):
         t0 = time.perf_counter()

@@ -19,6 +19,28 @@ SIX_U_PLUS_2_NAF = [
 ]
 
 
+def canonical_naf(n):
+    """the non-adjacent form of n, least significant digit first (minimal weight among the signed binary representations)"""
+    out = []
+    while n:
+        z = 2 - (n % 4) if n & 1 else 0
+        n -= z
+        out.append(z)
+        n >>= 1
+    return out
+
+
+# The reference's table above has 65 digits, 26 of them non-zero: 64 doublings and 25 additions behind the top digit.  The canonical NAF of
+# 6 x + 2 has 66 digits and 22 non-zero ones: ONE doubling more, FOUR additions less.  The Miller VALUE depends on the chain (by factors
+# from proper subfields: vertical lines, the projective lines' scales), pairing(p, q) = final_exp_native(miller_loop_native(q, p)) does not --
+# (p^6 - 1) kills them -- so every path that ends in the final exponentiation walks the canonical NAF (round 5); miller_loop_native /
+# multi_miller_loop_native themselves keep the reference's table, digit for digit.
+SIX_U_PLUS_2_CANONICAL_NAF = canonical_naf(6 * BN_X + 2)
+assert len(SIX_U_PLUS_2_CANONICAL_NAF) == 66 and sum(1 for d in SIX_U_PLUS_2_CANONICAL_NAF if d) == 22 and SIX_U_PLUS_2_CANONICAL_NAF[64] == 0
+assert sum(d << k for k, d in enumerate(SIX_U_PLUS_2_CANONICAL_NAF)) == sum(d << k for k, d in enumerate(SIX_U_PLUS_2_NAF)) == 6 * BN_X + 2
+
+
+
 # ------------------------------------------------------------------------------------------ emitter
 class Emitter:
     """Instruction list with SGPR read/write annotations + hazard post-pass.

@@ -26,7 +26,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from asmcore import Emitter, P_INT, BN_X, SIX_U_PLUS_2_NAF, max_branch_distance, place_with_islands  # noqa: E402
+from asmcore import Emitter, P_INT, BN_X, SIX_U_PLUS_2_NAF, SIX_U_PLUS_2_CANONICAL_NAF, max_branch_distance, place_with_islands  # noqa: E402
 from kgen4 import DIGIT_ADD as K4_DIGIT_ADD, S_HALF as K4_S_HALF  # noqa: E402
 from kgen4 import (A0, B0, HOME0, L1V4_NAMES, L1v4, LB, MUL3_KEEP_DY, N0P, N_AGPR_SLOTS, N_HOME, N_LDS_SLOTS, NL, P_L, REDN_C, S_M30, S_N0, S_P, S_REDN,  # noqa: E402
                    S_RET1, S_RET2, S_RET3, SLOT_DW, SLOT_BYTES, V_FLAG, V_GOFF, V_GOFF8, V_IDX, V_IDX8, V_LDS, V_LTAIL, V_TID, bal_limbs, hx, mont4)
@@ -207,6 +207,12 @@ FISSION = bool(int(os.environ.get("KGEN_FISSION", "0")))
 # not depend on f; the two lines wait in six slots that nothing in the loop touches (LDS 2 .. 5, which the Miller phase of this kernel
 # never used, and the two AGPR slots of the addition point, free outside addition steps).  Iterations with a non-zero digit keep the
 # round-4 sequence.  ONE copy of each code: the park set is picked by a scalar register (S_PARK).
+# Round 5 -- the kernels whose Miller value goes straight into the final exponentiation (k_pairing, k_mpairing) walk the CANONICAL NAF of
+# 6 x + 2 (66 digits, 22 non-zero: 65 doublings + 21 additions) instead of the reference's digit table (65 digits, 26 non-zero: 64 + 25):
+# the chain changes the Miller value by factors from proper subfields only (vertical lines, line scales), which (p^6 - 1) kills --
+# pairing(p, q) and the products of pairings come out limb for limb the same (tools/asmcore.py).  One doubling iteration more (22 k
+# instructions), four addition steps less (16 k each) per pair.  k_miller / k_mmiller (the exact values) keep the reference's table.
+CANONICAL_CHAIN = bool(int(os.environ.get("KGEN_CANONICAL_CHAIN", "1")))
 CHUNK2 = bool(int(os.environ.get("KGEN_CHUNK2", "1")))
 CHUNK_LAYOUT = bool(int(os.environ.get("KGEN_CHUNK_LAYOUT", "0")))     # measured: the contiguous f half LOSES the chunking's +0.24 % again (profiles/r05_ab.txt)
 S_PARK = 50                                    # (s50 / s51: the split-loop experiment's cursors, free without it)
@@ -1675,6 +1681,20 @@ class KernelBuilder:
         return f"{name}_%="
 
     @property
+    def naf(self):
+        """the digits of 6 x + 2 this kernel's Miller loop walks (least significant first; the top one is R = Q, f = 1)"""
+        if CANONICAL_CHAIN and self.do_miller and self.do_fexp and not self.track and not FISSION:
+            return SIX_U_PLUS_2_CANONICAL_NAF
+        return SIX_U_PLUS_2_NAF
+
+    @property
+    def naf_first(self):
+        """digit index of the first doubling (L2_dblfirst): 63 with the reference's table, 64 with the canonical NAF (whose digit 64 is zero:
+        the loop's 64-bit digit masks hold digits 0..63 either way)"""
+        assert len(self.naf) - 2 == 63 or self.naf[64] == 0
+        return len(self.naf) - 2
+
+    @property
     def chunk2(self):
         """two doubling iterations per chunk with both lines parked on chip: the untracked one-pair kernels (k_pairing)"""
         return (CHUNK2 and self.do_miller and not self.track and not self.multi and not self.helper and not self.generate and LINE_IN_REGS
@@ -2130,10 +2150,11 @@ class KernelBuilder:
             dn, an = ("L2_dblmul_s", "L2_addmul_s") if self.multi else ("L2_dblmul", "L2_addmul")
             if self.multi:
                 run("L2_prefetch")
-            i = 63
+            naf, first = self.naf, self.naf_first
+            i = first
             while i >= 0:
-                if i != 63:
-                    if self.chunk2 and SIX_U_PLUS_2_NAF[i] == 0 and i > 0:
+                if i != first:
+                    if self.chunk2 and naf[i] == 0 and i > 0:
                         for name in ("L2_dbl_p", "L2_dbl_p", "L2_sqr", "L2_sp034_c", "L2_sqr", "L2_sp034_c"):
                             run(name)
                         i -= 1
@@ -2143,7 +2164,7 @@ class KernelBuilder:
                             run("L2_sqscale")
                         for _ in range(k_pairs):
                             run(dn)
-                if SIX_U_PLUS_2_NAF[i] != 0:
+                if naf[i] != 0:
                     for _ in range(k_pairs):
                         run(an)
                 i -= 1
@@ -2423,7 +2444,7 @@ class KernelBuilder:
         if K4_DIGIT_ADD:
             e.salu(f"s_mov_b32 s{K4_S_HALF}, 0x{1 << (LB - 1):x}")
             e.salu(f"s_mov_b32 s{K4_S_HALF + 1}, 0")
-        nz, neg = naf_masks(SIX_U_PLUS_2_NAF[:64])
+        nz, neg = naf_masks(self.naf[:64])
         e.salu(f"s_mov_b32 s68, 0x{nz & 0xFFFFFFFF:x}")
         e.salu(f"s_mov_b32 s69, 0x{nz >> 32:x}")
         e.salu(f"s_mov_b32 s70, 0x{neg & 0xFFFFFFFF:x}")
@@ -3051,10 +3072,11 @@ class KernelBuilder:
         if self.fission:
             self._fission_loops(e, p, single=True)
             return self._miller_end_steps(e, p)
-        e.salu(f"s_mov_b32 s{S_I}, 63")
+        first = self.naf_first
+        e.salu(f"s_mov_b32 s{S_I}, {first}")
         e.label(L("L_mloop"))
-        e.salu(f"s_cmp_eq_u32 s{S_I}, 63")
-        e.salu(f"s_cbranch_scc1 {L('L_mskip')}")
+        e.salu(f"s_cmp_eq_u32 s{S_I}, {first}")
+        e.salu(f"s_cbranch_scc1 {L('L_mskip') if first == 63 else L('L_mnoadd')}")       # (digit 64 of the canonical NAF is zero and outside the masks)
         if self.chunk2:
             # digit i zero and an iteration i - 1 exists: the two doubling steps first (lines parked), then the two f^2 + sparse
             # multiplications; iteration i - 1's addition step (if its digit is not zero) follows below
@@ -3234,10 +3256,11 @@ class KernelBuilder:
             e.salu(f"s_mov_b32 s{self.S_NEXTP}, 0")
             e.salu(f"s_mov_b32 s{S_JP}, -1")                              # (no pair is "the same as the next one" yet)
         self.call2(e, "L2_prefetch")
-        e.salu(f"s_mov_b32 s{S_I}, 63")
+        first = self.naf_first
+        e.salu(f"s_mov_b32 s{S_I}, {first}")
         e.label(L("L_mloop"))
-        e.salu(f"s_cmp_eq_u32 s{S_I}, 63")
-        e.salu(f"s_cbranch_scc1 {L('L_mskip')}")
+        e.salu(f"s_cmp_eq_u32 s{S_I}, {first}")
+        e.salu(f"s_cbranch_scc1 {L('L_mskip') if first == 63 else L('L_mnoadd')}")
         self.call2(e, "L2_sqr")
         if self.track:
             self.call2(e, "L2_sqscale")
