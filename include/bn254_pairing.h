@@ -202,7 +202,12 @@ long bn254_get_naf(const uint64_t* exp, size_t exp_limbs, int8_t* naf);
 /* frob_coeffs(index) -> Fq2 as 8 u64 (c0 limbs, c1 limbs)     src/final_exp_native.rs:183-192
  * index 0..11 (the only values frobenius_map_native uses, :22). */
 int bn254_frob_coeffs(size_t index, uint64_t* out8);
-/* SIX_U_PLUS_2_NAF (miller_loop_native.rs:314-318) and BN_X (final_exp_native.rs:15) */
+/* SIX_U_PLUS_2_NAF (miller_loop_native.rs:314-318) and BN_X (final_exp_native.rs:15).
+ * bn254_miller_loop_batch / bn254_multi_pairing_batch(do_final_exp = 0) walk this table digit for digit -- their values are the
+ * reference's.  The entry points whose Miller value goes straight into the final exponentiation (bn254_pairing_batch,
+ * bn254_multi_pairing_batch(do_final_exp = 1), bn254_multi_pairing_check_batch) walk a minimal-weight signed binary form of the same
+ * number 6x + 2 instead (65 digits, 22 non-zero: the same doublings, four additions less): the chain changes the Miller value by
+ * factors from proper subfields only, which the final exponentiation removes -- their results are the reference's limb for limb. */
 const int8_t* bn254_six_u_plus_2_naf(void); /* 65 entries */
 uint64_t bn254_bn_x(void);
 /* index map MyFq12 -> ark Fq12 flat order (`.into()` at src/pairing.rs:21):

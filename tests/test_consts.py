@@ -43,6 +43,20 @@ def test_kernel_constants():
     assert (K4P.THREE_B.c0, K4P.THREE_B.c1) == R.fq2_mul((3, 0), R.TWIST_B)
     assert sum(d << i for i, d in enumerate(K4P.X_DIGITS)) == R.BN_X
     assert K4P.SIX_U_PLUS_2_NAF == R.SIX_U_PLUS_2_NAF
+    # the chain of the Miller loops that end in the final exponentiation: the same number, 65 digits like the reference's table, and no
+    # signed binary form of 65 digits has fewer non-zero ones (dynamic programme over the digits)
+    import functools
+    import asmcore
+    short, n = asmcore.SIX_U_PLUS_2_SHORT, 6 * R.BN_X + 2
+    assert len(short) == 65 and set(short) <= {-1, 0, 1} and sum(d << i for i, d in enumerate(short)) == n
+
+    @functools.lru_cache(None)
+    def least(v, digits):
+        if digits == 0:
+            return 0 if v == 0 else 1 << 20
+        return min(least((v - d) // 2, digits - 1) + (d != 0) for d in (-1, 0, 1) if (v - d) % 2 == 0)
+    assert least(n, 65) == sum(1 for d in short if d) == 22 and sum(1 for d in R.SIX_U_PLUS_2_NAF if d) == 26
+    assert least(n, 64) >= 1 << 20 and least(n, 66) == 22          # 64 digits cannot hold it; a 66th digit buys nothing
     # limb form: balanced digits, Montgomery R' = 2^261
     assert K4.from_limbs(K4.P_L) == R.P and all(-K4.HALF <= l < K4.HALF for l in K4.P_L[:-1])
     assert (K4.N0P * R.P + 1) % (1 << K4.LB) == 0

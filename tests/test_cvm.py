@@ -70,7 +70,7 @@ def test_pairing_program_equals_the_reference_pairing():
 
 
 def test_miller_half_program_of_the_two_launch_pairing():
-    """MILLER_U (round 5): the Miller loop of pairing() without the line scale, on the canonical NAF of 6 x + 2, scheduled for sixteen lanes in
+    """MILLER_U (round 5): the Miller loop of pairing() without the line scale, on the minimal-weight 65-digit form of 6 x + 2, scheduled for sixteen lanes in
     at most 142 slots (eight waves per CU in the 36-byte layout).  Its value differs from miller_loop_native's by a factor from Fq6 only --
     final_exp_native of it IS pairing(P, Q), limb for limb -- and the scheduled program obeys the no-write-while-read rule of every program."""
     g = cvm.build_miller_u()
@@ -79,16 +79,16 @@ def test_miller_half_program_of_the_two_launch_pairing():
     flat = pr.run(FLAT)
     f = [(flat[2 * i], flat[2 * i + 1]) for i in range(6)]
     assert R.fq12_to_fp2s(R.final_exp_native(R.fq12_from_fp2s(f))) == R.fq12_to_fp2s(R.pairing_myfq12(P_PT, Q_PT))
-    # against miller_loop_native's own value: a factor from the subfield Fq6 (the lines' Fq2 scales, and -- the program walks the canonical
-    # NAF of 6 x + 2, the reference its own digit table -- vertical lines): fixed by the p^6-Frobenius, which is the conjugation
+    # against miller_loop_native's own value: a factor from the subfield Fq6 (the lines' Fq2 scales, and -- the program walks the minimal-weight
+    # 65-digit form of 6 x + 2, the reference its own digit table -- vertical lines): fixed by the p^6-Frobenius, which is the conjugation
     ratio = R.fq12_div(R.fq12_from_fp2s(f), R.miller_loop_native(Q_PT, P_PT))
     assert R.fq12_conjugate(ratio) == ratio and ratio != R.fq12_one()
     # ... and with the reference's table the factor is ONE Fq2 element for all six coefficients
-    cvm.CANONICAL_CHAIN = False
+    cvm.SHORT_CHAIN = False
     try:
         flat_r = cvm.Program(cvm.Lowered(cvm.build_miller_u()), nr=CK.NR).run(FLAT)
     finally:
-        cvm.CANONICAL_CHAIN = True
+        cvm.SHORT_CHAIN = True
     fr = [(flat_r[2 * i], flat_r[2 * i + 1]) for i in range(6)]
     exact = R.fq12_to_fp2s(R.miller_loop_native(Q_PT, P_PT))
     r2 = R.fq2_mul(fr[0], R.fq2_inv(exact[0]))

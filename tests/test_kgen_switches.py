@@ -3,7 +3,7 @@
   KGEN_FISSION=1   the split Miller loop (built, verified, measured, not adopted -- its line traffic costs more clock
                    than its cycles save).  Kept as a reproducible experiment: one pairing of k_pairing against the golden fixtures, with
                    the call sequence the bound certification walked (a k = 2 group of k_mpairing: `_run("multi", ...)` by hand).
-  all round-4 switches off: the generator still emits round 3's kernels (the A/B baseline `lib_base.so` of profiles/r04_ab.txt).
+  all round-4 switches (and round 5's shorter chain of the Miller loop) off: the generator still emits round 3's kernels (the A/B baseline `lib_base.so` of profiles/r04_ab.txt).
 The switches are read at import time, so each case runs in a fresh interpreter."""
 import os
 import subprocess
@@ -51,6 +51,6 @@ def test_split_miller_loop_builds_and_is_exact():
 
 def test_round3_baseline_switches():
     off = {k: "0" for k in ("KGEN_MUL6_KEEP_DIFFS", "KGEN_DBL_LAZY_Y3", "KGEN_CYC_WIDE_M", "KGEN_FQINV_WIDE_M", "KGEN_MUL3_KEEP_DY", "KGEN_ADD_INJECT",
-                            "KGEN_BOUSTRO", "KGEN_INV_FUSED", "KGEN_INV_SAFEGCD", "KGEN_DIGIT_ADD")}
+                            "KGEN_BOUSTRO", "KGEN_INV_FUSED", "KGEN_INV_SAFEGCD", "KGEN_DIGIT_ADD", "KGEN_SHORT_CHAIN")}
     n_r3 = _run("single", off)
     assert 3_660_000 < n_r3 < 3_680_000                    # round 3: 3.672 M instructions per pairing (profiles/r03_instr_histogram.json)

@@ -31,14 +31,15 @@ def canonical_naf(n):
 
 
 # The reference's table above has 65 digits, 26 of them non-zero: 64 doublings and 25 additions behind the top digit.  The canonical NAF of
-# 6 x + 2 has 66 digits and 22 non-zero ones: ONE doubling more, FOUR additions less.  The Miller VALUE depends on the chain (by factors
-# from proper subfields: vertical lines, the projective lines' scales), pairing(p, q) = final_exp_native(miller_loop_native(q, p)) does not --
-# (p^6 - 1) kills them -- so every path that ends in the final exponentiation walks the canonical NAF (round 5); miller_loop_native /
-# multi_miller_loop_native themselves keep the reference's table, digit for digit.
-SIX_U_PLUS_2_CANONICAL_NAF = canonical_naf(6 * BN_X + 2)
-assert len(SIX_U_PLUS_2_CANONICAL_NAF) == 66 and sum(1 for d in SIX_U_PLUS_2_CANONICAL_NAF if d) == 22 and SIX_U_PLUS_2_CANONICAL_NAF[64] == 0
-assert sum(d << k for k, d in enumerate(SIX_U_PLUS_2_CANONICAL_NAF)) == sum(d << k for k, d in enumerate(SIX_U_PLUS_2_NAF)) == 6 * BN_X + 2
-
+# 6 x + 2 has 66 digits and 22 non-zero ones (one doubling more, four additions less); the NAF of 6 x + 2 - 2^64 under the top digit 2^64 has
+# 65 digits and 22 non-zero ones -- the same 64 doublings as the reference, FOUR additions less (no signed binary form of 65 digits has fewer
+# non-zero digits: checked exhaustively by tests/test_consts.py).  The Miller VALUE depends on the chain (by factors from proper subfields:
+# vertical lines, the projective lines' scales), pairing(p, q) = final_exp_native(miller_loop_native(q, p)) does not -- (p^6 - 1) kills
+# them -- so every path that ends in the final exponentiation walks this form (round 5); miller_loop_native / multi_miller_loop_native
+# themselves keep the reference's table, digit for digit.
+SIX_U_PLUS_2_SHORT = (lambda t: t + [0] * (64 - len(t)) + [1])(canonical_naf(6 * BN_X + 2 - (1 << 64)))
+assert len(SIX_U_PLUS_2_SHORT) == 65 and sum(1 for d in SIX_U_PLUS_2_SHORT if d) == 22
+assert sum(d << k for k, d in enumerate(SIX_U_PLUS_2_SHORT)) == sum(d << k for k, d in enumerate(SIX_U_PLUS_2_NAF)) == 6 * BN_X + 2
 
 
 # ------------------------------------------------------------------------------------------ emitter

@@ -30,7 +30,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from asmcore import P_INT, BN_X, SIX_U_PLUS_2_NAF, SIX_U_PLUS_2_CANONICAL_NAF  # noqa: E402
+from asmcore import P_INT, BN_X, SIX_U_PLUS_2_NAF, SIX_U_PLUS_2_SHORT  # noqa: E402
 
 P = P_INT
 XI = (9, 1)
@@ -39,7 +39,7 @@ BANK_AWARE = bool(int(os.environ.get("CVM_BANKS", "1")))       # LDS slots by li
 BANK_SLACK = int(os.environ.get("CVM_BANK_SLACK", "0"))        # slots the class-aware assignment may use beyond the liveness-only count
 INPUT_SLOTS_EXPIRE = bool(int(os.environ.get("CVM_INPUT_EXPIRE", "1")))      # an input's slot is reused once its last reader has run (YCH1 takes 36 input values: 146 -> 141 slots)
 N_TRASH = int(os.environ.get("CVM_TRASH", "1"))      # trash slots per item (Program.encode)
-CANONICAL_CHAIN = bool(int(os.environ.get("CVM_CANONICAL_CHAIN", "1")))      # Miller loops that end in the final exponentiation walk the canonical NAF of 6 x + 2
+SHORT_CHAIN = bool(int(os.environ.get("CVM_SHORT_CHAIN", "1")))      # Miller loops that end in the final exponentiation walk the minimal-weight 65-digit form of 6 x + 2 (tools/asmcore.py)
 GH_SHORT = bool(int(os.environ.get("CVM_GH_SHORT", "0")))      # add_step: G - H = 3 G - E - F beside H instead of behind it
 MAX_LIN_SRC = 6             # sources of an Fq2-level combination (the Fq operation it lowers to takes eight terms)
 
@@ -489,9 +489,9 @@ class Graph:
         of a doubling, Z of an addition), which the final exponentiation removes; exact=True tracks their product and divides it
         out at the end -- the reference's value itself."""
         # exact: the reference's digit table (miller_loop_native.rs:314-318: 65 digits, 26 non-zero), digit for digit.  Otherwise the value
-        # goes into the final exponentiation, which does not see the chain: the canonical NAF (66 digits, 22 non-zero: one doubling more,
+        # goes into the final exponentiation, which does not see the chain: the 65-digit form with 22 non-zero digits (the same doublings,
         # four additions less -- tools/asmcore.py)
-        enc = SIX_U_PLUS_2_NAF if exact or not CANONICAL_CHAIN else SIX_U_PLUS_2_CANONICAL_NAF
+        enc = SIX_U_PLUS_2_NAF if exact or not SHORT_CHAIN else SIX_U_PLUS_2_SHORT
         first = len(enc) - 2                          # the digit of the first doubling (the top digit is R = Q, f = 1)
         one, zero = self.const((1, 0)), self.const((0, 0))
         nQy = [self.neg(Q[1]) for _, Q in pairs]

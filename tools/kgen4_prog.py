@@ -26,7 +26,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from asmcore import Emitter, P_INT, BN_X, SIX_U_PLUS_2_NAF, SIX_U_PLUS_2_CANONICAL_NAF, max_branch_distance, place_with_islands  # noqa: E402
+from asmcore import Emitter, P_INT, BN_X, SIX_U_PLUS_2_NAF, SIX_U_PLUS_2_SHORT, max_branch_distance, place_with_islands  # noqa: E402
 from kgen4 import DIGIT_ADD as K4_DIGIT_ADD, S_HALF as K4_S_HALF  # noqa: E402
 from kgen4 import (A0, B0, HOME0, L1V4_NAMES, L1v4, LB, MUL3_KEEP_DY, N0P, N_AGPR_SLOTS, N_HOME, N_LDS_SLOTS, NL, P_L, REDN_C, S_M30, S_N0, S_P, S_REDN,  # noqa: E402
                    S_RET1, S_RET2, S_RET3, SLOT_DW, SLOT_BYTES, V_FLAG, V_GOFF, V_GOFF8, V_IDX, V_IDX8, V_LDS, V_LTAIL, V_TID, bal_limbs, hx, mont4)
@@ -207,12 +207,12 @@ FISSION = bool(int(os.environ.get("KGEN_FISSION", "0")))
 # not depend on f; the two lines wait in six slots that nothing in the loop touches (LDS 2 .. 5, which the Miller phase of this kernel
 # never used, and the two AGPR slots of the addition point, free outside addition steps).  Iterations with a non-zero digit keep the
 # round-4 sequence.  ONE copy of each code: the park set is picked by a scalar register (S_PARK).
-# Round 5 -- the kernels whose Miller value goes straight into the final exponentiation (k_pairing, k_mpairing) walk the CANONICAL NAF of
-# 6 x + 2 (66 digits, 22 non-zero: 65 doublings + 21 additions) instead of the reference's digit table (65 digits, 26 non-zero: 64 + 25):
-# the chain changes the Miller value by factors from proper subfields only (vertical lines, line scales), which (p^6 - 1) kills --
-# pairing(p, q) and the products of pairings come out limb for limb the same (tools/asmcore.py).  One doubling iteration more (22 k
-# instructions), four addition steps less (16 k each) per pair.  k_miller / k_mmiller (the exact values) keep the reference's table.
-CANONICAL_CHAIN = bool(int(os.environ.get("KGEN_CANONICAL_CHAIN", "1")))
+# Round 5 -- the kernels whose Miller value goes straight into the final exponentiation (k_pairing, k_mpairing) walk the MINIMAL-WEIGHT
+# 65-digit form of 6 x + 2 (22 non-zero digits: 64 doublings + 21 additions) instead of the reference's digit table (65 digits, 26 non-zero:
+# 64 + 25): the chain changes the Miller value by factors from proper subfields only (vertical lines, line scales), which (p^6 - 1) kills --
+# pairing(p, q) and the products of pairings come out limb for limb the same (tools/asmcore.py).  Four addition steps (16 k instructions
+# each) less per pair.  k_miller / k_mmiller (the exact values) keep the reference's table.
+SHORT_CHAIN = bool(int(os.environ.get("KGEN_SHORT_CHAIN", "1")))
 CHUNK2 = bool(int(os.environ.get("KGEN_CHUNK2", "1")))
 CHUNK_LAYOUT = bool(int(os.environ.get("KGEN_CHUNK_LAYOUT", "0")))     # measured: the contiguous f half LOSES the chunking's +0.24 % again (profiles/r05_ab.txt)
 S_PARK = 50                                    # (s50 / s51: the split-loop experiment's cursors, free without it)
@@ -1683,14 +1683,14 @@ class KernelBuilder:
     @property
     def naf(self):
         """the digits of 6 x + 2 this kernel's Miller loop walks (least significant first; the top one is R = Q, f = 1)"""
-        if CANONICAL_CHAIN and self.do_miller and self.do_fexp and not self.track and not FISSION:
-            return SIX_U_PLUS_2_CANONICAL_NAF
+        if SHORT_CHAIN and self.do_miller and self.do_fexp and not self.track and not FISSION:
+            return SIX_U_PLUS_2_SHORT
         return SIX_U_PLUS_2_NAF
 
     @property
     def naf_first(self):
-        """digit index of the first doubling (L2_dblfirst): 63 with the reference's table, 64 with the canonical NAF (whose digit 64 is zero:
-        the loop's 64-bit digit masks hold digits 0..63 either way)"""
+        """digit index of the first doubling (L2_dblfirst): 63 for a 65-digit form (the reference's table, the minimal-weight form); a
+        66-digit form (the canonical NAF: first = 64) must have digit 64 zero -- the loop's 64-bit digit masks hold digits 0..63"""
         assert len(self.naf) - 2 == 63 or self.naf[64] == 0
         return len(self.naf) - 2
 
