@@ -97,8 +97,8 @@ int bn254_reserve(int device, void* stream, size_t n, size_t k);
  * The throughput kernels put one item on one lane: 3.6 M dependent instructions for a pairing, 6.5 ms however small the batch.
  * Behind the same entry points -- bn254_pairing_batch, bn254_miller_loop_batch, bn254_final_exp_batch, bn254_multi_pairing_batch
  * with k <= 4 pairs (both values of do_final_exp), bn254_multi_pairing_check_batch, their `_dev` and `_elems` forms -- sits a second,
- * lane-cooperative kernel: one item on sixteen lanes, four items per wave (pairing: 0.49 M instructions deep, 1.01 ms -- 0.55 ms on
- * more lanes, below; a four-pair product check 0.75 ms instead of 13.4), the same values bit for bit.  Batches of at most `n` items take it, per function scaled by
+ * lane-cooperative kernel: one item on sixteen lanes, four items per wave (pairing: 0.49 M instructions deep, 1.01 ms -- 0.53 ms on
+ * more lanes, below; a four-pair product check 0.74 ms instead of 13.4), the same values bit for bit.  Batches of at most `n` items take it, per function scaled by
  * its measured crossover against the throughput kernel (round 5: x1.5 pairing, miller_loop_native, final_exp_native and the products of two and three
  * pairings, x1.75 the product of four, x1.75 / x1 / x1.5 the exact values of two / three / four pairs: with the default, pairing() up to 24 576 items -- above 4 096 as seven launches of
  * programs small enough for eight waves per CU: the Miller loop, then the final exponentiation in six pieces through per-stream buffers); 0 turns it off.  Process-wide DEFAULT
@@ -107,7 +107,7 @@ void bn254_set_latency_threshold(size_t n);
 size_t bn254_get_latency_threshold(void);
 /* The lane-cooperative programs exist for sixteen lanes per item (four items per wave; every function), for thirty-two (two items per
  * wave: fewer, fuller rounds -- pairing 0.70 ms instead of 1.01 -- for twice the lanes) and for sixty-four
- * (one item per wave: pairing 0.55 ms -- the accumulator's chain runs as single products there, the sums in the combinations that follow;
+ * (one item per wave: pairing 0.53 ms -- the accumulator's chain runs as single products there, the sums in the combinations that follow;
  * the lines of a step of three or four pairs are multiplied with each other off the accumulator's chain).
  * 0 (default): sixty-four / thirty-two while the launch is at most one wave per SIMD (1024 / 2048 items on MI355X), sixteen beyond;
  * 16 / 32 / 64: that family whatever the size (measurements, tests; a function without a program of the family takes the next
