@@ -53,4 +53,6 @@ def test_round3_baseline_switches():
     off = {k: "0" for k in ("KGEN_MUL6_KEEP_DIFFS", "KGEN_DBL_LAZY_Y3", "KGEN_CYC_WIDE_M", "KGEN_FQINV_WIDE_M", "KGEN_MUL3_KEEP_DY", "KGEN_ADD_INJECT",
                             "KGEN_BOUSTRO", "KGEN_INV_FUSED", "KGEN_INV_SAFEGCD", "KGEN_DIGIT_ADD", "KGEN_SHORT_CHAIN")}
     n_r3 = _run("single", off)
-    assert 3_660_000 < n_r3 < 3_680_000                    # round 3: 3.672 M instructions per pairing (profiles/r03_instr_histogram.json)
+    # round 3: 3.672 M instructions per pairing (profiles/r03_instr_histogram.json); the x-powers' digit set is a constant of the generator, not
+    # a switch: with round 5's {1, 15, 19} (3 x 20.5 k instructions less than {1, 5, 9, 13}) the same switches give 3.617 M
+    assert 3_605_000 < n_r3 < 3_630_000

@@ -590,17 +590,17 @@ class Graph:
         two rounds on the critical path, a squaring three."""
         w = self.pow_window
         if w == "fixed":
-            # the throughput kernels' signed fixed-set recoding (tools/kgen4_prog.py X_DIGITS, found by tools/exp/xchain.py): digits in
-            # {0, +-1, +-5, +-9, +-13}, 59 squarings + 12 multiplications in the loop, b^4, b^5, b^9, b^13 from 2 squarings + 3 multiplications
-            from kgen4_prog import X_DIGITS
+            # the throughput kernels' signed fixed-set recoding (tools/kgen4_prog.py X_DIGITS, found by tools/exp/xchain2.py): digits in
+            # {0, +-1, +-15, +-19}, 58 squarings + 11 multiplications in the loop, b^4, b^16 from 4 squarings, b^15 = b^16 conj(b), b^19 = b^15 b^4
+            from kgen4_prog import X_DIGITS, X_POWERS
+            assert X_POWERS == (1, 15, 19)
             digits = list(X_DIGITS)
             top = len(digits) - 1
             b4 = self.cyc_sqr(self.cyc_sqr(a))
-            b4x = self.fq12_mul_pre(b4)
+            b16 = self.cyc_sqr(self.cyc_sqr(b4))
             odd = {1: a}
-            odd[5] = self.fq12_mul(a, b4, b4x)
-            odd[9] = self.fq12_mul(odd[5], b4, b4x)
-            odd[13] = self.fq12_mul(odd[9], b4, b4x)
+            odd[15] = self.fq12_mul(self.fq12_conj(a), b16, self.fq12_mul_pre(b16))
+            odd[19] = self.fq12_mul(odd[15], b4, self.fq12_mul_pre(b4))
         else:
             digits = []
             e = BN_X

@@ -151,16 +151,18 @@ THREE_B = _three_b()        # 3 b' = 9 / xi (twist curve y^2 = x^3 + 3/xi)
 
 # ---- x-power schedule of the final exponentiation (F <- F^BN_X for cyclotomic F, three times per pairing).
 # pow_native (final_exp_native.rs:56-84) walks the NAF of BN_X: 62 squarings + 23 multiplications.  The value F^x does
-# not depend on the chain, so the kernels use a signed fixed-set recoding instead: digits in {0, +-1, +-5, +-9, +-13}
-# (found by exhaustive search over digit sets, tools/exp/xchain.py): 59 squarings + 12 multiplications in the loop and
-# b^4, b^5, b^9, b^13 from 2 squarings + 3 multiplications: 61 S + 15 M instead of 62 S + 23 M (a squaring costs a
-# third of a multiplication).  Negative digits multiply by the conjugate (= inverse of a unitary element).
-X_POWERS = (1, 5, 9, 13)
-X_DIGITS = (-13, -1, 0, 0, 0, 0, 0, 0, 0, 5, 0, 0, 0, 0, 0, 0, 9, 0, 0, 0, 0, -13, 0, 0, 0, 0, -13, 0, 0, 0, 0, 9, 0, 0, 0, 0, -5, 0, 0, 0, -13,
-            0, 0, 0, 0, 13, 0, 0, 0, 0, 0, 5, 0, 0, -13, 0, 0, 0, 0, 9)            # least significant first
-assert sum(d << i for i, d in enumerate(X_DIGITS)) == BN_X and X_DIGITS[-1] in X_POWERS
+# not depend on the chain, so the kernels use a signed fixed-set recoding instead.  Rounds 2 - 4: digits in {0, +-1, +-5, +-9, +-13}, 61 S
+# + 15 M.  Round 5 (tools/exp/xchain2.py: every set of up to three odd powers below 64, the optimal recoding of each by dynamic
+# programming over (bit, carry), the table's own squarings and multiplications counted): digits in {0, +-1, +-15, +-19} -- 58 squarings +
+# 11 multiplications in the loop, b^4, b^16 by four squarings, b^15 = b^16 conj(b), b^19 = b^15 b^4: **62 S + 13 M** (a squaring is 4.5 k
+# instructions, a multiplication 12.5 k: -20.5 k per x-power).  Negative digits multiply by the conjugate (= inverse of a unitary element).
+X_POWERS = (1, 15, 19)
+X_HOT = 19                       # ten of the twelve non-zero digits: conj(b^19) stays in the on-chip register LREG
+X_DIGITS = (-15, 0, 0, 0, 0, 0, 0, 0, 0, -19, 0, 0, 19, 0, 0, 0, 0, 0, 0, -19, 0, 0, 0, 0, -1, 0, 19, 0, 0, 0, 0, 0, 0, 0, -19, 0, 0, 0, 0, 0, 19,
+            0, 0, 0, 0, 0, 0, 19, 0, 0, 0, 0, 0, -19, -19, 0, 0, 0, 19)            # least significant first
+assert sum(d << i for i, d in enumerate(X_DIGITS)) == BN_X and X_DIGITS[-1] == X_HOT
 assert all(d == 0 or abs(d) in X_POWERS for d in X_DIGITS)
-G_POW = {5: 8, 9: 9, 13: 10}     # scratch Fq12 registers of b^5, b^9, b^13 (b itself: the caller's register)
+G_POW = {15: 8}                  # scratch Fq12 register of b^15 (b itself: the caller's register; b^19: LREG)
 G_B4 = 11                        # b^4 (only while the powers are built)
 N_GREG = 12                      # Fq12 scratch registers G0..G11 = slots 0..71
 GLOB_TMP0 = 6 * N_GREG           # eight overflow temporaries: slots 72..79
@@ -1940,7 +1942,7 @@ class KernelBuilder:
                 + ([] if self.track or self.SCALE.kind == "agpr" else [self.SCALE]) + [GLOB(GLOB_TMP0 + i) for i in range(8)])
 
     # An on-chip Fq12 register of the final exponentiation: six of the eight LDS slots (free there since fq12_mul works with three
-    # temporaries -- home block 8, AGPR 13 and, outside the inversion, AGPR 9).  It holds conj(b^13) during an x-power (half of the
+    # temporaries -- home block 8, AGPR 13 and, outside the inversion, AGPR 9).  It holds conj(b^19) during an x-power (most of the
     # twelve digit multiplications use it: no operand fetch) and T0 during the y-chain.
     LREG = [LDS(i, f"L{i - 2}") for i in range(2, 8)]
 
@@ -2248,21 +2250,20 @@ class KernelBuilder:
     def powx_ops(self, store_base):
         """The x-power F <- F^BN_X as a straight list of steps (emitted by _powx_routine, replayed by certify_values):
         ("st" | "ld" | "mul" | "mulc" | "pf", register) with register = an Fq12 scratch register number or "base" (the caller's),
-        ("call", L2 routine).  b^13 -- half of the digit multiplications -- never goes to scratch: conj(b^13) sits in the on-chip
-        register LREG (the first digit that uses it is -13; the one +13 conjugates f around the multiplication instead)."""
+        ("call", L2 routine).  b^19 -- ten of the twelve digit multiplications -- never goes to scratch: conj(b^19) sits in the on-chip
+        register LREG (negative digits multiply by it, positive ones conjugate f around the multiplication instead)."""
         ops = [("st", "base")] if store_base else []
-        ops += [("pf", "base"), ("cyc", 2), ("st", G_B4),                              # b^4 (the operand b is fetched under the squarings)
-                ("mul_w", "base"), ("pf", G_B4), ("st", G_POW[5]),                     # b^5 = b^4 b
-                ("mul_w", G_B4), ("st", G_POW[9]),                                     # b^9 = b^5 b^4
-                ("call", "L2_mul_body"), ("call", "L2_conjF"), ("call", "L2_stL")]     # conj(b^13) = conj(b^9 b^4) -> LREG (b^4 is still in the operand slots)
-        top = X_DIGITS[-1]
-        ops.append(("ld", "base" if top == 1 else G_POW[top]) if top != 13 else ("call", "L2_ldLc"))
+        ops += [("pf", "base"), ("cyc", 2), ("st", G_B4), ("cyc", 2),                  # b^4 (kept), b^16 (the operand b is fetched under the squarings)
+                ("mulc_w", "base"), ("pf", G_B4), ("st", G_POW[15]),                   # b^15 = b^16 conj(b)
+                ("mul_w", G_B4),                                                       # b^19 = b^15 b^4
+                ("call", "L2_conjF"), ("call", "L2_stL"), ("call", "L2_conjF")]        # conj(b^19) -> LREG; F = b^19: the top digit
+        assert X_DIGITS[-1] == X_HOT
         run = 0                                                                        # squarings since the last multiplication: ONE resident run
         for d in reversed(X_DIGITS[:-1]):
             run += 1
             if d == 0:
                 continue
-            if abs(d) == 13:
+            if abs(d) == X_HOT:
                 ops.append(("cyc", run))
                 ops += [("call", "L2_mulL")] if d < 0 else [("call", "L2_conjF"), ("call", "L2_mulL"), ("call", "L2_conjF")]
             else:
@@ -2277,7 +2278,7 @@ class KernelBuilder:
         """F <- F^BN_X for cyclotomic F (base b = F on entry, S_GBASE = its scratch register): the X_DIGITS schedule, unrolled
         (control code only: every step is a call).  Same value as pow_native(a, [BN_X]) (final_exp_native.rs:56-84) for unitary a.
         Entry L3_powx stores b into its register first, L3_powx_ns finds it there already."""
-        assert X_DIGITS[-1] != 13
+        assert X_DIGITS[-1] == X_HOT
         e = Emitter()
         L = self.lab
         name = {"st": "L2_stG", "ld": "L2_ldG", "mul": "L2_mulG", "mulc": "L2_mulGc", "pf": "L2_pfB", "mul_w": "L2_mulG_w", "mulc_w": "L2_mulGc_w"}
