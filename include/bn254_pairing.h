@@ -99,8 +99,8 @@ int bn254_reserve(int device, void* stream, size_t n, size_t k);
  * with k <= 4 pairs (both values of do_final_exp), bn254_multi_pairing_check_batch, their `_dev` and `_elems` forms -- sits a second,
  * lane-cooperative kernel: one item on sixteen lanes, four items per wave (pairing: 0.49 M instructions deep, 1.01 ms -- 0.53 ms on
  * more lanes, below; a four-pair product check 0.74 ms instead of 13.4), the same values bit for bit.  Batches of at most `n` items take it, per function scaled by
- * its measured crossover against the throughput kernel (round 5: x1.5 pairing, miller_loop_native and the products of two and three
- * pairings, x1.25 final_exp_native, x1.75 the product of four, x1.75 / x1 / x1.5 the exact values of two / three / four pairs: with the default, pairing() up to 24 576 items -- above 4 096 as seven launches of
+ * its measured crossover against the throughput kernel (round 5: x1.5 pairing, miller_loop_native, final_exp_native and the products of two and three
+ * pairings, x1.75 the product of four, x1.75 / x1 / x1.5 the exact values of two / three / four pairs: with the default, pairing() up to 24 576 items -- above 4 096 as seven launches of
  * programs small enough for eight waves per CU: the Miller loop, then the final exponentiation in six pieces through per-stream buffers); 0 turns it off.  Process-wide DEFAULT
  * (a stream may carry its own: bn254_set_stream_latency); default 16384. */
 void bn254_set_latency_threshold(size_t n);

@@ -32,13 +32,12 @@ constexpr size_t MAX_K = 64;                            // pairs per group of th
 #ifndef BN254_LATENCY_THRESHOLD_DEFAULT
 // per mille of the threshold each program takes batches up to: its own measured crossover against the throughput kernel, re-measured in
 // round 5 on the bank-aware programs (profiles/r05_latency.json; the sixteen-lane programs run in passes of 4 096 items, four waves per CU):
-// pairing (seven launches above 4 096 items) 5.88 ms at 24 576 against 6.22, 6.73 at 28 672 against 6.22; miller_loop_native 3.19 at 24 576 against 3.72; final_exp_native
-// (six launches) 2.56 at 20 480 against 2.98, 3.02 at 24 576 against 2.98 (the throughput kernel's x-powers got cheaper in round 5: x1.25); 2-pair product (Miller half +
-// six pieces above 4 096 groups, as the others) 7.58 at 24 576 against 8.50, 8.75 at 28 672 against 8.49; 4-pair product 12.75 at 28 672 against 13.04; exact 2-pair value
-// 5.98 at 28 672 against 6.34; exact 4-pair value 11.35 at 24 576 against 11.53
+// pairing (seven launches above 4 096 items) 5.54 ms at 24 576 against 6.16, 6.33 at 28 672 against 6.16; miller_loop_native 3.20 at 24 576 against 3.69; final_exp_native
+// (six launches) 2.72 at 24 576 against 2.95, 3.11 at 28 672 against 2.97; 2-pair product (Miller half + six pieces above 4 096 groups, as the others) 7.25 at 24 576
+// against 8.48; 4-pair product 12.31 at 28 672 against 12.85; exact 2-pair value 5.88 at 28 672 against 6.28; exact 4-pair value 11.19 at 24 576 against 11.43
 #define BN254_CVM_PM_PAIRING 1500
 #define BN254_CVM_PM_MILLER 1500
-#define BN254_CVM_PM_FEXP 1250
+#define BN254_CVM_PM_FEXP 1500
 #define BN254_CVM_PM_MMILLER 1000
 #ifndef BN254_CVM_SPLIT_MIN
 #define BN254_CVM_SPLIT_MIN 4096        // pairing() on the lane-cooperative kernel in two launches above this many items (one wave per SIMD of the fused program)
