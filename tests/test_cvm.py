@@ -52,7 +52,7 @@ def test_graph_builders_against_the_schedule_model():
 def test_pairing_program_equals_the_reference_pairing():
     """graph -> Fq operations -> sixteen-lane schedule with slot allocation: each level evaluates to pairing(P, Q)"""
     want = R.fq12_to_fp2s(R.pairing_myfq12(P_PT, Q_PT))
-    g = cvm.build_pairing()
+    g = cvm.build_pairing(pow_window="x19")          # (as shipped: tools/gen_kernels.py CVM_PROGRAMS)
     assert g.evaluate([(P_PT[0], 0), (P_PT[1], 0), Q_PT[0], Q_PT[1]]) == want
     low = cvm.Lowered(g)
     flat_want = [c for x in want for c in x]
@@ -259,9 +259,10 @@ def test_other_programs_equal_the_reference_functions():
     for k in (2, 3):
         m = R.multi_miller_loop_native([(P[j], Q[j]) for j in range(k)])
         check(cvm.build_multi(k, final_exp=False), flat(k), m)
-        check(cvm.build_multi(k, final_exp=True), flat(k), R.final_exp_native(m))
+        check(cvm.build_multi(k, final_exp=True, pow_window="x19"), flat(k), R.final_exp_native(m))
     f = R.miller_loop_native(Q[1], P[2])
-    check(cvm.build_final_exp(), [c for x in R.fq12_to_fp2s(f) for c in x], R.final_exp_native(f))
+    check(cvm.build_final_exp(pow_window="x19"), [c for x in R.fq12_to_fp2s(f) for c in x], R.final_exp_native(f))
+    check(cvm.build_final_exp(), [c for x in R.fq12_to_fp2s(f) for c in x], R.final_exp_native(f))          # (the three-bit window: not shipped any more, still a valid schedule)
 
 
 def test_wide_programs_equal_the_reference_functions():
@@ -333,7 +334,7 @@ def test_sixty_four_lane_programs_equal_the_reference_functions():
 
 def test_whole_pairing_on_the_simulator():
     """the shipped program (csrc/cvm_asm_gen.h) on sixteen simulated lanes: pairing(P, Q), bit for bit"""
-    low = cvm.Lowered(cvm.build_pairing())
+    low = cvm.Lowered(cvm.build_pairing(pow_window="x19"))
     pr = cvm.Program(low, nr=CK.NR)
     want = [c for x in R.fq12_to_fp2s(R.pairing_myfq12(P_PT, Q_PT)) for c in x]
     ms, rounds = _sim(pr, want)

@@ -41,6 +41,9 @@ INPUT_SLOTS_EXPIRE = bool(int(os.environ.get("CVM_INPUT_EXPIRE", "1")))      # a
 N_TRASH = int(os.environ.get("CVM_TRASH", "1"))      # trash slots per item (Program.encode)
 SHORT_CHAIN = bool(int(os.environ.get("CVM_SHORT_CHAIN", "1")))      # Miller loops that end in the final exponentiation walk the minimal-weight 65-digit form of 6 x + 2 (tools/asmcore.py)
 GH_SHORT = bool(int(os.environ.get("CVM_GH_SHORT", "0")))      # add_step: G - H = 3 G - E - F beside H instead of behind it
+X19_DIGITS = (-19, 0, 1, 0, 0, 0, 0, 0, 0, -19, 0, 0, 19, 0, 0, 0, 0, 0, 0, -19, 0, 0, 0, 0, -1, 0, 19, 0, 0, 0, 0, 0, 0, 0, -19, 0, 0, 0, 0, 0, 19, 0, 0,
+              0, 0, 0, 0, 19, 0, 0, 0, 0, 0, 19, 0, -19, 0, 0, 19)      # BN_X over {0, +-1, +-19}, least significant first (pow_x "x19")
+assert sum(d << i for i, d in enumerate(X19_DIGITS)) == BN_X
 MAX_LIN_SRC = 6             # sources of an Fq2-level combination (the Fq operation it lowers to takes eight terms)
 
 
@@ -601,6 +604,17 @@ class Graph:
             odd = {1: a}
             odd[15] = self.fq12_mul(self.fq12_conj(a), b16, self.fq12_mul_pre(b16))
             odd[19] = self.fq12_mul(odd[15], b4, self.fq12_mul_pre(b4))
+        elif w == "x19":
+            # two table entries like the three-bit window ({1, 3}: 63 squarings + 18 multiplications), but the digit set {1, 19} of the search in
+            # tools/exp/xchain2.py: 58 squarings + 12 multiplications in the loop, b^2 .. b^16 by four squarings, b^19 = b^16 b^2 b -- 62 S + 14 M
+            # (the sixteen-lane programs, whose slot budget has no room for a third entry)
+            digits = list(X19_DIGITS)
+            top = len(digits) - 1
+            b2 = self.cyc_sqr(a)
+            b16 = self.cyc_sqr(self.cyc_sqr(self.cyc_sqr(b2)))
+            b18 = self.fq12_mul(b16, b2, self.fq12_mul_pre(b2))
+            odd = {1: a}
+            odd[19] = self.fq12_mul(b18, a, self.fq12_mul_pre(a))
         else:
             digits = []
             e = BN_X
