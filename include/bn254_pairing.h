@@ -88,7 +88,7 @@ int bn254_last_status(int device, void* stream);
 size_t bn254_scratch_bytes(size_t n, size_t k);
 /* Sizes everything the library keeps for (device, stream) -- scratch for k pairs per lane, the status word, the verdict's
  * Fq12 buffer, the sub-group buffers of groups of more than 64 pairs, the pow_native digit buffer, four pinned staging
- * slots and the device copies of the latency path's round programs (thirty-five programs, 29 MB, once per device; without bn254_reserve the first
+ * slots and the device copies of the latency path's round programs (thirty-five programs, 28 MB, once per device; without bn254_reserve the first
  * small call of each kind uploads its program with a blocking copy) -- for calls of up to n lanes (units) x k pairs.  Afterwards `_dev` calls of that size or smaller neither allocate
  * nor wait.  Does not wait for the stream either (buffers that must grow are retired, see STREAM). */
 int bn254_reserve(int device, void* stream, size_t n, size_t k);
