@@ -267,7 +267,7 @@ int bn254_check_points(const uint64_t* g1, const uint64_t* g2, size_t n, int dev
  * The `_dev` form sets the stream's sticky point-check status (reported by the next bn254_last_status in the order above, whatever
  * ran in between); the host-pointer form returns it.  COST: not free and not part of the hot path -- the subgroup check is a 63-bit
  * scalar multiplication on the twist per pair (about 1.0 k Fq2 products: a sixth of a pairing's field work, in plain HIP C++):
- * measured 0.07 ms (infinity) / 0.29 ms (+ on-curve) / 67.7 ms (+ subgroup: 15.5 M pairs/s, 0.65 of the pairings' own time) per 2^20
+ * measured 0.07 ms (infinity) / 0.29 ms (+ on-curve) / 54.8 ms (+ subgroup: 19.1 M pairs/s, 0.54 of the pairings' own time) per 2^20
  * resident pairs on MI355X.  HBM: the 192 input bytes per pair once (+ 1 byte out). */
 #define BN254_CHECK_INFINITY 1
 #define BN254_CHECK_ON_CURVE 2

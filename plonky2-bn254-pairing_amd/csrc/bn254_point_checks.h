@@ -14,10 +14,10 @@
 //                               Checked against [r]Q == O on subgroup and non-subgroup twist points by tests/test_point_checks.py
 //                               through the big-int restatement.)   G1 has cofactor one: on the curve is in the subgroup.
 //
-// Cost (stated, not hidden): per G2 point 62 doublings + 30 additions in Jacobian coordinates = ~1.0 k Fq2 products, i.e. about a
-// sixth of a pairing's field work, in compiler-scheduled 64-bit arithmetic (several times slower per product than the generated
+// Cost (stated, not hidden): per G2 point 62 doublings + 23 mixed and 4 general additions in Jacobian coordinates = ~0.75 k Fq2 products,
+// i.e. about an eighth of a pairing's field work, in compiler-scheduled 64-bit arithmetic (several times slower per product than the generated
 // kernels).  MEASURED on MI355X (tools/exp/check_cost.py, 2^20 pairs resident): infinity 0.07 ms, + on-curve 0.29 ms, + subgroup
-// 67.7 ms = 15.5 M pairs/s -- 0.65 of the time of the 2^20 pairings themselves.  HBM: 192 input bytes per pair, once.
+// 54.8 ms = 19.1 M pairs/s -- 0.54 of the time of the 2^20 pairings themselves.  HBM: 192 input bytes per pair, once.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -170,6 +170,24 @@ __device__ __noinline__ Jac jac_add(const Jac& p, const Jac& q) {
     r.z = f2_mul(f2_sub(f2_sub(f2_sqr(f2_add(p.z, q.z)), Z1Z1), Z2Z2), H);
     return r;
 }
+// mixed addition p + (qx, qy, 1) (madd-2007-bl: seven products and four squarings instead of eleven and five), same exceptional cases
+__device__ __noinline__ Jac jac_madd(const Jac& p, const Fq2& qx, const Fq2& qy, const Fq2& one) {
+    if (f2_is_zero(p.z)) return {qx, qy, one};
+    Fq2 Z1Z1 = f2_sqr(p.z);
+    Fq2 U2 = f2_mul(qx, Z1Z1), S2 = f2_mul(f2_mul(qy, p.z), Z1Z1);
+    Fq2 H = f2_sub(U2, p.x), rr = f2_dbl(f2_sub(S2, p.y));
+    if (f2_is_zero(H)) {
+        if (f2_is_zero(rr)) return jac_dbl(p);
+        Jac inf = {p.x, p.y, {{{0, 0, 0, 0}}, {{0, 0, 0, 0}}}};
+        return inf;
+    }
+    Fq2 HH = f2_sqr(H), I = f2_dbl(f2_dbl(HH)), J = f2_mul(H, I), V = f2_mul(p.x, I);
+    Jac r;
+    r.x = f2_sub(f2_sub(f2_sqr(rr), J), f2_dbl(V));
+    r.y = f2_sub(f2_mul(rr, f2_sub(V, r.x)), f2_dbl(f2_mul(p.y, J)));
+    r.z = f2_sub(f2_sub(f2_sqr(f2_add(p.z, H)), Z1Z1), HH);
+    return r;
+}
 // psi on Jacobian coordinates: (c2 conj(X), c3 conj(Y), conj(Z)),  c2 = xi^((p-1)/3), c3 = xi^((p-1)/2)
 // (the reference's twisted_frobenius, miller_loop_native.rs:298-304, on x = X/Z^2, y = Y/Z^3: conjugation is a field automorphism)
 __device__ __forceinline__ Jac jac_psi(const Jac& p, const Fq2& c2, const Fq2& c3) {
@@ -232,11 +250,14 @@ __global__ void __launch_bounds__(64) k_check_points_ex(const uint64_t* __restri
                 else if (flags & CHECK_SUBGROUP) {
                     Fq2 c2 = f2_const(K.c2), c3 = f2_const(K.c3);
                     Jac Q = {qx, qy, {fq_const(K.one), {{0, 0, 0, 0}}}};
-                    Jac a = Q;                                   // [x]Q, x = BN_X: plain double-and-add from the top bit
-                    const uint64_t X = 4965661367192848881ull;   // final_exp_native.rs:15
+                    Jac a = Q;                                   // [x]Q, x = BN_X (final_exp_native.rs:15) by its non-adjacent form, top digit first:
+                    // 63 digits, 24 of them non-zero (the binary form has 28 ones) -- 62 doublings, 23 MIXED additions of +-Q (Q is affine);
+                    // tests/test_point_checks.py checks the masks against the number
+                    const uint64_t X_NZ = 0x452a95544aa90a11ull, X_NEG = 0x0020815000200010ull;
+                    const Fq2 nqy = {fq_neg(qy.a), fq_neg(qy.b)};
                     for (int bit = 61; bit >= 0; bit--) {
                         a = jac_dbl(a);
-                        if ((X >> bit) & 1) a = jac_add(a, Q);
+                        if ((X_NZ >> bit) & 1) a = jac_madd(a, qx, ((X_NEG >> bit) & 1) ? nqy : qy, Q.z);
                     }
                     Jac b = jac_psi(a, c2, c3);                  // psi([x]Q)
                     Jac lhs = jac_add(jac_add(jac_psi(b, c2, c3), b), jac_add(a, Q));

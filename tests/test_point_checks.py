@@ -8,6 +8,7 @@ engine computes a value for any coordinates; callers with untrusted points run t
 CPU: the one-scalar-multiplication criterion the kernel uses ([x+1]Q + psi([x]Q) + psi^2([x]Q) == psi^3([2x]Q), ePrint 2022/348)
 agrees with the definition [r]Q == O on subgroup points, random twist points and a cofactor-cleared point (big-int restatement).
 GPU: every flag, precedence, the per-point bytes, and the documented async flow (check, compute, ONE status read at the end)."""
+import os
 import random
 
 import numpy as np
@@ -259,3 +260,13 @@ def test_two_threads_two_streams_two_kernel_selections():
     assert pk.last_kernel(0, streams[0]) != 1 if keep[0] >= n else pk.last_kernel(0, streams[0]) == 1
     for s in streams:
         pk.release_stream(0, s)
+
+
+def test_subgroup_check_walks_the_naf_of_x():
+    """csrc/bn254_point_checks.h computes [x]Q by the non-adjacent form of BN_X: its two digit masks are that number's NAF"""
+    import re
+    txt = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "plonky2-bn254-pairing_amd", "csrc", "bn254_point_checks.h")).read()
+    nz, neg = (int(x, 16) for x in re.search(r"X_NZ = (0x[0-9a-f]+)ull, X_NEG = (0x[0-9a-f]+)ull", txt).groups())
+    assert neg & ~nz == 0 and nz >> 62 == 1 and not (neg >> 62) & 1          # 63 digits, the top one is +1 (the loop starts from Q)
+    assert sum((-1 if (neg >> i) & 1 else 1) << i for i in range(63) if (nz >> i) & 1) == R.BN_X
+    assert nz & (nz >> 1) == 0 and bin(nz).count("1") == 24                  # non-adjacent, 24 digits
