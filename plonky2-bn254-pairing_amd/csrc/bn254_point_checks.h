@@ -14,7 +14,7 @@
 //                               Checked against [r]Q == O on subgroup and non-subgroup twist points by tests/test_point_checks.py
 //                               through the big-int restatement.)   G1 has cofactor one: on the curve is in the subgroup.
 //
-// Cost (stated, not hidden): per G2 point 62 doublings + 23 mixed and 4 general additions in Jacobian coordinates = ~0.75 k Fq2 products,
+// Cost (stated, not hidden): per G2 point 62 doublings + 24 mixed and 3 general additions in Jacobian coordinates = ~0.75 k Fq2 products,
 // i.e. about an eighth of a pairing's field work, in compiler-scheduled 64-bit arithmetic (several times slower per product than the generated
 // kernels).  MEASURED on MI355X (tools/exp/check_cost.py, 2^20 pairs resident): infinity 0.07 ms, + on-curve 0.29 ms, + subgroup
 // 54.8 ms = 19.1 M pairs/s -- 0.54 of the time of the 2^20 pairings themselves.  HBM: 192 input bytes per pair, once.
@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(64) k_check_points_ex(const uint64_t* __restri
                         if ((X_NZ >> bit) & 1) a = jac_madd(a, qx, ((X_NEG >> bit) & 1) ? nqy : qy, Q.z);
                     }
                     Jac b = jac_psi(a, c2, c3);                  // psi([x]Q)
-                    Jac lhs = jac_add(jac_add(jac_psi(b, c2, c3), b), jac_add(a, Q));
+                    Jac lhs = jac_add(jac_add(jac_psi(b, c2, c3), b), jac_madd(a, qx, qy, Q.z));
                     Jac rhs = jac_dbl(jac_psi(jac_psi(b, c2, c3), c2, c3));          // psi^3([2x]Q)
                     if (!jac_eq(lhs, rhs)) bad |= PT_NOT_IN_SUBGROUP;
                 }
