@@ -527,10 +527,13 @@ def run_rank(args):
         sync()
         dist.barrier()
         t0 = time.perf_counter()
+        if os.environ.get("BENCH_TEST_FAIL_IN_GATHER") == str(rank) and os.environ.get("PYTEST_CURRENT_TEST"):
+            raise RuntimeError("injected fault (BENCH_TEST_FAIL_IN_GATHER, a pytest-only hook): this rank dies after the timed steps, inside the gather")
         gathered = sharded.gather_outputs(out, n_total, dist, device=dev)
         sync()
         dist.barrier()
         exchange["gather_ms"] = (time.perf_counter() - t0) * 1e3
+        exchange["p2p_group"] = sharded.p2p_group_mode()
         if on_gpu and rank == 0:
             exchange["rank0_peak_device_bytes_after_gather"] = int(torch.cuda.max_memory_allocated(dev))
         exchange["bytes_scattered"] = 192 * (n_total - n)
@@ -540,6 +543,7 @@ def run_rank(args):
                             "wall-clock incl. the staging copies, outside the timed steps")
 
     rc = 0
+    t_post = time.perf_counter()        # from here to the verdict broadcast the peers wait for rank 0 (calibration child, oracle gate)
     if rank == 0:
         total = n_total * args.steps
         value = total / elapsed
@@ -614,6 +618,9 @@ def run_rank(args):
             rec["exchange"] = exchange
             step_ms = elapsed / args.steps * 1e3
             rec["value_incl_exchange"] = n_total / ((step_ms + exchange["scatter_ms"] + exchange["gather_ms"]) * 1e-3)
+            exchange["exchange_share_of_step"] = (exchange["scatter_ms"] + exchange["gather_ms"]) / (step_ms + exchange["scatter_ms"] + exchange["gather_ms"])
+            exchange["overlap"] = ("none by design: the pairing kernel holds every register and 144 KiB of LDS of every CU, a communication kernel cannot "
+                                   "co-reside (profiles/r03_coresidency.txt); one scatter + one gather per step would add exchange_share_of_step to a step")
         # correctness gate: oracle spot checks on every run (first / last lanes, a work-item boundary, other ranks' slices)
         if on_gpu:
             threads = min(32, usable_cores(host_cpu_info()))
@@ -646,6 +653,16 @@ def run_rank(args):
             g1h = g1.view(8, n)[:, :m].cpu().numpy().view(np.uint64).reshape(-1).copy()
             g2h = g2.view(16, n)[:, :m].cpu().numpy().view(np.uint64).reshape(-1).copy()
             rec["cpu_baseline"] = cpu_baseline(pkg, g1h, g2h, m, args.cpu_seconds)
+        if multi:
+            # what the peers sit through in the verdict broadcast below: must stay well inside the collective timeout
+            tmo_s = float(os.environ.get("BENCH_DIST_TIMEOUT_S", "120"))
+            rec["rank0_post_steps_s"] = {"seconds": time.perf_counter() - t_post, "limit": tmo_s / 4,
+                                         "what": "rank 0 alone between the last collective of the timed part and the verdict broadcast: same-lease calibration "
+                                                 "(child process) + oracle gate on its own and the peers' slices; the peers wait in dist.broadcast "
+                                                 f"(timeout BENCH_DIST_TIMEOUT_S = {tmo_s:g} s)"}
+            if rec["rank0_post_steps_s"]["seconds"] > tmo_s / 4:
+                print(f"bench.py: rank 0 spent {rec['rank0_post_steps_s']['seconds']:.1f} s alone (> a quarter of BENCH_DIST_TIMEOUT_S = {tmo_s:g} s): "
+                      "raise the timeout or set BENCH_NO_CALIB=1", file=sys.stderr, flush=True)
         if rc == 0:
             print(json.dumps(rec), flush=True)
     if dist:

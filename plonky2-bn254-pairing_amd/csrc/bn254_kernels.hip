@@ -39,9 +39,7 @@ constexpr size_t MAX_K = 64;                            // pairs per group of th
 #define BN254_CVM_PM_MILLER 1500
 #define BN254_CVM_PM_FEXP 1500
 #define BN254_CVM_PM_MMILLER 1000
-#ifndef BN254_CVM_SPLIT_MIN
-#define BN254_CVM_SPLIT_MIN 4096        // pairing() on the lane-cooperative kernel in two launches above this many items (one wave per SIMD of the fused program)
-#endif
+// (BN254_CVM_SPLIT_MIN, when defined at build time, replaces cvm_split_min()'s 16 items per CU: 4 096 on the 256 CUs of an MI355X)
 #define BN254_LATENCY_THRESHOLD_DEFAULT 16384
 #endif
 
@@ -446,6 +444,26 @@ size_t resident_waves(size_t lds) {
     return w > 8 ? 8 : (w ? w : 1);
 }
 
+// pairing() / final_exp_native on the lane-cooperative kernel go in several launches above this many items: one wave per SIMD of the fused
+// program (4 waves x 4 items per CU)
+int n_cu_of(int device) { return device >= 0 && device < 64 ? g_ctx[device].n_cu : 0; }      // 0 before the device's first launch
+size_t cvm_split_min(int n_cu) {
+#ifdef BN254_CVM_SPLIT_MIN
+    (void)n_cu;
+    return (size_t)BN254_CVM_SPLIT_MIN;
+#else
+    return (size_t)16 * (size_t)(n_cu > 0 ? n_cu : 256);
+#endif
+}
+// ... and the largest item count that path can take under threshold `thr`: thr x the largest per-mille share of a program that has the
+// several-launch form (pairing, final_exp_native, the 2 / 3 / 4-pair products), below the kernels' 2^22-lane limit
+size_t cvm_split_max(size_t thr) {
+    uint32_t pm = 0;
+    for (int prog : {0, 2, 3, 4, 5}) if (CVM_PROGRAMS[prog].per_mille > pm) pm = CVM_PROGRAMS[prog].per_mille;
+    unsigned __int128 cap = (unsigned __int128)thr * pm / 1000u;
+    return cap >= ((size_t)1 << 22) ? ((size_t)1 << 22) - 1 : (size_t)cap;
+}
+
 int launch_cvm(int prog, int lanes, const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in, uint64_t* out, size_t n, size_t k, int device, void* stream) {
     LaunchCtx c;
     int rc = ctx_get(device, stream, 1, 1, &c);          // the status word and the stream context; the kernel needs no scratch
@@ -500,9 +518,11 @@ int launch_cvm(int prog, int lanes, const uint64_t* g1, const uint64_t* g2, cons
 
 // final_exp_native on a mid-size batch as SIX launches of the lane-cooperative kernel -- easy part, the three x-powers (one program,
 // three times), the y-chain in two parts (the first takes three Fq12 batches through the g1 / g2 / f_in arguments, the second two) --
-// through per-stream buffers.  The whole program holds 277 slots per item (four waves per CU); its pieces 70 / 117 / 146 / 143 (eight,
-// eight, seven, seven): two waves per SIMD, one's operand fetch under the other's arithmetic.  Same values: the same operations in the
-// same order on the same limbs (tests/test_cvm.py composes the pieces on integers; tests/test_gpu_latency.py on the GPU).
+// through per-stream buffers.  The whole program holds 274 slots per item (BN254_CVM_FEXP_SLOTS: four waves per CU); its pieces 63 / 141 /
+// 141 / 135 (BN254_CVM_EASY / POWX / YCH1 / YCH2_SLOTS): eight waves per CU -- two per SIMD, one's operand fetch under the other's
+// arithmetic -- the easy part in either LDS layout, the other three through the 36-byte split layout only (the contiguous layout would hold
+// six or seven, which resident_waves() clamps to four).  Same values: the same operations in the same order on the same limbs
+// (tests/test_cvm.py composes the pieces on integers; tests/test_gpu_latency.py on the GPU).
 int launch_fexp_pieces(const uint64_t* f_in, uint64_t* out, size_t n, int device, void* stream) {
     LaunchCtx hold;
     int rc = ctx_get(device, stream, 1, 1, &hold);
@@ -563,12 +583,12 @@ int launch_pairing(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in,
             // n_groups * 1000 <= thr * per_mille without the overflow of a huge threshold ("always": SIZE_MAX)
             unsigned __int128 lhs = (unsigned __int128)n_groups * 1000u, rhs = (unsigned __int128)thr * CVM_PROGRAMS[prog].per_mille;
             if (lhs <= rhs) {
-                // pairing(), mid-size batch: SEVEN launches -- the Miller loop without the line scale (136 slots per item: eight waves per
+                // pairing(), mid-size batch: SEVEN launches -- the Miller loop without the line scale (117 slots per item: eight waves per
                 // CU, two per SIMD, one wave's operand fetch under the other's arithmetic), then final_exp_native on its values in six
                 // pieces (launch_fexp_pieces) -- while the launch has more waves than one per SIMD (below that nothing overlaps).
-                // (the k-pair products likewise: their Miller halves keep four waves per CU -- 163 .. 242 slots -- but the final exponentiation's pieces
+                // (the k-pair products likewise: their Miller halves keep four waves per CU -- 155 .. 231 slots -- but the final exponentiation's pieces
                 // run with eight)
-                if (M && F && k <= 4 && lanes == 0 && n_groups > (size_t)BN254_CVM_SPLIT_MIN) {
+                if (M && F && k <= 4 && lanes == 0 && n_groups > cvm_split_min(n_cu_of(device))) {
                     LaunchCtx hold;
                     int rc = ctx_get(device, stream, 1, 1, &hold);
                     if (rc) return rc;
@@ -577,7 +597,7 @@ int launch_pairing(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in,
                     if ((rc = launch_cvm(k == 1 ? CVM_MILLER_U : CVM_MMILLER_U + (int)k, 16, g1, g2, nullptr, mid, n_groups, k, device, stream))) return rc;
                     return launch_fexp_pieces(mid, out, n_groups, device, stream);
                 }
-                if (!M && F && lanes == 0 && n_groups > (size_t)BN254_CVM_SPLIT_MIN)          // final_exp_native alone, mid-size batch: the same six launches
+                if (!M && F && lanes == 0 && n_groups > cvm_split_min(n_cu_of(device)))          // final_exp_native alone, mid-size batch: the same six launches
                     return launch_fexp_pieces(f_in, out, n_groups, device, stream);
                 return launch_cvm(prog, lanes, g1, g2, f_in, out, n_groups, k, device, stream);
             }
@@ -1024,9 +1044,18 @@ int bn254_reserve(int device, void* stream, size_t n, size_t k) {
         if ((rc = ensure(sc, sc->scratch, need))) return rc;
     }
     if ((rc = ensure(sc, sc->tmp, 384 * (n ? n : 1)))) return rc;                                   // the `== one` verdict's Fq12 values
-    if (n <= ((size_t)1 << 17) && (rc = ensure(sc, sc->mid, 384 * (n ? n : 1)))) return rc;         // pairing() / final_exp_native in several launches (mid-size
-    for (Buf& b : sc->fx)                                                                           // batches on the lane-cooperative kernel): the values in between
-        if (n <= ((size_t)1 << 17) && (rc = ensure(sc, b, 384 * (n ? n : 1)))) return rc;
+    {   // pairing() / final_exp_native in several launches (mid-size batches on the lane-cooperative kernel): the values in between.  Sized for the
+        // LARGEST item count that path can take under this stream's (else the process') threshold -- whatever n is: after reserve(2^20) a call of
+        // 8 192 items must not allocate either (and a hipGraph capture of it must not meet a hipMalloc).  Nothing when the path is switched off.
+        size_t thr = sc->lat_threshold.load() == (size_t)-1 ? g_latency_threshold.load() : sc->lat_threshold.load();
+        size_t split_max = cvm_split_max(thr);
+        if (split_max > n) split_max = n;
+        if (split_max > cvm_split_min(c.n_cu)) {
+            if ((rc = ensure(sc, sc->mid, 384 * split_max))) return rc;
+            for (Buf& b : sc->fx)
+                if ((rc = ensure(sc, b, 384 * split_max))) return rc;
+        }
+    }
     if ((rc = ensure(sc, sc->naf, 65536 + 64))) return rc;                                          // pow_native digits (16-bit length field)
     if (k > MAX_K && ((rc = ensure(sc, sc->sub[0], 64 * n * MAX_K)) || (rc = ensure(sc, sc->sub[1], 128 * n * MAX_K)) ||
                       (rc = ensure(sc, sc->sub[2], 384 * n)) || (rc = ensure(sc, sc->sub[3], 384 * n))))
@@ -1039,7 +1068,7 @@ int bn254_reserve(int device, void* stream, size_t n, size_t k) {
         sc->naf_ring.push_back(ns);
     }
     if (!sc->status_host && hipHostMalloc((void**)&sc->status_host, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) return BN254_ERR_ALLOC;
-    if ((sc->lat_threshold.load() == (size_t)-1 ? g_latency_threshold.load() : sc->lat_threshold.load()) != 0)                    // the latency path's round programs (25 MB in all): small calls upload nothing later
+    if ((sc->lat_threshold.load() == (size_t)-1 ? g_latency_threshold.load() : sc->lat_threshold.load()) != 0)                    // the latency path's round programs (28 MB in all): small calls upload nothing later
         for (int prog = 0; prog < CVM_N_PROGRAMS; prog++)
             if ((rc = cvm_upload(device, prog))) return rc;
     return BN254_OK;

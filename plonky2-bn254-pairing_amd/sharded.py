@@ -2,7 +2,8 @@
 SoA batch per rank, NO data-path collective -- the units (`pairing(p, q)`, /root/reference/src/pairing.rs:20-22)
 are independent.  The only exchanges are the north star's scatter of the G1/G2 inputs from rank 0 and the gather
 of the Fq12 outputs to rank 0, as grouped point-to-point operations (`torch.distributed.batch_isend_irecv`:
-one grouped RCCL launch per direction under backend "nccl", the same code under "gloo").  A slice of a limb-major batch is
+one grouped RCCL launch per peer and direction under backend "nccl" -- or one per direction, or none: `p2p_group_mode` --, the same
+code under "gloo").  A slice of a limb-major batch is
 one contiguous run per limb plane, so the transfers go plane by plane straight out of / into the whole-batch tensors on
 rank 0: no temporaries and no second copy on either side (round 4).
 
@@ -59,7 +60,7 @@ class _P2P:
     receive."""
 
     def __init__(self, dist, kind, tensor, peer):
-        self.kind, self.tensor, self.bounce = kind, tensor, None
+        self.kind, self.tensor, self.bounce, self.peer = kind, tensor, None, peer
         wire = tensor
         if tensor.is_cuda and not _moves_device_memory(dist):
             import torch
@@ -74,12 +75,42 @@ class _P2P:
             self.tensor.copy_(self.bounce)
 
 
-def _run(dist, xfers):
-    if xfers:
-        for w in dist.batch_isend_irecv([x.op for x in xfers]):
-            w.wait()
+P2P_GROUP_MODES = ("peer", "all", "op")
+
+
+def p2p_group_mode(mode=None):
+    """How the transfers of one exchange step are grouped: "peer" (default) -- one `batch_isend_irecv` group per peer (24 plane runs in
+    the scatter, 48 in the gather: one grouped RCCL launch per peer, every group posted before the first wait); "all" -- the whole step as
+    ONE group (168 / 336 operations to seven peers on rank 0: fewest launches, most operations per RCCL group); "op" -- every plane run its
+    own isend / irecv, posted in the same (peer, plane) order on both sides (the most conservative form).  The environment variable
+    BENCH_P2P_GROUP (or BN254_P2P_GROUP) switches it without a code change; the bytes and where they land are the same in all three."""
+    mode = mode or os.environ.get("BENCH_P2P_GROUP") or os.environ.get("BN254_P2P_GROUP") or "peer"
+    if mode not in P2P_GROUP_MODES:
+        raise ValueError(f"p2p group mode {mode!r}: expected one of {P2P_GROUP_MODES}")
+    return mode
+
+
+def _run(dist, xfers, mode=None):
+    """Posts the transfers of one exchange step (grouped as `p2p_group_mode` says), waits for all of them, finishes the bounces."""
+    if not xfers:
+        return
+    mode = p2p_group_mode(mode)
+    if mode == "all":
+        groups = [xfers]
+    elif mode == "peer":
+        by_peer = {}
         for x in xfers:
-            x.finish()
+            by_peer.setdefault(x.peer, []).append(x)
+        groups = [by_peer[r] for r in sorted(by_peer)]
+    else:
+        groups = [[x] for x in xfers]
+    works = []
+    for g in groups:
+        works += dist.batch_isend_irecv([x.op for x in g])
+    for w in works:
+        w.wait()
+    for x in xfers:
+        x.finish()
 
 
 def hip_compute(device_index=None):
@@ -98,11 +129,11 @@ def hip_compute(device_index=None):
     return compute
 
 
-def scatter_inputs(full_g1, full_g2, n, g1_local, g2_local, dist):
+def scatter_inputs(full_g1, full_g2, n, g1_local, g2_local, dist, p2p_group=None):
     """Rank 0 holds the whole SoA batch (8n / 16n words); every rank receives its slice into g1_local / g2_local
     (8 n_local / 16 n_local words).  Empty slices are skipped on both sides.  A slice of an SoA batch is one contiguous run
     per limb plane: rank 0 sends the 8 + 16 plane runs of a peer's slice straight out of the whole-batch tensors (no
-    temporaries), the peer receives them into the planes of its local tensors; all transfers of the step form ONE group."""
+    temporaries), the peer receives them into the planes of its local tensors; the transfers are grouped per peer (`p2p_group_mode`)."""
     world, rank = dist.get_world_size(), dist.get_rank()
     lo, hi = shard_bounds(n, world, rank)
     ops = []
@@ -119,20 +150,20 @@ def scatter_inputs(full_g1, full_g2, n, g1_local, g2_local, dist):
     elif hi > lo:
         m = hi - lo
         ops = [_P2P(dist, "recv", v, 0) for v in _planes(g1_local, 8, m, 0, m) + _planes(g2_local, 16, m, 0, m)]
-    _run(dist, ops)
+    _run(dist, ops, p2p_group)
 
 
-def gather_outputs(out_local, n, dist, device=None):
+def gather_outputs(out_local, n, dist, device=None, p2p_group=None):
     """Every rank's 48 n_local output words travel to rank 0, which returns the whole SoA batch (48 n words); other
     ranks return None.  Rank 0 receives each peer's 48 plane runs STRAIGHT into the whole-batch tensor (contiguous views:
-    no temporaries, no second copy); one group of transfers."""
+    no temporaries, no second copy); one group of 48 transfers per peer by default (`p2p_group_mode`)."""
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
     lo, hi = shard_bounds(n, world, rank)
     if rank != 0:
         if hi > lo:
             m = hi - lo
-            _run(dist, [_P2P(dist, "send", v, 0) for v in _planes(out_local, 48, m, 0, m)])
+            _run(dist, [_P2P(dist, "send", v, 0) for v in _planes(out_local, 48, m, 0, m)], p2p_group)
         return None
     full = torch.empty(48 * n, dtype=torch.int64, device=device if device is not None else out_local.device)
     ops = []
@@ -143,7 +174,7 @@ def gather_outputs(out_local, n, dist, device=None):
         ops += [_P2P(dist, "recv", v, r) for v in _planes(full, 48, n, rlo, rhi)]
     if hi > lo:
         full.view(48, n)[:, lo:hi].copy_(out_local.view(48, hi - lo))
-    _run(dist, ops)
+    _run(dist, ops, p2p_group)
     return full
 
 

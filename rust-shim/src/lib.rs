@@ -148,6 +148,8 @@ pub fn latency_lanes() -> i32 { unsafe { bn254_get_latency_lanes() } }
 /// its contract.  Callers that want it REPORTED use this: the flags of the structs first (no device work), then the engine's check of the
 /// coordinates (ark's affine identity is x = y = 0); `Err(-7)` = BN254_ERR_INFINITY.
 pub fn check_points(ps: &[G1Affine], qs: &[G2Affine]) -> Result<(), i32> {
+    assert_eq!(ps.len(), qs.len());       // the planes of both arrays are packed with stride n: a shorter `qs` would be read past its end
+    if ps.is_empty() { return Ok(()); }
     if ps.iter().any(|p| p.infinity) || qs.iter().any(|q| q.infinity) { return Err(-7); }
     let (g1, g2) = (pack_g1(ps), pack_g2(qs));
     match unsafe { bn254_check_points(g1.as_ptr(), g2.as_ptr(), ps.len(), 0, core::ptr::null_mut()) } { 0 => Ok(()), rc => Err(rc) }
@@ -158,6 +160,8 @@ pub fn check_points(ps: &[G1Affine], qs: &[G2Affine]) -> Result<(), i32> {
 /// any coordinates; this runs its optional check (flags 1 | 2 | 4: infinity, on-curve, G2 subgroup) and panics like the reference would:
 /// `Err(-7 / -8 / -9)` = infinity / not on the curve / G2 not in the subgroup.
 pub fn check_points_full(ps: &[G1Affine], qs: &[G2Affine]) -> Result<(), i32> {
+    assert_eq!(ps.len(), qs.len());
+    if ps.is_empty() { return Ok(()); }
     if ps.iter().any(|p| p.infinity) || qs.iter().any(|q| q.infinity) { return Err(-7); }
     let (g1, g2) = (pack_g1(ps), pack_g2(qs));
     match unsafe { bn254_check_points_ex(g1.as_ptr(), g2.as_ptr(), ps.len(), 7, core::ptr::null_mut(), 0, core::ptr::null_mut()) } { 0 => Ok(()), rc => Err(rc) }

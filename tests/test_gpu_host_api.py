@@ -418,3 +418,41 @@ def test_dev_calls_are_capturable_into_a_hip_graph_after_reserve():
             want.append(got[0][:48].clone())
         assert not torch.equal(want[0], want[1])            # the replays really ran on new inputs
     pk.release_stream(0, side)
+
+
+def test_mid_size_call_is_capturable_after_a_large_reserve():
+    """bn254_reserve(2^20) sizes the several-launch path's intermediates (StreamCtx::mid, fx[0..4]) for the LARGEST item count that path can
+    take under the stream's threshold, not for n: an 8 192-item pairing, a 6 000-group 2-pair product and an 8 192-item final_exp_native
+    (seven / seven / six launches through those buffers) are then plain launches -- capturable into a hipGraph, which a hipMalloc in
+    launch_pairing / launch_fexp_pieces would break -- and the replay equals the eager results."""
+    import torch
+    pk = H.pkg()
+    dev = torch.device("cuda:0")
+    side = torch.cuda.Stream(dev)
+    n_mid, n_grp = 8192, 6000
+    with torch.cuda.stream(side):
+        m1 = torch.zeros(8 * 2 * n_grp, dtype=torch.int64, device=dev)
+        m2 = torch.zeros(16 * 2 * n_grp, dtype=torch.int64, device=dev)
+        out = torch.zeros(48 * n_mid, dtype=torch.int64, device=dev)
+        out_g = torch.zeros(48 * n_grp, dtype=torch.int64, device=dev)
+        out_f = torch.zeros(48 * n_mid, dtype=torch.int64, device=dev)
+        pk.generate_pairs_dev(0x6B01, m1, m2, 2 * n_grp, 0, side)
+        pk.reserve(1 << 20, 2, 0, side)
+        pk.last_status(0, side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            pk.pairing_batch_dev(m1, m2, out, n_mid, 0, side)
+            pk.multi_pairing_batch_dev(m1, m2, out_g, n_grp, 2, True, 0, side)
+            pk.final_exp_batch_dev(out, out_f, n_mid, 0, side)
+        assert pk.last_kernel(0, side) == 16
+        graph.replay()
+        side.synchronize()
+        got = (out.clone(), out_g.clone(), out_f.clone())
+        out.zero_(); out_g.zero_(); out_f.zero_()
+        pk.pairing_batch_dev(m1, m2, out, n_mid, 0, side)
+        pk.multi_pairing_batch_dev(m1, m2, out_g, n_grp, 2, True, 0, side)
+        pk.final_exp_batch_dev(out, out_f, n_mid, 0, side)
+        pk.last_status(0, side)
+        assert torch.equal(got[0], out) and torch.equal(got[1], out_g) and torch.equal(got[2], out_f)
+        assert int(out.abs().sum()) != 0 and int(out_g.abs().sum()) != 0
+    pk.release_stream(0, side)

@@ -151,6 +151,53 @@ def test_bench_launcher_eight_ranks_cpu():
     assert rec["value"] > 0 and abs(rec["value"] - 256 * 2 / (rec["ms_per_step"] * 2e-3)) < 1e-6 * rec["value"]
 
 
+@pytest.mark.parametrize("mode", ["peer", "all", "op"])
+def test_bench_p2p_group_modes_three_ranks_cpu(mode):
+    """BENCH_P2P_GROUP switches how the scatter / gather transfers are grouped (one batch_isend_irecv group per peer -- the default --, one per
+    step, or one operation at a time) without a code change: same bytes, same places -- the gathered batch equals the whole-batch
+    recomputation in every mode, and the N > 1 line says which mode ran, what share of a step the exchange would be, and how long rank 0
+    kept its peers waiting after the timed steps."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(BENCH_TEST_ENGINE="fake_engine:Engine", BENCH_DIST_BACKEND="gloo", OMP_NUM_THREADS="1", BENCH_P2P_GROUP=mode)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "1", "--warmup", "0", "--log2-batch", "5"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rec = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert rec["gathered_equals_whole_batch_recomputation"] is True
+    ex = rec["exchange"]
+    assert ex["p2p_group"] == mode and 0.0 < ex["exchange_share_of_step"] < 1.0
+    assert abs(rec["value_incl_exchange"] - rec["config"]["pairings_total"] / ((rec["ms_per_step"] + ex["scatter_ms"] + ex["gather_ms"]) * 1e-3)) < 1e-6 * rec["value"]
+    post = rec["rank0_post_steps_s"]
+    assert 0.0 <= post["seconds"] < post["limit"] == 30.0
+
+
+def test_bench_unknown_p2p_group_mode_is_an_error():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(BENCH_TEST_ENGINE="fake_engine:Engine", BENCH_DIST_BACKEND="gloo", OMP_NUM_THREADS="1", BENCH_P2P_GROUP="pairs", BENCH_DIST_TIMEOUT_S="30")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--log2-batch", "4"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "p2p group mode" in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.parametrize("dead", [1, 0])
+def test_bench_rank_dying_inside_the_gather_ends_the_job_with_its_reason(dead):
+    """A rank that dies AFTER the timed steps, inside gather_outputs (its peer is blocked in the matching receive / send), must end the whole
+    job within the collective timeout, with its reason on stderr and no measurement line -- not leave the other rank waiting."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(BENCH_TEST_ENGINE="fake_engine:Engine", BENCH_DIST_BACKEND="gloo", OMP_NUM_THREADS="1", BENCH_TEST_FAIL_IN_GATHER=str(dead),
+               BENCH_DIST_TIMEOUT_S="60")
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--log2-batch", "4"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    dt = time.time() - t0
+    assert p.returncode != 0
+    assert "BENCH_TEST_FAIL_IN_GATHER" in p.stderr and f"rank {dead} of 2 failed" in p.stderr, p.stderr[-2000:]
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert dt < 60 + 45, f"the job took {dt:.0f} s to end"          # the collective timeout + torchrun's own teardown
+
+
 def test_bench_refuses_the_engine_hook_outside_pytest():
     """BENCH_TEST_ENGINE is honoured only under pytest: a plain environment cannot make bench.py print a `value` from a stand-in."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "PYTEST_CURRENT_TEST")}
