@@ -127,6 +127,23 @@ int bn254_last_kernel(int device, void* stream);
  * this frees what the library holds for `stream` (call it before destroying a stream you used). */
 int bn254_release_stream(int device, void* stream);
 
+/* PAGE-LOCKED HOST MEMORY.  The reference's callers hold their values in host memory (`pairing(p: G1Affine, q: G2Affine)`, src/pairing.rs:20;
+ * `Vec<(&G1Affine, &G2Affine)>`, miller_loop_native.rs:324), so a binding's batch calls go through the host-pointer entry points.  From pageable
+ * memory every byte passes the HIP runtime's staging buffers (a host memcpy on the issuing thread); from page-locked memory the copy engines move it
+ * at the link rate underneath the kernels, and the chunked pipeline of the large-batch calls (bn254_pairing_batch, bn254_multi_pairing_batch, their
+ * `_elems` and `_sharded` forms above 65 536 units) then delivers the resident-data rate minus the first chunk's copy-in and the last chunk's copy-out.
+ * The entry points detect page-locked buffers themselves (hipPointerGetAttributes on all three arrays): nothing else changes for the caller.
+ *   bn254_alloc_pinned / bn254_free_pinned: page-locked memory from the runtime (hipHostMalloc, portable across devices);
+ *   bn254_host_register / bn254_host_unregister: page-lock memory the caller already owns, in place (hipHostRegister; a Rust `Vec`'s buffer,
+ *     a numpy array) -- registering costs about as much as one pageable copy of the range, so do it once for buffers that are reused;
+ *   bn254_host_is_pinned: 1 when [ptr, ptr + bytes) is page-locked memory the runtime knows, else 0 (diagnostic).
+ * Memory the caller page-locked itself through HIP is recognised the same way. */
+int bn254_alloc_pinned(size_t bytes, void** out);
+int bn254_free_pinned(void* ptr);
+int bn254_host_register(void* ptr, size_t bytes);
+int bn254_host_unregister(void* ptr);
+int bn254_host_is_pinned(const void* ptr, size_t bytes);
+
 /* ---- the hot path -------------------------------------------------------------------- */
 
 /* pairing(p, q) = final_exp_native(miller_loop_native(&q, &p))      src/pairing.rs:20-22

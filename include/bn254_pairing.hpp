@@ -135,6 +135,41 @@ inline const uint64_t* words(const void* p) { return static_cast<const uint64_t*
 inline uint64_t* words(void* p) { return static_cast<uint64_t*>(p); }
 }  // namespace detail
 
+// PAGE-LOCKED HOST MEMORY (bn254_pairing.h: the host-pointer entry points copy by DMA under the kernels when all three arrays are
+// page-locked, and a large batch then runs at the resident-data rate).  `pinned_vector<T>` allocates from the runtime; `HostRegistration`
+// page-locks memory the caller already owns for its lifetime; the pointer forms below (`*_into`) take either.
+template <class T> struct PinnedAllocator {
+    using value_type = T;
+    PinnedAllocator() = default;
+    template <class U> PinnedAllocator(const PinnedAllocator<U>&) {}
+    T* allocate(size_t n) { void* p = nullptr; check(bn254_alloc_pinned(n * sizeof(T), &p)); return static_cast<T*>(p); }
+    void deallocate(T* p, size_t) noexcept { (void)bn254_free_pinned(p); }
+    template <class U> bool operator==(const PinnedAllocator<U>&) const { return true; }
+    template <class U> bool operator!=(const PinnedAllocator<U>&) const { return false; }
+};
+template <class T> using pinned_vector = std::vector<T, PinnedAllocator<T>>;
+class HostRegistration {
+    void* p_;
+public:
+    HostRegistration(void* p, size_t bytes) : p_(p) { check(bn254_host_register(p, bytes)); }
+    template <class V> explicit HostRegistration(V& v) : HostRegistration(v.data(), v.size() * sizeof(*v.data())) {}
+    ~HostRegistration() { (void)bn254_host_unregister(p_); }
+    HostRegistration(const HostRegistration&) = delete;
+    HostRegistration& operator=(const HostRegistration&) = delete;
+};
+// n x pairing(p, q) from / into the caller's arrays (page-locked or not): MyFq12 order, or ark's Fq12 order exactly as src/pairing.rs:20-22 returns it
+inline void pairing_batch_into(const G1Affine* ps, const G2Affine* qs, MyFq12* out, size_t n, int device = 0) {
+    check(bn254_pairing_batch_elems(detail::words(ps), detail::words(qs), detail::words(out), n, BN254_FQ12_MYFQ12, device, nullptr));
+}
+inline void pairing_batch_fq12_into(const G1Affine* ps, const G2Affine* qs, Fq12* out, size_t n, int device = 0) {
+    check(bn254_pairing_batch_elems(detail::words(ps), detail::words(qs), detail::words(out), n, BN254_FQ12_ARK, device, nullptr));
+}
+inline void multi_pairing_batch_into(const G1Affine* ps, const G2Affine* qs, MyFq12* out, size_t n_groups, size_t k, bool do_final_exp = true, int device = 0) {
+    if (k == 0) throw Panic(BN254_ERR_INVALID_ARG);
+    check(bn254_multi_pairing_batch_elems(detail::words(ps), detail::words(qs), detail::words(out), n_groups, k, do_final_exp ? 1 : 0, BN254_FQ12_MYFQ12,
+                                          device, nullptr));
+}
+
 inline std::vector<MyFq12> pairing_batch(const std::vector<G1Affine>& ps, const std::vector<G2Affine>& qs, int device = 0) {
     const size_t n = ps.size();
     if (qs.size() != n) throw Panic(BN254_ERR_INVALID_ARG);

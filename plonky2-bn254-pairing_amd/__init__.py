@@ -85,6 +85,11 @@ _PROTOS = {
     "bn254_multi_pairing_sharded_dev": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                                                        ctypes.c_void_p]),
     "bn254_release_stream": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p]),
+    "bn254_host_register": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t]),
+    "bn254_host_unregister": (ctypes.c_int, [ctypes.c_void_p]),
+    "bn254_alloc_pinned": (ctypes.c_int, [ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]),
+    "bn254_free_pinned": (ctypes.c_int, [ctypes.c_void_p]),
+    "bn254_host_is_pinned": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t]),
     "bn254_check_points_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "bn254_check_points": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "bn254_check_points_ex_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
@@ -202,12 +207,56 @@ def _np_in(a, words, n):
     return a
 
 
+def _np_out(out, size, dtype=np.uint64):
+    """the result array of a host-pointer call: a fresh one, or the caller's (e.g. page-locked: `alloc_pinned`)"""
+    if out is None:
+        return np.empty(size, dtype=dtype)
+    if not isinstance(out, np.ndarray) or out.dtype != dtype or out.size != size or not out.flags.c_contiguous or not out.flags.writeable:
+        raise Bn254Error(ERR_INVALID_ARG, f"out: expected a writable contiguous {np.dtype(dtype).name} array of {size} entries")
+    return out
+
+
+# ----------------------------------------------------------------------------- page-locked host memory
+def alloc_pinned(words):
+    """A page-locked uint64 array of `words` entries (bn254_alloc_pinned = hipHostMalloc): host-pointer calls on such arrays (inputs AND
+    `out=`) copy by DMA at the link rate instead of through the runtime's staging buffers.  Free it with `free_pinned`."""
+    ptr = ctypes.c_void_p()
+    _check(load_library().bn254_alloc_pinned(8 * max(int(words), 1), ctypes.byref(ptr)), "alloc_pinned")
+    buf = (ctypes.c_uint64 * int(words)).from_address(ptr.value)
+    a = np.frombuffer(buf, dtype=np.uint64)
+    _PINNED[a.ctypes.data] = ptr.value
+    return a
+
+
+def free_pinned(a):
+    ptr = _PINNED.pop(a.ctypes.data, None)
+    if ptr is None:
+        raise Bn254Error(ERR_INVALID_ARG, "free_pinned: not an array from alloc_pinned")
+    _check(load_library().bn254_free_pinned(ptr), "free_pinned")
+
+
+_PINNED = {}
+
+
+def host_register(a):
+    """Page-locks the memory of an existing contiguous numpy array in place (bn254_host_register = hipHostRegister)."""
+    _check(load_library().bn254_host_register(_ptr(a), a.nbytes), "host_register")
+
+
+def host_unregister(a):
+    _check(load_library().bn254_host_unregister(_ptr(a)), "host_unregister")
+
+
+def host_is_pinned(a):
+    return bool(load_library().bn254_host_is_pinned(_ptr(a), a.nbytes))
+
+
 # ----------------------------------------------------------------------------- batch API (host numpy buffers, SoA)
-def pairing_batch(g1, g2, n, device=0):
+def pairing_batch(g1, g2, n, device=0, out=None):
     """n x pairing(p, q)  (src/pairing.rs:20-22), MyFq12 coefficient order, SoA."""
     lib = load_library()
     g1, g2 = _np_in(g1, G1_WORDS, n), _np_in(g2, G2_WORDS, n)
-    out = np.empty(FQ12_WORDS * n, dtype=np.uint64)
+    out = _np_out(out, FQ12_WORDS * n)
     _check(lib.bn254_pairing_batch(_ptr(g1), _ptr(g2), _ptr(out), n, device, None), "pairing")
     return out
 
@@ -230,11 +279,11 @@ def final_exp_batch(f, n, device=0):
     return out
 
 
-def multi_pairing_batch(g1, g2, n_groups, k, do_final_exp=True, device=0):
+def multi_pairing_batch(g1, g2, n_groups, k, do_final_exp=True, device=0, out=None):
     """n_groups x multi_miller_loop_native(k pairs) [+ final_exp_native]  (:324-326)."""
     lib = load_library()
     g1, g2 = _np_in(g1, G1_WORDS, n_groups * k), _np_in(g2, G2_WORDS, n_groups * k)
-    out = np.empty(FQ12_WORDS * n_groups, dtype=np.uint64)
+    out = _np_out(out, FQ12_WORDS * n_groups)
     _check(lib.bn254_multi_pairing_batch(_ptr(g1), _ptr(g2), _ptr(out), n_groups, k, 1 if do_final_exp else 0, device, None),
            "multi_miller_loop_native")
     return out
@@ -295,11 +344,11 @@ def pow_batch(a, exp, n, device=0):
 
 # ----------------------------------------------------------------------------- element-major API (host numpy buffers)
 # elems[i*W + w]: the order the reference's callers hold &[G1Affine] / Vec<MyFq12> / Vec<Fq12> in; the planes are made on the device.
-def pairing_batch_elems(g1, g2, n, out_order=FQ12_MYFQ12, device=0):
+def pairing_batch_elems(g1, g2, n, out_order=FQ12_MYFQ12, device=0, out=None):
     """n x pairing(p, q); out_order = FQ12_ARK gives ark `Fq12` words, the value src/pairing.rs:20-22 returns."""
     lib = load_library()
     g1, g2 = _np_in(g1, G1_WORDS, n), _np_in(g2, G2_WORDS, n)
-    out = np.empty(FQ12_WORDS * n, dtype=np.uint64)
+    out = _np_out(out, FQ12_WORDS * n)
     _check(lib.bn254_pairing_batch_elems(_ptr(g1), _ptr(g2), _ptr(out), n, out_order, device, None), "pairing")
     return out
 
@@ -312,10 +361,10 @@ def miller_loop_batch_elems(g1, g2, n, device=0):
     return out
 
 
-def multi_pairing_batch_elems(g1, g2, n_groups, k, do_final_exp=True, out_order=FQ12_MYFQ12, device=0):
+def multi_pairing_batch_elems(g1, g2, n_groups, k, do_final_exp=True, out_order=FQ12_MYFQ12, device=0, out=None):
     lib = load_library()
     g1, g2 = _np_in(g1, G1_WORDS, n_groups * k), _np_in(g2, G2_WORDS, n_groups * k)
-    out = np.empty(FQ12_WORDS * n_groups, dtype=np.uint64)
+    out = _np_out(out, FQ12_WORDS * n_groups)
     _check(lib.bn254_multi_pairing_batch_elems(_ptr(g1), _ptr(g2), _ptr(out), n_groups, k, 1 if do_final_exp else 0, out_order, device, None),
            "multi_miller_loop_native")
     return out

@@ -228,6 +228,7 @@ struct DeviceCtx {
     std::map<hipStream_t, std::shared_ptr<StreamCtx>> streams;   // shared: a call keeps its context alive across a concurrent release
     std::mutex pipe_mu;        // one host-pointer pipeline at a time per device (its two workers fill the chip anyway)
     hipStream_t pipe_stream[2] = {nullptr, nullptr};   // the workers' private streams: created once, their scratch and staging kept
+    hipEvent_t pipe_ev[2] = {nullptr, nullptr};        // ... and the event each worker waits for its chunk on
     std::mutex shard_mu;       // one device-pointer sharded call at a time per device
     std::vector<hipStream_t> shard_streams;            // private streams of bn254_*_sharded_dev (one per shard on this device)
 };
@@ -751,6 +752,7 @@ struct HostFmt {               // how the caller's host arrays are laid out
 };
 static int run_pipeline(const int* devices, int n_dev, const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_units, size_t k,
                         int do_final_exp, HostFmt fmt = HostFmt());
+static bool host_pinned(const void* p, size_t bytes);
 
 int bn254_device_count(void) {
     int cnt = 0;
@@ -993,6 +995,47 @@ int bn254_release_stream(int device, void* stream) {
     return BN254_OK;
 }
 
+// ---- page-locked host memory for the host-pointer entry points.  The reference's callers hold their G1Affine / G2Affine / Fq12 values in
+// host memory (src/pairing.rs:20, miller_loop_native.rs:324); from pageable memory every byte goes through the runtime's staging buffers
+// (a host memcpy on the issuing thread: ~5 GB/s), from page-locked memory the copy engines move it at the link rate under the kernels.
+int bn254_host_register(void* ptr, size_t bytes) {
+    if (!ptr || !bytes) return BN254_ERR_INVALID_ARG;
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) return BN254_ERR_NO_DEVICE;
+    hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterPortable);
+    if (e == hipErrorHostMemoryAlreadyRegistered) { (void)hipGetLastError(); return BN254_OK; }
+    if (e != hipSuccess) { (void)hipGetLastError(); return e == hipErrorOutOfMemory ? BN254_ERR_ALLOC : BN254_ERR_HIP; }
+    return BN254_OK;
+}
+int bn254_host_unregister(void* ptr) {
+    if (!ptr) return BN254_ERR_INVALID_ARG;
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) return BN254_ERR_NO_DEVICE;
+    if (hipHostUnregister(ptr) != hipSuccess) { (void)hipGetLastError(); return BN254_ERR_INVALID_ARG; }
+    return BN254_OK;
+}
+int bn254_alloc_pinned(size_t bytes, void** out) {
+    if (!out) return BN254_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!bytes) return BN254_ERR_INVALID_ARG;
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) return BN254_ERR_NO_DEVICE;
+    if (hipHostMalloc(out, bytes, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return BN254_ERR_ALLOC; }
+    return BN254_OK;
+}
+int bn254_free_pinned(void* ptr) {
+    if (!ptr) return BN254_OK;
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) return BN254_ERR_NO_DEVICE;
+    if (hipHostFree(ptr) != hipSuccess) { (void)hipGetLastError(); return BN254_ERR_INVALID_ARG; }
+    return BN254_OK;
+}
+int bn254_host_is_pinned(const void* ptr, size_t bytes) {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) return 0;
+    return host_pinned(ptr, bytes) ? 1 : 0;
+}
+
 #ifdef BN254_DEBUG_STAMPS
 // DIAGNOSTIC builds only (tools/exp/build_variant.sh with KGEN_CLOCK_STAMP=1 and -DBN254_DEBUG_STAMPS; not part of the ABI): the
 // kernels of such a build leave, per wave, (d s_memtime, d s_memrealtime) around their item loop in the slack at the end of their
@@ -1226,11 +1269,29 @@ static hipError_t copy_rows(void* dst, const void* src, size_t bytes, hipMemcpyK
     return e;
 }
 
-static int run_chunks(int dev, hipStream_t st, const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_units, size_t k, int do_final_exp,
+// Is [p, p + bytes) page-locked memory the HIP runtime knows (hipHostMalloc / hipHostRegister, also through bn254_alloc_pinned /
+// bn254_host_register)?  Copies from / to such memory are true asynchronous DMA at the link rate; pageable memory goes through the
+// runtime's staging buffers (a host memcpy on the issuing thread).
+static bool host_pinned(const void* p, size_t bytes) {
+    if (!p || !bytes) return false;
+    for (const char* q : {(const char*)p, (const char*)p + bytes - 1}) {
+        hipPointerAttribute_t a;
+        if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (a.type != hipMemoryTypeHost) return false;
+    }
+    return true;
+}
+struct PipeWorker {            // one worker of the host-pointer pipeline: its private stream and the event it waits for its chunks on
+    hipStream_t st;
+    hipEvent_t out_done;
+};
+
+static int run_chunks(int dev, PipeWorker pw, const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_units, size_t k, int do_final_exp,
                       size_t u0, size_t cnt, size_t chunk, size_t first, size_t step, HostFmt fmt) {
     if (cnt == 0 || first * chunk >= cnt) return BN254_OK;
     if (hipSetDevice(dev) != hipSuccess) return BN254_ERR_INVALID_ARG;
     int rc = BN254_OK;
+    hipStream_t st = pw.st;
     {
         Stage s; uint64_t *d1, *d2, *d3, *e1 = nullptr, *e2 = nullptr, *e3 = nullptr;
         size_t cap = cnt < chunk ? cnt : chunk, np_all = n_units * k;
@@ -1239,8 +1300,8 @@ static int run_chunks(int dev, hipStream_t st, const uint64_t* g1, const uint64_
         for (size_t c0 = first * chunk; c0 < cnt; c0 += step * chunk) {
             size_t m = cnt - c0 < chunk ? cnt - c0 : chunk, np = m * k, base = u0 + c0;
             if (fmt.elems) {           // a chunk of an element-major array is one contiguous run; the planes are made on the device
-                if (copy_rows(e1, g1 + base * k * 8, np * 64, hipMemcpyHostToDevice, st) != hipSuccess ||
-                    copy_rows(e2, g2 + base * k * 16, np * 128, hipMemcpyHostToDevice, st) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
+                if ((copy_rows(e1, g1 + base * k * 8, np * 64, hipMemcpyHostToDevice, st)) != hipSuccess ||
+                    (copy_rows(e2, g2 + base * k * 16, np * 128, hipMemcpyHostToDevice, st)) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
                 if ((rc = launch_layout(true, e1, d1, 8, np, 0, dev, st)) || (rc = launch_layout(true, e2, d2, 16, np, 0, dev, st))) goto done;
             } else if (hipMemcpy2DAsync(d1, np * 8, g1 + base * k, np_all * 8, np * 8, 8, hipMemcpyHostToDevice, st) != hipSuccess ||
                        hipMemcpy2DAsync(d2, np * 8, g2 + base * k, np_all * 8, np * 8, 16, hipMemcpyHostToDevice, st) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
@@ -1251,8 +1312,12 @@ static int run_chunks(int dev, hipStream_t st, const uint64_t* g1, const uint64_
                 if ((rc = launch_layout(false, d3, e3, 48, m, fmt.out_order, dev, st))) goto done;
                 if (copy_rows(out + base * 48, e3, m * 384, hipMemcpyDeviceToHost, st) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
             } else if (hipMemcpy2DAsync(out + base, n_units * 8, d3, m * 8, m * 8, 48, hipMemcpyDeviceToHost, st) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
-            if ((rc = bn254_last_status(dev, st))) goto done;        // also: the buffers are free for the next chunk
+            // the buffers are free for the next chunk once the stream has drained -- waited for on an EVENT: the status read-back that used to
+            // stand here is an 8-byte copy, which the runtime performs with a blit kernel, and that kernel waited for the other worker's launch
+            // to leave the CUs (0.2 ms per chunk between the kernels).  The sticky status words are read once, behind the last chunk.
+            if (hipEventRecord(pw.out_done, st) != hipSuccess || hipEventSynchronize(pw.out_done) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
         }
+        rc = bn254_last_status(dev, st);
     done:
         (void)hipStreamSynchronize(st);
     }
@@ -1263,6 +1328,9 @@ static int run_chunks(int dev, hipStream_t st, const uint64_t* g1, const uint64_
 static int run_pipeline(const int* devices, int n_dev, const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_units, size_t k,
                         int do_final_exp, HostFmt fmt) {
     size_t chunk = PIPE_CHUNK;                        // lanes = units (one unit per lane whatever k is)
+    // (element-major data passes two small kernels on the way in and one on the way out (k_layout); a pairing launch holds every register of every
+    // CU, so they run at the launch boundaries: 0.5 ms per chunk, 8 %.  Launches of one CU less do not help -- the other worker's launch takes the
+    // free CU: measured 116 ms against 109.5 for 2^20 -- nor does a third stream per worker: copies behind a cross-stream event run as blit kernels.)
     size_t per = (n_units + (size_t)n_dev - 1) / (size_t)n_dev;
     // the workers' streams (and with them the scratch and the staging buffers, which are kept per stream) live as long as
     // the library: a pipeline call costs no allocation after the first.  Devices are locked in ascending order.
@@ -1275,6 +1343,8 @@ static int run_pipeline(const int* devices, int n_dev, const uint64_t* g1, const
         locks.emplace_back(c.pipe_mu);
         for (hipStream_t& st : c.pipe_stream)
             if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return BN254_ERR_HIP;
+        for (hipEvent_t& ev : c.pipe_ev)
+            if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return BN254_ERR_HIP;
     }
     std::vector<int> rcs;
     std::vector<std::thread> th;
@@ -1287,8 +1357,9 @@ static int run_pipeline(const int* devices, int n_dev, const uint64_t* g1, const
             rcs.push_back(BN254_OK);
             int* slot = &rcs.back();
             int dev = devices[d];
-            hipStream_t st = g_ctx[dev].pipe_stream[w];
-            th.emplace_back([=] { *slot = run_chunks(dev, st, g1, g2, out, n_units, k, do_final_exp, u0, c, chunk, w, workers, fmt); });
+            DeviceCtx& dc = g_ctx[dev];
+            PipeWorker pw{dc.pipe_stream[w], dc.pipe_ev[w]};
+            th.emplace_back([=] { *slot = run_chunks(dev, pw, g1, g2, out, n_units, k, do_final_exp, u0, c, chunk, w, workers, fmt); });
         }
     }
     for (auto& t : th) t.join();

@@ -18,6 +18,10 @@ extern "C" {
     fn bn254_multi_pairing_check_batch(g1: *const u64, g2: *const u64, verdict: *mut u8, n_groups: usize, k: usize, device: c_int,
                                        stream: *mut c_void) -> c_int;
     fn bn254_reserve(device: c_int, stream: *mut c_void, n: usize, k: usize) -> c_int;
+    fn bn254_alloc_pinned(bytes: usize, out: *mut *mut c_void) -> c_int;
+    fn bn254_free_pinned(ptr: *mut c_void) -> c_int;
+    fn bn254_host_register(ptr: *mut c_void, bytes: usize) -> c_int;
+    fn bn254_host_unregister(ptr: *mut c_void) -> c_int;
     fn bn254_set_latency_threshold(n: usize);
     fn bn254_get_latency_threshold() -> usize;
     fn bn254_set_latency_lanes(lanes: c_int);
@@ -169,6 +173,51 @@ pub fn check_points_full(ps: &[G1Affine], qs: &[G2Affine]) -> Result<(), i32> {
 /// Kernel selection of the NULL stream of device 0 (the stream this shim uses) alone, whatever other users of the library set
 /// process-wide: `threshold = usize::MAX` / `lanes = -1` return to the defaults.
 pub fn set_stream_latency(threshold: usize, lanes: i32) { ok(unsafe { bn254_set_stream_latency(0, core::ptr::null_mut(), threshold, lanes) }) }
+
+/// Page-locked staging for the batch functions: the reference's callers hold `repr(Rust)` structs, so a batch is copied limb by limb into
+/// u64 words anyway -- into page-locked words (`bn254_alloc_pinned`) the engine then copies by DMA underneath its kernels, and a large batch
+/// runs at the resident-data rate instead of the pageable-copy rate (include/bn254_pairing.h, PAGE-LOCKED HOST MEMORY).  Keep one
+/// `PinnedWords` per array and reuse it across calls: allocating page-locked memory is slow.
+pub struct PinnedWords { ptr: *mut u64, cap: usize }
+impl PinnedWords {
+    pub fn new() -> Self { PinnedWords { ptr: core::ptr::null_mut(), cap: 0 } }
+    /// at least `words` u64 (contents unspecified after growth)
+    pub fn reserve(&mut self, words: usize) -> &mut [u64] {
+        if words > self.cap {
+            if !self.ptr.is_null() { ok(unsafe { bn254_free_pinned(self.ptr as *mut c_void) }); self.ptr = core::ptr::null_mut(); self.cap = 0; }
+            let mut p: *mut c_void = core::ptr::null_mut();
+            ok(unsafe { bn254_alloc_pinned(8 * words.max(1), &mut p) });
+            self.ptr = p as *mut u64; self.cap = words;
+        }
+        unsafe { core::slice::from_raw_parts_mut(self.ptr, words) }
+    }
+}
+impl Drop for PinnedWords { fn drop(&mut self) { if !self.ptr.is_null() { unsafe { bn254_free_pinned(self.ptr as *mut c_void); } } } }
+/// Page-locks a buffer the caller owns for the lifetime of the guard (`bn254_host_register`): for `Vec<u64>` staging that is reused.
+pub struct HostRegistration { ptr: *mut c_void }
+impl HostRegistration {
+    pub fn new(buf: &mut [u64]) -> Self { ok(unsafe { bn254_host_register(buf.as_mut_ptr() as *mut c_void, 8 * buf.len()) }); HostRegistration { ptr: buf.as_mut_ptr() as *mut c_void } }
+}
+impl Drop for HostRegistration { fn drop(&mut self) { unsafe { bn254_host_unregister(self.ptr); } } }
+/// Reusable page-locked staging of one caller (three arrays: G1 words, G2 words, Fq12 words).
+pub struct BatchStaging { g1: PinnedWords, g2: PinnedWords, out: PinnedWords }
+impl BatchStaging { pub fn new() -> Self { BatchStaging { g1: PinnedWords::new(), g2: PinnedWords::new(), out: PinnedWords::new() } } }
+/// `pairing_batch_fq12` through page-locked staging: n x `pairing(p, q)` as `Fq12` (src/pairing.rs:20-22) at the engine's resident-data rate.
+pub fn pairing_batch_fq12_pinned(st: &mut BatchStaging, ps: &[G1Affine], qs: &[G2Affine]) -> Vec<Fq12> {
+    assert_eq!(ps.len(), qs.len()); let n = ps.len();
+    if n == 0 { return Vec::new(); }
+    let g1 = st.g1.reserve(8 * n);
+    for (i, p) in ps.iter().enumerate() { g1[8 * i..8 * i + 4].copy_from_slice(&limbs(&p.x)); g1[8 * i + 4..8 * i + 8].copy_from_slice(&limbs(&p.y)); }
+    let g2 = st.g2.reserve(16 * n);
+    for (i, q) in qs.iter().enumerate() {
+        g2[16 * i..16 * i + 4].copy_from_slice(&limbs(&q.x.c0)); g2[16 * i + 4..16 * i + 8].copy_from_slice(&limbs(&q.x.c1));
+        g2[16 * i + 8..16 * i + 12].copy_from_slice(&limbs(&q.y.c0)); g2[16 * i + 12..16 * i + 16].copy_from_slice(&limbs(&q.y.c1));
+    }
+    let (p1, p2) = (st.g1.ptr as *const u64, st.g2.ptr as *const u64);
+    let out = st.out.reserve(48 * n);
+    ok(unsafe { bn254_pairing_batch_elems(p1, p2, out.as_mut_ptr(), n, FQ12_ARK, 0, core::ptr::null_mut()) });
+    out.chunks_exact(48).map(fq12_from_ark_words).collect()
+}
 
 /// New: whole batches in one launch (what the engine is for).  Output: MyFq12 per pairing.
 pub fn pairing_batch(ps: &[G1Affine], qs: &[G2Affine]) -> Vec<MyFq12> {

@@ -62,6 +62,17 @@ int main() {
                 std::vector<MyFq12> my = pairing_batch(ps, qs);
                 for (auto& e : ark) { std::printf("bark"); for (auto& c : e.flat) pr_fq(c); std::printf("\n"); }
                 for (auto& e : my) pr_fq12("bmy", e);
+                {   // the same batch from / into page-locked memory: pinned_vector (bn254_alloc_pinned) and a registered std::vector
+                    pinned_vector<G1Affine> pp(ps.begin(), ps.end()); pinned_vector<G2Affine> pq(qs.begin(), qs.end()); pinned_vector<Fq12> po(n);
+                    pairing_batch_fq12_into(pp.data(), pq.data(), po.data(), n);
+                    std::vector<MyFq12> ro(n);
+                    int reg_pinned;
+                    { HostRegistration r1(ps), r2(qs), r3(ro); reg_pinned = bn254_host_is_pinned(ro.data(), n * sizeof(MyFq12)); pairing_batch_into(ps.data(), qs.data(), ro.data(), n); }
+                    bool same = true;
+                    for (size_t j = 0; j < n; j++) same = same && po[j].flat == ark[j].flat && ro[j] == my[j];
+                    std::printf("bpin %d %d %d %d\n", same ? 1 : 0, bn254_host_is_pinned(po.data(), n * sizeof(Fq12)), reg_pinned,
+                                bn254_host_is_pinned(ro.data(), n * sizeof(MyFq12)));
+                }
             } else if (op == "check") {
                 size_t k = (size_t)rd(in), n = (size_t)rd(in);
                 std::vector<G1Affine> ps(k * n); std::vector<G2Affine> qs(k * n);

@@ -456,3 +456,52 @@ def test_mid_size_call_is_capturable_after_a_large_reserve():
         assert torch.equal(got[0], out) and torch.equal(got[1], out_g) and torch.equal(got[2], out_f)
         assert int(out.abs().sum()) != 0 and int(out_g.abs().sum()) != 0
     pk.release_stream(0, side)
+
+
+def test_page_locked_host_buffers_same_limbs_and_detected():
+    """bn254_alloc_pinned / bn254_host_register (include/bn254_pairing.h, PAGE-LOCKED HOST MEMORY): the host-pointer pipeline of a batch above
+    one chunk takes plain asynchronous copies when all three arrays are page-locked -- the same limbs as from pageable memory, limb-major and
+    element-major, pairings and 2-pair groups, ragged sizes; the library recognises both kinds of page-locked memory and forgets a
+    registration that ended."""
+    import torch
+    pk = H.pkg()
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev)
+    n = (1 << 17) + 1234                       # three chunks, the last one ragged
+    g1 = torch.zeros(8 * n, dtype=torch.int64, device=dev)
+    g2 = torch.zeros(16 * n, dtype=torch.int64, device=dev)
+    pk.generate_pairs_dev(0x6C01, g1, g2, n, 0, st)
+    pk.last_status(0, st)
+    h1, h2 = g1.cpu().numpy().view(np.uint64).copy(), g2.cpu().numpy().view(np.uint64).copy()
+    want = pk.pairing_batch(h1, h2, n)                                           # pageable
+    p1, p2, po = pk.alloc_pinned(8 * n), pk.alloc_pinned(16 * n), pk.alloc_pinned(48 * n)
+    assert pk.host_is_pinned(p1) and pk.host_is_pinned(po) and not pk.host_is_pinned(h1)
+    p1[:], p2[:], po[:] = h1, h2, 0
+    assert pk.pairing_batch(p1, p2, n, out=po) is po and np.array_equal(po, want)
+    # mixed (inputs page-locked, result pageable) falls back to the staged copies: same limbs
+    assert np.array_equal(pk.pairing_batch(p1, p2, n), want)
+    # element-major, ark order, registered numpy arrays
+    e1, e2 = pk.layout.to_aos(h1, 8).copy(), pk.layout.to_aos(h2, 16).copy()
+    want_e = pk.pairing_batch_elems(e1, e2, n, out_order=pk.FQ12_ARK)
+    eo = np.zeros(48 * n, dtype=np.uint64)
+    for a in (e1, e2, eo):
+        pk.host_register(a)
+    assert pk.host_is_pinned(e1) and pk.host_is_pinned(eo)
+    pk.pairing_batch_elems(e1, e2, n, out_order=pk.FQ12_ARK, out=eo)
+    assert np.array_equal(eo, want_e)
+    # 2-pair groups through the same page-locked arrays (n // 2 groups: one plane stride for inputs, another for the result)
+    groups = n // 2
+    m1, m2 = pk.layout.to_soa(e1[: 8 * 2 * groups], 8), pk.layout.to_soa(e2[: 16 * 2 * groups], 16)
+    want_m = pk.multi_pairing_batch(m1, m2, groups, 2)
+    go = pk.alloc_pinned(48 * groups)
+    q1, q2 = pk.alloc_pinned(8 * 2 * groups), pk.alloc_pinned(16 * 2 * groups)
+    q1[:], q2[:] = m1, m2
+    pk.multi_pairing_batch(q1, q2, groups, 2, out=go)
+    assert np.array_equal(go, want_m)
+    for a in (e1, e2, eo):
+        pk.host_unregister(a)
+    assert not pk.host_is_pinned(eo)
+    for a in (p1, p2, po, go, q1, q2):
+        pk.free_pinned(a)
+    with pytest.raises(pk.Bn254Error):
+        pk.pairing_batch(h1, h2, n, out=np.zeros(3, dtype=np.uint64))

@@ -86,6 +86,11 @@ def test_host_binding_program_on_golden_inputs(tmp_path):
     want += [("bark", R.myfq12_to_ark(HX(vec["pairing"][i]))) for i in idx] + [("bmy", HX(vec["pairing"][i])) for i in idx]
     lines.append("fexp " + _words([0] * 12))                  # final_exp_native(0): the reference panics (division by zero)
     out = _run(exe, lines)
+    # the page-locked forms of the same batch (pinned_vector + *_into, HostRegistration on the caller's vectors): same limbs, and the
+    # library recognises both kinds of memory -- and that the registration ended with its guard
+    pin = [g for g in out if g and g[0] == "bpin"]
+    assert pin == [["bpin", "1", "1", "1", "0"]], pin
+    out = [g for g in out if not (g and g[0] == "bpin")]
     for (tag, w), got in zip(want, out):
         assert got[0] == tag and _ints(got[1:]) == w, tag
     assert out[len(want)] == ["panic", "-4"]
