@@ -283,12 +283,17 @@ int bn254_check_points(const uint64_t* g1, const uint64_t* g2, size_t n, int dev
  * `per_point` (may be NULL): one byte per pair, the OR of 2 (infinity), 4 (not on curve), 8 (not in subgroup) -- which pair it was.
  * The `_dev` form sets the stream's sticky point-check status (reported by the next bn254_last_status in the order above, whatever
  * ran in between); the host-pointer form returns it.  COST: not free and not part of the hot path -- the subgroup check is a 63-bit
- * scalar multiplication on the twist per pair (about 1.0 k Fq2 products: a sixth of a pairing's field work, in plain HIP C++):
- * measured 0.07 ms (infinity) / 0.29 ms (+ on-curve) / 54.8 ms (+ subgroup: 19.1 M pairs/s, 0.54 of the pairings' own time) per 2^20
- * resident pairs on MI355X.  HBM: the 192 input bytes per pair once (+ 1 byte out). */
+ * scalar multiplication on the twist per pair (63 doublings, 24 mixed and 2 general additions in Jacobian coordinates: about 0.75 k Fq2
+ * products, an eighth of a pairing's field work).  It runs on a generated gfx950 kernel like the pairings (k_subcheck: 0.50 M instructions
+ * per point); infinity and on-curve stay plain HIP C++ (HBM-bound).  Measured per 2^20 resident pairs on MI355X: 0.07 ms (infinity) /
+ * 0.29 ms (+ on-curve) / 14.4 ms (+ subgroup: 72.8 M pairs/s, 0.14 of the pairings' own time; the portable C++ form of the same criterion: 54.5 ms).  HBM: the 192 input bytes per pair
+ * twice (+ 5 bytes of verdicts).
+ *   BN254_CHECK_SUBGROUP_PORTABLE   the subgroup check on the compiler-scheduled HIP C++ kernel instead (csrc/bn254_point_checks.h: the same
+ *                          criterion with every exceptional case of the group law spelled out) -- the generated kernel's cross-check */
 #define BN254_CHECK_INFINITY 1
 #define BN254_CHECK_ON_CURVE 2
 #define BN254_CHECK_SUBGROUP 4
+#define BN254_CHECK_SUBGROUP_PORTABLE 8
 int bn254_check_points_ex_dev(const uint64_t* g1, const uint64_t* g2, size_t n, int flags, uint8_t* per_point, int device, void* stream);
 int bn254_check_points_ex(const uint64_t* g1, const uint64_t* g2, size_t n, int flags, uint8_t* per_point, int device, void* stream);
 

@@ -36,6 +36,7 @@ ERR_INFINITY = -7
 ERR_NOT_ON_CURVE = -8
 ERR_NOT_IN_SUBGROUP = -9
 CHECK_INFINITY, CHECK_ON_CURVE, CHECK_SUBGROUP = 1, 2, 4       # bn254_check_points_ex flags
+CHECK_SUBGROUP_PORTABLE = 8                                    # ... the subgroup check on the portable HIP C++ kernel (cross-check of the generated one)
 PT_INFINITY, PT_NOT_ON_CURVE, PT_NOT_IN_SUBGROUP = 2, 4, 8     # bits of its per-point verdict byte
 LATENCY_INHERIT = (1 << (8 * ctypes.sizeof(ctypes.c_size_t))) - 1
 

@@ -76,6 +76,7 @@ BN254_ASM_KERNEL(k_mpairing, BN254_ASM_MPAIRING)    // k pairs per lane, shared 
 BN254_ASM_KERNEL(k_mmiller, BN254_ASM_MMILLER)      // k pairs per lane, exact multi_miller_loop_native value
 BN254_ASM_KERNEL(k_op, BN254_ASM_OP)                // MyFq12 Mul / frobenius_map_native / pow_native (k = op | power << 8 | naf_len << 16)
 BN254_ASM_KERNEL(k_generate, BN254_ASM_GENERATE)    // synthetic subgroup points: g1 / g2 = outputs, f_in = table, out = seed
+BN254_ASM_KERNEL(k_subcheck, BN254_ASM_SUBCHECK)    // G2 in the r-torsion? (ark's G2Affine::new, miller_loop_native.rs:303,311): g2 = points, out = one verdict word per point
 
 // The LATENCY path of the scalar signatures (pairing, miller_loop_native, multi_miller_loop_native, final_exp_native): one item on
 // sixteen lanes, four items per wave, one wave per workgroup.  The kernel is an interpreter of the round programs in cvm_asm_gen.h
@@ -305,7 +306,7 @@ int ctx_get(int device, void* stream, size_t k, size_t n_items, LaunchCtx* out, 
             HIPCHK(hipGetDeviceProperties(&prop, device));
             c.n_cu = prop.multiProcessorCount;
             const void* kernels[] = {(const void*)k_pairing, (const void*)k_miller, (const void*)k_fexp, (const void*)k_mpairing,
-                                     (const void*)k_mmiller, (const void*)k_op, (const void*)k_generate};
+                                     (const void*)k_mmiller, (const void*)k_op, (const void*)k_generate, (const void*)k_subcheck};
             for (const void* f : kernels) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
             c.init = true;
         }
@@ -928,16 +929,48 @@ int bn254_check_points_dev(const uint64_t* g1, const uint64_t* g2, size_t n, int
     HIPCHK(hipGetLastError());
     return BN254_OK;
 }
+// The subgroup criterion runs on the generated kernel k_subcheck (one G2 point per lane, 0.50 M instructions: 62 doublings + 24 mixed and 2 general
+// additions in Jacobian coordinates on the 29-bit limbs); the plain HIP C++ kernel of bn254_point_checks.h does everything else (infinity, on the
+// curve) and decides which points are ELIGIBLE for the subgroup verdict (finite and on the twist -- for anything else the criterion's value means
+// nothing); a third, tiny kernel merges the two.  BN254_CHECK_SUBGROUP_PORTABLE keeps the whole check on the C++ kernel: the cross-check of the
+// generated one (tests/test_point_checks.py).
+__global__ void __launch_bounds__(256) k_subcheck_merge(const uint32_t* __restrict__ fails, uint8_t* __restrict__ flags_io, uint8_t* __restrict__ per_point,
+                                                        size_t n, int* __restrict__ status) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        int bad = flags_io[i];
+        if (!(bad & bn254_chk::PT_SKIP_SUBGROUP) && fails[i]) { bad |= bn254_chk::PT_NOT_IN_SUBGROUP; atomicOr(status, bn254_chk::PT_NOT_IN_SUBGROUP); }
+        if (per_point) per_point[i] = (uint8_t)(bad & ~bn254_chk::PT_SKIP_SUBGROUP);
+    }
+}
+
 int bn254_check_points_ex_dev(const uint64_t* g1, const uint64_t* g2, size_t n, int flags, uint8_t* per_point, int device, void* stream) {
     if (n == 0) return BN254_OK;
-    if (!g1 || !g2 || n >= (1ull << 29) || (flags & ~7) || !flags) return BN254_ERR_INVALID_ARG;
+    if (!g1 || !g2 || n >= (1ull << 29) || (flags & ~15) || !(flags & 15)) return BN254_ERR_INVALID_ARG;
+    const bool portable = (flags & BN254_CHECK_SUBGROUP_PORTABLE) != 0;
+    if (portable) flags = (flags & 7) | BN254_CHECK_SUBGROUP;
+    const bool generated = (flags & BN254_CHECK_SUBGROUP) && !portable;
     LaunchCtx c;
-    int rc = ctx_get(device, stream, 1, 1, &c);
+    int rc = ctx_get(device, stream, 1, generated ? (n + BLOCK - 1) / BLOCK : 1, &c);
     if (rc) return rc;
     static const bn254_chk::Consts K = BN254_CHK_CONSTS;
     size_t blocks = (n + 63) / 64, cap = (size_t)c.n_cu * 32;       // one point per thread; wave-sized workgroups spread small batches over the CUs
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(bn254_chk::k_check_points_ex, dim3((uint32_t)blocks), dim3(64), 0, (hipStream_t)stream, g1, g2, n, flags, K, per_point, c.status + 1);
+    hipStream_t st = (hipStream_t)stream;
+    if (!generated) {
+        hipLaunchKernelGGL(bn254_chk::k_check_points_ex, dim3((uint32_t)blocks), dim3(64), 0, st, g1, g2, n, flags, K, per_point, c.status + 1);
+        HIPCHK(hipGetLastError());
+        return BN254_OK;
+    }
+    // the stream's verdict buffer (bn254_reserve sizes it: 384 n bytes) takes the verdict words (4 n) and the eligibility / flag bytes (n)
+    if ((rc = ensure(c.s.get(), c.s->tmp, 8 * n))) return rc;
+    uint32_t* fails = (uint32_t*)c.s->tmp.p;
+    uint8_t* fl = (uint8_t*)c.s->tmp.p + 4 * n;
+    hipLaunchKernelGGL(bn254_chk::k_check_points_ex, dim3((uint32_t)blocks), dim3(64), 0, st, g1, g2, n, flags | bn254_chk::CHECK_DEFER_SUBGROUP, K, fl, c.status + 1);
+    hipLaunchKernelGGL(k_subcheck, dim3(c.grid), dim3(BLOCK), LDS_BYTES, st, g1, g2, (const uint64_t*)nullptr, (uint64_t*)fails, (uint32_t)n, 1u, c.scratch,
+                       c.stride, c.status);
+    size_t mb = (n + 255) / 256;
+    if (mb > 4096) mb = 4096;
+    hipLaunchKernelGGL(k_subcheck_merge, dim3((uint32_t)mb), dim3(256), 0, st, (const uint32_t*)fails, fl, per_point, n, c.status + 1);
     HIPCHK(hipGetLastError());
     return BN254_OK;
 }

@@ -14,10 +14,12 @@
 //                               Checked against [r]Q == O on subgroup and non-subgroup twist points by tests/test_point_checks.py
 //                               through the big-int restatement.)   G1 has cofactor one: on the curve is in the subgroup.
 //
-// Cost (stated, not hidden): per G2 point 62 doublings + 24 mixed and 3 general additions in Jacobian coordinates = ~0.75 k Fq2 products,
+// Cost (stated, not hidden): per G2 point 63 doublings + 24 mixed and 2 general additions in Jacobian coordinates = ~0.75 k Fq2 products,
 // i.e. about an eighth of a pairing's field work, in compiler-scheduled 64-bit arithmetic (several times slower per product than the generated
 // kernels).  MEASURED on MI355X (tools/exp/check_cost.py, 2^20 pairs resident): infinity 0.07 ms, + on-curve 0.29 ms, + subgroup
-// 54.8 ms = 19.1 M pairs/s -- 0.54 of the time of the 2^20 pairings themselves.  HBM: 192 input bytes per pair, once.
+// 54.8 ms = 19.1 M pairs/s.  Since round 6 the subgroup criterion of bn254_check_points_ex runs on the generated kernel k_subcheck
+// (tools/kgen4_prog.py: _subcheck_routines); this kernel keeps infinity / on-curve, marks the points the criterion does not apply to
+// (CHECK_DEFER_SUBGROUP) and remains the whole check's portable form (BN254_CHECK_SUBGROUP_PORTABLE): the generated kernel's cross-check.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -202,10 +204,12 @@ __device__ __noinline__ bool jac_eq(const Jac& p, const Jac& q) {
 }
 
 // flag bits of the per-point verdict byte and of the stream's point-check status word
-enum { PT_INFINITY = 2, PT_NOT_ON_CURVE = 4, PT_NOT_IN_SUBGROUP = 8 };
+enum { PT_INFINITY = 2, PT_NOT_ON_CURVE = 4, PT_NOT_IN_SUBGROUP = 8,
+       PT_SKIP_SUBGROUP = 0x80 };       // internal (never leaves the library): the G2 point is infinite or off the twist -- no subgroup verdict for it
 
 // what to check (bn254_pairing.h: BN254_CHECK_*)
-enum { CHECK_INFINITY = 1, CHECK_ON_CURVE = 2, CHECK_SUBGROUP = 4 };
+enum { CHECK_INFINITY = 1, CHECK_ON_CURVE = 2, CHECK_SUBGROUP = 4,
+       CHECK_DEFER_SUBGROUP = 0x100 };  // internal: the criterion itself runs on the generated kernel (k_subcheck); mark the points it does not apply to
 
 struct Consts {
     uint64_t one[4];        // R mod p
@@ -247,7 +251,8 @@ __global__ void __launch_bounds__(64) k_check_points_ex(const uint64_t* __restri
                 bool ok = !fq_geq_p(qx.a) && !fq_geq_p(qx.b) && !fq_geq_p(qy.a) && !fq_geq_p(qy.b);
                 if (ok) ok = f2_eq(f2_sqr(qy), f2_add(f2_mul(f2_sqr(qx), qx), f2_const(K.twist_b)));
                 if (!ok) bad |= PT_NOT_ON_CURVE;
-                else if (flags & CHECK_SUBGROUP) {
+                else if (flags & CHECK_DEFER_SUBGROUP) {
+                } else if (flags & CHECK_SUBGROUP) {
                     Fq2 c2 = f2_const(K.c2), c3 = f2_const(K.c3);
                     Jac Q = {qx, qy, {fq_const(K.one), {{0, 0, 0, 0}}}};
                     Jac a = Q;                                   // [x]Q, x = BN_X (final_exp_native.rs:15) by its non-adjacent form, top digit first:
@@ -266,8 +271,9 @@ __global__ void __launch_bounds__(64) k_check_points_ex(const uint64_t* __restri
                 }
             }
         }
-        if (per_point) per_point[i] = (uint8_t)bad;
         if (bad) atomicOr(status, bad);
+        if ((flags & CHECK_DEFER_SUBGROUP) && (inf2 || (bad & PT_NOT_ON_CURVE))) bad |= PT_SKIP_SUBGROUP;
+        if (per_point) per_point[i] = (uint8_t)bad;
     }
 }
 

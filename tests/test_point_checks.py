@@ -270,3 +270,43 @@ def test_subgroup_check_walks_the_naf_of_x():
     assert neg & ~nz == 0 and nz >> 62 == 1 and not (neg >> 62) & 1          # 63 digits, the top one is +1 (the loop starts from Q)
     assert sum((-1 if (neg >> i) & 1 else 1) << i for i in range(63) if (nz >> i) & 1) == R.BN_X
     assert nz & (nz >> 1) == 0 and bin(nz).count("1") == 24                  # non-adjacent, 24 digits
+
+
+@pytest.mark.gpu
+def test_generated_subgroup_kernel_equals_the_portable_kernel_point_by_point():
+    """The subgroup criterion runs on the generated kernel k_subcheck (tools/kgen4_prog.py: Jacobian steps without the group law's exceptional
+    branches, a final Z = 0 counted as a failure); BN254_CHECK_SUBGROUP_PORTABLE keeps it on the HIP C++ kernel that spells every exceptional
+    case out.  Same per-point bytes and the same status on a ragged batch that mixes r-torsion points, random twist points, cofactor-cleared
+    twist points, points off the twist, non-canonical coordinates and the point at infinity -- under every flag combination that asks for
+    the subgroup check -- and both say what the big-int definition [r]Q == O says."""
+    pk = H.pkg()
+    rng = random.Random(2025)
+    n = 333
+    Ps, Qs = H.subgroup_points(n, seed=93)
+    Ps, Qs = list(Ps), list(Qs)
+    expect = [0] * n
+    for i in range(0, n, 7):                                   # random twist points: not in the subgroup
+        Qs[i] = twist_point(rng)
+        expect[i] = pk.PT_NOT_IN_SUBGROUP
+    for i in (3, 150, n - 1):                                  # cofactor-cleared: in the subgroup again
+        Qs[i] = R.g2_mul(twist_point(rng), 2 * P - R.R_ORDER)
+    for i in (5, 200):                                         # off the twist
+        q = Qs[i]
+        Qs[i] = (q[0], ((q[1][0] + 1) % P, q[1][1]))
+        expect[i] = pk.PT_NOT_ON_CURVE
+    g1, g2 = _batch(Ps, Qs)
+    g2.reshape(16, n)[:, 41] = 0                               # the point at infinity (ark's x = y = 0)
+    expect[41] = pk.PT_INFINITY
+    for i in range(n):
+        if expect[i] in (0, pk.PT_NOT_IN_SUBGROUP) and i != 41:
+            assert (R.g2_mul(Qs[i], R.R_ORDER) is None) == (expect[i] == 0), i
+    ALL = pk.CHECK_INFINITY | pk.CHECK_ON_CURVE | pk.CHECK_SUBGROUP
+    for flags in (ALL, pk.CHECK_SUBGROUP, pk.CHECK_SUBGROUP | pk.CHECK_ON_CURVE, pk.CHECK_SUBGROUP | pk.CHECK_INFINITY):
+        rc_g, per_g = pk.check_points_ex(g1, g2, n, flags, want_per_point=True)
+        rc_p, per_p = pk.check_points_ex(g1, g2, n, flags | pk.CHECK_SUBGROUP_PORTABLE, want_per_point=True)
+        assert rc_g == rc_p and np.array_equal(per_g, per_p), flags
+        want = [e if (e != pk.PT_INFINITY or (flags & pk.CHECK_INFINITY)) else 0 for e in expect]
+        assert list(per_g) == want, flags
+    # the portable flag alone selects the subgroup check too
+    rc, per = pk.check_points_ex(g1, g2, n, pk.CHECK_SUBGROUP_PORTABLE, want_per_point=True)
+    assert rc == pk.ERR_NOT_ON_CURVE and list(per) == [e if e != pk.PT_INFINITY else 0 for e in expect]

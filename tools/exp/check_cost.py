@@ -11,7 +11,7 @@ for log2 in (16, 20):
     g1 = torch.zeros(8 * n, dtype=torch.int64, device=dev); g2 = torch.zeros(16 * n, dtype=torch.int64, device=dev)
     per = torch.zeros(n, dtype=torch.uint8, device=dev)
     pk.generate_pairs_dev(0xC0571, g1, g2, n, 0, st); pk.last_status(0, st)
-    for name, flags in (("infinity", 1), ("infinity + on-curve", 3), ("infinity + on-curve + G2 subgroup", 7)):
+    for name, flags in (("infinity", 1), ("infinity + on-curve", 3), ("infinity + on-curve + G2 subgroup", 7), ("... subgroup on the portable C++ kernel", 15)):
         ts = []
         for _ in range(4):
             torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -1601,6 +1601,63 @@ class Prog:
         self.rel(th, mu, T, U, Cc, D, E)
 
 
+    # ---- Jacobian arithmetic on the twist (x = X / Z^2, y = Y / Z^3), no lines: the G2 subgroup check (KernelBuilder subcheck).
+    # The formulas of csrc/bn254_point_checks.h (dbl-2009-l, madd-2007-bl, add-2007-bl) WITHOUT their exceptional branches: an
+    # exceptional case makes H = 0, hence Z3 = 0, and Z stays 0 through every later step -- the caller treats a final Z = 0 as "not in the
+    # subgroup" (a point of the r-torsion never meets one: the partial scalars of [x]Q are below 2^63, tests/test_point_checks.py).
+    def jac_dbl(self, R):
+        X, Y, Z = R
+        tA, tB, tC, tD, tE = [self.tmp() for _ in range(5)]
+        self.A(X).sqr().to(tA)
+        self.A(Y).sqr().to(tB)
+        self.A(tB).sqr().to(tC)
+        self.A(X).add(tB).sqr().sub(tA).sub(tC).dbl().to(tD)          # D = 2 ((X + B)^2 - A - C)
+        self.A(Y).mul(Z).dbl().to(Z)                                  # Z3 = 2 Y Z
+        self.A(tA).scale(3).to(tE)                                    # E = 3 A
+        self.A(tE).sqr().sub(tD).sub(tD).to(X)                        # X3 = E^2 - 2 D
+        self.A(tC).scale(8).to(tC)
+        self.A(tD).sub(X).mul(tE).sub(tC).to(Y)                       # Y3 = E (D - X3) - 8 C
+        self.rel(tA, tB, tC, tD, tE)
+
+    def jac_madd(self, R, Q):
+        """R <- R + (qx, qy, 1)"""
+        X, Y, Z = R
+        qx, qy = Q
+        zz, h, hh, i, j, r, v = [self.tmp() for _ in range(7)]
+        self.A(Z).sqr().to(zz)
+        self.A(qx).mul(zz).sub(X).to(h)                               # H = U2 - X1
+        self.A(qy).mul(Z).mul(zz).sub(Y).dbl().to(r)                  # r = 2 (S2 - Y1)
+        self.A(h).sqr().to(hh)
+        self.A(Z).add(h).sqr().sub(zz).sub(hh).to(Z)                  # Z3 = (Z1 + H)^2 - Z1Z1 - HH
+        self.A(hh).scale(4).to(i)
+        self.A(h).mul(i).to(j)
+        self.A(X).mul(i).to(v)
+        self.A(r).sqr().sub(j).sub(v).sub(v).to(X)                    # X3 = r^2 - J - 2 V
+        self.A(Y).mul(j).dbl().to(hh)
+        self.A(v).sub(X).mul(r).sub(hh).to(Y)                         # Y3 = r (V - X3) - 2 Y1 J
+        self.rel(zz, h, hh, i, j, r, v)
+
+    def jac_add(self, P1, P2):
+        """P1 <- P1 + P2 (both projective)"""
+        X1, Y1, Z1 = P1
+        X2, Y2, Z2 = P2
+        z1z1, z2z2, u1, s1, h, r, i, j, v = [self.tmp() for _ in range(9)]
+        self.A(Z1).sqr().to(z1z1)
+        self.A(Z2).sqr().to(z2z2)
+        self.A(X1).mul(z2z2).to(u1)
+        self.A(X2).mul(z1z1).sub(u1).to(h)                            # H = U2 - U1
+        self.A(Y1).mul(Z2).mul(z2z2).to(s1)
+        self.A(Y2).mul(Z1).mul(z1z1).sub(s1).dbl().to(r)              # r = 2 (S2 - S1)
+        self.A(Z1).add(Z2).sqr().sub(z1z1).sub(z2z2).mul(h).to(Z1)    # Z3 = ((Z1 + Z2)^2 - Z1Z1 - Z2Z2) H
+        self.A(h).dbl().sqr().to(i)                                   # I = (2 H)^2
+        self.A(h).mul(i).to(j)
+        self.A(u1).mul(i).to(v)
+        self.A(r).sqr().sub(j).sub(v).sub(v).to(X1)
+        self.A(s1).mul(j).dbl().to(i)
+        self.A(v).sub(X1).mul(r).sub(i).to(Y1)
+        self.rel(z1z1, z2z2, u1, s1, h, r, i, j, v)
+
+
 # ======================================================================================================================
 class _PhaseList(list):
     """The builder's section list: remembers in which phase (Miller loop / final exponentiation) a section was added."""
@@ -1655,16 +1712,23 @@ class KernelBuilder:
 
     COLD = ("L2_inv", "L2_frob1", "L2_frob2", "L2_frob3", "L2_dblfirst", "L2_addmul_last", "L2_descale", "L2_fqinv")
 
-    def __init__(self, do_miller=True, do_fexp=True, track=False, multi=False, helper=False, generate=False):
+    def __init__(self, do_miller=True, do_fexp=True, track=False, multi=False, helper=False, generate=False, subcheck=False):
         """track: keep the running line scale and divide it out (the exact miller_loop_native value).
         multi: k pairs per lane with a shared f (multi_miller_loop_native, miller_loop_native.rs:192-282).
         helper: the batched public helpers of the reference on Fq12 batches -- MyFq12 `Mul`, frobenius_map_native
         (final_exp_native.rs:17-54), pow_native (:56-84) -- selected at run time by the kernel's `k` argument."""
         if helper:
             do_miller, do_fexp, track, multi = False, True, False, False
-        if generate:
+        if generate or subcheck:
             do_miller, do_fexp, track, multi = False, False, False, False
         self.generate = generate
+        # subcheck: ark's `G2Affine::new` contract (miller_loop_native.rs:303,311) -- is the lane's G2 point in the r-torsion?  One verdict word per
+        # point into `out`; the point state lives in AGPR slots only (_subcheck_routines)
+        self.subcheck = subcheck
+        if subcheck:
+            self.R = [AGPR(0, "RX"), AGPR(1, "RY"), AGPR(2, "RZ")]
+            self.QX, self.QY = AGPR(3, "QX"), AGPR(4, "QY")
+            self.SX, self.SY = self.QX, AGPR(5, "SY")
         self.do_miller, self.do_fexp, self.track = do_miller, do_fexp, track
         self.multi = multi
         self.helper = helper
@@ -1685,6 +1749,13 @@ class KernelBuilder:
     @property
     def naf(self):
         """the digits of 6 x + 2 this kernel's Miller loop walks (least significant first; the top one is R = Q, f = 1)"""
+        if self.subcheck:            # the scalar multiplication [x]Q walks the non-adjacent form of x (63 digits, 24 non-zero), padded to the masks' 64
+            d, n = [], BN_X
+            while n:
+                z = (2 - n % 4) if n & 1 else 0
+                d.append(z)
+                n = (n - z) // 2
+            return d + [0] * (66 - len(d))
         if SHORT_CHAIN and self.do_miller and self.do_fexp and not self.track and not FISSION:
             return SIX_U_PLUS_2_SHORT
         return SIX_U_PLUS_2_NAF
@@ -2017,6 +2088,8 @@ class KernelBuilder:
             self.l2_routine("L2_fqinv", self._fq_inv, gt)
             self.l2_routine("L2_ptadd", lambda p: p.pt_add(self.R, (self.SX, self.SY)), gt)
             self.l2_routine("L2_affine", self._to_affine, gt)
+        if self.subcheck:
+            self._subcheck_routines()
         self._phase = "fexp"
         if self.do_fexp:
             if not (self.do_miller and self.track):
@@ -2794,8 +2867,8 @@ class KernelBuilder:
         p.temp_keys = frozenset()            # the main program's stores all cross routine boundaries
         p.norm_keys = self.norm_keys("miller")
         self.main_prog = p
-        if self.generate:
-            self.generate_main(e, p)
+        if self.generate or self.subcheck:
+            (self.generate_main if self.generate else self.subcheck_main)(e, p)
             e.salu(f"s_add_u32 s{S_ITEM}, s{S_ITEM}, s{S_GRID}")
             e.salu(f"s_branch {L('L_item')}")
             e.label(L("L_done"))
@@ -3485,6 +3558,130 @@ class KernelBuilder:
         e.emit(f"v_lshrrev_b32_e32 v{V_TID}, 4, v{V_LDS}", vw=[V_TID])
         p.reset_tags()
 
+
+    # ---------------------------------------------------------------------------------------------
+    # G2 subgroup check (bn254_check_points_ex with BN254_CHECK_SUBGROUP): ark's `G2Affine::new` asserts it, the reference calls that on the
+    # Frobenius images of Q (miller_loop_native.rs:303,311).  Criterion (El Housni - Guillevic - Piellard, ePrint 2022/348; the same as
+    # csrc/bn254_point_checks.h, which stays as this kernel's cross-check):
+    #     [x + 1] Q + psi([x] Q) + psi^2([x] Q) == psi^3([2 x] Q),      psi = the reference's twisted_frobenius (:298-304)
+    # [x]Q by the non-adjacent form of x, top digit first: 62 doublings + 23 mixed additions of +-Q in Jacobian coordinates; then three psi
+    # (two Fq2 products each), one mixed and two general additions, one doubling, and the comparison of the two projective points by
+    # cross-multiplication, on canonical limbs (cvtout).  Everything lives in AGPR slots and home registers: no LDS, no scratch.
+    SUB_B = [AGPR(6, "BX"), AGPR(7, "BY"), AGPR(8, "BZ")]
+    SUB_C = [AGPR(9, "CX"), AGPR(10, "CY"), AGPR(11, "CZ")]
+    V_SUB_DIFF, V_SUB_Z = 252, 253          # OR of the canonical limbs of the two cross-differences / of Z_lhs Z_rhs (free VGPRs: V_P3T of the k-pair kernels)
+
+    def sub_temps(self):
+        return [HOME(i) for i in range(8)] + [AGPR(12), AGPR(13)] + [LDS(i) for i in range(N_LDS_SLOTS)] + [GLOB(GLOB_TMP0 + i) for i in range(8)]
+
+    def _sub_psi(self, p, src, dst):
+        """dst <- psi(src) on Jacobian coordinates: (c2 conj(X), c3 conj(Y), conj(Z))"""
+        C2, C3 = self._twist_consts()
+        p.A(src[0]).conj().mul(C2).to(dst[0])
+        p.A(src[1]).conj().mul(C3).to(dst[1])
+        p.A(src[2]).conj().to(dst[2])
+
+    def _sub_or_limbs(self, p, slot, acc, first):
+        """v[acc] (|)= OR of the sixteen canonical dwords of the Fq2 in `slot` (zero iff the value is 0 mod p in both components)"""
+        e = p.e
+        for half in range(2):
+            p.tagA = None
+            p.A(slot)
+            p.redn()
+            p.wait()
+            if half == 1:
+                for i in range(NL):
+                    e.emit(f"v_mov_b32_e32 v{A0 + i}, v{A0 + NL + i}", vw=[A0 + i])
+            self.cvt_call(e, "cvtout")
+            for i in range(8):
+                if first and half == 0 and i == 0:
+                    e.emit(f"v_mov_b32_e32 v{acc}, v{A0}", vw=[acc])
+                else:
+                    e.emit(f"v_or_b32_e32 v{acc}, v{acc}, v{A0 + i}", vw=[acc])
+        p.reset_tags()
+
+    def _sub_final(self, p):
+        a, B, C = self.R, self.SUB_B, self.SUB_C
+        self._sub_psi(p, a, B)                         # psi([x]Q)
+        self._sub_psi(p, B, C)                         # psi^2([x]Q)
+        p.jac_madd(a, (self.QX, self.QY))              # [x + 1]Q
+        p.jac_add(a, B)
+        p.jac_add(a, C)                                # the left-hand side
+        self._sub_psi(p, C, B)                         # psi^3([x]Q)
+        p.jac_dbl(B)                                   # the right-hand side
+        # equal as points: X1 Z2^2 == X2 Z1^2 and Y1 Z2^3 == Y2 Z1^3, and neither is the point at infinity
+        z1z1, z2z2, t, d = [p.tmp() for _ in range(4)]
+        p.A(a[2]).sqr().to(z1z1)
+        p.A(B[2]).sqr().to(z2z2)
+        p.A(B[0]).mul(z1z1).to(t)
+        p.A(a[0]).mul(z2z2).sub(t).to(d)
+        self._sub_or_limbs(p, d, self.V_SUB_DIFF, True)
+        p.A(B[1]).mul(a[2]).mul(z1z1).to(t)
+        p.A(a[1]).mul(B[2]).mul(z2z2).sub(t).to(d)
+        self._sub_or_limbs(p, d, self.V_SUB_DIFF, False)
+        p.A(a[2]).mul(B[2]).to(d)
+        self._sub_or_limbs(p, d, self.V_SUB_Z, True)
+        p.rel(z1z1, z2z2, t, d)
+
+    def _subcheck_routines(self):
+        st = self.sub_temps()
+        self.l2_routine("L2_sdbl", lambda p: p.jac_dbl(self.R), st)
+        self.l2_routine("L2_smadd", lambda p: p.jac_madd(self.R, (self.QX, self.SY)), st)
+        self.l2_routine("L2_sfin", self._sub_final, st)
+
+    def subcheck_main(self, e, p):
+        L = self.lab
+        top = max(i for i, d in enumerate(self.naf) if d)
+        assert self.naf[top] == 1 and top == 62
+        self.io_walk_begin(e, S_G2)
+        self.io_load_fq2_into_A(e, p)                            # Q.x
+        p.to(self.QX)
+        p.to(self.R[0])
+        self.io_load_fq2_into_A(e, p)                            # Q.y
+        p.to(self.QY)
+        p.to(self.R[1])
+        self.one_into_A(e)
+        p.set_A_fresh()
+        p.to(self.R[2])
+        p.reset_tags()
+        e.salu(f"s_mov_b32 s{S_I}, {top - 1}")
+        e.label(L("L_sloop"))
+        self.call2(e, "L2_sdbl")
+        e.salu(f"s_bitcmp1_b64 {S_NAF_NZ}, s{S_I}")
+        e.salu(f"s_cbranch_scc0 {L('L_snoadd')}")
+        p.reset_tags()                                           # SY <- +-Q.y by the digit's sign
+        p.A(self.QY)
+        p.wait()
+        e.salu(f"s_bitcmp1_b64 {S_NAF_NEG}, s{S_I}")
+        e.salu(f"s_cbranch_scc0 {L('L_spos')}")
+        e.salu(f"s_call_b64 {S_RET1}, {self.labels['neg']}")
+        e.label(L("L_spos"))
+        p.tagA = None
+        p.to(self.SY)
+        self.call2(e, "L2_smadd")
+        e.label(L("L_snoadd"))
+        e.salu(f"s_sub_u32 s{S_I}, s{S_I}, 1")
+        e.salu(f"s_cbranch_scc0 {L('L_sloop')}")
+        p.reset_tags()
+        self.call2(e, "L2_sfin")
+        # verdict word: 1 = the criterion does not hold (a cross-difference is not zero, or one side is the point at infinity)
+        D, Z = self.V_SUB_DIFF, self.V_SUB_Z
+        e.emit(f"v_cmp_ne_u32_e32 vcc, 0, v{D}", w=["vcc"])
+        e.raw("s_nop 1")
+        e.emit(f"v_cndmask_b32_e64 v{D}, 0, 1, vcc", r=["vcc"], vw=[D])
+        e.emit(f"v_cmp_eq_u32_e32 vcc, 0, v{Z}", w=["vcc"])
+        e.raw("s_nop 1")
+        e.emit(f"v_cndmask_b32_e64 v{Z}, 0, 1, vcc", r=["vcc"], vw=[Z])
+        e.emit(f"v_or_b32_e32 v{D}, v{D}, v{Z}", vw=[D])
+        e.emit(f"v_lshlrev_b32_e32 v{Z}, 2, v{V_IDX}", vw=[Z])
+        e.emit(f"v_cmp_gt_u32_e32 vcc, s{S_N}, v{V_IDX}", w=["vcc"])      # lanes past the end of the batch do not store
+        e.raw("s_nop 1")
+        e.salu(f"s_and_saveexec_b64 {S_SAVE_EXEC}, vcc")
+        e.emit(f"global_store_dword v{Z}, v{D}, {S_OUT}", kind="vmem")
+        e.salu(f"s_mov_b64 exec, {S_SAVE_EXEC}")
+        e.raw("s_waitcnt vmcnt(0)")
+        e.emit(f"v_lshrrev_b32_e32 v{V_TID}, 4, v{V_LDS}", vw=[V_TID])
+        p.reset_tags()
 
     # ---------------------------------------------------------------------------------------------
     # multi-pairing main loop: STREAMED pair state.  The k pairs of a group share f, so their points take turns; their
