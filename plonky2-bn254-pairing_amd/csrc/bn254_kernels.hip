@@ -541,9 +541,29 @@ int launch_fexp_pieces(const uint64_t* f_in, uint64_t* out, size_t n, int device
     return launch_cvm(CVM_YCH2, 16, m, nullptr, t1, out, n, 1, device, stream);
 }
 
+// I/O layout of a launch of the generated kernels (bits 28..30 of their k argument, tools/kgen4_prog.py: S_MODE): which of the arrays are
+// ELEMENT-major -- one G1Affine / G2Affine / Fq12 after the other, as the reference's callers hold them -- instead of limb-major planes
+enum { IO_IN_ELEMS = 1, IO_OUT_ELEMS = 2, IO_OUT_ARK = 4 };
+
+// would launch_pairing<M, F> serve this batch on the lane-cooperative kernel (whose programs read limb-major planes only)?
 template <bool M, bool F>
-int launch_pairing(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in, uint64_t* out, size_t n_groups, size_t k, int device, void* stream) {
+bool takes_latency_kernel(size_t n_groups, size_t k, int device, void* stream) {
+    int prog = cvm_program<M, F>(k);
+    if (prog < 0 || n_groups * k >= (1u << 22)) return false;
+    size_t thr; int lanes;
+    latency_cfg(device, stream, &thr, &lanes);
+    return (unsigned __int128)n_groups * 1000u <= (unsigned __int128)thr * CVM_PROGRAMS[prog].per_mille;
+}
+// can the throughput kernel take this batch straight from / into element-major arrays? (32-bit lane offsets: 128 bytes per G2 element, 384 per Fq12)
+template <bool M, bool F>
+bool direct_elems_ok(size_t n_groups, size_t k, int device, void* stream) {
+    return k >= 1 && k <= MAX_K && n_groups * k < ((size_t)1 << 24) && !takes_latency_kernel<M, F>(n_groups, k, device, stream);
+}
+
+template <bool M, bool F>
+int launch_pairing(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in, uint64_t* out, size_t n_groups, size_t k, int device, void* stream, int io_mode = 0) {
     if (n_groups == 0) return BN254_OK;
+    if (io_mode && !direct_elems_ok<M, F>(n_groups, k, device, stream)) return BN254_ERR_INVALID_ARG;      // (callers ask first)
     if (!out || (M && (!g1 || !g2)) || (!M && !f_in) || k == 0 || (!M && k != 1)) return BN254_ERR_INVALID_ARG;
     if (n_groups * k >= (1ull << 29) || n_groups * k / k != n_groups) return BN254_ERR_INVALID_ARG;   // 32-bit byte offsets of the SoA planes in the kernels
     hipStream_t st = (hipStream_t)stream;
@@ -577,7 +597,7 @@ int launch_pairing(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in,
         if (F) return launch_pairing<false, true>(nullptr, nullptr, acc, out, n_groups, 1, device, stream);
         return BN254_OK;
     }
-    {
+    if (!io_mode) {
         int prog = cvm_program<M, F>(k);
         if (prog >= 0 && n_groups * k < (1u << 22)) {
             size_t thr; int lanes;
@@ -609,7 +629,7 @@ int launch_pairing(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in,
     int rc = ctx_get(device, stream, k, (n_groups + BLOCK - 1) / BLOCK, &c);
     if (rc) return rc;
     auto go = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3(c.grid), dim3(BLOCK), LDS_BYTES, st, g1, g2, f_in, out, (uint32_t)n_groups, (uint32_t)k,
+        hipLaunchKernelGGL(kern, dim3(c.grid), dim3(BLOCK), LDS_BYTES, st, g1, g2, f_in, out, (uint32_t)n_groups, (uint32_t)k | ((uint32_t)io_mode << 28),
                            c.scratch, c.stride, c.status);
     };
     if (k == 1) {
@@ -1250,8 +1270,17 @@ int bn254_multi_pairing_batch_elems(const uint64_t* g1, const uint64_t* g2, uint
         return run_pipeline(&device, 1, g1, g2, out, n_groups, k, do_final_exp, fmt);
     }
     Stage s; uint64_t *e1, *e2, *e3, *d1, *d2, *d3; size_t np = n_groups * k;
-    if ((rc = s.init(device, stream)) || (rc = s.up(g1, 64 * np, &e1)) || (rc = s.up(g2, 128 * np, &e2)) || (rc = s.up(nullptr, 384 * n_groups, &e3)) ||
-        (rc = s.up(nullptr, 64 * np, &d1)) || (rc = s.up(nullptr, 128 * np, &d2)) || (rc = s.up(nullptr, 384 * n_groups, &d3))) return rc;
+    if ((rc = s.init(device, stream)) || (rc = s.up(g1, 64 * np, &e1)) || (rc = s.up(g2, 128 * np, &e2)) || (rc = s.up(nullptr, 384 * n_groups, &e3))) return rc;
+    {   // the throughput kernels read and write element-major arrays themselves: no transposition pass on either side
+        const int mode = IO_IN_ELEMS | IO_OUT_ELEMS | (out_order == BN254_FQ12_ARK ? IO_OUT_ARK : 0);
+        if (do_final_exp ? direct_elems_ok<true, true>(n_groups, k, device, stream) : direct_elems_ok<true, false>(n_groups, k, device, stream)) {
+            rc = do_final_exp ? launch_pairing<true, true>(e1, e2, nullptr, e3, n_groups, k, device, stream, mode)
+                              : launch_pairing<true, false>(e1, e2, nullptr, e3, n_groups, k, device, stream, mode);
+            if (rc) return rc;
+            return finish_host(out, e3, 384 * n_groups, device, stream);
+        }
+    }
+    if ((rc = s.up(nullptr, 64 * np, &d1)) || (rc = s.up(nullptr, 128 * np, &d2)) || (rc = s.up(nullptr, 384 * n_groups, &d3))) return rc;
     if ((rc = launch_layout(true, e1, d1, 8, np, 0, device, stream)) || (rc = launch_layout(true, e2, d2, 16, np, 0, device, stream))) return rc;
     rc = (k == 1 && do_final_exp) ? bn254_pairing_batch_dev(d1, d2, d3, n_groups, device, stream)
                                   : bn254_multi_pairing_batch_dev(d1, d2, d3, n_groups, k, do_final_exp, device, stream);
@@ -1277,9 +1306,15 @@ int bn254_miller_loop_batch_elems(const uint64_t* g1, const uint64_t* g2, uint64
 int bn254_final_exp_batch_elems(const uint64_t* f_in, uint64_t* out, size_t n, int in_order, int out_order, int device, void* stream) {
     if (n == 0) return BN254_OK;
     if (!f_in || !out) return BN254_ERR_INVALID_ARG;
+    if ((in_order != BN254_FQ12_MYFQ12 && in_order != BN254_FQ12_ARK) || (out_order != BN254_FQ12_MYFQ12 && out_order != BN254_FQ12_ARK)) return BN254_ERR_INVALID_ARG;
     Stage s; uint64_t *e1, *e3, *d1, *d3; int rc;
-    if ((rc = s.init(device, stream)) || (rc = s.up(f_in, 384 * n, &e1)) || (rc = s.up(nullptr, 384 * n, &e3)) || (rc = s.up(nullptr, 384 * n, &d1)) ||
-        (rc = s.up(nullptr, 384 * n, &d3))) return rc;
+    if ((rc = s.init(device, stream)) || (rc = s.up(f_in, 384 * n, &e1)) || (rc = s.up(nullptr, 384 * n, &e3))) return rc;
+    if (in_order == BN254_FQ12_MYFQ12 && direct_elems_ok<false, true>(n, 1, device, stream)) {      // (an ark-ordered INPUT still takes the transposition pass)
+        if ((rc = launch_pairing<false, true>(nullptr, nullptr, e1, e3, n, 1, device, stream, IO_IN_ELEMS | IO_OUT_ELEMS | (out_order == BN254_FQ12_ARK ? IO_OUT_ARK : 0))))
+            return rc;
+        return finish_host(out, e3, 384 * n, device, stream);
+    }
+    if ((rc = s.up(nullptr, 384 * n, &d1)) || (rc = s.up(nullptr, 384 * n, &d3))) return rc;
     if ((rc = launch_layout(true, e1, d1, 48, n, in_order, device, stream)) || (rc = bn254_final_exp_batch_dev(d1, d3, n, device, stream)) ||
         (rc = launch_layout(false, d3, e3, 48, n, out_order, device, stream))) return rc;
     return finish_host(out, e3, 384 * n, device, stream);
@@ -1332,17 +1367,25 @@ static int run_chunks(int dev, PipeWorker pw, const uint64_t* g1, const uint64_t
         if (fmt.elems && ((rc = s.up(nullptr, 64 * cap * k, &e1)) || (rc = s.up(nullptr, 128 * cap * k, &e2)) || (rc = s.up(nullptr, 384 * cap, &e3)))) goto done;
         for (size_t c0 = first * chunk; c0 < cnt; c0 += step * chunk) {
             size_t m = cnt - c0 < chunk ? cnt - c0 : chunk, np = m * k, base = u0 + c0;
-            if (fmt.elems) {           // a chunk of an element-major array is one contiguous run; the planes are made on the device
-                if ((copy_rows(e1, g1 + base * k * 8, np * 64, hipMemcpyHostToDevice, st)) != hipSuccess ||
-                    (copy_rows(e2, g2 + base * k * 16, np * 128, hipMemcpyHostToDevice, st)) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
-                if ((rc = launch_layout(true, e1, d1, 8, np, 0, dev, st)) || (rc = launch_layout(true, e2, d2, 16, np, 0, dev, st))) goto done;
+            // a chunk of an element-major array is one contiguous run, and the throughput kernels take it as it is (no transposition pass, which --
+            // a kernel -- would wait for the other worker's launch to leave the CUs); the lane-cooperative programs of a small last chunk read
+            // planes: those are then made on the device
+            const bool direct = fmt.elems && (do_final_exp ? direct_elems_ok<true, true>(m, k, dev, st) : direct_elems_ok<true, false>(m, k, dev, st));
+            if (fmt.elems) {
+                if (copy_rows(e1, g1 + base * k * 8, np * 64, hipMemcpyHostToDevice, st) != hipSuccess ||
+                    copy_rows(e2, g2 + base * k * 16, np * 128, hipMemcpyHostToDevice, st) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
+                if (!direct && ((rc = launch_layout(true, e1, d1, 8, np, 0, dev, st)) || (rc = launch_layout(true, e2, d2, 16, np, 0, dev, st)))) goto done;
             } else if (hipMemcpy2DAsync(d1, np * 8, g1 + base * k, np_all * 8, np * 8, 8, hipMemcpyHostToDevice, st) != hipSuccess ||
                        hipMemcpy2DAsync(d2, np * 8, g2 + base * k, np_all * 8, np * 8, 16, hipMemcpyHostToDevice, st) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
-            rc = (k == 1 && do_final_exp) ? bn254_pairing_batch_dev(d1, d2, d3, m, dev, st)
-                                          : bn254_multi_pairing_batch_dev(d1, d2, d3, m, k, do_final_exp, dev, st);
+            if (direct) {
+                const int mode = IO_IN_ELEMS | IO_OUT_ELEMS | (fmt.out_order == BN254_FQ12_ARK ? IO_OUT_ARK : 0);
+                rc = do_final_exp ? launch_pairing<true, true>(e1, e2, nullptr, e3, m, k, dev, st, mode) : launch_pairing<true, false>(e1, e2, nullptr, e3, m, k, dev, st, mode);
+            } else
+                rc = (k == 1 && do_final_exp) ? bn254_pairing_batch_dev(d1, d2, d3, m, dev, st)
+                                              : bn254_multi_pairing_batch_dev(d1, d2, d3, m, k, do_final_exp, dev, st);
             if (rc) goto done;
             if (fmt.elems) {
-                if ((rc = launch_layout(false, d3, e3, 48, m, fmt.out_order, dev, st))) goto done;
+                if (!direct && (rc = launch_layout(false, d3, e3, 48, m, fmt.out_order, dev, st))) goto done;
                 if (copy_rows(out + base * 48, e3, m * 384, hipMemcpyDeviceToHost, st) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
             } else if (hipMemcpy2DAsync(out + base, n_units * 8, d3, m * 8, m * 8, 48, hipMemcpyDeviceToHost, st) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
             // the buffers are free for the next chunk once the stream has drained -- waited for on an EVENT: the status read-back that used to

@@ -177,3 +177,42 @@ def test_elems_pipeline_large_batch():
     pk.last_status(0, st)
     got = pk.multi_pairing_batch_elems(e1[:8 * groups * k], e2[:16 * groups * k], groups, k)
     assert np.array_equal(got, H.to_aos(og.cpu().numpy().view(np.uint64), 48))
+
+
+@pytest.mark.parametrize("threshold", [0, 1 << 20])
+def test_elems_direct_kernel_io_equals_the_transposition_route(threshold):
+    """The throughput kernels read and write element-major arrays themselves (I/O mode bits of their k argument, tools/kgen4_prog.py:
+    io_walk_begin): with the latency path switched off for the NULL stream every `_elems` call below launches k_pairing / k_miller / k_fexp /
+    k_mpairing / k_mmiller straight on the element arrays; with it switched on the same calls take the lane-cooperative programs behind the
+    transposition kernels.  Both give the limb-major entry points' words: ragged sizes, groups of 1 - 3 and 5 pairs, both Fq12 orders."""
+    pk = H.pkg()
+    pk.set_stream_latency(threshold, -1, 0, None)
+    try:
+        n = 301
+        Ps, Qs = H.subgroup_points(24, seed=78)
+        P = [Ps[i % 24] for i in range(n)]
+        Q = [Qs[(5 * i + i // 24) % 24] for i in range(n)]
+        e1, e2 = H.g1_aos(P), H.g2_aos(Q)
+        s1, s2 = H.to_soa(e1, 8), H.to_soa(e2, 16)
+        idx = [pk.load_library().bn254_myfq12_to_ark_index(j) for j in range(12)]
+        want = H.to_aos(pk.pairing_batch(s1, s2, n), 48)
+        assert np.array_equal(pk.pairing_batch_elems(e1, e2, n), want)
+        assert np.array_equal(pk.pairing_batch_elems(e1, e2, n, out_order=pk.FQ12_ARK).reshape(n, 12, 4), want.reshape(n, 12, 4)[:, idx, :])
+        mil = H.to_aos(pk.miller_loop_batch(s1, s2, n), 48)
+        assert np.array_equal(pk.miller_loop_batch_elems(e1, e2, n), mil)
+        for k in (2, 3, 5):
+            g = n // k
+            a1, a2 = e1[: 8 * g * k], e2[: 16 * g * k]
+            b1, b2 = H.to_soa(a1, 8), H.to_soa(a2, 16)
+            for fe in (True, False):
+                w = H.to_aos(pk.multi_pairing_batch(b1, b2, g, k, do_final_exp=fe), 48)
+                assert np.array_equal(pk.multi_pairing_batch_elems(a1, a2, g, k, do_final_exp=fe), w), (k, fe)
+                assert np.array_equal(pk.multi_pairing_batch_elems(a1, a2, g, k, do_final_exp=fe, out_order=pk.FQ12_ARK).reshape(g, 12, 4),
+                                      w.reshape(g, 12, 4)[:, idx, :]), (k, fe)
+        fe_want = H.to_aos(pk.final_exp_batch(H.to_soa(mil, 48), n), 48)
+        assert np.array_equal(pk.final_exp_batch_elems(mil, n), fe_want)
+        assert np.array_equal(pk.final_exp_batch_elems(mil, n, out_order=pk.FQ12_ARK).reshape(n, 12, 4), fe_want.reshape(n, 12, 4)[:, idx, :])
+        ark_in = mil.reshape(n, 12, 4)[:, idx, :].reshape(-1).copy()
+        assert np.array_equal(pk.final_exp_batch_elems(ark_in, n, in_order=pk.FQ12_ARK), fe_want)
+    finally:
+        pk.set_stream_latency(pk.LATENCY_INHERIT, -1, 0, None)

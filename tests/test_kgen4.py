@@ -557,3 +557,87 @@ def test_subgroup_check_kernel():
         assert m.gmem[OUTB] == (0 if want_in else 1), (Q, m.gmem[OUTB])
         assert m.max_acc < (1 << 63) and STAT not in m.gmem
     print("subgroup check kernel:", m.count, "instructions per point")
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3, 7])
+def test_pairing_kernel_element_major_io(vec, mode):
+    """The I/O layout bits of the kernels' k argument (bits 28..30: inputs element-major / output element-major / ... in ark's Fq12 order):
+    k_pairing on lane 2 of a four-pair batch reads / writes the same limbs at the element-major addresses -- what a caller of
+    src/pairing.rs:20-22 holds (`&[G1Affine]`, `&[G2Affine]`, `Vec<Fq12>`) goes to the kernel as it is."""
+    n, lane = 4, 2
+    rows1 = [HX(vec["g1"][i]) for i in range(n)]
+    rows2 = [HX(vec["g2"][i]) for i in range(n)]
+    elems = lambda rows: [w for el in rows for c in el for w in R.limbs4(R.to_mont(c))]
+    g1 = elems(rows1) if mode & 1 else _soa(rows1)
+    g2 = elems(rows2) if mode & 1 else _soa(rows2)
+    kb = K4P.KernelBuilder(do_miller=True, do_fexp=True)
+    lines = _concretize(kb.build()) + ["s_endpgm"]
+    m = S.Machine()
+    for base, words in ((G1B, g1), (G2B, g2)):
+        for i, w in enumerate(words):
+            m.gmem[base + 8 * i] = w & 0xFFFFFFFF
+            m.gmem[base + 8 * i + 4] = (w >> 32) & 0xFFFFFFFF
+    for name, val in (("s[2:3]", G1B), ("s[4:5]", G2B), ("s[6:7]", FINB), ("s[8:9]", OUTB), ("s10", n), ("s11", 1 | (mode << 28)), ("s[12:13]", SCR),
+                      ("s14", 256 * K4.SLOT_BYTES), ("s[16:17]", STAT), ("s18", 0), ("s19", 1)):
+        m.sset(name, val)
+    m.v[255] = lane
+    S.run(lines, m)
+    want = HX(vec["pairing"][lane])
+    got = []
+    for c in range(12):
+        v = 0
+        for l in range(4):
+            if mode & 2:
+                j = c if not (mode & 4) else [jj for jj in range(12) if _ark_to_my(jj) == c][0]
+                a = OUTB + (lane * 48 + j * 4 + l) * 8
+            else:
+                a = OUTB + ((c * 4 + l) * n + lane) * 8
+            v |= (m.gmem[a] | (m.gmem[a + 4] << 32)) << (64 * l)
+        got.append(R.from_mont(v))
+    assert got == want
+    # nothing was written outside the lane's own 384 bytes (element-major) / its own column (limb-major)
+    touched = {a for a in m.gmem if OUTB <= a < OUTB + 8 * 48 * n}
+    mine = {OUTB + (lane * 48 + w) * 8 + h for w in range(48) for h in (0, 4)} if mode & 2 else {OUTB + (w * n + lane) * 8 + h for w in range(48) for h in (0, 4)}
+    assert touched == mine
+
+
+def _ark_to_my(j):
+    """MyFq12 coefficient index held at position j of ark's flat Fq12 (include/bn254_pairing.h: bn254_myfq12_to_ark_index)"""
+    h, k, e = j // 6, (j % 6) // 2, j % 2
+    return (2 * k + h) + 6 * e
+
+
+@pytest.mark.parametrize("mode", [3, 7])
+def test_multi_pairing_kernel_element_major_io(vec, mode):
+    """The k-pair kernels in element-major mode: group 1 of three two-pair groups (lane 1) reads its pairs at (g k + j) x 64 / 128 bytes
+    and writes its Fq12 at g x 384 bytes (mode 7: in ark's coefficient order) -- the exact multi_miller_loop_native value of that group."""
+    k, n, lane = 2, 3, 1
+    gi = [[(g * k + j) % 12 for j in range(k)] for g in range(n)]
+    rows1 = [HX(vec["g1"][i]) for g in gi for i in g]
+    rows2 = [HX(vec["g2"][i]) for g in gi for i in g]
+    elems = lambda rows: [w for el in rows for c in el for w in R.limbs4(R.to_mont(c))]
+    want = None
+    for i in gi[lane]:
+        want = HX(vec["miller"][i]) if want is None else R.fq12_mul(want, HX(vec["miller"][i]))
+    kb = K4P.KernelBuilder(do_miller=True, do_fexp=False, track=True, multi=True)
+    lines = _concretize(kb.build()) + ["s_endpgm"]
+    m = S.Machine()
+    for base, words in ((G1B, elems(rows1)), (G2B, elems(rows2))):
+        for i, w in enumerate(words):
+            m.gmem[base + 8 * i] = w & 0xFFFFFFFF
+            m.gmem[base + 8 * i + 4] = (w >> 32) & 0xFFFFFFFF
+    for name, val in (("s[2:3]", G1B), ("s[4:5]", G2B), ("s[6:7]", FINB), ("s[8:9]", OUTB), ("s10", n), ("s11", k | (mode << 28)), ("s[12:13]", SCR),
+                      ("s14", 256 * K4.SLOT_BYTES), ("s[16:17]", STAT), ("s18", 0), ("s19", 1)):
+        m.sset(name, val)
+    m.v[255] = lane
+    S.run(lines, m)
+    got = []
+    for c in range(12):
+        j = c if not (mode & 4) else [jj for jj in range(12) if _ark_to_my(jj) == c][0]
+        v = 0
+        for l in range(4):
+            a = OUTB + (lane * 48 + j * 4 + l) * 8
+            v |= (m.gmem[a] | (m.gmem[a + 4] << 32)) << (64 * l)
+        got.append(R.from_mont(v))
+    assert got == want
+    assert {a for a in m.gmem if OUTB <= a < OUTB + 8 * 48 * n} == {OUTB + (lane * 48 + w) * 8 + h for w in range(48) for h in (0, 4)}

@@ -486,6 +486,8 @@ class VMKernel:
         self.epilogue()
         # every 8-byte instruction 8-byte aligned (asmcore.align_code: a straddling one costs a cycle on average -- measured on this
         # kernel: 5.1 cycles per instruction of the column passes without it)
+        if not int(os.environ.get("CVM_ALIGN", "1")):           # A/B switch (round 6: at two waves per SIMD a 32-bit VOP1 / VOP2 encoding issues in 2 cycles, its
+            return [".p2align 3"] + self.e.finalize()            # VOP3 re-encoding in 4: profiles/r06_occupancy_calib.txt)
         return [".p2align 3"] + align_code(self.e.finalize())
 
 

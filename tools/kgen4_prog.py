@@ -58,7 +58,12 @@ S_FIN = "s[94:95]"
 S_K = 96
 S_JP = 97                 # pair counter of the multi-pairing kernels
 S_SAVE_EXEC = "s[98:99]"
-S_PB = 48                 # byte offset of the base's scratch register during the x-power routine (s49: free)
+S_PB = 48                 # byte offset of the base's scratch register during the x-power routine
+S_MODE_SINGLE, S_MODE_MULTI = 49, 51      # I/O layout of this launch (bits 28..30 of the kernel's k argument; KernelBuilder.s_mode): 1 inputs element-major,
+                          # 2 output element-major, 4 ... in ark's Fq12 order.  (s49 is the k-pair kernels' S_GNEXT, s51 the split-loop experiment's cursor step)
+S_IOSTRIDE = 75           # bytes between consecutive words of the array being walked: the plane stride (limb-major) or 8 (element-major)
+V_IOOFF = 247             # the lane's byte offset into the array being walked: index * 8 (limb-major) or index * 8 * words per element
+MODE_IN_ELEMS, MODE_OUT_ELEMS, MODE_OUT_ARK = 0, 1, 2      # bit numbers in S_MODE
 BLOCK = 256
 
 
@@ -1747,6 +1752,14 @@ class KernelBuilder:
         return f"{name}_%="
 
     @property
+    def s_mode(self):
+        """scalar register of the launch's I/O layout bits, or None where the kernel is limb-major only (k_op: its k argument is full; k_generate;
+        the split-loop experiment of the k-pair kernels, which owns every spare scalar register)"""
+        if self.helper or self.generate or (self.multi and FISSION):
+            return None
+        return S_MODE_MULTI if self.multi else S_MODE_SINGLE
+
+    @property
     def naf(self):
         """the digits of 6 x + 2 this kernel's Miller loop walks (least significant first; the top one is R = Q, f = 1)"""
         if self.subcheck:            # the scalar multiplication [x]Q walks the non-adjacent form of x (63 digits, 24 non-zero), padded to the masks' 64
@@ -2484,7 +2497,11 @@ class KernelBuilder:
         e.salu(f"s_mov_b64 {S_FIN}, %2")
         e.salu(f"s_mov_b64 {S_OUT}, %3")
         e.salu(f"s_mov_b32 s{S_N}, %4")
-        e.salu(f"s_mov_b32 s{S_K}, %5")
+        if self.s_mode is None:
+            e.salu(f"s_mov_b32 s{S_K}, %5")                        # (k_op: k = op | power << 8 | naf_len << 16; limb-major I/O only)
+        else:
+            e.salu(f"s_and_b32 s{S_K}, %5, 0x0fffffff")
+            e.salu(f"s_lshr_b32 s{self.s_mode}, %5, 28")
         e.salu(f"s_mov_b32 s{S_GSTRIDE}, " + (f"{WG_SLOT_PITCH}" if SCRATCH_WG else "%7"))
         e.salu(f"s_mov_b64 {S_STATUS}, %8")
         e.salu(f"s_mov_b32 s{S_ITEM}, %10")
@@ -2530,22 +2547,35 @@ class KernelBuilder:
         e.salu(f"s_branch {self.lab('L_main')}")
 
     # ---------------------------------------------------------------------------------------------
-    def io_walk_begin(self, e, base):
+    def io_walk_begin(self, e, base, words=None, out=False):
+        """The walk over the words of the lane's element of the batch at `base` starts.  Limb-major batches (the engine's own layout): word w
+        of element i at (w n + i) * 8 -- V_IDX8 = i * 8 is the lane's offset, consecutive words lie S_NSTRIDE = 8 n apart.  ELEMENT-major
+        batches (`words` per element: what the reference's callers hold, src/pairing.rs:20, miller_loop_native.rs:324; S_MODE says which side
+        of the launch is): word w of element i at (i words + w) * 8.  Same loads and stores either way: only the lane offset and the step
+        differ (576 bytes per pairing against 2.3 M multiply-adds: coalescing is not what matters here)."""
         e.salu(f"s_mov_b64 {S_IOADDR}, {base}")
+        if words is None or self.s_mode is None:
+            e.salu(f"s_mov_b32 s{S_IOSTRIDE}, s{S_NSTRIDE}")
+            e.emit(f"v_mov_b32_e32 v{V_IOOFF}, v{V_IDX8}", vw=[V_IOOFF])
+            return
+        e.salu(f"s_bitcmp1_b32 s{self.s_mode}, {MODE_OUT_ELEMS if out else MODE_IN_ELEMS}")
+        e.salu(f"s_cselect_b32 s{S_IOSTRIDE}, 8, s{S_NSTRIDE}")
+        e.salu(f"s_cselect_b32 s{S_TMP0}, {words}, 1")
+        e.emit(f"v_mul_lo_u32 v{V_IOOFF}, v{V_IDX8}, s{S_TMP0}", vw=[V_IOOFF])
 
     def io_walk_next(self, e):
-        e.salu(f"s_add_u32 s88, s88, s{S_NSTRIDE}")
+        e.salu(f"s_add_u32 s88, s88, s{S_IOSTRIDE}")
         e.salu("s_addc_u32 s89, s89, 0")
 
     def io_load_fq(self, e, reg0):
         """Loads one Fq (4 u64 limbs of the SoA batch at the walking address) into v[reg0:reg0+7]."""
         for l in range(4):
-            e.emit(f"global_load_dwordx2 v[{reg0 + 2 * l}:{reg0 + 2 * l + 1}], v{V_IDX8}, {S_IOADDR}", kind="vmem", vw=[reg0 + 2 * l, reg0 + 2 * l + 1])
+            e.emit(f"global_load_dwordx2 v[{reg0 + 2 * l}:{reg0 + 2 * l + 1}], v{V_IOOFF}, {S_IOADDR}", kind="vmem", vw=[reg0 + 2 * l, reg0 + 2 * l + 1])
             self.io_walk_next(e)
 
     def io_store_fq(self, e, reg0):
         for l in range(4):
-            e.emit(f"global_store_dwordx2 v{V_IDX8}, v[{reg0 + 2 * l}:{reg0 + 2 * l + 1}], {S_IOADDR}", kind="vmem")
+            e.emit(f"global_store_dwordx2 v{V_IOOFF}, v[{reg0 + 2 * l}:{reg0 + 2 * l + 1}], {S_IOADDR}", kind="vmem")
             self.io_walk_next(e)
 
     def zero_block(self, e, blk, n=SLOT_DW):
@@ -2930,7 +2960,7 @@ class KernelBuilder:
         """F <- the lane's MyFq12 of the SoA batch at `ptr` (components 0..5 are the c0 parts of w^0..w^5, 6..11 the c1
         parts): two passes over the planes, c0 parts first into AGPR staging (the operand slots, free at that point)."""
         stage = SLOT_DW * self.BOP[0].idx
-        self.io_walk_begin(e, ptr)
+        self.io_walk_begin(e, ptr, 48)
         for k in range(6):
             self.io_load_fq(e, A0)
             e.raw("s_waitcnt vmcnt(0)")
@@ -3124,12 +3154,12 @@ class KernelBuilder:
 
     def miller_main(self, e, p):
         L = self.lab
-        self.io_walk_begin(e, S_G1)
+        self.io_walk_begin(e, S_G1, 8)
         self.io_load_fq2_into_A(e, p, c1_present=False)          # Px
         p.to(self.PX)
         self.io_load_fq2_into_A(e, p, c1_present=False)          # Py
         p.to(self.PY)
-        self.io_walk_begin(e, S_G2)
+        self.io_walk_begin(e, S_G2, 16)
         self.io_load_fq2_into_A(e, p)                            # Q.x
         p.to(self.QX)
         p.to(self.R[0])
@@ -3255,12 +3285,12 @@ class KernelBuilder:
             # element offset of pair j = (group*k + j) * 8
             e.salu(f"s_lshl_b32 s{S_TMP1}, s{S_JP}, 3")
             e.emit(f"v_add_u32_e32 v{V_IDX8}, s{S_TMP1}, v{V_IDX8}", vw=[V_IDX8])
-            self.io_walk_begin(e, S_G1)
+            self.io_walk_begin(e, S_G1, 8)
             self.io_load_fq2_into_A(e, p, c1_present=False)
             p.to(GlobDyn(0))
             self.io_load_fq2_into_A(e, p, c1_present=False)
             p.to(GlobDyn(1))
-            self.io_walk_begin(e, S_G2)
+            self.io_walk_begin(e, S_G2, 16)
             self.io_load_fq2_into_A(e, p)
             p.to(GlobDyn(2))
             p.to(GlobDyn(4))
@@ -4044,9 +4074,21 @@ class KernelBuilder:
         e.emit(f"v_cmp_gt_u32_e32 vcc, s{S_N}, v{V_IDX}", w=["vcc"])      # lanes past the end of the batch do not store
         e.raw("s_nop 1")
         e.salu(f"s_and_saveexec_b64 {S_SAVE_EXEC}, vcc")
-        self.io_walk_begin(e, S_OUT)
+        self.io_walk_begin(e, S_OUT, 48, out=True)
+        # MyFq12 coefficient c = half * 6 + k goes to position c of the element -- or, element-major in ark's Fq12 order (the `.into()` of
+        # src/pairing.rs:21; bn254_myfq12_to_ark_index), to position j(c): the walk then jumps by (j(c) - j(c - 1) - 1) * 32 bytes in between
+        ark_pos = {(2 * kk + h) + 6 * ee: (h * 3 + kk) * 2 + ee for h in range(2) for kk in range(3) for ee in range(2)}
+        prev = -1
         for half in range(2):
             for k in range(6):
+                jump = 32 * (ark_pos[half * 6 + k] - prev - 1)
+                prev = ark_pos[half * 6 + k]
+                if jump and self.s_mode is not None:
+                    e.salu(f"s_bitcmp1_b32 s{self.s_mode}, {MODE_OUT_ARK}")
+                    e.salu(f"s_cselect_b32 s{S_TMP0}, 0x{jump & 0xFFFFFFFF:x}, 0")
+                    e.salu(f"s_ashr_i32 s{S_TMP1}, s{S_TMP0}, 31")
+                    e.salu(f"s_add_u32 s88, s88, s{S_TMP0}")
+                    e.salu(f"s_addc_u32 s89, s89, s{S_TMP1}")
                 p.load(A0, self.F[k])
                 p.wait()
                 if half == 1:

@@ -509,6 +509,12 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None, start_pc=None, 
                 r = m.vsrc(a[1], False) >> (m.vsrc(a[2], False) & 31)
                 m.sset(a[0], r)
                 m.scc = 1 if r else 0
+            elif op == "s_ashr_i32":
+                x = m.vsrc(a[1], False) & M32
+                x = x - (1 << 32) if x >> 31 else x
+                r = (x >> (m.vsrc(a[2], False) & 31)) & M32
+                m.sset(a[0], r)
+                m.scc = 1 if r else 0
             elif op == "s_and_b32":
                 r = m.vsrc(a[1], False) & m.vsrc(a[2], False)
                 m.sset(a[0], r)
