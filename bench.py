@@ -55,8 +55,8 @@ NOMINAL_PEAK_MUL32_PER_S = 9.83e12
 NOMINAL_ISSUE_PEAK_MUL32_PER_S = 1024 * 2.4e9 / 4 * 64
 LOG2_SINGLE = 20                         # configs[2]
 LOG2_PER_GPU_MULTI = 21                  # configs[4]: 2^24 over 8 GPUs
-PMC_SUMMARY = os.environ.get("BENCH_PMC_SUMMARY", os.path.join(ROOT, "profiles", "r05_pmc.json"))
-PMC_SUMMARY_GROTH16 = os.environ.get("BENCH_PMC_SUMMARY_GROTH16", os.path.join(ROOT, "profiles", "r05_groth16_pmc.json"))
+PMC_SUMMARY = os.environ.get("BENCH_PMC_SUMMARY", os.path.join(ROOT, "profiles", "r06_pmc.json"))
+PMC_SUMMARY_GROTH16 = os.environ.get("BENCH_PMC_SUMMARY_GROTH16", os.path.join(ROOT, "profiles", "r06_groth16_pmc.json"))
 CALIB_R01_MUL32_PER_S = PEAK_MUL32_PER_S   # profiles/valu_calib_r01.txt (one box, round 1): kept for comparison with earlier rounds only
 KERNEL_HEADER = os.path.join(ROOT, "plonky2-bn254-pairing_amd", "csrc", "pairing_asm_gen.h")
 
@@ -576,7 +576,7 @@ def run_rank(args):
                          "frac_of_calibrated_peak_r01": achieved / CALIB_R01_MUL32_PER_S,
                          "achieved_note": "work-normalised: SURVEY.md 8(d)'s algorithmic mul32 per pairing x pairings/s (kernel time from HIP events), "
                                           "not the multiply-adds the kernel executes (the figure is the REFERENCE's schedule: its digit table of 6x+2 with 25 additions; "
-                                          "the kernel walks a 21-addition form of the same number -- the pairing's value does not see the chain, DESIGN.md section 8 -- "
+                                          "the kernel walks a 21-addition form of the same number -- the pairing's value does not see the chain, DESIGN.md section 4.2 -- "
                                           "and executes 2.47 M multiply-adds of 3.475 M instructions per pairing)",
                          "traffic_note": f"HBM bytes per launch from the committed PMC summary {os.path.relpath(PMC_SUMMARY, ROOT)} (separate --pmc passes of this "
                                          "command; raw and corrected counters there), not measured in this run; algorithmic bytes per launch = 576 B x pairings"

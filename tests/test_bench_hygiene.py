@@ -37,7 +37,7 @@ def test_pmc_summary_is_dropped_when_it_does_not_describe_the_run(tmp_path, monk
 def test_committed_pmc_summaries_are_consistent():
     """the committed summaries carry the corrected fields; the Groth16 one counts 4 pairs in and one Fq12 out per unit"""
     for name, k, log2 in (("r03_pmc.json", 1, 20), ("r03_groth16_pmc.json", 4, 18), ("r04_pmc.json", 1, 20), ("r04_groth16_pmc.json", 4, 18),
-                         ("r05_pmc.json", 1, 20), ("r05_groth16_pmc.json", 4, 18)):
+                         ("r05_pmc.json", 1, 20), ("r05_groth16_pmc.json", 4, 18), ("r06_pmc.json", 1, 20), ("r06_groth16_pmc.json", 4, 18)):
         with open(os.path.join(ROOT, "profiles", name)) as f:
             n = json.load(f)["_notes"]
         assert n["pairs_per_unit"] == k and n["log2_batch"] == log2

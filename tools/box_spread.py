@@ -2,7 +2,7 @@
 """box_spread.py <out.json> <bench line files...> -- the spread of the SAME build over several fresh GPU leases.
 
 Each input file holds the JSON line of one `python bench.py --steps 5 --warmup 1 --no-cpu-baseline` run on its own gpurun lease (the
-boxes of the pool differ by a few per cent in the clock they hold under this load: DESIGN.md section 5).  Output: per configuration
+boxes of the pool differ by a few per cent in the clock they hold under this load: DESIGN.md section 6).  Output: per configuration
 (BASELINE.json configs[1], [2], [3]) the kernel time of every lease and median / min / max, with the roofline fractions against both
 peaks, plus the kernel-code digest the runs share."""
 import json

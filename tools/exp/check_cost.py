@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""check_cost.py -- what bn254_check_points_ex costs (DESIGN.md section 8): wall ms of one `_dev` call on 2^log2 generated pairs for each flag set."""
+"""check_cost.py -- what bn254_check_points_ex costs (DESIGN.md section 4.4): wall ms of one `_dev` call on 2^log2 generated pairs for each flag set."""
 import importlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
