@@ -249,6 +249,12 @@ int bn254_soa_to_elems_dev(const uint64_t* soa, uint64_t* elems, size_t words, s
 /* host pointers, element-major in and out: pairing() (src/pairing.rs:20-22), miller_loop_native (:320),
  * multi_miller_loop_native (:324; pair j of group g = element g*k + j) and final_exp_native (final_exp_native.rs:209) */
 int bn254_pairing_batch_elems(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n, int out_order, int device, void* stream);
+/* ... on DEVICE-resident element-major arrays (another device library's `G1Affine` / `G2Affine` arrays, a `Vec<Fq12>` to be filled): the
+ * throughput kernels read and write element-major arrays themselves (a launch, nothing else); batches small enough for the lane-cooperative
+ * programs, which read planes, pass the transposition kernels and per-stream staging buffers (allocated on first use). */
+int bn254_pairing_batch_elems_dev(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n, int out_order, int device, void* stream);
+int bn254_multi_pairing_batch_elems_dev(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_groups, size_t k, int do_final_exp,
+                                        int out_order, int device, void* stream);
 int bn254_miller_loop_batch_elems(const uint64_t* g1, const uint64_t* g2, uint64_t* f_out, size_t n, int device, void* stream);
 int bn254_multi_pairing_batch_elems(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_groups, size_t k, int do_final_exp,
                                     int out_order, int device, void* stream);

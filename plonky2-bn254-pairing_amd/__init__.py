@@ -117,6 +117,8 @@ _PROTOS = {
     "bn254_soa_from_elems_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "bn254_soa_to_elems_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "bn254_pairing_batch_elems": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_pairing_batch_elems_dev": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_multi_pairing_batch_elems_dev": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "bn254_miller_loop_batch_elems": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "bn254_multi_pairing_batch_elems": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "bn254_pairing_sharded_elems": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_int]),
@@ -440,6 +442,16 @@ def final_exp_batch_dev(f, out, n, device=0, stream=None):
 def multi_pairing_batch_dev(g1, g2, out, n_groups, k, do_final_exp=True, device=0, stream=None):
     _check(load_library().bn254_multi_pairing_batch_dev(_dev(g1), _dev(g2), _dev(out), n_groups, k, 1 if do_final_exp else 0, device,
                                                         _stream(stream)), "multi_miller_loop_native")
+
+
+def multi_pairing_batch_elems_dev(g1, g2, out, n_groups, k, do_final_exp=True, out_order=FQ12_MYFQ12, device=0, stream=None):
+    """device-resident ELEMENT-major arrays in and out (one G1Affine / G2Affine / Fq12 after the other): a plain launch for the throughput kernels"""
+    _check(load_library().bn254_multi_pairing_batch_elems_dev(_dev(g1), _dev(g2), _dev(out), n_groups, k, 1 if do_final_exp else 0, out_order, device,
+                                                              _stream(stream)), "multi_miller_loop_native")
+
+
+def pairing_batch_elems_dev(g1, g2, out, n, out_order=FQ12_MYFQ12, device=0, stream=None):
+    _check(load_library().bn254_pairing_batch_elems_dev(_dev(g1), _dev(g2), _dev(out), n, out_order, device, _stream(stream)), "pairing")
 
 
 def multi_pairing_check_batch_dev(g1, g2, verdict, n_groups, k, device=0, stream=None):

@@ -1287,6 +1287,29 @@ int bn254_multi_pairing_batch_elems(const uint64_t* g1, const uint64_t* g2, uint
     if (rc || (rc = launch_layout(false, d3, e3, 48, n_groups, out_order, device, stream))) return rc;
     return finish_host(out, e3, 384 * n_groups, device, stream);
 }
+// Device-resident element-major batches: the throughput kernels take them as they are; batches that the lane-cooperative programs serve
+// (which read planes) go through the transposition kernels and per-stream staging buffers.
+int bn254_multi_pairing_batch_elems_dev(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_groups, size_t k, int do_final_exp,
+                                        int out_order, int device, void* stream) {
+    if (n_groups == 0) return BN254_OK;
+    if (!g1 || !g2 || !out || k == 0 || (out_order != BN254_FQ12_MYFQ12 && out_order != BN254_FQ12_ARK) || n_groups * k >= (1ull << 29)) return BN254_ERR_INVALID_ARG;
+    int rc = check_device(device);
+    if (rc) return rc;
+    const int mode = IO_IN_ELEMS | IO_OUT_ELEMS | (out_order == BN254_FQ12_ARK ? IO_OUT_ARK : 0);
+    if (do_final_exp ? direct_elems_ok<true, true>(n_groups, k, device, stream) : direct_elems_ok<true, false>(n_groups, k, device, stream))
+        return do_final_exp ? launch_pairing<true, true>(g1, g2, nullptr, out, n_groups, k, device, stream, mode)
+                            : launch_pairing<true, false>(g1, g2, nullptr, out, n_groups, k, device, stream, mode);
+    Stage s; uint64_t *d1, *d2, *d3; size_t np = n_groups * k;
+    if ((rc = s.init(device, stream)) || (rc = s.up(nullptr, 64 * np, &d1)) || (rc = s.up(nullptr, 128 * np, &d2)) || (rc = s.up(nullptr, 384 * n_groups, &d3))) return rc;
+    if ((rc = launch_layout(true, g1, d1, 8, np, 0, device, stream)) || (rc = launch_layout(true, g2, d2, 16, np, 0, device, stream))) return rc;
+    rc = (k == 1 && do_final_exp) ? bn254_pairing_batch_dev(d1, d2, d3, n_groups, device, stream)
+                                  : bn254_multi_pairing_batch_dev(d1, d2, d3, n_groups, k, do_final_exp, device, stream);
+    if (rc) return rc;
+    return launch_layout(false, d3, out, 48, n_groups, out_order, device, stream);
+}
+int bn254_pairing_batch_elems_dev(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n, int out_order, int device, void* stream) {
+    return bn254_multi_pairing_batch_elems_dev(g1, g2, out, n, 1, 1, out_order, device, stream);
+}
 int bn254_multi_pairing_check_batch_elems(const uint64_t* g1, const uint64_t* g2, uint8_t* verdict, size_t n_groups, size_t k, int device, void* stream) {
     if (n_groups == 0) return BN254_OK;
     if (!g1 || !g2 || !verdict || k == 0) return BN254_ERR_INVALID_ARG;

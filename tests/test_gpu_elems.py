@@ -216,3 +216,39 @@ def test_elems_direct_kernel_io_equals_the_transposition_route(threshold):
         assert np.array_equal(pk.final_exp_batch_elems(ark_in, n, in_order=pk.FQ12_ARK), fe_want)
     finally:
         pk.set_stream_latency(pk.LATENCY_INHERIT, -1, 0, None)
+
+
+def test_elems_dev_entry_points():
+    """bn254_pairing_batch_elems_dev / bn254_multi_pairing_batch_elems_dev on device-resident element-major arrays: a 2^16 + 77 batch (the
+    throughput kernel, straight on the element arrays) and a 500-item one (the lane-cooperative programs behind the transposition kernels)
+    give the words of the limb-major `_dev` launch, in either Fq12 order; groups of two pairs likewise; words behind the result stay untouched."""
+    import torch
+    pk = H.pkg()
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev)
+    idx = [pk.load_library().bn254_myfq12_to_ark_index(j) for j in range(12)]
+    for n in ((1 << 16) + 77, 500):
+        g1 = torch.zeros(8 * n, dtype=torch.int64, device=dev)
+        g2 = torch.zeros(16 * n, dtype=torch.int64, device=dev)
+        out = torch.zeros(48 * n, dtype=torch.int64, device=dev)
+        pk.generate_pairs_dev(0xB2540009 + n, g1, g2, n, 0, st)
+        pk.pairing_batch_dev(g1, g2, out, n, 0, st)
+        e1, e2 = torch.empty_like(g1), torch.empty_like(g2)
+        pk.soa_to_elems_dev(g1, e1, 8, n, 0, 0, st)
+        pk.soa_to_elems_dev(g2, e2, 16, n, 0, 0, st)
+        want = out.view(48, n).t().contiguous().view(n, 12, 4)
+        for order in (pk.FQ12_MYFQ12, pk.FQ12_ARK):
+            eo = torch.full((48 * n + 64,), -7, dtype=torch.int64, device=dev)
+            pk.pairing_batch_elems_dev(e1, e2, eo, n, order, 0, st)
+            pk.last_status(0, st)
+            got = eo[: 48 * n].view(n, 12, 4)
+            assert torch.equal(got, want if order == pk.FQ12_MYFQ12 else want[:, idx, :]), (n, order)
+            assert bool((eo[48 * n:] == -7).all())
+        k, g = 2, n // 2
+        og = torch.zeros(48 * g, dtype=torch.int64, device=dev)
+        sel = lambda t, planes: t.view(planes, n)[:, : g * k].contiguous().view(-1)
+        pk.multi_pairing_batch_dev(sel(g1, 8), sel(g2, 16), og, g, k, False, 0, st)
+        eg = torch.zeros(48 * g, dtype=torch.int64, device=dev)
+        pk.multi_pairing_batch_elems_dev(e1[: 8 * g * k], e2[: 16 * g * k], eg, g, k, False, pk.FQ12_MYFQ12, 0, st)
+        pk.last_status(0, st)
+        assert torch.equal(eg.view(g, 48), og.view(48, g).t().contiguous())
