@@ -368,6 +368,7 @@ def extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n, sample_power=F
         lay[name] = {"ms": ms, "GB_per_s": 2 * 8 * words * n / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": 2 * 8 * words * n / (ms * 1e-3) / HBM_PEAK}
         del dst
     out["layout kernels at 2^20 elements (roofline bound: hbm, 8 TB/s)"] = lay
+    out["host-resident batches: one host-pointer call, copies both ways included (PCIe-inclusive; never `value`)"] = host_path(pkg, torch, g1, g2, n, local_rank, dev)
     # the reference's functions are SCALAR (one pairing / one group per call): wall time of one call on one item, launch to completion,
     # on the throughput kernel (one item per lane) and on the lane-cooperative kernel that small batches take
     if scalar_latency and hasattr(pkg, "set_stream_latency"):
@@ -404,6 +405,49 @@ def extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n, sample_power=F
         out["scalar signatures: one item per call, wall ms (launch to completion, inputs resident)"] = lat
     pkg.last_status(local_rank, stream)
     return out
+
+
+def host_path(pkg, torch, g1, g2, n, local_rank, dev):
+    """What a binding of src/pairing.rs:20-22 gets: its callers hold their values in HOST memory, so its batch calls are the host-pointer
+    entry points (chunked two-worker pipeline above 65 536 units, copies under the kernels).  Wall time of one call, second of two, from
+    pageable numpy arrays and from page-locked ones (bn254_alloc_pinned); limb-major, and element-major with ark's Fq12 order on the way out."""
+    import time as _t
+    import numpy as np
+    res = {}
+    h1 = g1.cpu().numpy().view(np.uint64).copy()
+    h2 = g2.cpu().numpy().view(np.uint64).copy()
+    shapes = (("2^16 pairings", 1 << 16, 1), ("2^20 pairings", n, 1), ("Groth16 shape: 2^18 groups x 4 pairs", n // 4, 4))
+    for label, units, k in shapes:
+        np_ = units * k
+        s1 = np.ascontiguousarray(h1.reshape(8, n)[:, :np_]).reshape(-1)
+        s2 = np.ascontiguousarray(h2.reshape(16, n)[:, :np_]).reshape(-1)
+        row = {}
+        for fmt in ("limb-major", "element-major, ark Fq12 out"):
+            a1, a2 = (s1, s2) if fmt == "limb-major" else (pkg.layout.to_aos(s1, 8), pkg.layout.to_aos(s2, 16))
+            for mem in ("pageable", "page-locked"):
+                if mem == "pageable":
+                    b1, b2, bo = a1, a2, np.empty(48 * units, dtype=np.uint64)
+                else:
+                    b1, b2, bo = pkg.alloc_pinned(a1.size), pkg.alloc_pinned(a2.size), pkg.alloc_pinned(48 * units)
+                    b1[:], b2[:] = a1, a2
+                if fmt == "limb-major":
+                    call = (lambda: pkg.pairing_batch(b1, b2, units, device=local_rank, out=bo)) if k == 1 else \
+                           (lambda: pkg.multi_pairing_batch(b1, b2, units, k, True, device=local_rank, out=bo))
+                else:
+                    call = (lambda: pkg.pairing_batch_elems(b1, b2, units, out_order=pkg.FQ12_ARK, device=local_rank, out=bo)) if k == 1 else \
+                           (lambda: pkg.multi_pairing_batch_elems(b1, b2, units, k, True, out_order=pkg.FQ12_ARK, device=local_rank, out=bo))
+                call()
+                ts = []
+                for _ in range(2):
+                    t0 = _t.perf_counter()
+                    call()
+                    ts.append(_t.perf_counter() - t0)
+                row[f"{fmt}, {mem}"] = {"ms": min(ts) * 1e3, "pairings_per_s": np_ / min(ts), "units_per_s": units / min(ts)}
+                if mem == "page-locked":
+                    for b in (b1, b2, bo):
+                        pkg.free_pinned(b)
+        res[label] = row
+    return res
 
 
 def run_rank(args):
