@@ -195,9 +195,11 @@ def _to_e64(text):
     return base + "_e64" + text[len(op):]
 
 
-def align_code(lines, src_map=None):
+def align_code(lines, src_map=None, nop_only=False):
     """src_map (optional, an empty list): receives, for every output line, the index of the input line it is (None for an
-    inserted s_nop); re-encoded lines keep their index."""
+    inserted s_nop); re-encoded lines keep their index.  nop_only: never re-encode a 32-bit VOP1 / VOP2 instruction as VOP3 to gain the four
+    bytes -- pad with `s_nop 0` instead (kernels that run two waves per SIMD: the VOP3 form costs 4 issue cycles there, the 32-bit form 2, and
+    the other wave issues under the s_nop; profiles/r06_occupancy_calib.txt)."""
     out, off, last = [], 0, None            # last: index in `out` of the previous instruction if it may be re-encoded
     src = [] if src_map is None else src_map
 
@@ -219,7 +221,7 @@ def align_code(lines, src_map=None):
             continue
         size = insn_size(t)
         if size == 8 and off % 8:
-            conv = _to_e64(out[last]) if last is not None else None
+            conv = _to_e64(out[last]) if (last is not None and not nop_only) else None
             if conv is not None:
                 out[last] = conv
             else:

@@ -488,6 +488,8 @@ class VMKernel:
         # kernel: 5.1 cycles per instruction of the column passes without it)
         if not int(os.environ.get("CVM_ALIGN", "1")):           # A/B switch (round 6: at two waves per SIMD a 32-bit VOP1 / VOP2 encoding issues in 2 cycles, its
             return [".p2align 3"] + self.e.finalize()            # VOP3 re-encoding in 4: profiles/r06_occupancy_calib.txt)
+        if int(os.environ.get("CVM_ALIGN", "1")) == 2:            # A/B switch: alignment by s_nop only
+            return [".p2align 3"] + align_code(self.e.finalize(), nop_only=True)
         return [".p2align 3"] + align_code(self.e.finalize())
 
 
