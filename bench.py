@@ -357,6 +357,27 @@ def extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n, sample_power=F
             torch.cuda.synchronize(dev)
         g16["package_power"] = ps.summary()
     out["configs[3]: Groth16 shape, 2^18 groups x 4 pairs, shared final exp"] = g16
+    if hasattr(pkg, "pairing_fixed_g2_batch_dev"):
+        # the same function when three of a group's four G2 points are THE SAME for the whole batch (a Groth16 verifier's beta, gamma, delta): their point
+        # steps are done once (a line table), the per-group work of a fixed pair is one line scaling + one sparse multiplication per step
+        kf = 3
+        g2var = g2.view(16, groups, k)[:, :, 0].contiguous().view(-1)
+        g2fix = g2.view(16, n)[:, 1:1 + kf].contiguous().view(-1)
+        table = torch.zeros(pkg.g2_lines_bytes(kf) // 8, dtype=torch.int64, device=dev)
+        pkg.g2_lines_dev(g2fix, kf, table, device=local_rank, stream=stream)
+        o3 = torch.zeros(48 * groups, dtype=torch.int64, device=dev)
+        ms_f = timed(lambda: pkg.pairing_fixed_g2_batch_dev(g1, g2var, table, kf, o3, groups, device=local_rank, stream=stream), 2)
+        exp = g2.view(16, groups, k).clone()
+        for j in range(kf):
+            exp[:, :, 1 + j] = g2fix.view(16, kf)[:, j:j + 1]
+        pkg.multi_pairing_batch_dev(g1, exp.contiguous().view(-1), o2, groups, k, True, device=local_rank, stream=stream)
+        torch.cuda.synchronize(dev)
+        out["configs[3] with a fixed verifying key: 2^18 groups of 1 + 3 pairs, three G2 points shared by the batch (bn254_pairing_fixed_g2_batch_dev)"] = {
+            "ms": ms_f, "groups_per_s": groups / (ms_f * 1e-3), "kernel": "k_fpairing", "same_limbs_as_k_mpairing_on_the_expanded_pairs": bool(torch.equal(o2, o3)),
+            "speedup_over_four_free_pairs": g16["ms"] / ms_f,
+            "work_normalised_frac_of_nominal_issue_peak": groups / (ms_f * 1e-3) * W_MUL32_PER_GROTH16_GROUP / NOMINAL_ISSUE_PEAK_MUL32_PER_S,
+            "note": "the algorithmic work of the four-pair product (SURVEY.md 8d) over this kernel's time: the fixed pairs' point steps are not executed per group at all"}
+        del exp, o3, table
     # data formats either side of the path: element-major <-> limb-major on the device (HBM-bound: every word read once, written once)
     HBM_PEAK = 8.0e12
     lay = {}

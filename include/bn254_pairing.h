@@ -267,6 +267,34 @@ int bn254_multi_pairing_sharded_elems(const uint64_t* g1, const uint64_t* g2, ui
 int bn254_multi_pairing_check_batch_elems(const uint64_t* g1, const uint64_t* g2, uint8_t* verdict, size_t n_groups, size_t k, int device,
                                           void* stream);
 
+/* ---- fixed G2 points --------------------------------------------------------------------
+ * multi_miller_loop_native (src/miller_loop_native.rs:192-282, :324-326) takes any pairs; its real consumer, a Groth16 verifier, calls it with
+ * three of its four G2 points -- beta, gamma, delta of the verifying key -- THE SAME for every proof.  The point steps of such a pair do not depend on
+ * the proof at all.  bn254_g2_lines_dev walks them once per fixed point and leaves every step's line coefficients in `table` (device memory,
+ * bn254_g2_lines_bytes(k_fixed) bytes, in the engine's internal limb form: opaque, valid for the library build that made it); the batch calls then compute,
+ * per group g,
+ *     final_exp_native(multi_miller_loop_native([(P[g][0], Q0[g]), (P[g][1], Qfix_1), ..., (P[g][k], Qfix_k)]))          (k = k_fixed <= 4)
+ * with the fixed pairs reduced to one scaling of a table line by (Px, Py) and one sparse multiplication per step: 5.74 M instructions per group of
+ * 1 + 3 pairs against 7.11 M for four free pairs, and no per-lane point state but the group's own.  The same limbs as
+ * bn254_multi_pairing_batch_dev(do_final_exp = 1) on the expanded pairs (the value after the final exponentiation does not see how the Miller value was
+ * reached).  g1: n x (1 + k_fixed) G1 points, group-major like every multi-pairing batch (limb-major planes of n (1 + k) points; or element-major for
+ * the `_elems` form); g2_var: n G2 points; out: n Fq12.  The `_check` form gives the `== MyFq12::one` verdict byte per group instead
+ * (final_exp_native.rs:245-263).  The G2 points of the table must be in the r-torsion like any other (bn254_check_points_ex). */
+size_t bn254_g2_lines_bytes(size_t k_fixed);
+int bn254_g2_lines_dev(const uint64_t* g2_fixed, size_t k_fixed, uint64_t* table, int device, void* stream);
+int bn254_pairing_fixed_g2_batch_dev(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* table, size_t k_fixed, uint64_t* out, size_t n, int device,
+                                     void* stream);
+int bn254_pairing_fixed_g2_batch_elems_dev(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* table, size_t k_fixed, uint64_t* out, size_t n,
+                                           int out_order, int device, void* stream);
+int bn254_pairing_fixed_g2_check_batch_dev(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* table, size_t k_fixed, uint8_t* verdict, size_t n,
+                                           int device, void* stream);
+/* host-pointer forms (what a binding uses): g2_fixed = the k_fixed fixed points themselves; the table is made inside the call (1.3 ms).  One launch of the
+ * throughput kernel whatever n is (there is no lane-cooperative program for this shape: a single group costs 8 ms).  `_elems`: every array element-major. */
+int bn254_pairing_fixed_g2_batch(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* g2_fixed, size_t k_fixed, uint64_t* out, size_t n, int device,
+                                 void* stream);
+int bn254_pairing_fixed_g2_batch_elems(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* g2_fixed, size_t k_fixed, uint64_t* out, size_t n,
+                                       int out_order, int device, void* stream);
+
 /* ---- input validation (optional) ----------------------------------------------------------
  * The reference never checks for the point at infinity: its line functions read raw x / y (src/miller_loop_native.rs:10-44) and
  * ignore `G1Affine::infinity` / `G2Affine::infinity`, so an infinite input is outside its contract and outside the hot path's.

@@ -119,6 +119,13 @@ _PROTOS = {
     "bn254_pairing_batch_elems": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "bn254_pairing_batch_elems_dev": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "bn254_multi_pairing_batch_elems_dev": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_g2_lines_bytes": (ctypes.c_size_t, [ctypes.c_size_t]),
+    "bn254_g2_lines_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_pairing_fixed_g2_batch_dev": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_pairing_fixed_g2_batch_elems_dev": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_pairing_fixed_g2_check_batch_dev": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_pairing_fixed_g2_batch": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_pairing_fixed_g2_batch_elems": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "bn254_miller_loop_batch_elems": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "bn254_multi_pairing_batch_elems": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "bn254_pairing_sharded_elems": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_int]),
@@ -452,6 +459,42 @@ def multi_pairing_batch_elems_dev(g1, g2, out, n_groups, k, do_final_exp=True, o
 
 def pairing_batch_elems_dev(g1, g2, out, n, out_order=FQ12_MYFQ12, device=0, stream=None):
     _check(load_library().bn254_pairing_batch_elems_dev(_dev(g1), _dev(g2), _dev(out), n, out_order, device, _stream(stream)), "pairing")
+
+
+def pairing_fixed_g2_batch(g1, g2_var, g2_fixed, k_fixed, n, device=0, elems=False, out_order=FQ12_MYFQ12):
+    """host arrays: n groups of (own pair + k_fixed pairs whose G2 points, g2_fixed, are the same for every group); limb-major, or everything element-major"""
+    lib = load_library()
+    g1, g2_var, g2_fixed = _np_in(g1, G1_WORDS, n * (1 + k_fixed)), _np_in(g2_var, G2_WORDS, n), _np_in(g2_fixed, G2_WORDS, k_fixed)
+    out = np.empty(FQ12_WORDS * n, dtype=np.uint64)
+    if elems:
+        _check(lib.bn254_pairing_fixed_g2_batch_elems(_ptr(g1), _ptr(g2_var), _ptr(g2_fixed), k_fixed, _ptr(out), n, out_order, device, None), "pairing (fixed G2)")
+    else:
+        _check(lib.bn254_pairing_fixed_g2_batch(_ptr(g1), _ptr(g2_var), _ptr(g2_fixed), k_fixed, _ptr(out), n, device, None), "pairing (fixed G2)")
+    return out
+
+
+def g2_lines_bytes(k_fixed):
+    return load_library().bn254_g2_lines_bytes(k_fixed)
+
+
+def g2_lines_dev(g2_fixed, k_fixed, table, device=0, stream=None):
+    """table (device tensor of g2_lines_bytes(k_fixed) bytes) <- every step's line coefficients of the k_fixed G2 points (limb-major device tensor)"""
+    _check(load_library().bn254_g2_lines_dev(_dev(g2_fixed), k_fixed, _dev(table), device, _stream(stream)), "g2_lines")
+
+
+def pairing_fixed_g2_batch_dev(g1, g2_var, table, k_fixed, out, n, device=0, stream=None):
+    """n groups: final_exp_native(multi_miller_loop_native([(P0, Q0)] + [(P_j, Qfix_j)])) with the Qfix_j of `table`; g1: n x (1 + k_fixed) points"""
+    _check(load_library().bn254_pairing_fixed_g2_batch_dev(_dev(g1), _dev(g2_var), _dev(table), k_fixed, _dev(out), n, device, _stream(stream)), "pairing (fixed G2)")
+
+
+def pairing_fixed_g2_batch_elems_dev(g1, g2_var, table, k_fixed, out, n, out_order=FQ12_MYFQ12, device=0, stream=None):
+    _check(load_library().bn254_pairing_fixed_g2_batch_elems_dev(_dev(g1), _dev(g2_var), _dev(table), k_fixed, _dev(out), n, out_order, device, _stream(stream)),
+           "pairing (fixed G2)")
+
+
+def pairing_fixed_g2_check_batch_dev(g1, g2_var, table, k_fixed, verdict, n, device=0, stream=None):
+    _check(load_library().bn254_pairing_fixed_g2_check_batch_dev(_dev(g1), _dev(g2_var), _dev(table), k_fixed, _dev(verdict), n, device, _stream(stream)),
+           "pairing check (fixed G2)")
 
 
 def multi_pairing_check_batch_dev(g1, g2, verdict, n_groups, k, device=0, stream=None):

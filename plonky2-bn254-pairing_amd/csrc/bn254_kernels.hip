@@ -76,6 +76,8 @@ BN254_ASM_KERNEL(k_mpairing, BN254_ASM_MPAIRING)    // k pairs per lane, shared 
 BN254_ASM_KERNEL(k_mmiller, BN254_ASM_MMILLER)      // k pairs per lane, exact multi_miller_loop_native value
 BN254_ASM_KERNEL(k_op, BN254_ASM_OP)                // MyFq12 Mul / frobenius_map_native / pow_native (k = op | power << 8 | naf_len << 16)
 BN254_ASM_KERNEL(k_generate, BN254_ASM_GENERATE)    // synthetic subgroup points: g1 / g2 = outputs, f_in = table, out = seed
+BN254_ASM_KERNEL(k_g2lines, BN254_ASM_G2LINES)      // line table of FIXED G2 points (one point per lane): g2 = points, out = table
+BN254_ASM_KERNEL(k_fpairing, BN254_ASM_FPAIRING)    // pairing(P0, Q0) x prod_j pairing(P_j, Qfix_j): g1 = 1 + k points per group, g2 = Q0, f_in = the table of the k fixed points
 BN254_ASM_KERNEL(k_subcheck, BN254_ASM_SUBCHECK)    // G2 in the r-torsion? (ark's G2Affine::new, miller_loop_native.rs:303,311): g2 = points, out = one verdict word per point
 
 // The LATENCY path of the scalar signatures (pairing, miller_loop_native, multi_miller_loop_native, final_exp_native): one item on
@@ -306,7 +308,8 @@ int ctx_get(int device, void* stream, size_t k, size_t n_items, LaunchCtx* out, 
             HIPCHK(hipGetDeviceProperties(&prop, device));
             c.n_cu = prop.multiProcessorCount;
             const void* kernels[] = {(const void*)k_pairing, (const void*)k_miller, (const void*)k_fexp, (const void*)k_mpairing,
-                                     (const void*)k_mmiller, (const void*)k_op, (const void*)k_generate, (const void*)k_subcheck};
+                                     (const void*)k_mmiller, (const void*)k_op, (const void*)k_generate, (const void*)k_subcheck,
+                                     (const void*)k_g2lines, (const void*)k_fpairing};
             for (const void* f : kernels) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
             c.init = true;
         }
@@ -1026,6 +1029,85 @@ int bn254_multi_pairing_check_batch_dev(const uint64_t* g1, const uint64_t* g2, 
     hipLaunchKernelGGL(k_is_one, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, (const uint64_t*)c.s->tmp.p, verdict, n_groups);
     HIPCHK(hipGetLastError());
     return BN254_OK;
+}
+
+// ---- fixed G2 points (a Groth16 verifier's beta, gamma, delta: the same for every proof).  bn254_g2_lines_dev walks the point steps of each
+// fixed point ONCE and leaves every step's line coefficients in a table; bn254_pairing_fixed_g2_batch_dev then computes, per group,
+// final_exp_native(multi_miller_loop_native([(P0, Q0), (P1, Qfix_1), ..., (Pk, Qfix_k)])) with the fixed pairs reduced to one line scaling and one
+// sparse multiplication per step (no point step, no per-lane point state): miller_loop_native.rs:192-282 with k of the b's shared by the batch.
+size_t bn254_g2_lines_bytes(size_t k_fixed) { return k_fixed * (size_t)BN254_FIXED_LINES * 3 * SLOT_BYTES; }
+
+int bn254_g2_lines_dev(const uint64_t* g2_fixed, size_t k_fixed, uint64_t* table, int device, void* stream) {
+    if (!g2_fixed || !table || k_fixed == 0 || k_fixed > (size_t)BN254_FIXED_MAX) return BN254_ERR_INVALID_ARG;
+    LaunchCtx c;
+    int rc = ctx_get(device, stream, 1, 1, &c);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_g2lines, dim3(1), dim3(BLOCK), LDS_BYTES, (hipStream_t)stream, (const uint64_t*)nullptr, g2_fixed, (const uint64_t*)nullptr, table, (uint32_t)k_fixed, 1u,
+                       c.scratch, c.stride, c.status);
+    HIPCHK(hipGetLastError());
+    return BN254_OK;
+}
+
+static int launch_fixed(const uint64_t* g1, const uint64_t* g2, const uint64_t* table, size_t k_fixed, uint64_t* out, size_t n, int io_mode, int device, void* stream) {
+    if (n == 0) return BN254_OK;
+    if (!g1 || !g2 || !table || !out || k_fixed == 0 || k_fixed > (size_t)BN254_FIXED_MAX || n * (k_fixed + 1) >= ((size_t)1 << 24)) return BN254_ERR_INVALID_ARG;
+    LaunchCtx c;
+    int rc = ctx_get(device, stream, 1, (n + BLOCK - 1) / BLOCK, &c);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_fpairing, dim3(c.grid), dim3(BLOCK), LDS_BYTES, (hipStream_t)stream, g1, g2, table, out, (uint32_t)n, (uint32_t)k_fixed | ((uint32_t)io_mode << 28),
+                       c.scratch, c.stride, c.status);
+    HIPCHK(hipGetLastError());
+    c.s->last_kernel = 1;
+    return BN254_OK;
+}
+int bn254_pairing_fixed_g2_batch_dev(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* table, size_t k_fixed, uint64_t* out, size_t n, int device, void* stream) {
+    return launch_fixed(g1, g2_var, table, k_fixed, out, n, 0, device, stream);
+}
+int bn254_pairing_fixed_g2_batch_elems_dev(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* table, size_t k_fixed, uint64_t* out, size_t n, int out_order,
+                                           int device, void* stream) {
+    if (out_order != BN254_FQ12_MYFQ12 && out_order != BN254_FQ12_ARK) return BN254_ERR_INVALID_ARG;
+    return launch_fixed(g1, g2_var, table, k_fixed, out, n, IO_IN_ELEMS | IO_OUT_ELEMS | (out_order == BN254_FQ12_ARK ? IO_OUT_ARK : 0), device, stream);
+}
+int bn254_pairing_fixed_g2_check_batch_dev(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* table, size_t k_fixed, uint8_t* verdict, size_t n, int device,
+                                           void* stream) {
+    if (n == 0) return BN254_OK;
+    if (!verdict) return BN254_ERR_INVALID_ARG;
+    LaunchCtx c;
+    int rc = ctx_get(device, stream, 1, (n + BLOCK - 1) / BLOCK, &c);
+    if (rc) return rc;
+    if ((rc = ensure(c.s.get(), c.s->tmp, 384 * n))) return rc;
+    if ((rc = launch_fixed(g1, g2_var, table, k_fixed, (uint64_t*)c.s->tmp.p, n, 0, device, stream))) return rc;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_is_one, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, (const uint64_t*)c.s->tmp.p, verdict, n);
+    HIPCHK(hipGetLastError());
+    return BN254_OK;
+}
+
+// host-pointer forms: stage, make the table (1.3 ms), launch, copy back.  `elems`: every array element-major (the fixed points too), result in out_order.
+static int fixed_host(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* g2_fixed, size_t k_fixed, uint64_t* out, size_t n, bool elems, int out_order,
+                      int device, void* stream) {
+    if (n == 0) return BN254_OK;
+    if (!g1 || !g2_var || !g2_fixed || !out || k_fixed == 0 || k_fixed > (size_t)BN254_FIXED_MAX || n * (k_fixed + 1) >= ((size_t)1 << 24) ||
+        (out_order != BN254_FQ12_MYFQ12 && out_order != BN254_FQ12_ARK))
+        return BN254_ERR_INVALID_ARG;
+    Stage s; uint64_t *d1, *d2, *df, *dt, *d3, *dl = nullptr; int rc;
+    if ((rc = s.init(device, stream)) || (rc = s.up(g1, 64 * n * (k_fixed + 1), &d1)) || (rc = s.up(g2_var, 128 * n, &d2)) || (rc = s.up(g2_fixed, 128 * k_fixed, &df)) ||
+        (rc = s.up(nullptr, bn254_g2_lines_bytes(k_fixed), &dt)) || (rc = s.up(nullptr, 384 * n, &d3)) || (elems && (rc = s.up(nullptr, 128 * k_fixed, &dl))))
+        return rc;
+    if (elems && (rc = launch_layout(true, df, dl, 16, k_fixed, 0, device, stream))) return rc;      // (the table kernel reads limb-major planes)
+    if ((rc = bn254_g2_lines_dev(elems ? dl : df, k_fixed, dt, device, stream))) return rc;
+    rc = elems ? bn254_pairing_fixed_g2_batch_elems_dev(d1, d2, dt, k_fixed, d3, n, out_order, device, stream)
+               : bn254_pairing_fixed_g2_batch_dev(d1, d2, dt, k_fixed, d3, n, device, stream);
+    if (rc) return rc;
+    return finish_host(out, d3, 384 * n, device, stream);
+}
+int bn254_pairing_fixed_g2_batch(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* g2_fixed, size_t k_fixed, uint64_t* out, size_t n, int device, void* stream) {
+    return fixed_host(g1, g2_var, g2_fixed, k_fixed, out, n, false, BN254_FQ12_MYFQ12, device, stream);
+}
+int bn254_pairing_fixed_g2_batch_elems(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* g2_fixed, size_t k_fixed, uint64_t* out, size_t n, int out_order,
+                                       int device, void* stream) {
+    return fixed_host(g1, g2_var, g2_fixed, k_fixed, out, n, true, out_order, device, stream);
 }
 
 int bn254_release_stream(int device, void* stream) {

@@ -46,6 +46,8 @@ extern "C" {
     fn bn254_pairing_sharded_elems(g1: *const u64, g2: *const u64, out: *mut u64, n: usize, out_order: c_int, n_devices: c_int) -> c_int;
     fn bn254_multi_pairing_check_batch_elems(g1: *const u64, g2: *const u64, verdict: *mut u8, n_groups: usize, k: usize, device: c_int,
                                              stream: *mut c_void) -> c_int;
+    fn bn254_pairing_fixed_g2_batch_elems(g1: *const u64, g2_var: *const u64, g2_fixed: *const u64, k_fixed: usize, out: *mut u64, n: usize, out_order: c_int,
+                                          device: c_int, stream: *mut c_void) -> c_int;
 }
 const FQ12_MYFQ12: c_int = 0;
 const FQ12_ARK: c_int = 1;
@@ -255,5 +257,15 @@ pub fn multi_pairing_check_batch(ps: &[G1Affine], qs: &[G2Affine], k: usize) -> 
     let (g1, g2) = (elems_g1(ps), elems_g2(qs)); let mut v = vec![0u8; n_groups];
     ok(unsafe { bn254_multi_pairing_check_batch_elems(g1.as_ptr(), g2.as_ptr(), v.as_mut_ptr(), n_groups, k, 0, core::ptr::null_mut()) });
     v.into_iter().map(|b| b != 0).collect()
+}
+/// New: groups whose last `fixed.len()` G2 points are the same for the whole batch (a Groth16 verifier's beta, gamma, delta): `ps` holds
+/// 1 + fixed.len() G1 points per group (the group's own first), `qs` the groups' own G2 points.  `final_exp_native(multi_miller_loop_native(..))`
+/// per group -- the same value as `multi_pairing_batch` on the expanded pairs -- with the fixed pairs' point steps done once for the batch.
+pub fn pairing_fixed_g2_batch(ps: &[G1Affine], qs: &[G2Affine], fixed: &[G2Affine]) -> Vec<MyFq12> {
+    let (n, kf) = (qs.len(), fixed.len());
+    assert!(kf > 0 && kf <= 4 && ps.len() == n * (kf + 1));
+    let (g1, g2, gf) = (elems_g1(ps), elems_g2(qs), elems_g2(fixed)); let mut out = vec![0u64; 48 * n];
+    ok(unsafe { bn254_pairing_fixed_g2_batch_elems(g1.as_ptr(), g2.as_ptr(), gf.as_ptr(), kf, out.as_mut_ptr(), n, FQ12_MYFQ12, 0, core::ptr::null_mut()) });
+    out.chunks_exact(48).map(unpack_fq12).collect()
 }
 #[allow(dead_code)] fn _ark_index(j: i32) -> i32 { unsafe { bn254_myfq12_to_ark_index(j) } }

@@ -1,0 +1,129 @@
+"""Fixed G2 points (round 6): `multi_miller_loop_native` (/root/reference/src/miller_loop_native.rs:192-282, :324-326) with some of the G2 points the
+same for every group of the batch -- a Groth16 verifier's beta, gamma, delta.  `bn254_g2_lines_dev` makes the line table of the fixed points once;
+`bn254_pairing_fixed_g2_batch_dev` must give, limb for limb, what `bn254_multi_pairing_batch_dev(do_final_exp = 1)` gives on the expanded pairs
+(and the oracle's final_exp_native(multi_miller_loop_native(...)) on spot-checked groups)."""
+import numpy as np
+import pytest
+
+import helpers as H
+from helpers import R
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(pk, torch, dev, st, n, kf, seed):
+    k = 1 + kf
+    g1 = torch.zeros(8 * n * k, dtype=torch.int64, device=dev)
+    g2all = torch.zeros(16 * n * k, dtype=torch.int64, device=dev)
+    pk.generate_pairs_dev(seed, g1, g2all, n * k, 0, st)
+    f1 = torch.zeros(8 * kf, dtype=torch.int64, device=dev)
+    g2fix = torch.zeros(16 * kf, dtype=torch.int64, device=dev)
+    pk.generate_pairs_dev(seed ^ 0x5555, f1, g2fix, kf, 0, st)
+    # the group's own Q = the generated Q of its first pair; the expanded batch has the fixed points in the other places
+    g2var = g2all.view(16, n, k)[:, :, 0].contiguous().view(-1)
+    exp = g2all.view(16, n, k).clone()
+    for j in range(kf):
+        exp[:, :, 1 + j] = g2fix.view(16, kf)[:, j:j + 1]
+    table = torch.zeros(pk.g2_lines_bytes(kf) // 8, dtype=torch.int64, device=dev)
+    pk.g2_lines_dev(g2fix, kf, table, 0, st)
+    return g1, g2var, exp.contiguous().view(-1), table
+
+
+@pytest.mark.parametrize("kf", [1, 2, 3, 4])
+def test_fixed_g2_equals_the_expanded_multi_pairing_on_every_lane(kf):
+    import torch
+    pk = H.pkg()
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev)
+    pk.set_stream_latency(0, -1, 0, st)          # the reference value from the throughput kernel as well (any size)
+    try:
+        n, k = 1000 + 77 * kf, 1 + kf
+        g1, g2var, g2exp, table = _setup(pk, torch, dev, st, n, kf, 0xF1D0 + kf)
+        want = torch.zeros(48 * n, dtype=torch.int64, device=dev)
+        pk.multi_pairing_batch_dev(g1, g2exp, want, n, k, True, 0, st)
+        got = torch.full((48 * n + 64,), -7, dtype=torch.int64, device=dev)
+        pk.pairing_fixed_g2_batch_dev(g1, g2var, table, kf, got, n, 0, st)
+        pk.last_status(0, st)
+        assert torch.equal(got[: 48 * n], want) and bool((got[48 * n:] == -7).all()) and int(want.abs().sum()) != 0
+        # element-major in, ark order out
+        e1 = torch.empty_like(g1)
+        e2 = torch.empty_like(g2var)
+        pk.soa_to_elems_dev(g1, e1, 8, n * k, 0, 0, st)
+        pk.soa_to_elems_dev(g2var, e2, 16, n, 0, 0, st)
+        eo = torch.zeros(48 * n, dtype=torch.int64, device=dev)
+        pk.pairing_fixed_g2_batch_elems_dev(e1, e2, table, kf, eo, n, pk.FQ12_ARK, 0, st)
+        pk.last_status(0, st)
+        idx = [pk.load_library().bn254_myfq12_to_ark_index(j) for j in range(12)]
+        assert torch.equal(eo.view(n, 12, 4), want.view(48, n).t().contiguous().view(n, 12, 4)[:, idx, :])
+        # the oracle on three groups
+        pos = [0, n // 2, n - 1]
+        sel = torch.as_tensor([p * k + j for p in pos for j in range(k)], device=dev)
+        g1h = g1.view(8, n * k)[:, sel].cpu().numpy().view(np.uint64).reshape(-1).copy()
+        g2h = g2exp.view(16, n * k)[:, sel].cpu().numpy().view(np.uint64).reshape(-1).copy()
+        ora = H.oracle_multi_pairing(pk.layout.to_aos(g1h, 8), pk.layout.to_aos(g2h, 16), len(pos), k)
+        mine = got[: 48 * n].view(48, n)[:, torch.as_tensor(pos, device=dev)].cpu().numpy().view(np.uint64).reshape(-1).copy()
+        assert np.array_equal(pk.layout.to_aos(mine, 48), ora)
+    finally:
+        pk.set_stream_latency(pk.LATENCY_INHERIT, -1, 0, st)
+
+
+def test_fixed_g2_full_grid_and_verdicts():
+    """2^16 + 300 groups of 1 + 3 pairs (the Groth16 shape with a fixed verifying key) against k_mpairing on the expanded batch; the verdict bytes
+    on crafted groups: e([6]G1, G2) e(-[2]G1, [3]G2) == 1 with [3]G2 fixed, a generic group != 1."""
+    import torch
+    pk = H.pkg()
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev)
+    n, kf = (1 << 16) + 300, 3
+    g1, g2var, g2exp, table = _setup(pk, torch, dev, st, n, kf, 0xF1DF)
+    want = torch.zeros(48 * n, dtype=torch.int64, device=dev)
+    pk.multi_pairing_batch_dev(g1, g2exp, want, n, 1 + kf, True, 0, st)
+    got = torch.zeros(48 * n, dtype=torch.int64, device=dev)
+    pk.pairing_fixed_g2_batch_dev(g1, g2var, table, kf, got, n, 0, st)
+    pk.last_status(0, st)
+    assert torch.equal(got, want)
+    # verdicts
+    G1, G2 = R.G1_GEN, R.G2_GEN
+    Qf = R.g2_mul(G2, 3)
+    grp = [(R.g1_mul(G1, 6), R.g1_neg(R.g1_mul(G1, 2))), (R.g1_mul(G1, 6), R.g1_mul(G1, 2)), (R.g1_mul(G1, 9), R.g1_neg(R.g1_mul(G1, 3)))]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64).copy()).to(dev)
+    g1c = t(pk.layout.to_soa(H.g1_aos([p for g in grp for p in g]), 8))
+    g2c = t(pk.layout.to_soa(H.g2_aos([G2] * len(grp)), 16))
+    qf = t(pk.layout.to_soa(H.g2_aos([Qf]), 16))
+    tab = torch.zeros(pk.g2_lines_bytes(1) // 8, dtype=torch.int64, device=dev)
+    pk.g2_lines_dev(qf, 1, tab, 0, st)
+    v = torch.full((len(grp),), 9, dtype=torch.uint8, device=dev)
+    pk.pairing_fixed_g2_check_batch_dev(g1c, g2c, tab, 1, v, len(grp), 0, st)
+    pk.last_status(0, st)
+    assert v.tolist() == [1, 0, 1]
+
+
+def test_fixed_g2_argument_checks():
+    import torch
+    pk = H.pkg()
+    dev = torch.device("cuda:0")
+    z = torch.zeros(64, dtype=torch.int64, device=dev)
+    for kf in (0, 5):
+        with pytest.raises(pk.Bn254Error) as e:
+            pk.pairing_fixed_g2_batch_dev(z, z, z, kf, z, 1)
+        assert e.value.status == pk.ERR_INVALID_ARG
+    with pytest.raises(pk.Bn254Error):
+        pk.g2_lines_dev(z, 5, z)
+    assert pk.g2_lines_bytes(3) == 3 * 87 * 3 * 72
+
+
+def test_fixed_g2_host_pointer_forms():
+    """bn254_pairing_fixed_g2_batch / _elems on host arrays (the table is made inside the call) against bn254_multi_pairing_batch on the expanded pairs"""
+    pk = H.pkg()
+    n, kf = 130, 2
+    k = 1 + kf
+    Ps, Qs = H.subgroup_points(n * k + kf, seed=95)
+    P, Qv, Qf = list(Ps[: n * k]), [Qs[g * k] for g in range(n)], list(Qs[n * k:])
+    e1, e2, ef = H.g1_aos(P), H.g2_aos(Qv), H.g2_aos(Qf)
+    exp = H.g2_aos([Qv[g] if j == 0 else Qf[j - 1] for g in range(n) for j in range(k)])
+    want = pk.multi_pairing_batch(H.to_soa(e1, 8), H.to_soa(exp, 16), n, k)
+    got = pk.pairing_fixed_g2_batch(H.to_soa(e1, 8), H.to_soa(e2, 16), H.to_soa(ef, 16), kf, n)
+    assert np.array_equal(got, want)
+    got_e = pk.pairing_fixed_g2_batch(e1, e2, ef, kf, n, elems=True, out_order=pk.FQ12_ARK)
+    idx = [pk.load_library().bn254_myfq12_to_ark_index(j) for j in range(12)]
+    assert np.array_equal(got_e.reshape(n, 12, 4), H.to_aos(want, 48).reshape(n, 12, 4)[:, idx, :])

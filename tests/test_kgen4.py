@@ -641,3 +641,71 @@ def test_multi_pairing_kernel_element_major_io(vec, mode):
         got.append(R.from_mont(v))
     assert got == want
     assert {a for a in m.gmem if OUTB <= a < OUTB + 8 * 48 * n} == {OUTB + (lane * 48 + w) * 8 + h for w in range(48) for h in (0, 4)}
+
+
+def test_fixed_g2_kernels(vec):
+    """The line-table kernel (one fixed G2 point per lane: every step's line coefficients without an evaluation point) and the fixed-G2
+    pairing kernel that consumes it: group = the group's own pair + two pairs whose G2 points are fixed for the batch.  Lane 1 of a
+    two-group batch (limb-major, then element-major with ark order out) gives final_exp_native of the product of the three Miller values --
+    multi_miller_loop_native's value (miller_loop_native.rs:192-282) after the final exponentiation, which does not see the chain."""
+    kf, n, lane = 2, 2, 1
+    fixed_idx = [4, 7]
+    grp = [[1, 2, 3], [5, 6, 8]]                     # golden indices of (own pair, P of fixed pair 0, P of fixed pair 1)
+    TABB = 0x700000
+    kl = K4P.KernelBuilder(lines=True)
+    lines_l = _concretize(kl.build()) + ["s_endpgm"]
+    for n_ in ("L2_ldbl", "L2_ladd", "L2_ladd_last"):
+        assert kl._check_routine(n_) <= K4P.V_CAP
+    gmem = {}
+    g2f = _soa([HX(vec["g2"][i]) for i in fixed_idx])
+    for ln in range(kf):
+        m = S.Machine()
+        m.gmem.update(gmem)
+        for i, w in enumerate(g2f):
+            m.gmem[G2B + 8 * i] = w & 0xFFFFFFFF
+            m.gmem[G2B + 8 * i + 4] = (w >> 32) & 0xFFFFFFFF
+        for name, val in (("s[2:3]", G1B), ("s[4:5]", G2B), ("s[6:7]", FINB), ("s[8:9]", TABB), ("s10", kf), ("s11", 1), ("s[12:13]", SCR),
+                          ("s14", 256 * K4.SLOT_BYTES), ("s[16:17]", STAT), ("s18", 0), ("s19", 1)):
+            m.sset(name, val)
+        m.v[255] = ln
+        S.run(lines_l, m)
+        gmem = {a: v for a, v in m.gmem.items() if TABB <= a < TABB + (1 << 20)}
+    tab_bytes = kf * kl.n_fixed_lines * 3 * K4.SLOT_BYTES
+    assert len(gmem) == tab_bytes // 4 and kl.n_fixed_lines == 87
+    kb = K4P.KernelBuilder(fixed=True)
+    assert kb.n_fixed_lines == kl.n_fixed_lines and kb.naf == kl.naf
+    lines_f = _concretize(kb.build()) + ["s_endpgm"]
+    for n_ in [f"L2_fix{k_}_{j}" for k_ in ("034", "235") for j in range(4)] + ["L2_fsp034", "L2_fsp235"]:
+        assert kb._check_routine(n_) <= K4P.V_CAP
+    want = None
+    for pi, qi in zip(grp[lane], [grp[lane][0]] + fixed_idx):
+        # e(P_pi, Q_qi): the golden Miller values are for equal indices only -- compute through the big-int restatement
+        mv = R.miller_loop_native((tuple(HX(vec["g2"][qi])[:2]), tuple(HX(vec["g2"][qi])[2:])), tuple(HX(vec["g1"][pi])))
+        want = mv if want is None else R.fq12_mul(want, mv)
+    want = R.final_exp_native(want)
+    rows1 = [HX(vec["g1"][i]) for g in grp for i in g]
+    rows2 = [HX(vec["g2"][g[0]]) for g in grp]
+    elems = lambda rows: [w for el in rows for c in el for w in R.limbs4(R.to_mont(c))]
+    for mode in (0, 7):
+        m = S.Machine()
+        m.gmem.update(gmem)
+        for base, words in ((G1B, elems(rows1) if mode else _soa(rows1)), (G2B, elems(rows2) if mode else _soa(rows2))):
+            for i, w in enumerate(words):
+                m.gmem[base + 8 * i] = w & 0xFFFFFFFF
+                m.gmem[base + 8 * i + 4] = (w >> 32) & 0xFFFFFFFF
+        for name, val in (("s[2:3]", G1B), ("s[4:5]", G2B), ("s[6:7]", TABB), ("s[8:9]", OUTB), ("s10", n), ("s11", kf | (mode << 28)), ("s[12:13]", SCR),
+                          ("s14", 256 * K4.SLOT_BYTES), ("s[16:17]", STAT), ("s18", 0), ("s19", 1)):
+            m.sset(name, val)
+        m.v[255] = lane
+        S.run(lines_f, m)
+        got = []
+        for c in range(12):
+            j = c if not (mode & 4) else [jj for jj in range(12) if _ark_to_my(jj) == c][0]
+            v = 0
+            for l in range(4):
+                a = (OUTB + (lane * 48 + j * 4 + l) * 8) if mode & 2 else (OUTB + ((c * 4 + l) * n + lane) * 8)
+                v |= (m.gmem[a] | (m.gmem[a + 4] << 32)) << (64 * l)
+            got.append(R.from_mont(v))
+        assert got == want, mode
+        assert m.max_acc < (1 << 63) and STAT not in m.gmem
+    print("fixed-G2 kernel:", m.count, "instructions for one group of 1 + 2 pairs")

@@ -62,6 +62,8 @@ S_PB = 48                 # byte offset of the base's scratch register during th
 S_MODE_SINGLE, S_MODE_MULTI = 49, 51      # I/O layout of this launch (bits 28..30 of the kernel's k argument; KernelBuilder.s_mode): 1 inputs element-major,
                           # 2 output element-major, 4 ... in ark's Fq12 order.  (s49 is the k-pair kernels' S_GNEXT, s51 the split-loop experiment's cursor step)
 S_IOSTRIDE = 75           # bytes between consecutive words of the array being walked: the plane stride (limb-major) or 8 (element-major)
+S_TAB = "s[72:73]"        # fixed-G2 kernels: address of the current line triple of the current fixed pair in the line table (s74: the cursor in bytes)
+S_TABCUR = 74
 V_IOOFF = 247             # the lane's byte offset into the array being walked: index * 8 (limb-major) or index * 8 * words per element
 MODE_IN_ELEMS, MODE_OUT_ELEMS, MODE_OUT_ARK = 0, 1, 2      # bit numbers in S_MODE
 BLOCK = 256
@@ -106,6 +108,13 @@ class GlobLine:
 
     def __init__(self, k):
         self.kind, self.k = "globline", k
+
+
+class Tab:
+    """Slot k of the line triple at the table cursor S_TAB (fixed-G2 kernels): 72 contiguous bytes at S_TAB + 72 k + the lane's V_IOOFF."""
+
+    def __init__(self, k):
+        self.kind, self.k = "tab", k
 
 
 class Const:
@@ -347,7 +356,7 @@ class Prog:
     # ---------------------------------------------------------------- bounds
     @staticmethod
     def key(slot):
-        if slot.kind in ("globdyn", "globline"):
+        if slot.kind in ("globdyn", "globline", "tab"):
             return (slot.kind, slot.k)
         if slot.kind == "const":
             return ("const", slot.name)
@@ -432,6 +441,12 @@ class Prog:
             w = bal_limbs(mont4(slot.c0)) + bal_limbs(mont4(slot.c1))
             for i in range(SLOT_DW):
                 e.emit(f"v_mov_b32_e32 v{blk + i}, {hx(w[i])}", vw=[blk + i])
+        elif slot.kind == "tab":
+            for c in range(self.N_B128):
+                e.emit(f"global_load_dwordx4 v[{blk + 4 * c}:{blk + 4 * c + 3}], v{V_IOOFF}, {S_TAB} offset:{SLOT_BYTES * slot.k + 16 * c}", kind="vmem",
+                       vw=range(blk + 4 * c, blk + 4 * c + 4))
+            e.emit(f"global_load_dwordx2 v[{blk + 16}:{blk + 17}], v{V_IOOFF}, {S_TAB} offset:{SLOT_BYTES * slot.k + 64}", kind="vmem", vw=[blk + 16, blk + 17])
+            self.vm_pending = True
         elif slot.kind in ("glob", "globdyn", "globline") and EXP_NO_SCRATCH:
             pass
         elif slot.kind in ("glob", "globdyn", "globline"):
@@ -460,6 +475,12 @@ class Prog:
         elif slot.kind == "agpr":
             for i in range(SLOT_DW):
                 e.emit(f"v_accvgpr_write_b32 a{SLOT_DW * slot.idx + i}, v{blk + i}")
+        elif slot.kind == "tab":
+            for c in range(self.N_B128):
+                e.emit(f"global_store_dwordx4 v{V_IOOFF}, v[{blk + 4 * c}:{blk + 4 * c + 3}], {S_TAB} offset:{SLOT_BYTES * slot.k + 16 * c}", kind="vmem",
+                       store=range(blk + 4 * c, blk + 4 * c + 4))
+            e.emit(f"global_store_dwordx2 v{V_IOOFF}, v[{blk + 16}:{blk + 17}], {S_TAB} offset:{SLOT_BYTES * slot.k + 64}", kind="vmem", store=[blk + 16, blk + 17])
+            e.raw("s_nop 1")
         elif slot.kind in ("glob", "globdyn", "globline") and EXP_NO_SCRATCH:
             pass
         elif slot.kind in ("glob", "globdyn", "globline"):
@@ -623,6 +644,16 @@ class Prog:
     def sub(self, y): return self._bin("sub", y)
     def rsub(self, y): return self._bin("rsub", y)
     def mulfq(self, y): return self._bin("mulfq", y)      # A * (Fq in y.c0)
+
+    def mulfq_c1(self, y):
+        """A * (the Fq in y.c1): y is a slot that packs two Fq values (the evaluation point (Px, Py) of a fixed pair)"""
+        self._B(y)
+        self.wait()
+        for i in range(NL):
+            self.e.emit(f"v_mov_b32_e32 v{B0 + i}, v{B0 + NL + i}", vw=[B0 + i])
+        self.tagB = None
+        return self.call("mulfq", self.r_of(y), vB=self.v_of(y))
+
     def sqr(self): return self.call("sqr")
     def dbl(self): return self.call("dbl")
     def neg(self): return self.call("neg")
@@ -1717,15 +1748,23 @@ class KernelBuilder:
 
     COLD = ("L2_inv", "L2_frob1", "L2_frob2", "L2_frob3", "L2_dblfirst", "L2_addmul_last", "L2_descale", "L2_fqinv")
 
-    def __init__(self, do_miller=True, do_fexp=True, track=False, multi=False, helper=False, generate=False, subcheck=False):
+    MAX_FIXED = 4             # fixed pairs per group of the fixed-G2 kernel: their evaluation points fill LDS slots 2..5
+    FIX_P = [LDS(2 + j, f"Pfix{j}") for j in range(4)]
+
+    def __init__(self, do_miller=True, do_fexp=True, track=False, multi=False, helper=False, generate=False, subcheck=False, fixed=False, lines=False):
         """track: keep the running line scale and divide it out (the exact miller_loop_native value).
         multi: k pairs per lane with a shared f (multi_miller_loop_native, miller_loop_native.rs:192-282).
         helper: the batched public helpers of the reference on Fq12 batches -- MyFq12 `Mul`, frobenius_map_native
         (final_exp_native.rs:17-54), pow_native (:56-84) -- selected at run time by the kernel's `k` argument."""
         if helper:
             do_miller, do_fexp, track, multi = False, True, False, False
-        if generate or subcheck:
+        if generate or subcheck or lines:
             do_miller, do_fexp, track, multi = False, False, False, False
+        if fixed:
+            do_miller, do_fexp, track, multi = True, True, False, False
+        # fixed: pairing(P0, Q0) x prod_j pairing(P_j, Qfix_j) with the Qfix_j THE SAME for every group of the batch (a Groth16 verifier's
+        # beta / gamma / delta): their line coefficients come from a table that the `lines` kernel makes once (_fixed_routines).
+        self.fixed, self.lines = fixed, lines
         self.generate = generate
         # subcheck: ark's `G2Affine::new` contract (miller_loop_native.rs:303,311) -- is the lane's G2 point in the r-torsion?  One verdict word per
         # point into `out`; the point state lives in AGPR slots only (_subcheck_routines)
@@ -1755,7 +1794,7 @@ class KernelBuilder:
     def s_mode(self):
         """scalar register of the launch's I/O layout bits, or None where the kernel is limb-major only (k_op: its k argument is full; k_generate;
         the split-loop experiment of the k-pair kernels, which owns every spare scalar register)"""
-        if self.helper or self.generate or (self.multi and FISSION):
+        if self.helper or self.generate or self.lines or (self.multi and FISSION):
             return None
         return S_MODE_MULTI if self.multi else S_MODE_SINGLE
 
@@ -1769,7 +1808,7 @@ class KernelBuilder:
                 d.append(z)
                 n = (n - z) // 2
             return d + [0] * (66 - len(d))
-        if SHORT_CHAIN and self.do_miller and self.do_fexp and not self.track and not FISSION:
+        if SHORT_CHAIN and ((self.do_miller and self.do_fexp and not self.track and not FISSION) or self.lines):
             return SIX_U_PLUS_2_SHORT
         return SIX_U_PLUS_2_NAF
 
@@ -1784,7 +1823,7 @@ class KernelBuilder:
     def chunk2(self):
         """two doubling iterations per chunk with both lines parked on chip: the untracked one-pair kernels (k_pairing)"""
         return (CHUNK2 and self.do_miller and not self.track and not self.multi and not self.helper and not self.generate and LINE_IN_REGS
-                and Prog.FUSED_STEPS and not FISSION and self.F_IN_AGPR)
+                and Prog.FUSED_STEPS and not FISSION and self.F_IN_AGPR and not self.fixed)
 
     def chunk_park(self):
         return [[LDS(3, "parkA0"), LDS(4, "parkA1"), LDS(5, "parkA2")], [LDS(2, "parkB0"), self.SX, self.SY]]
@@ -1969,6 +2008,8 @@ class KernelBuilder:
         else:       # the point state of the Miller loop (and its per-pair copies in scratch): operands of the fused steps
             keys += [Prog.key(s_) for s_ in (*self.R, self.QX, self.QY, self.PX, self.PY, self.SX, self.SY)]
             keys += [("globdyn", i) for i in range(7)]
+            if self.fixed:
+                keys += [Prog.key(s_) for s_ in self.FIX_P]
             if self.multi and self.r0_resident():
                 keys += [Prog.key(s_) for s_ in self.R0_LDS] + [Prog.key(s_) for s_ in self.r1_slots()]
             if self.fission:
@@ -2007,7 +2048,7 @@ class KernelBuilder:
         self.l2_phase[name] = self._phase
         # (home registers never carry a value across a routine boundary: they are every routine's workspace)
         # (... nor does the line area of the split loop: its bounds travel from the phase-1 routines to the phase-2 ones, _fission_routines)
-        self.l2_exit[name] = {k: v for k, v in p.slot_v.items() if k not in tk and k[0] not in ("home", "globline")}
+        self.l2_exit[name] = {k: v for k, v in p.slot_v.items() if k not in tk and k[0] not in ("home", "globline")}      # ("tab": to() keeps the contract)
         self.l2_maxv[name] = p.max_v
         return p
 
@@ -2019,6 +2060,8 @@ class KernelBuilder:
         fa, fl = self.MILLER_FREE
         if self.fission and not self.multi:      # LDS 3..5 hold RZ, PX, PY during phase 2 of the split loop
             fl = []
+        if self.fixed:                           # LDS 2..5 hold the fixed pairs' evaluation points for the whole Miller loop
+            return homes + fa + list(extra) + [GLOB(GLOB_TMP0 + i) for i in range(8)]
         if in_loop and self.multi and self.r0_resident():    # (f^2 of the streamed loop) LDS 3..5 hold pair 0's R, LDS 2 pair 1's X there: never temporaries
             return (homes + fa + list(extra) + ([] if self.track or self.SCALE.kind == "agpr" or self.r1_slots() else [self.SCALE])
                     + [GLOB(GLOB_TMP0 + i) for i in range(8)])
@@ -2103,6 +2146,10 @@ class KernelBuilder:
             self.l2_routine("L2_affine", self._to_affine, gt)
         if self.subcheck:
             self._subcheck_routines()
+        if self.fixed:
+            self._fixed_routines()
+        if self.lines:
+            self._lines_routines()
         self._phase = "fexp"
         if self.do_fexp:
             if not (self.do_miller and self.track):
@@ -2897,14 +2944,16 @@ class KernelBuilder:
         p.temp_keys = frozenset()            # the main program's stores all cross routine boundaries
         p.norm_keys = self.norm_keys("miller")
         self.main_prog = p
-        if self.generate or self.subcheck:
-            (self.generate_main if self.generate else self.subcheck_main)(e, p)
+        if self.generate or self.subcheck or self.lines:
+            (self.generate_main if self.generate else (self.subcheck_main if self.subcheck else self.lines_main))(e, p)
             e.salu(f"s_add_u32 s{S_ITEM}, s{S_ITEM}, s{S_GRID}")
             e.salu(f"s_branch {L('L_item')}")
             e.label(L("L_done"))
             return
         if self.do_miller and self.multi:
             self.miller_main_multi(e, p)
+        elif self.fixed:
+            self.miller_main_fixed(e, p)
         elif self.do_miller:
             self.miller_main(e, p)
         else:
@@ -3588,6 +3637,198 @@ class KernelBuilder:
         e.emit(f"v_lshrrev_b32_e32 v{V_TID}, 4, v{V_LDS}", vw=[V_TID])
         p.reset_tags()
 
+
+    # ---------------------------------------------------------------------------------------------
+    # FIXED G2 POINTS.  multi_miller_loop_native (miller_loop_native.rs:192-282) takes any pairs; a Groth16 verifier calls it with three of its
+    # four G2 points -- beta, gamma, delta of the verifying key -- THE SAME for every proof.  The point steps of such a pair do not depend on
+    # the lane at all: the `lines` kernel walks them once per fixed point (one lane each, the generic step routines, evaluation point (1, 1)) and
+    # leaves every step's line coefficients in a table; the `fixed` kernel is k_pairing for the group's own pair plus, per step and fixed
+    # pair, one table line scaled by that pair's (Px, Py) and one sparse multiplication -- no point step, no R anywhere but the variable
+    # pair's resident one.  Same chain as the fused kernels (the table is made for it); any Fq2 factor of a line dies in the easy part.
+    #   table: [fixed pair][line][3 slots of 72 bytes], lines in the order the loop consumes them: the first doubling, then per digit the
+    #   doubling and (digit != 0) the addition, then the two Frobenius steps.
+    @property
+    def n_fixed_lines(self):
+        return 1 + self.naf_first + sum(1 for d in self.naf[:self.naf_first + 1] if d) + 2
+
+    def _tab_cursor(self, e, base, pair):
+        """S_TAB <- base + pair * (lines per pair) * 216 + S_TABCUR"""
+        lo, hi = (int(x) for x in base.strip("s[]").split(":"))
+        off = pair * self.n_fixed_lines * 3 * SLOT_BYTES
+        e.salu(f"s_add_u32 s72, s{lo}, s{S_TABCUR}")
+        e.salu(f"s_addc_u32 s73, s{hi}, 0")
+        if off:
+            e.salu(f"s_add_u32 s72, s72, 0x{off:x}")
+            e.salu("s_addc_u32 s73, s73, 0")
+
+    def _fixed_routines(self):
+        tm = self.miller_temps(extra=(self.SX, self.SY))
+
+        def fixline(kind, j):
+            def body(p):
+                e = p.e
+                self._tab_cursor(e, S_FIN, j)
+                e.emit(f"v_mov_b32_e32 v{V_IOOFF}, 0", vw=[V_IOOFF])
+                Pj = self.FIX_P[j]
+                if kind == "034":                                   # (L0, H Py, -3 X^2 Px): dbl_step's line with the evaluation point put back
+                    p.A(Tab(0)).to(self.LINE[0])
+                    p.A(Tab(1)).mulfq_c1(Pj).to(self.LINE[1])
+                    p.A(Tab(2)).mulfq(Pj).to(self.LINE[2])
+                else:                                               # (-mu Py, theta Px, L5): add_step's
+                    p.A(Tab(0)).mulfq_c1(Pj).to(self.LINE[0])
+                    p.A(Tab(1)).mulfq(Pj).to(self.LINE[1])
+                    p.A(Tab(2)).to(self.LINE[2])
+            return body
+        for j in range(self.MAX_FIXED):
+            self.l2_routine(f"L2_fix034_{j}", fixline("034", j), tm)
+            self.l2_routine(f"L2_fix235_{j}", fixline("235", j), tm)
+        self.l2_routine("L2_fsp034", lambda p: p.mul_by_034(self.F, *self.LINE), tm)
+        self.l2_routine("L2_fsp235", lambda p: p.mul_by_235(self.F, *self.LINE), tm)
+
+    def _fixed_lines(self, e, kind):
+        """f *= the current line of every fixed pair (S_K of them); the table cursor moves on by one line"""
+        u = self.uid()
+        done = self.lab(f"L_fx_done_{u}")
+        for j in range(self.MAX_FIXED):
+            e.salu(f"s_cmp_gt_u32 s{S_K}, {j}")
+            e.salu(f"s_cbranch_scc0 {done}")
+            self.call2(e, f"L2_fix{kind}_{j}")
+            self.call2(e, f"L2_fsp{kind}")
+        e.label(done)
+        e.salu(f"s_add_u32 s{S_TABCUR}, s{S_TABCUR}, {3 * SLOT_BYTES}")
+
+    def miller_main_fixed(self, e, p):
+        """g1: 1 + S_K points per group, group-major (the group's own P first, then the P_j of the fixed pairs); g2: the group's own Q;
+        f_in: the line table of the S_K fixed points."""
+        L = self.lab
+        e.salu(f"s_add_u32 s{S_TMP1}, s{S_K}, 1")
+        e.salu(f"s_mul_i32 s{S_NSTRIDE}, s{S_N}, s{S_TMP1}")
+        e.salu(f"s_lshl_b32 s{S_NSTRIDE}, s{S_NSTRIDE}, 3")          # bytes between limb planes of the G1 batch
+        e.emit(f"v_mul_lo_u32 v{V_IDX8}, v{V_IDX8}, s{S_TMP1}", vw=[V_IDX8])   # byte offset of the group's first point
+        self.io_walk_begin(e, S_G1, 8)
+        self.io_load_fq2_into_A(e, p, c1_present=False)          # Px
+        p.to(self.PX)
+        self.io_load_fq2_into_A(e, p, c1_present=False)          # Py
+        p.to(self.PY)
+        skip = L("L_fx_pts")
+        for j in range(self.MAX_FIXED):                          # (Px_j, Py_j) packed into one slot: c0 = Px, c1 = Py
+            e.salu(f"s_cmp_gt_u32 s{S_K}, {j}")
+            e.salu(f"s_cbranch_scc0 {skip}")
+            e.emit(f"v_add_u32_e32 v{V_IDX8}, 8, v{V_IDX8}", vw=[V_IDX8])
+            self.io_walk_begin(e, S_G1, 8)
+            self.io_load_fq2_into_A(e, p)
+            p.to(self.FIX_P[j])
+            p.reset_tags()
+        e.label(skip)
+        e.salu(f"s_lshl_b32 s{S_NSTRIDE}, s{S_N}, 3")                # G2 and the result: one element per group
+        e.salu(f"s_sub_u32 s{S_TMP1}, s{S_N}, 1")
+        e.emit(f"v_min_u32_e32 v{V_IDX8}, s{S_TMP1}, v{V_IDX}", vw=[V_IDX8])
+        e.emit(f"v_lshlrev_b32_e32 v{V_IDX8}, 3, v{V_IDX8}", vw=[V_IDX8])
+        self.io_walk_begin(e, S_G2, 16)
+        self.io_load_fq2_into_A(e, p)                            # Q.x
+        p.to(self.QX)
+        p.to(self.R[0])
+        self.io_load_fq2_into_A(e, p)                            # Q.y
+        p.to(self.QY)
+        p.to(self.R[1])
+        self.one_into_A(e)
+        p.set_A_fresh()
+        p.to(self.R[2])
+        p.reset_tags()
+        e.salu(f"s_mov_b32 s{S_TABCUR}, 0")
+        self.call2(e, "L2_dblfirst")
+        self._fixed_lines(e, "034")
+        first = self.naf_first
+        assert first == 63
+        e.salu(f"s_mov_b32 s{S_I}, {first}")
+        e.label(L("L_mloop"))
+        e.salu(f"s_cmp_eq_u32 s{S_I}, {first}")
+        e.salu(f"s_cbranch_scc1 {L('L_mskip')}")
+        self.call2(e, "L2_sqr")
+        self.call2(e, "L2_dblmul")
+        self._fixed_lines(e, "034")
+        e.label(L("L_mskip"))
+        e.salu(f"s_bitcmp1_b64 {S_NAF_NZ}, s{S_I}")
+        e.salu(f"s_cbranch_scc0 {L('L_mnoadd')}")
+        self._select_pm_q(e, p)
+        self.call2(e, "L2_addmul")
+        self._fixed_lines(e, "235")
+        e.label(L("L_mnoadd"))
+        e.salu(f"s_sub_u32 s{S_I}, s{S_I}, 1")
+        e.salu(f"s_cbranch_scc0 {L('L_mloop')}")
+        self._frobenius_points(p)                                # + pi(Q), then the line through the result and -pi^2(Q)
+        self.call2(e, "L2_addmul")
+        self._fixed_lines(e, "235")
+        p.reset_tags()
+        p.mov(self.SX, self.QX)
+        p.mov(self.SY, self.QY)
+        self.call2(e, "L2_addmul_last")
+        self._fixed_lines(e, "235")
+        p.reset_tags()
+
+    # the table's maker: one fixed G2 point per lane (g2: S_N points), out = the table
+    def _lines_routines(self):
+        self.COLD = self.COLD + ("L2_ldbl", "L2_ladd", "L2_ladd_last")
+        tm = self.miller_temps()
+
+        def step(kind):
+            def body(p):
+                if kind == "dbl":
+                    p.dbl_step(self.R, (self.PX, self.PY), self.LINE)
+                else:
+                    p.add_step(self.R, (self.SX, self.SY), (self.PX, self.PY), self.LINE, update=(kind == "add"))
+                for i in range(3):
+                    p.A(self.LINE[i]).to(Tab(i))
+                p.wait()
+                p.e.salu(f"s_add_u32 s72, s72, {3 * SLOT_BYTES}")
+                p.e.salu("s_addc_u32 s73, s73, 0")
+            return body
+        self.l2_routine("L2_ldbl", step("dbl"), tm, local=self.LINE)
+        self.l2_routine("L2_ladd", step("add"), tm, local=self.LINE)
+        self.l2_routine("L2_ladd_last", step("last"), tm, local=self.LINE)
+
+    def lines_main(self, e, p):
+        L = self.lab
+        self.io_walk_begin(e, S_G2)
+        self.io_load_fq2_into_A(e, p)
+        p.to(self.QX)
+        p.to(self.R[0])
+        self.io_load_fq2_into_A(e, p)
+        p.to(self.QY)
+        p.to(self.R[1])
+        self.one_into_A(e)
+        p.set_A_fresh()
+        p.to(self.R[2])
+        p.to(self.PX)                                            # the lines are left WITHOUT an evaluation point: (Px, Py) = (1, 1)
+        p.to(self.PY)
+        p.reset_tags()
+        e.salu(f"s_mov_b64 {S_TAB}, {S_OUT}")
+        e.salu(f"s_mov_b32 s{S_TMP0}, 0x{self.n_fixed_lines * 3 * SLOT_BYTES:x}")
+        e.emit(f"v_lshrrev_b32_e32 v{V_IOOFF}, 3, v{V_IDX8}", vw=[V_IOOFF])       # (clamped) index of this lane's point
+        e.emit(f"v_mul_lo_u32 v{V_IOOFF}, v{V_IOOFF}, s{S_TMP0}", vw=[V_IOOFF])   # its part of the table
+        self.call2(e, "L2_ldbl")
+        first = self.naf_first
+        e.salu(f"s_mov_b32 s{S_I}, {first}")
+        e.label(L("L_mloop"))
+        e.salu(f"s_cmp_eq_u32 s{S_I}, {first}")
+        e.salu(f"s_cbranch_scc1 {L('L_mskip')}")
+        self.call2(e, "L2_ldbl")
+        e.label(L("L_mskip"))
+        e.salu(f"s_bitcmp1_b64 {S_NAF_NZ}, s{S_I}")
+        e.salu(f"s_cbranch_scc0 {L('L_mnoadd')}")
+        self._select_pm_q(e, p)
+        self.call2(e, "L2_ladd")
+        e.label(L("L_mnoadd"))
+        e.salu(f"s_sub_u32 s{S_I}, s{S_I}, 1")
+        e.salu(f"s_cbranch_scc0 {L('L_mloop')}")
+        self._frobenius_points(p)
+        self.call2(e, "L2_ladd")
+        p.reset_tags()
+        p.mov(self.SX, self.QX)
+        p.mov(self.SY, self.QY)
+        self.call2(e, "L2_ladd_last")
+        e.raw("s_waitcnt vmcnt(0)")
+        p.reset_tags()
 
     # ---------------------------------------------------------------------------------------------
     # G2 subgroup check (bn254_check_points_ex with BN254_CHECK_SUBGROUP): ark's `G2Affine::new` asserts it, the reference calls that on the

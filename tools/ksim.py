@@ -546,6 +546,8 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None, start_pc=None, 
                 m.scc = 1 if m.vsrc(a[0], False) < m.vsrc(a[1], False) else 0
             elif op == "s_cmp_ge_u32":
                 m.scc = 1 if m.vsrc(a[0], False) >= m.vsrc(a[1], False) else 0
+            elif op == "s_cmp_gt_u32":
+                m.scc = 1 if m.vsrc(a[0], False) > m.vsrc(a[1], False) else 0
             elif op == "s_cmp_le_u32":
                 m.scc = 1 if m.vsrc(a[0], False) <= m.vsrc(a[1], False) else 0
             elif op == "s_bitcmp1_b64":
