@@ -71,6 +71,8 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-power", action="store_true", help="do not sample the package power (rocm-smi) during the timed steps")
     ap.add_argument("--no-extra", action="store_true", help="skip configs[1] and configs[3] (reported under \"extra\" at N = 1)")
+    ap.add_argument("--no-host-path", action="store_true",
+                    help="skip the PCIe-inclusive host-pointer calls of `extra` (profiling runs: their chunk launches would enter the per-launch counter averages)")
     ap.add_argument("--no-scalar-latency", action="store_true",
                     help="skip the one-item calls of the scalar signatures in \"extra\" (profiling runs: their small launches would enter the kernel averages)")
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="wall-clock budget of the cpu_baseline legs (single thread + all cores)")
@@ -305,7 +307,7 @@ def spot_check(pkg, torch, g1, g2, out, n, positions, threads):
     return bool(np.array_equal(pkg.layout.to_aos(got, 48), want))
 
 
-def extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n, sample_power=False, scalar_latency=True, calib_peak=None):
+def extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n, sample_power=False, scalar_latency=True, calib_peak=None, host=True):
     """BASELINE.json configs[1] and configs[3] on one GPU (not the headline `value`); inputs: the resident 2^20 batch."""
     out = {}
 
@@ -389,7 +391,8 @@ def extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n, sample_power=F
         lay[name] = {"ms": ms, "GB_per_s": 2 * 8 * words * n / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": 2 * 8 * words * n / (ms * 1e-3) / HBM_PEAK}
         del dst
     out["layout kernels at 2^20 elements (roofline bound: hbm, 8 TB/s)"] = lay
-    out["host-resident batches: one host-pointer call, copies both ways included (PCIe-inclusive; never `value`)"] = host_path(pkg, torch, g1, g2, n, local_rank, dev)
+    if host:
+        out["host-resident batches: one host-pointer call, copies both ways included (PCIe-inclusive; never `value`)"] = host_path(pkg, torch, g1, g2, n, local_rank, dev)
     # the reference's functions are SCALAR (one pairing / one group per call): wall time of one call on one item, launch to completion,
     # on the throughput kernel (one item per lane) and on the lane-cooperative kernel that small batches take
     if scalar_latency and hasattr(pkg, "set_stream_latency"):
@@ -712,7 +715,7 @@ def run_rank(args):
                 rc = 3
         if rc == 0 and on_gpu and not multi and not args.no_extra and log2 == LOG2_SINGLE:
             rec["extra"] = extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n, sample_power=power is not None,
-                                           scalar_latency=not args.no_scalar_latency, calib_peak=calib_peak)
+                                           scalar_latency=not args.no_scalar_latency, calib_peak=calib_peak, host=not args.no_host_path)
         if rc == 0 and on_gpu and not multi and not args.no_cpu_baseline:
             m = min(n, 1 << 15)
             g1h = g1.view(8, n)[:, :m].cpu().numpy().view(np.uint64).reshape(-1).copy()

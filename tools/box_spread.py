@@ -28,9 +28,9 @@ def main():
     for f, r in runs:
         rows["configs[2]: 2^20 independent pairings (headline)"].append(r["roofline"]["kernel_ms_avg"])
         for k, v in r.get("extra", {}).items():
-            if k.startswith("configs[1]"):
+            if k.startswith("configs[1]:"):
                 rows["configs[1]: 2^16 independent pairings"].append(v["ms"])
-            if k.startswith("configs[3]"):
+            if k.startswith("configs[3]:"):
                 rows["configs[3]: Groth16 shape, 2^18 groups x 4 pairs"].append(v["ms"])
     units = {"configs[2]: 2^20 independent pairings (headline)": (1 << 20, W1), "configs[1]: 2^16 independent pairings": (1 << 16, W1),
              "configs[3]: Groth16 shape, 2^18 groups x 4 pairs": (1 << 18, W4)}

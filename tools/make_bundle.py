@@ -58,7 +58,7 @@ def main():
     g16 = None
     if bench:
         for k, v in (bench.get("extra") or {}).items():
-            if k.startswith("configs[3]"):
+            if k.startswith("configs[3]:"):
                 g16 = v
     bundle = {
         "what": "one lease: calibration -> bench.py --steps 20 -> rocprofv3 trace + PMC passes (k_pairing, k_mpairing) -> in-kernel clock -> calibration",
