@@ -3670,14 +3670,22 @@ class KernelBuilder:
                 self._tab_cursor(e, S_FIN, j)
                 e.emit(f"v_mov_b32_e32 v{V_IOOFF}, 0", vw=[V_IOOFF])
                 Pj = self.FIX_P[j]
+                # the three coefficients travel together (block A and two home temporaries): ONE exposed memory latency per line, not three
+                t1, t2 = p.tmp(), p.tmp()
+                assert t1.kind == "home" and t2.kind == "home"
+                p.A(Tab(0))
+                for t_, k_ in ((t1, 1), (t2, 2)):
+                    p.load(HOME0 + SLOT_DW * t_.idx, Tab(k_))
+                    p.slot_r[p.key(t_)], p.slot_v[p.key(t_)] = p.UNKNOWN, V_STORE
                 if kind == "034":                                   # (L0, H Py, -3 X^2 Px): dbl_step's line with the evaluation point put back
-                    p.A(Tab(0)).to(self.LINE[0])
-                    p.A(Tab(1)).mulfq_c1(Pj).to(self.LINE[1])
-                    p.A(Tab(2)).mulfq(Pj).to(self.LINE[2])
+                    p.to(self.LINE[0])
+                    p.A(t1).mulfq_c1(Pj).to(self.LINE[1])
+                    p.A(t2).mulfq(Pj).to(self.LINE[2])
                 else:                                               # (-mu Py, theta Px, L5): add_step's
-                    p.A(Tab(0)).mulfq_c1(Pj).to(self.LINE[0])
-                    p.A(Tab(1)).mulfq(Pj).to(self.LINE[1])
-                    p.A(Tab(2)).to(self.LINE[2])
+                    p.mulfq_c1(Pj).to(self.LINE[0])
+                    p.A(t1).mulfq(Pj).to(self.LINE[1])
+                    p.A(t2).to(self.LINE[2])
+                p.rel(t1, t2)
             return body
         for j in range(self.MAX_FIXED):
             self.l2_routine(f"L2_fix034_{j}", fixline("034", j), tm)
