@@ -279,7 +279,8 @@ int bn254_multi_pairing_check_batch_elems(const uint64_t* g1, const uint64_t* g2
  * bn254_multi_pairing_batch_dev(do_final_exp = 1) on the expanded pairs (the value after the final exponentiation does not see how the Miller value was
  * reached).  g1: n x (1 + k_fixed) G1 points, group-major like every multi-pairing batch (limb-major planes of n (1 + k) points; or element-major for
  * the `_elems` form); g2_var: n G2 points; out: n Fq12.  The `_check` form gives the `== MyFq12::one` verdict byte per group instead
- * (final_exp_native.rs:245-263).  The G2 points of the table must be in the r-torsion like any other (bn254_check_points_ex). */
+ * (final_exp_native.rs:245-263).  The G2 points of the table must be in the r-torsion like any other (bn254_check_points_ex).  One launch:
+ * n (1 + k_fixed) <= 2^23 points per call. */
 size_t bn254_g2_lines_bytes(size_t k_fixed);
 int bn254_g2_lines_dev(const uint64_t* g2_fixed, size_t k_fixed, uint64_t* table, int device, void* stream);
 int bn254_pairing_fixed_g2_batch_dev(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* table, size_t k_fixed, uint64_t* out, size_t n, int device,

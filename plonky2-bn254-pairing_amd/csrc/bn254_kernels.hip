@@ -557,10 +557,11 @@ bool takes_latency_kernel(size_t n_groups, size_t k, int device, void* stream) {
     latency_cfg(device, stream, &thr, &lanes);
     return (unsigned __int128)n_groups * 1000u <= (unsigned __int128)thr * CVM_PROGRAMS[prog].per_mille;
 }
-// can the throughput kernel take this batch straight from / into element-major arrays? (32-bit lane offsets: 128 bytes per G2 element, 384 per Fq12)
+// can the throughput kernel take this batch straight from / into element-major arrays?  The lane offsets are 32-bit: 128 bytes per G2 element, 384
+// per Fq12 -- 2^23 units keep the largest (the result's: 3.2 GB) below 4 GB; larger batches take the transposition route (64-bit plane walks)
 template <bool M, bool F>
 bool direct_elems_ok(size_t n_groups, size_t k, int device, void* stream) {
-    return k >= 1 && k <= MAX_K && n_groups * k < ((size_t)1 << 24) && !takes_latency_kernel<M, F>(n_groups, k, device, stream);
+    return k >= 1 && k <= MAX_K && n_groups * k <= ((size_t)1 << 23) && !takes_latency_kernel<M, F>(n_groups, k, device, stream);
 }
 
 template <bool M, bool F>
@@ -1050,7 +1051,7 @@ int bn254_g2_lines_dev(const uint64_t* g2_fixed, size_t k_fixed, uint64_t* table
 
 static int launch_fixed(const uint64_t* g1, const uint64_t* g2, const uint64_t* table, size_t k_fixed, uint64_t* out, size_t n, int io_mode, int device, void* stream) {
     if (n == 0) return BN254_OK;
-    if (!g1 || !g2 || !table || !out || k_fixed == 0 || k_fixed > (size_t)BN254_FIXED_MAX || n * (k_fixed + 1) >= ((size_t)1 << 24)) return BN254_ERR_INVALID_ARG;
+    if (!g1 || !g2 || !table || !out || k_fixed == 0 || k_fixed > (size_t)BN254_FIXED_MAX || n * (k_fixed + 1) > ((size_t)1 << 23)) return BN254_ERR_INVALID_ARG;      // (32-bit lane offsets of the element-major form: 384 n < 4 GB)
     LaunchCtx c;
     int rc = ctx_get(device, stream, 1, (n + BLOCK - 1) / BLOCK, &c);
     if (rc) return rc;
@@ -1088,7 +1089,7 @@ int bn254_pairing_fixed_g2_check_batch_dev(const uint64_t* g1, const uint64_t* g
 static int fixed_host(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* g2_fixed, size_t k_fixed, uint64_t* out, size_t n, bool elems, int out_order,
                       int device, void* stream) {
     if (n == 0) return BN254_OK;
-    if (!g1 || !g2_var || !g2_fixed || !out || k_fixed == 0 || k_fixed > (size_t)BN254_FIXED_MAX || n * (k_fixed + 1) >= ((size_t)1 << 24) ||
+    if (!g1 || !g2_var || !g2_fixed || !out || k_fixed == 0 || k_fixed > (size_t)BN254_FIXED_MAX || n * (k_fixed + 1) > ((size_t)1 << 23) ||
         (out_order != BN254_FQ12_MYFQ12 && out_order != BN254_FQ12_ARK))
         return BN254_ERR_INVALID_ARG;
     Stage s; uint64_t *d1, *d2, *df, *dt, *d3, *dl = nullptr; int rc;
