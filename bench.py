@@ -379,6 +379,21 @@ def extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n, sample_power=F
             "speedup_over_four_free_pairs": g16["ms"] / ms_f,
             "work_normalised_frac_of_nominal_issue_peak": groups / (ms_f * 1e-3) * W_MUL32_PER_GROTH16_GROUP / NOMINAL_ISSUE_PEAK_MUL32_PER_S,
             "note": "the algorithmic work of the four-pair product (SURVEY.md 8d) over this kernel's time: the fixed pairs' point steps are not executed per group at all"}
+        if hasattr(pkg, "pairing_fixed_g2_check_target_batch_dev"):
+            # a Groth16 verifier's whole check: gamma, delta fixed, e(alpha, beta) held as the comparison target: 1 + 2 pairs per proof, one verdict byte out
+            kv = 2
+            g1v = g1.view(8, groups, k)[:, :, :1 + kv].contiguous().view(-1)
+            tab2 = torch.zeros(pkg.g2_lines_bytes(kv) // 8, dtype=torch.int64, device=dev)
+            pkg.g2_lines_dev(g2fix.view(16, kf)[:, :kv].contiguous().view(-1), kv, tab2, device=local_rank, stream=stream)
+            pkg.pairing_fixed_g2_batch_dev(g1v, g2var, tab2, kv, o3, groups, device=local_rank, stream=stream)
+            target = o3.view(48, groups)[:, 0].contiguous().cpu().numpy().view("uint64")               # group 0's own product: exactly one group must match
+            verdict = torch.zeros(groups, dtype=torch.uint8, device=dev)
+            ms_v = timed(lambda: pkg.pairing_fixed_g2_check_target_batch_dev(g1v, g2var, tab2, kv, target, verdict, groups, device=local_rank, stream=stream), 2)
+            torch.cuda.synchronize(dev)
+            out["Groth16 verifier check: 2^18 proofs, e(A, B) e(L, gamma) e(C, delta) == e(alpha, beta) with gamma, delta fixed (bn254_pairing_fixed_g2_check_target_batch_dev)"] = {
+                "ms": ms_v, "proofs_per_s": groups / (ms_v * 1e-3), "kernels": "k_fpairing + k_is_one", "speedup_over_four_free_pairs": g16["ms"] / ms_v,
+                "verdicts_as_expected": bool(int(verdict[0]) == 1 and int(verdict.sum()) == 1)}
+            del tab2, g1v, verdict
         del exp, o3, table
     # data formats either side of the path: element-major <-> limb-major on the device (HBM-bound: every word read once, written once)
     HBM_PEAK = 8.0e12

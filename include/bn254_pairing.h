@@ -182,6 +182,12 @@ int bn254_multi_pairing_check_batch_dev(const uint64_t* g1, const uint64_t* g2, 
                                         int device, void* stream);
 int bn254_multi_pairing_check_batch(const uint64_t* g1, const uint64_t* g2, uint8_t* verdict, size_t n_groups, size_t k,
                                     int device, void* stream);
+/* The same check against a value the caller holds: verdict[g] = 1 iff group g's product equals `target` -- 48 words in HOST memory, MyFq12
+ * coefficient order, the canonical limbs the pairing entry points return (it travels in the kernel's arguments: no upload, capturable); NULL =
+ * MyFq12::one.  A Groth16 verifier keeps e(alpha, beta) with its verifying key and compares e(A, B) e(-L, gamma) e(-C, delta) with it: one pair
+ * less per proof than the product == one form. */
+int bn254_multi_pairing_check_target_batch_dev(const uint64_t* g1, const uint64_t* g2, const uint64_t* target, uint8_t* verdict, size_t n_groups,
+                                               size_t k, int device, void* stream);
 
 /* ---- one process, several GPUs: host pointers, contiguous slices of the batch per device
  * 0..n_devices-1, no exchange step; every device runs the same kernels on a private stream.  Independent
@@ -289,12 +295,20 @@ int bn254_pairing_fixed_g2_batch_elems_dev(const uint64_t* g1, const uint64_t* g
                                            int out_order, int device, void* stream);
 int bn254_pairing_fixed_g2_check_batch_dev(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* table, size_t k_fixed, uint8_t* verdict, size_t n,
                                            int device, void* stream);
+/* ... against `target` (48 host words, NULL = one; see bn254_multi_pairing_check_target_batch_dev): with gamma, delta fixed and e(alpha, beta) as the
+ * target a Groth16 proof costs 1 + 2 pairs, 4.97 M instructions instead of 5.74 M. */
+int bn254_pairing_fixed_g2_check_target_batch_dev(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* table, size_t k_fixed, const uint64_t* target,
+                                                  uint8_t* verdict, size_t n, int device, void* stream);
 /* host-pointer forms (what a binding uses): g2_fixed = the k_fixed fixed points themselves; the table is made inside the call (1.3 ms).  One launch of the
  * throughput kernel whatever n is (there is no lane-cooperative program for this shape: a single group costs 8 ms).  `_elems`: every array element-major. */
 int bn254_pairing_fixed_g2_batch(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* g2_fixed, size_t k_fixed, uint64_t* out, size_t n, int device,
                                  void* stream);
 int bn254_pairing_fixed_g2_batch_elems(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* g2_fixed, size_t k_fixed, uint64_t* out, size_t n,
                                        int out_order, int device, void* stream);
+/* a Groth16 verifier's whole pairing check on host structs (element-major as above): verdict[g] = 1 iff the group's product equals `target` (48 host words,
+ * MyFq12 order; NULL = MyFq12::one); one byte per group comes back instead of 384 */
+int bn254_pairing_fixed_g2_check_batch_elems(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* g2_fixed, size_t k_fixed, const uint64_t* target,
+                                             uint8_t* verdict, size_t n, int device, void* stream);
 
 /* ---- input validation (optional) ----------------------------------------------------------
  * The reference never checks for the point at infinity: its line functions read raw x / y (src/miller_loop_native.rs:10-44) and

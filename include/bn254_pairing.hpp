@@ -220,6 +220,18 @@ inline std::vector<MyFq12> pairing_fixed_g2_batch(const std::vector<G1Affine>& p
     return r;
 }
 
+// A Groth16 verifier's pairing check for a batch of proofs: verdict[g] = (product of group g's 1 + fixed.size() pairings == *target), target == nullptr:
+// MyFq12::one.  With gamma, delta as `fixed` and target = pairing(alpha, beta) a proof costs 1 + 2 pairs.
+inline std::vector<uint8_t> pairing_fixed_g2_check_batch(const std::vector<G1Affine>& ps, const std::vector<G2Affine>& qs, const std::vector<G2Affine>& fixed,
+                                                         const MyFq12* target = nullptr, int device = 0) {
+    const size_t n = qs.size(), kf = fixed.size();
+    if (kf == 0 || ps.size() != n * (kf + 1)) throw Panic(BN254_ERR_INVALID_ARG);
+    std::vector<uint8_t> verdict(n);
+    check(bn254_pairing_fixed_g2_check_batch_elems(detail::words(ps.data()), detail::words(qs.data()), detail::words(fixed.data()), kf,
+                                                   target ? detail::words(target) : nullptr, verdict.data(), n, device, nullptr));
+    return verdict;
+}
+
 // ark's implicit input contract for untrusted points (`G1Affine::new` / `G2Affine::new`: on the curve, G2 in the r-torsion -- the reference
 // calls the latter itself, miller_loop_native.rs:303,311, and panics there): throws Panic(BN254_ERR_INFINITY / _NOT_ON_CURVE /
 // _NOT_IN_SUBGROUP) like the reference would; per_point (optional) receives one flag byte per pair (2 | 4 | 8).

@@ -124,6 +124,9 @@ _PROTOS = {
     "bn254_pairing_fixed_g2_batch_dev": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "bn254_pairing_fixed_g2_batch_elems_dev": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "bn254_pairing_fixed_g2_check_batch_dev": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_pairing_fixed_g2_check_batch_elems": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_pairing_fixed_g2_check_target_batch_dev": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_multi_pairing_check_target_batch_dev": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "bn254_pairing_fixed_g2_batch": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "bn254_pairing_fixed_g2_batch_elems": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "bn254_miller_loop_batch_elems": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
@@ -473,6 +476,16 @@ def pairing_fixed_g2_batch(g1, g2_var, g2_fixed, k_fixed, n, device=0, elems=Fal
     return out
 
 
+def pairing_fixed_g2_check_batch_elems(g1, g2_var, g2_fixed, k_fixed, n, target=None, device=0):
+    """HOST element-major arrays (n x (1 + k_fixed) G1 structs, n G2, k_fixed fixed G2) -> n verdict bytes: product == target (48 words; None = one)"""
+    g1, g2_var, g2_fixed = _np_in(g1, 8, n * (1 + k_fixed)), _np_in(g2_var, 16, n), _np_in(g2_fixed, 16, k_fixed)
+    verdict = np.zeros(n, dtype=np.uint8)
+    keep, tp = _target_words(target)
+    _check(load_library().bn254_pairing_fixed_g2_check_batch_elems(_ptr(g1), _ptr(g2_var), _ptr(g2_fixed), k_fixed, tp, _ptr(verdict), n, device, None),
+           "pairing check (fixed G2)")
+    return verdict
+
+
 def g2_lines_bytes(k_fixed):
     return load_library().bn254_g2_lines_bytes(k_fixed)
 
@@ -499,6 +512,30 @@ def pairing_fixed_g2_check_batch_dev(g1, g2_var, table, k_fixed, verdict, n, dev
 
 def multi_pairing_check_batch_dev(g1, g2, verdict, n_groups, k, device=0, stream=None):
     _check(load_library().bn254_multi_pairing_check_batch_dev(_dev(g1), _dev(g2), _dev(verdict), n_groups, k, device, _stream(stream)),
+           "multi-pairing check")
+
+
+def _target_words(target):
+    """48 host words (MyFq12 order, canonical Montgomery limbs) of a comparison target, or None = MyFq12::one"""
+    if target is None:
+        return None, None
+    t = np.ascontiguousarray(np.asarray(target, dtype=np.uint64).reshape(-1))
+    if t.size != 48:
+        raise ValueError("target: one Fq12 = 48 words")
+    return t, _ptr(t)
+
+
+def pairing_fixed_g2_check_target_batch_dev(g1, g2_var, table, k_fixed, target, verdict, n, device=0, stream=None):
+    """verdict[g] = 1 iff the group's product equals `target` (48 host words as the pairing calls return them; None = one): a Groth16 verifier's
+    e(A, B) e(-L, gamma) e(-C, delta) == e(alpha, beta) with gamma, delta in the table"""
+    keep, tp = _target_words(target)
+    _check(load_library().bn254_pairing_fixed_g2_check_target_batch_dev(_dev(g1), _dev(g2_var), _dev(table), k_fixed, tp, _dev(verdict), n, device,
+                                                                         _stream(stream)), "pairing check (fixed G2)")
+
+
+def multi_pairing_check_target_batch_dev(g1, g2, target, verdict, n_groups, k, device=0, stream=None):
+    keep, tp = _target_words(target)
+    _check(load_library().bn254_multi_pairing_check_target_batch_dev(_dev(g1), _dev(g2), tp, _dev(verdict), n_groups, k, device, _stream(stream)),
            "multi-pairing check")
 
 

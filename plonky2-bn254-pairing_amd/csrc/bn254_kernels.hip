@@ -100,18 +100,17 @@ BN254_CVM_KERNEL(k_cvm_split, BN254_ASM_CVM_SPLIT)   // 36 bytes per slot: four 
 BN254_CVM_KERNEL(k_cvm_wide, BN254_ASM_CVM_WIDE)     // thirty-two lanes per item, two items per wave (launches of at most one wave per SIMD)
 BN254_CVM_KERNEL(k_cvm_full, BN254_ASM_CVM_FULL)     // sixty-four lanes per item: products of three and four pairings, at most one wave per SIMD
 
-// verdict[i] = 1 iff Fq12 element i equals MyFq12::one (coeffs[0] = R mod p in ark's Montgomery limbs, the rest 0):
-// the check pattern of final_exp_native.rs:245-263 (a Groth16-style product of pairings == 1), one byte per group.
-__global__ void __launch_bounds__(256) k_is_one(const uint64_t* __restrict__ f, uint8_t* __restrict__ verdict, size_t n) {
-    const uint64_t one[4] = BN254_FQ_ONE_LIMBS;
+// verdict[i] = 1 iff Fq12 element i equals the target (MyFq12 coefficient order, ark's Montgomery limbs; by value in the kernel arguments: nothing
+// to upload, capturable).  The default target is MyFq12::one (coeffs[0] = R mod p, the rest 0): the check pattern of final_exp_native.rs:245-263
+// (a Groth16-style product of pairings == 1), one byte per group; a verifier that holds e(alpha, beta) compares with THAT and saves the pair.
+struct Fq12Words { uint64_t w[48]; };
+__global__ void __launch_bounds__(256) k_is_one(const uint64_t* __restrict__ f, Fq12Words t, uint8_t* __restrict__ verdict, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         uint64_t diff = 0;
-        for (int c = 0; c < 12; c++)
-            for (int l = 0; l < 4; l++) diff |= f[((size_t)c * 4 + l) * n + i] ^ (c == 0 ? one[l] : 0ull);
+        for (int w = 0; w < 48; w++) diff |= f[(size_t)w * n + i] ^ t.w[w];
         verdict[i] = diff == 0 ? 1 : 0;
     }
 }
-
 // Pairs [j0, j0 + ks) of every k-pair group, as a contiguous ks-pair batch (groups of more than MAX_K pairs are walked in
 // sub-groups, launch_pairing): plane w of the source has n*k entries, pair j of group g at g*k + j.  HBM-bound, coalesced
 // on the destination side.
@@ -238,6 +237,18 @@ struct DeviceCtx {
 DeviceCtx g_ctx[64];
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { return BN254_ERR_HIP; } } while (0)
+
+// target: 48 words in HOST memory (canonical Montgomery limbs, what the pairing entry points return), or null = MyFq12::one
+static int launch_is_equal(const uint64_t* f, const uint64_t* target, uint8_t* verdict, size_t n, void* stream) {
+    Fq12Words t;
+    const uint64_t one[4] = BN254_FQ_ONE_LIMBS;
+    for (int w = 0; w < 48; w++) t.w[w] = target ? target[w] : (w < 4 ? one[w] : 0ull);
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_is_one, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, f, t, verdict, n);
+    HIPCHK(hipGetLastError());
+    return BN254_OK;
+}
 
 int check_device(int device) {
     int cnt = 0;
@@ -1016,8 +1027,8 @@ int bn254_check_points(const uint64_t* g1, const uint64_t* g2, size_t n, int dev
     return bn254_last_status(device, stream);
 }
 
-int bn254_multi_pairing_check_batch_dev(const uint64_t* g1, const uint64_t* g2, uint8_t* verdict, size_t n_groups, size_t k, int device,
-                                        void* stream) {
+int bn254_multi_pairing_check_target_batch_dev(const uint64_t* g1, const uint64_t* g2, const uint64_t* target, uint8_t* verdict, size_t n_groups, size_t k,
+                                               int device, void* stream) {
     if (n_groups == 0) return BN254_OK;
     if (!g1 || !g2 || !verdict || k == 0) return BN254_ERR_INVALID_ARG;
     LaunchCtx c;
@@ -1025,11 +1036,11 @@ int bn254_multi_pairing_check_batch_dev(const uint64_t* g1, const uint64_t* g2, 
     if (rc) return rc;
     if ((rc = ensure(c.s.get(), c.s->tmp, 384 * n_groups))) return rc;
     if ((rc = launch_pairing<true, true>(g1, g2, nullptr, (uint64_t*)c.s->tmp.p, n_groups, k, device, stream))) return rc;
-    size_t blocks = (n_groups + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_is_one, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, (const uint64_t*)c.s->tmp.p, verdict, n_groups);
-    HIPCHK(hipGetLastError());
-    return BN254_OK;
+    return launch_is_equal((const uint64_t*)c.s->tmp.p, target, verdict, n_groups, stream);
+}
+int bn254_multi_pairing_check_batch_dev(const uint64_t* g1, const uint64_t* g2, uint8_t* verdict, size_t n_groups, size_t k, int device,
+                                        void* stream) {
+    return bn254_multi_pairing_check_target_batch_dev(g1, g2, nullptr, verdict, n_groups, k, device, stream);
 }
 
 // ---- fixed G2 points (a Groth16 verifier's beta, gamma, delta: the same for every proof).  bn254_g2_lines_dev walks the point steps of each
@@ -1069,8 +1080,8 @@ int bn254_pairing_fixed_g2_batch_elems_dev(const uint64_t* g1, const uint64_t* g
     if (out_order != BN254_FQ12_MYFQ12 && out_order != BN254_FQ12_ARK) return BN254_ERR_INVALID_ARG;
     return launch_fixed(g1, g2_var, table, k_fixed, out, n, IO_IN_ELEMS | IO_OUT_ELEMS | (out_order == BN254_FQ12_ARK ? IO_OUT_ARK : 0), device, stream);
 }
-int bn254_pairing_fixed_g2_check_batch_dev(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* table, size_t k_fixed, uint8_t* verdict, size_t n, int device,
-                                           void* stream) {
+int bn254_pairing_fixed_g2_check_target_batch_dev(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* table, size_t k_fixed, const uint64_t* target,
+                                                  uint8_t* verdict, size_t n, int device, void* stream) {
     if (n == 0) return BN254_OK;
     if (!verdict) return BN254_ERR_INVALID_ARG;
     LaunchCtx c;
@@ -1078,11 +1089,11 @@ int bn254_pairing_fixed_g2_check_batch_dev(const uint64_t* g1, const uint64_t* g
     if (rc) return rc;
     if ((rc = ensure(c.s.get(), c.s->tmp, 384 * n))) return rc;
     if ((rc = launch_fixed(g1, g2_var, table, k_fixed, (uint64_t*)c.s->tmp.p, n, 0, device, stream))) return rc;
-    size_t blocks = (n + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_is_one, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, (const uint64_t*)c.s->tmp.p, verdict, n);
-    HIPCHK(hipGetLastError());
-    return BN254_OK;
+    return launch_is_equal((const uint64_t*)c.s->tmp.p, target, verdict, n, stream);
+}
+int bn254_pairing_fixed_g2_check_batch_dev(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* table, size_t k_fixed, uint8_t* verdict, size_t n, int device,
+                                           void* stream) {
+    return bn254_pairing_fixed_g2_check_target_batch_dev(g1, g2_var, table, k_fixed, nullptr, verdict, n, device, stream);
 }
 
 // host-pointer forms: stage, make the table (1.3 ms), launch, copy back.  `elems`: every array element-major (the fixed points too), result in out_order.
@@ -1109,6 +1120,21 @@ int bn254_pairing_fixed_g2_batch(const uint64_t* g1, const uint64_t* g2_var, con
 int bn254_pairing_fixed_g2_batch_elems(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* g2_fixed, size_t k_fixed, uint64_t* out, size_t n, int out_order,
                                        int device, void* stream) {
     return fixed_host(g1, g2_var, g2_fixed, k_fixed, out, n, true, out_order, device, stream);
+}
+// host pointers, element-major structs in, one verdict byte per group out (target: 48 host words or null = one): a Groth16 verifier's whole pairing check
+int bn254_pairing_fixed_g2_check_batch_elems(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* g2_fixed, size_t k_fixed, const uint64_t* target,
+                                             uint8_t* verdict, size_t n, int device, void* stream) {
+    if (n == 0) return BN254_OK;
+    if (!g1 || !g2_var || !g2_fixed || !verdict || k_fixed == 0 || k_fixed > (size_t)BN254_FIXED_MAX || n * (k_fixed + 1) > ((size_t)1 << 23)) return BN254_ERR_INVALID_ARG;
+    Stage s; uint64_t *d1, *d2, *df, *dt, *d3, *dl, *dv; int rc;
+    if ((rc = s.init(device, stream)) || (rc = s.up(g1, 64 * n * (k_fixed + 1), &d1)) || (rc = s.up(g2_var, 128 * n, &d2)) || (rc = s.up(g2_fixed, 128 * k_fixed, &df)) ||
+        (rc = s.up(nullptr, bn254_g2_lines_bytes(k_fixed), &dt)) || (rc = s.up(nullptr, 384 * n, &d3)) || (rc = s.up(nullptr, 128 * k_fixed, &dl)) ||
+        (rc = s.up(nullptr, (n + 7) & ~(size_t)7, &dv)))
+        return rc;
+    if ((rc = launch_layout(true, df, dl, 16, k_fixed, 0, device, stream)) || (rc = bn254_g2_lines_dev(dl, k_fixed, dt, device, stream)) ||
+        (rc = launch_fixed(d1, d2, dt, k_fixed, d3, n, IO_IN_ELEMS, device, stream)) || (rc = launch_is_equal(d3, target, (uint8_t*)dv, n, stream)))
+        return rc;
+    return finish_host(verdict, dv, n, device, stream);
 }
 
 int bn254_release_stream(int device, void* stream) {

@@ -48,6 +48,8 @@ extern "C" {
                                              stream: *mut c_void) -> c_int;
     fn bn254_pairing_fixed_g2_batch_elems(g1: *const u64, g2_var: *const u64, g2_fixed: *const u64, k_fixed: usize, out: *mut u64, n: usize, out_order: c_int,
                                           device: c_int, stream: *mut c_void) -> c_int;
+    fn bn254_pairing_fixed_g2_check_batch_elems(g1: *const u64, g2_var: *const u64, g2_fixed: *const u64, k_fixed: usize, target: *const u64, verdict: *mut u8,
+                                                n: usize, device: c_int, stream: *mut c_void) -> c_int;
 }
 const FQ12_MYFQ12: c_int = 0;
 const FQ12_ARK: c_int = 1;
@@ -267,5 +269,17 @@ pub fn pairing_fixed_g2_batch(ps: &[G1Affine], qs: &[G2Affine], fixed: &[G2Affin
     let (g1, g2, gf) = (elems_g1(ps), elems_g2(qs), elems_g2(fixed)); let mut out = vec![0u64; 48 * n];
     ok(unsafe { bn254_pairing_fixed_g2_batch_elems(g1.as_ptr(), g2.as_ptr(), gf.as_ptr(), kf, out.as_mut_ptr(), n, FQ12_MYFQ12, 0, core::ptr::null_mut()) });
     out.chunks_exact(48).map(unpack_fq12).collect()
+}
+/// New: a Groth16 verifier's pairing check for a batch of proofs: `product of the group's 1 + fixed.len() pairings == target` (`None`: `MyFq12::one`).
+/// With gamma, delta as `fixed` and `target = pairing(alpha, beta)` a proof costs 1 + 2 pairs.
+pub fn pairing_fixed_g2_check_batch(ps: &[G1Affine], qs: &[G2Affine], fixed: &[G2Affine], target: Option<&MyFq12>) -> Vec<bool> {
+    let (n, kf) = (qs.len(), fixed.len());
+    assert!(kf > 0 && kf <= 4 && ps.len() == n * (kf + 1));
+    if n == 0 { return Vec::new(); }
+    let (g1, g2, gf) = (elems_g1(ps), elems_g2(qs), elems_g2(fixed)); let mut v = vec![0u8; n];
+    let t: Option<[u64; 48]> = target.map(pack_fq12);
+    let tp = t.as_ref().map_or(core::ptr::null(), |w| w.as_ptr());
+    ok(unsafe { bn254_pairing_fixed_g2_check_batch_elems(g1.as_ptr(), g2.as_ptr(), gf.as_ptr(), kf, tp, v.as_mut_ptr(), n, 0, core::ptr::null_mut()) });
+    v.into_iter().map(|b| b != 0).collect()
 }
 #[allow(dead_code)] fn _ark_index(j: i32) -> i32 { unsafe { bn254_myfq12_to_ark_index(j) } }

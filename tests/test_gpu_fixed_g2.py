@@ -96,6 +96,23 @@ def test_fixed_g2_full_grid_and_verdicts():
     pk.pairing_fixed_g2_check_batch_dev(g1c, g2c, tab, 1, v, len(grp), 0, st)
     pk.last_status(0, st)
     assert v.tolist() == [1, 0, 1]
+    # ... against a target the verifier holds (e(alpha, beta) of a verifying key): e(P0, G2) e(P1, 3 G2) == e(4 G1, G2)
+    target = pk.pairing_batch(pk.layout.to_soa(H.g1_aos([R.g1_mul(G1, 4)]), 8), pk.layout.to_soa(H.g2_aos([G2]), 16), 1)
+    grp = [(R.g1_mul(G1, 7), R.g1_neg(G1)), (R.g1_mul(G1, 6), R.g1_neg(R.g1_mul(G1, 2))), (R.g1_mul(G1, 10), R.g1_neg(R.g1_mul(G1, 2)))]
+    g1c = t(pk.layout.to_soa(H.g1_aos([p for g in grp for p in g]), 8))
+    v = torch.full((len(grp),), 9, dtype=torch.uint8, device=dev)
+    pk.pairing_fixed_g2_check_target_batch_dev(g1c, g2c, tab, 1, target, v, len(grp), 0, st)
+    pk.last_status(0, st)
+    assert v.tolist() == [1, 0, 1]
+    g2x = t(pk.layout.to_soa(H.g2_aos([G2, Qf] * len(grp)), 16))                       # the same groups as free pairs
+    v2 = torch.full((len(grp),), 9, dtype=torch.uint8, device=dev)
+    pk.multi_pairing_check_target_batch_dev(g1c, g2x, target, v2, len(grp), 2, 0, st)
+    v3 = torch.full((len(grp),), 9, dtype=torch.uint8, device=dev)
+    pk.multi_pairing_check_batch_dev(g1c, g2x, v3, len(grp), 2, 0, st)                 # == one: only the middle group (6 - 6)
+    pk.last_status(0, st)
+    assert v2.tolist() == [1, 0, 1] and v3.tolist() == [0, 1, 0]
+    with pytest.raises(ValueError):
+        pk.pairing_fixed_g2_check_target_batch_dev(g1c, g2c, tab, 1, target[:47], v, len(grp), 0, st)
 
 
 def test_fixed_g2_argument_checks():
@@ -127,3 +144,10 @@ def test_fixed_g2_host_pointer_forms():
     got_e = pk.pairing_fixed_g2_batch(e1, e2, ef, kf, n, elems=True, out_order=pk.FQ12_ARK)
     idx = [pk.load_library().bn254_myfq12_to_ark_index(j) for j in range(12)]
     assert np.array_equal(got_e.reshape(n, 12, 4), H.to_aos(want, 48).reshape(n, 12, 4)[:, idx, :])
+    # the verdict form on the same host structs: target = one group's own value marks exactly the groups that share it
+    w = H.to_aos(want, 48).reshape(n, 48)
+    v = pk.pairing_fixed_g2_check_batch_elems(e1, e2, ef, kf, n, target=w[5])
+    assert v.dtype == np.uint8 and v.tolist() == [1 if np.array_equal(w[g], w[5]) else 0 for g in range(n)] and v[5] == 1 and v.sum() == 1
+    assert pk.pairing_fixed_g2_check_batch_elems(e1, e2, ef, kf, n).sum() == 0                  # none of the random products is one
+    with pytest.raises(pk.Bn254Error):
+        pk.pairing_fixed_g2_check_batch_elems(e1, e2, ef[: 16 * 1], 5, n)
