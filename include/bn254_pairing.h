@@ -286,7 +286,9 @@ int bn254_multi_pairing_check_batch_elems(const uint64_t* g1, const uint64_t* g2
  * reached).  g1: n x (1 + k_fixed) G1 points, group-major like every multi-pairing batch (limb-major planes of n (1 + k) points; or element-major for
  * the `_elems` form); g2_var: n G2 points; out: n Fq12.  The `_check` form gives the `== MyFq12::one` verdict byte per group instead
  * (final_exp_native.rs:245-263).  The G2 points of the table must be in the r-torsion like any other (bn254_check_points_ex).  One launch:
- * n (1 + k_fixed) <= 2^23 points per call. */
+ * n (1 + k_fixed) <= 2^23 points per call.  Small batches (below the latency threshold, bn254_set_latency_threshold; k_fixed <= 3) are a fraction of one
+ * grid of that kernel (8 ms whatever n is): the table carries the fixed points behind its lines, and such a call expands the pairs and runs the
+ * lane-cooperative k-pair program instead (one group of 1 + 3 pairs: 0.8 ms; the same limbs; its buffers are allocated on first use). */
 size_t bn254_g2_lines_bytes(size_t k_fixed);
 int bn254_g2_lines_dev(const uint64_t* g2_fixed, size_t k_fixed, uint64_t* table, int device, void* stream);
 int bn254_pairing_fixed_g2_batch_dev(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* table, size_t k_fixed, uint64_t* out, size_t n, int device,
@@ -299,8 +301,8 @@ int bn254_pairing_fixed_g2_check_batch_dev(const uint64_t* g1, const uint64_t* g
  * target a Groth16 proof costs 1 + 2 pairs, 4.97 M instructions instead of 5.74 M. */
 int bn254_pairing_fixed_g2_check_target_batch_dev(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* table, size_t k_fixed, const uint64_t* target,
                                                   uint8_t* verdict, size_t n, int device, void* stream);
-/* host-pointer forms (what a binding uses): g2_fixed = the k_fixed fixed points themselves; the table is made inside the call (1.3 ms).  One launch of the
- * throughput kernel whatever n is (there is no lane-cooperative program for this shape: a single group costs 8 ms).  `_elems`: every array element-major. */
+/* host-pointer forms (what a binding uses): g2_fixed = the k_fixed fixed points themselves; the table is made inside the call (1.3 ms).
+ * `_elems`: every array element-major. */
 int bn254_pairing_fixed_g2_batch(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* g2_fixed, size_t k_fixed, uint64_t* out, size_t n, int device,
                                  void* stream);
 int bn254_pairing_fixed_g2_batch_elems(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* g2_fixed, size_t k_fixed, uint64_t* out, size_t n,

@@ -1043,11 +1043,24 @@ int bn254_multi_pairing_check_batch_dev(const uint64_t* g1, const uint64_t* g2, 
     return bn254_multi_pairing_check_target_batch_dev(g1, g2, nullptr, verdict, n_groups, k, device, stream);
 }
 
+// The G2 points of n groups of 1 + kf pairs whose last kf points are the table's fixed ones, as limb-major planes of n (1 + kf) points (what the k-pair
+// programs read): pair 0 of group g = the group's own point (limb-major planes of n points, or element-major structs), pair j = fixed point j - 1
+// (planes of kf points, the tail of the line table).
+__global__ void __launch_bounds__(256) k_expand_fixed(const uint64_t* __restrict__ var, const uint64_t* __restrict__ fix, uint64_t* __restrict__ dst, size_t n, size_t kf,
+                                                      int var_elems) {
+    size_t k = kf + 1, per = n * k;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per * 16; i += (size_t)gridDim.x * blockDim.x) {
+        size_t w = i / per, r = i - w * per, g = r / k, j = r - g * k;
+        dst[i] = j ? fix[w * kf + (j - 1)] : (var_elems ? var[g * 16 + w] : var[w * n + g]);
+    }
+}
 // ---- fixed G2 points (a Groth16 verifier's beta, gamma, delta: the same for every proof).  bn254_g2_lines_dev walks the point steps of each
 // fixed point ONCE and leaves every step's line coefficients in a table; bn254_pairing_fixed_g2_batch_dev then computes, per group,
 // final_exp_native(multi_miller_loop_native([(P0, Q0), (P1, Qfix_1), ..., (Pk, Qfix_k)])) with the fixed pairs reduced to one line scaling and one
 // sparse multiplication per step (no point step, no per-lane point state): miller_loop_native.rs:192-282 with k of the b's shared by the batch.
-size_t bn254_g2_lines_bytes(size_t k_fixed) { return k_fixed * (size_t)BN254_FIXED_LINES * 3 * SLOT_BYTES; }
+static size_t g2_lines_only_bytes(size_t k_fixed) { return k_fixed * (size_t)BN254_FIXED_LINES * 3 * SLOT_BYTES; }
+// the lines, then the points themselves (limb-major planes of k_fixed points): small batches are served by the lane-cooperative k-pair programs on the expanded pairs
+size_t bn254_g2_lines_bytes(size_t k_fixed) { return g2_lines_only_bytes(k_fixed) + 128 * k_fixed; }
 
 int bn254_g2_lines_dev(const uint64_t* g2_fixed, size_t k_fixed, uint64_t* table, int device, void* stream) {
     if (!g2_fixed || !table || k_fixed == 0 || k_fixed > (size_t)BN254_FIXED_MAX) return BN254_ERR_INVALID_ARG;
@@ -1057,6 +1070,7 @@ int bn254_g2_lines_dev(const uint64_t* g2_fixed, size_t k_fixed, uint64_t* table
     hipLaunchKernelGGL(k_g2lines, dim3(1), dim3(BLOCK), LDS_BYTES, (hipStream_t)stream, (const uint64_t*)nullptr, g2_fixed, (const uint64_t*)nullptr, table, (uint32_t)k_fixed, 1u,
                        c.scratch, c.stride, c.status);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync((char*)table + g2_lines_only_bytes(k_fixed), g2_fixed, 128 * k_fixed, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return BN254_OK;
 }
 
@@ -1066,6 +1080,23 @@ static int launch_fixed(const uint64_t* g1, const uint64_t* g2, const uint64_t* 
     LaunchCtx c;
     int rc = ctx_get(device, stream, 1, (n + BLOCK - 1) / BLOCK, &c);
     if (rc) return rc;
+    if (takes_latency_kernel<true, true>(n, k_fixed + 1, device, stream)) {
+        // a batch this small is a fraction of one grid of the throughput kernel (8 ms whatever n is): expand the pairs and let the lane-cooperative k-pair
+        // program take them (a single group of 1 + 3 pairs: 0.74 ms) -- the same value, hence the same limbs (the final exponentiation does not see how the
+        // Miller value was reached)
+        StreamCtx* sc = c.s.get();
+        const size_t k = k_fixed + 1, np = n * k;
+        const bool in_e = io_mode & IO_IN_ELEMS, out_e = io_mode & IO_OUT_ELEMS;
+        if ((rc = ensure(sc, sc->sub[1], 128 * np)) || (in_e && (rc = ensure(sc, sc->sub[0], 64 * np))) || (out_e && (rc = ensure(sc, sc->sub[2], 384 * n)))) return rc;
+        uint64_t *p1 = (uint64_t*)sc->sub[0].p, *p2 = (uint64_t*)sc->sub[1].p, *p3 = (uint64_t*)sc->sub[2].p;
+        size_t blocks = (np * 16 + 255) / 256;
+        hipLaunchKernelGGL(k_expand_fixed, dim3((uint32_t)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream, g2,
+                           (const uint64_t*)((const char*)table + g2_lines_only_bytes(k_fixed)), p2, n, k_fixed, in_e ? 1 : 0);
+        HIPCHK(hipGetLastError());
+        if (in_e && (rc = launch_layout(true, g1, p1, 8, np, 0, device, stream))) return rc;
+        if ((rc = launch_pairing<true, true>(in_e ? p1 : g1, p2, nullptr, out_e ? p3 : out, n, k, device, stream))) return rc;
+        return out_e ? launch_layout(false, p3, out, 48, n, (io_mode & IO_OUT_ARK) ? BN254_FQ12_ARK : BN254_FQ12_MYFQ12, device, stream) : BN254_OK;
+    }
     hipLaunchKernelGGL(k_fpairing, dim3(c.grid), dim3(BLOCK), LDS_BYTES, (hipStream_t)stream, g1, g2, table, out, (uint32_t)n, (uint32_t)k_fixed | ((uint32_t)io_mode << 28),
                        c.scratch, c.stride, c.status);
     HIPCHK(hipGetLastError());

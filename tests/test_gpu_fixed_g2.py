@@ -126,14 +126,24 @@ def test_fixed_g2_argument_checks():
         assert e.value.status == pk.ERR_INVALID_ARG
     with pytest.raises(pk.Bn254Error):
         pk.g2_lines_dev(z, 5, z)
-    assert pk.g2_lines_bytes(3) == 3 * 87 * 3 * 72
+    assert pk.g2_lines_bytes(3) == 3 * 87 * 3 * 72 + 3 * 128              # the lines, then the points themselves
 
 
-def test_fixed_g2_host_pointer_forms():
+@pytest.mark.parametrize("route", ["throughput", "lane-cooperative"])
+def test_fixed_g2_host_pointer_forms(route):
     """bn254_pairing_fixed_g2_batch / _elems on host arrays (the table is made inside the call) against bn254_multi_pairing_batch on the expanded pairs"""
     pk = H.pkg()
     n, kf = 130, 2
     k = 1 + kf
+    old = pk.get_latency_threshold()
+    pk.set_latency_threshold(0 if route == "throughput" else old)       # 130 groups: below the default threshold the call expands the pairs for the k-pair program
+    try:
+        _host_forms(pk, n, kf, k)
+    finally:
+        pk.set_latency_threshold(old)
+
+
+def _host_forms(pk, n, kf, k):
     Ps, Qs = H.subgroup_points(n * k + kf, seed=95)
     P, Qv, Qf = list(Ps[: n * k]), [Qs[g * k] for g in range(n)], list(Qs[n * k:])
     e1, e2, ef = H.g1_aos(P), H.g2_aos(Qv), H.g2_aos(Qf)
@@ -151,3 +161,39 @@ def test_fixed_g2_host_pointer_forms():
     assert pk.pairing_fixed_g2_check_batch_elems(e1, e2, ef, kf, n).sum() == 0                  # none of the random products is one
     with pytest.raises(pk.Bn254Error):
         pk.pairing_fixed_g2_check_batch_elems(e1, e2, ef[: 16 * 1], 5, n)
+
+
+@pytest.mark.parametrize("kf", [1, 2, 3, 4])
+def test_fixed_g2_small_batches_take_the_lane_cooperative_programs(kf):
+    """Below the latency threshold a fixed-G2 call expands its pairs (the table carries the points) and runs the k-pair lane-cooperative program: the same
+    limbs as k_fpairing, 0.8 ms instead of 8; k_fixed = 4 (five pairs: no such program) stays on the throughput kernel."""
+    import torch
+    pk = H.pkg()
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev)
+    k = 1 + kf
+    idx = [pk.load_library().bn254_myfq12_to_ark_index(j) for j in range(12)]
+    for n in (1, 5, 300):
+        g1, g2var, g2exp, table = _setup(pk, torch, dev, st, n, kf, 0x5A11 + 16 * kf + n)
+        pk.set_stream_latency(0, -1, 0, st)
+        try:
+            want = torch.zeros(48 * n, dtype=torch.int64, device=dev)
+            pk.pairing_fixed_g2_batch_dev(g1, g2var, table, kf, want, n, 0, st)
+            assert pk.last_kernel(0, st) == 1
+        finally:
+            pk.set_stream_latency(pk.LATENCY_INHERIT, -1, 0, st)
+        got = torch.full((48 * n + 8,), -7, dtype=torch.int64, device=dev)
+        pk.pairing_fixed_g2_batch_dev(g1, g2var, table, kf, got, n, 0, st)
+        assert pk.last_kernel(0, st) == 1 if kf == 4 else pk.last_kernel(0, st) in (16, 32, 64)
+        e1, e2 = torch.empty_like(g1), torch.empty_like(g2var)
+        pk.soa_to_elems_dev(g1, e1, 8, n * k, 0, 0, st)
+        pk.soa_to_elems_dev(g2var, e2, 16, n, 0, 0, st)
+        eo = torch.full((48 * n + 8,), -7, dtype=torch.int64, device=dev)
+        pk.pairing_fixed_g2_batch_elems_dev(e1, e2, table, kf, eo, n, pk.FQ12_ARK, 0, st)
+        v = torch.full((n,), 9, dtype=torch.uint8, device=dev)
+        target = want.view(48, n)[:, n - 1].contiguous().cpu().numpy().view(np.uint64)
+        pk.pairing_fixed_g2_check_target_batch_dev(g1, g2var, table, kf, target, v, n, 0, st)
+        pk.last_status(0, st)
+        assert torch.equal(got[: 48 * n], want) and bool((got[48 * n:] == -7).all()) and int(want.abs().sum()) != 0
+        assert torch.equal(eo[: 48 * n].view(n, 12, 4), want.view(48, n).t().contiguous().view(n, 12, 4)[:, idx, :]) and bool((eo[48 * n:] == -7).all())
+        assert v.tolist() == [0] * (n - 1) + [1]
