@@ -1058,7 +1058,7 @@ __global__ void __launch_bounds__(256) k_expand_fixed(const uint64_t* __restrict
 // fixed point ONCE and leaves every step's line coefficients in a table; bn254_pairing_fixed_g2_batch_dev then computes, per group,
 // final_exp_native(multi_miller_loop_native([(P0, Q0), (P1, Qfix_1), ..., (Pk, Qfix_k)])) with the fixed pairs reduced to one line scaling and one
 // sparse multiplication per step (no point step, no per-lane point state): miller_loop_native.rs:192-282 with k of the b's shared by the batch.
-static size_t g2_lines_only_bytes(size_t k_fixed) { return k_fixed * (size_t)BN254_FIXED_LINES * 3 * SLOT_BYTES; }
+static size_t g2_lines_only_bytes(size_t k_fixed) { return k_fixed * (size_t)BN254_FIXED_LINES * BN254_FIXED_LINE_SLOTS * SLOT_BYTES; }
 // the lines, then the points themselves (limb-major planes of k_fixed points): small batches are served by the lane-cooperative k-pair programs on the expanded pairs
 size_t bn254_g2_lines_bytes(size_t k_fixed) { return g2_lines_only_bytes(k_fixed) + 128 * k_fixed; }
 

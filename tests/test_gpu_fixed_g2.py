@@ -126,7 +126,7 @@ def test_fixed_g2_argument_checks():
         assert e.value.status == pk.ERR_INVALID_ARG
     with pytest.raises(pk.Bn254Error):
         pk.g2_lines_dev(z, 5, z)
-    assert pk.g2_lines_bytes(3) == 3 * 87 * 3 * 72 + 3 * 128              # the lines, then the points themselves
+    assert pk.g2_lines_bytes(3) == 3 * 87 * 4 * 72 + 3 * 128              # the lines, then the points themselves
 
 
 @pytest.mark.parametrize("route", ["throughput", "lane-cooperative"])

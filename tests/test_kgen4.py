@@ -654,7 +654,7 @@ def test_fixed_g2_kernels(vec):
     TABB = 0x700000
     kl = K4P.KernelBuilder(lines=True)
     lines_l = _concretize(kl.build()) + ["s_endpgm"]
-    for n_ in ("L2_ldbl", "L2_ladd", "L2_ladd_last"):
+    for n_ in ("L2_ldbl", "L2_ladd", "L2_ladd_last", "L2_linv", "L2_lnorm"):
         assert kl._check_routine(n_) <= K4P.V_CAP
     gmem = {}
     g2f = _soa([HX(vec["g2"][i]) for i in fixed_idx])
@@ -670,13 +670,15 @@ def test_fixed_g2_kernels(vec):
         m.v[255] = ln
         S.run(lines_l, m)
         gmem = {a: v for a, v in m.gmem.items() if TABB <= a < TABB + (1 << 20)}
-    tab_bytes = kf * kl.n_fixed_lines * 3 * K4.SLOT_BYTES
+    tab_bytes = kf * kl.n_fixed_lines * kl.FIX_LINE_SLOTS * K4.SLOT_BYTES
     assert len(gmem) == tab_bytes // 4 and kl.n_fixed_lines == 87
     kb = K4P.KernelBuilder(fixed=True)
     assert kb.n_fixed_lines == kl.n_fixed_lines and kb.naf == kl.naf
     lines_f = _concretize(kb.build()) + ["s_endpgm"]
-    for n_ in [f"L2_fix{k_}_{j}" for k_ in ("034", "235") for j in range(4)] + ["L2_fsp034", "L2_fsp235"]:
+    assert len(kb.fsp_variant) == 4
+    for n_ in [f"L2_fix_{j}" for j in range(4)] + sorted(set(kb.fsp_variant)):
         assert kb._check_routine(n_) <= K4P.V_CAP
+    assert kb.certify_values(1)["max_stored"] <= K4P.V_CAP          # (walks the fixed lines of four pairs behind every step: every variant's entry bounds)
     want = None
     for pi, qi in zip(grp[lane], [grp[lane][0]] + fixed_idx):
         # e(P_pi, Q_qi): the golden Miller values are for equal indices only -- compute through the big-int restatement

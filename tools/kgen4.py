@@ -616,6 +616,24 @@ class L1v4:
         for r in extra:
             self.pool.free_regs.remove(r)
 
+    def r_mul2a(self):
+        """A <- A + H0*H1 + H2*H3 (Fq2 products): the dual column pass of r_mul3 with two Karatsuba products, the value in A ADDED to the result
+        (its limbs enter the upper half of the sums: one multiply-add per limb, the result comes out normalised like any pass result).  The
+        sparse multiplication by a line whose constant coefficient is ONE (the table lines of the fixed-G2 kernels).  Same operand rules, scratch
+        and kept difference vectors (of home blocks 1 and 3) as r_mul3; block B is not touched."""
+        blocks = [(HOME0, HOME0 + SLOT_DW, 1), (HOME0 + 2 * SLOT_DW, HOME0 + 3 * SLOT_DW, 3)]
+        extra = list(range(HOME0 + 6 * SLOT_DW, HOME0 + 9 * SLOT_DW))
+        if MUL3_KEEP_DY:
+            terms = [(self.fq2(x), self.fq2(y), None, self.MUL3_DY[w]) for x, y, w in blocks]
+            extra = [r for r in extra if not any(r in v for v in self.MUL3_DY.values())]
+        else:
+            terms = [(self.fq2(x), self.fq2(y)) for x, y, _ in blocks]
+        self.pool.free_regs += extra
+        a = self.fq2(A0)
+        self.kfips(terms, [], a[0], a[1], inject=(a[0], a[1]))
+        for r in extra:
+            self.pool.free_regs.remove(r)
+
     def r_sqr(self):
         """(a0 + a1 u)^2 = (a0+a1)(a0-a1) + 2 a0 a1 u ; both passes write in place.  A normalised."""
         a0, a1 = self.fq2(A0)
@@ -1129,11 +1147,14 @@ def routine_body(e, name):
     if name == "mul3" and MUL3_KEEP_DY:
         for w in ("B", 1, 3):
             g.mul3_dy(w)
+    if name == "mul2a" and MUL3_KEEP_DY:
+        for w in (1, 3):
+            g.mul3_dy(w)
     getattr(g, "r_" + name)()
     return g
 
 
-L1V4_NAMES = ["mul", "mul3", "mul6", "dblstep", "addstep", "sqr", "sqr4c", "sqr4cx", "mulfq", "add", "sub", "rsub", "dbl", "neg", "negc1", "mulxi", "mulxir", "norm",
+L1V4_NAMES = ["mul", "mul3", "mul2a", "mul6", "dblstep", "addstep", "sqr", "sqr4c", "sqr4cx", "mulfq", "add", "sub", "rsub", "dbl", "neg", "negc1", "mulxi", "mulxir", "norm",
               "redn", "fqmul", "fqsqr", "cvtin", "cvtout"]
 
 if __name__ == "__main__":

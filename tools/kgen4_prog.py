@@ -758,6 +758,28 @@ class Prog:
         self.rA = self.r_norm()
         return self                                  # (all five other operands survive)
 
+    def mul2a(self):
+        """A <- A + H0*H1 + H2*H3 (the value in A enters the pass's upper half: no product for it, no separate addition pass)"""
+        rA = self.rA if self.rA is not None else self.UNKNOWN
+        worst = mag(self.eH[0]) * mag(self.eH[1]) + mag(self.eH[2]) * mag(self.eH[3])
+        self._need(2 * NL * worst + mag(rA) / 256.0 <= COL_BUDGET, f"mul2a {worst}")
+        vs = (self.vA, *self.vH[:4])
+        self._need(max(vs) <= V_CAP, f"mul2a operand value {vs}")
+        self._need(max(mag(rA), *(mag(h) for h in self.eH[:4])) <= 3.9, "mul2a operand limbs")
+        assert getattr(self, "_scratch_reserved", ()) == self.MUL3_SCRATCH, "mul2a needs home blocks 6, 7, 8 as scratch"
+        self.vA = self.vA + 2 * (self.vH[0] * self.vH[1] + self.vH[2] * self.vH[3]) / K_RP + 0.5
+        if MUL3_KEEP_DY:
+            for w, tag in ((1, self.tagH[1]), (3, self.tagH[3])):
+                assert tag is not None
+                if self._dy_for[w] is not tag:
+                    self.wait()
+                    L1v4(self.e).mul3_dy(w)
+                    self._dy_for[w] = tag
+                    self._count("mul3_dy")
+        self._raw_call("mul2a")
+        self.rA = self.r_norm()
+        return self
+
     # ================================================================ L2 algorithms: Fq6 / Fq12
     def _load_norm_sum(self, blk, s1, s2):
         """register block blk <- s1 (+ s2), NORMALISED limbs (the fused routines take one-unit operands)."""
@@ -1147,6 +1169,31 @@ class Prog:
         between(4)
         self.ldH(0, F[2]).ldH(2, F[1])
         self.A(F[5]).mul3(L0).to(F[5])
+        for k in range(3):
+            self.mov(F[k], c[k])
+        self.rel(L3x, L4x, *c)
+        self.release_blocks()
+
+    def mul_by_034_one(self, F, L3, L4):
+        """f *= 1 + L3 w^3 + L4 w^4: the line's constant coefficient is ONE (a table line of a fixed G2 point, divided by its own constant coefficient
+        when the table was made), so every output is its own input plus TWO products -- six mul2a passes, 12 Fq2 products instead of 18.
+            c0 = a0 + a3 xiL3 + a2 xiL4   c1 = a1 + a4 xiL3 + a3 xiL4   c2 = a2 + a5 xiL3 + a4 xiL4
+            c3 = a3 + a0 L3 + a5 xiL4     c4 = a4 + a1 L3 + a0 L4       c5 = a5 + a2 L3 + a1 L4"""
+        self.marker("mul034one")
+        self.reserve_blocks(scratch=self.MUL3_SCRATCH)
+        L3x, L4x = self.tmp(), self.tmp()
+        self.A(L3).mulxi().to(L3x)
+        self.A(L4).mulxi().to(L4x)
+        c = [self.tmp() for _ in range(3)]
+        for k, (i0, i3, i4) in enumerate(((0, 3, 2), (1, 4, 3), (2, 5, 4))):
+            self.ldH(1, L3x).ldH(3, L4x).ldH(0, F[i3]).ldH(2, F[i4])
+            self.A(F[i0]).mul2a().to(c[k])
+        self.ldH(1, L3).ldH(3, L4x).ldH(0, F[0]).ldH(2, F[5])
+        self.A(F[3]).mul2a().to(F[3])
+        self.ldH(1, L3).ldH(3, L4).ldH(0, F[1]).ldH(2, F[0])
+        self.A(F[4]).mul2a().to(F[4])
+        self.ldH(0, F[2]).ldH(2, F[1])
+        self.A(F[5]).mul2a().to(F[5])
         for k in range(3):
             self.mov(F[k], c[k])
         self.rel(L3x, L4x, *c)
@@ -2027,11 +2074,19 @@ class KernelBuilder:
         p.cold = self._cold
         return e, p
 
-    def l2_routine(self, name, body, temps, local=()):
+    def l2_routine(self, name, body, temps, local=(), entry=None):
         """Also records the value bounds (units of p) the routine leaves in every non-temporary slot, given that all
-        its inputs were below V_STORE p: the basis of the inductive certification in certify_values()."""
+        its inputs were below V_STORE p: the basis of the inductive certification in certify_values().
+        entry: {slot key: bound} -- TIGHTER bounds this routine may assume for some of its inputs (its call sites guarantee them:
+        certify_values() checks every call against them)."""
         self._cold = name in self.COLD
         e, p = self.new_prog(temps)
+        if entry:
+            assert all(v <= V_STORE for v in entry.values())
+            p.entry_v = dict(entry)
+            if not hasattr(self, "l2_entry"):
+                self.l2_entry = {}
+            self.l2_entry[name] = dict(entry)
         # `local`: named slots that are written and consumed inside this routine (the line coefficients): no contract at its exit
         p.temp_keys = p.temp_keys | {Prog.key(s_) for s_ in local}
         e.label(self.lab(name))
@@ -2240,13 +2295,23 @@ class KernelBuilder:
         """Returns a report dict (call sequence, largest stored bound); raises on any contract violation."""
         worst, calls, seq = 0.0, 0, []
 
+        bound = {}                               # what the walked routines left in the slots (only read where a routine assumes less than the contract)
+        fixed_after = ("L2_dblfirst", "L2_dblmul", "L2_addmul", "L2_addmul_last") if self.fixed else ()
+
         def run(name, label=None):
             nonlocal worst, calls
             worst = max(worst, self._check_routine(name))
+            for k_, v_ in getattr(self, "l2_entry", {}).get(name, {}).items():
+                assert bound.get(k_, V_STORE) <= v_, f"{name} assumes {v_} p in {k_}, its caller leaves {bound.get(k_, V_STORE)}"
+            bound.update(self.l2_exit[name])
             calls += 1
             seq.append(label or name)
             if name in ("L2_descale", "L2_inv"):
                 seq.append("L2_fqinv")           # nested: the Fq inversion (fixed exponent)
+            if name in fixed_after:              # the fixed-G2 kernel: the current table line of every fixed pair (the most there can be)
+                for j in range(self.MAX_FIXED):
+                    run(f"L2_fix_{j}")
+                    run(self.fsp_variant[j])
 
         assert self.main_prog.max_v <= V_STORE, "the main program stores across routine boundaries only"
         fis = self.fission and k_pairs <= FIS_MAX_K
@@ -3645,65 +3710,84 @@ class KernelBuilder:
     # leaves every step's line coefficients in a table; the `fixed` kernel is k_pairing for the group's own pair plus, per step and fixed
     # pair, one table line scaled by that pair's (Px, Py) and one sparse multiplication -- no point step, no R anywhere but the variable
     # pair's resident one.  Same chain as the fused kernels (the table is made for it); any Fq2 factor of a line dies in the easy part.
-    #   table: [fixed pair][line][3 slots of 72 bytes], lines in the order the loop consumes them: the first doubling, then per digit the
-    #   doubling and (digit != 0) the addition, then the two Frobenius steps.
+    #   table: [fixed pair][line][FIX_LINE_SLOTS slots of 72 bytes], lines in the order the loop consumes them: the first doubling, then per digit
+    #   the doubling and (digit != 0) the addition, then the two Frobenius steps.
     @property
     def n_fixed_lines(self):
         return 1 + self.naf_first + sum(1 for d in self.naf[:self.naf_first + 1] if d) + 2
 
+    FIX_LINE_SLOTS = 4        # table slots per line: denominator (only while the table is made), B, C, prefix product (ditto)
+
     def _tab_cursor(self, e, base, pair):
-        """S_TAB <- base + pair * (lines per pair) * 216 + S_TABCUR"""
+        """S_TAB <- base + pair * (bytes per pair) + S_TABCUR"""
         lo, hi = (int(x) for x in base.strip("s[]").split(":"))
-        off = pair * self.n_fixed_lines * 3 * SLOT_BYTES
+        off = pair * self.n_fixed_lines * self.FIX_LINE_SLOTS * SLOT_BYTES
         e.salu(f"s_add_u32 s72, s{lo}, s{S_TABCUR}")
         e.salu(f"s_addc_u32 s73, s{hi}, 0")
         if off:
             e.salu(f"s_add_u32 s72, s72, 0x{off:x}")
             e.salu("s_addc_u32 s73, s73, 0")
 
+    # Every table line is left in ONE shape, 1 + B Py w^3 + C Px w^4:
+    #   a doubling's line  L0 + H Py w^3 - 3 X^2 Px w^4            is divided by L0;
+    #   an addition's line -mu Py w^2 + theta Px w^3 + L5 w^5      is multiplied by w / (xi L5)   (w^6 = xi).
+    # The factors 1 / L0, 1 / (xi L5) lie in Fq2; the w's of the lines that are followed by a squaring end up as even powers, and the two Frobenius lines
+    # bring w^2: everything lies in Fq6 and dies in the easy part like the projective lines' own scales.  With the constant coefficient ONE a sparse
+    # multiplication is six two-product passes (Prog.mul_by_034_one) instead of six three-product ones, and one routine serves every line.
     def _fixed_routines(self):
         tm = self.miller_temps(extra=(self.SX, self.SY))
+        n_last = sum(1 for d in self.naf[:1] if d) + 2            # lines behind the last squaring: the digit-0 addition (none: 6x + 2 is even) + the Frobenius pair
+        assert n_last % 2 == 0, "an odd number of w factors would survive the easy part"
 
-        def fixline(kind, j):
+        def fixline(j):
             def body(p):
                 e = p.e
                 self._tab_cursor(e, S_FIN, j)
                 e.emit(f"v_mov_b32_e32 v{V_IOOFF}, 0", vw=[V_IOOFF])
                 Pj = self.FIX_P[j]
-                # the three coefficients travel together (block A and two home temporaries): ONE exposed memory latency per line, not three
-                t1, t2 = p.tmp(), p.tmp()
-                assert t1.kind == "home" and t2.kind == "home"
-                p.A(Tab(0))
-                for t_, k_ in ((t1, 1), (t2, 2)):
-                    p.load(HOME0 + SLOT_DW * t_.idx, Tab(k_))
-                    p.slot_r[p.key(t_)], p.slot_v[p.key(t_)] = p.UNKNOWN, V_STORE
-                if kind == "034":                                   # (L0, H Py, -3 X^2 Px): dbl_step's line with the evaluation point put back
-                    p.to(self.LINE[0])
-                    p.A(t1).mulfq_c1(Pj).to(self.LINE[1])
-                    p.A(t2).mulfq(Pj).to(self.LINE[2])
-                else:                                               # (-mu Py, theta Px, L5): add_step's
-                    p.mulfq_c1(Pj).to(self.LINE[0])
-                    p.A(t1).mulfq(Pj).to(self.LINE[1])
-                    p.A(t2).to(self.LINE[2])
-                p.rel(t1, t2)
+                # the two coefficients travel together (block A and a home temporary): ONE exposed memory latency per line
+                t1 = p.tmp()
+                assert t1.kind == "home"
+                p.A(Tab(1))
+                p.load(HOME0 + SLOT_DW * t1.idx, Tab(2))
+                p.slot_r[p.key(t1)], p.slot_v[p.key(t1)] = p.UNKNOWN, V_STORE
+                p.mulfq_c1(Pj).to(self.LINE[1])                     # B Py
+                p.A(t1).mulfq(Pj).to(self.LINE[2])                  # C Px
+                p.rel(t1)
             return body
         for j in range(self.MAX_FIXED):
-            self.l2_routine(f"L2_fix034_{j}", fixline("034", j), tm)
-            self.l2_routine(f"L2_fix235_{j}", fixline("235", j), tm)
-        self.l2_routine("L2_fsp034", lambda p: p.mul_by_034(self.F, *self.LINE), tm)
-        self.l2_routine("L2_fsp235", lambda p: p.mul_by_235(self.F, *self.LINE), tm)
+            self.l2_routine(f"L2_fix_{j}", fixline(j), tm)
+        # A pass of the unit-coefficient multiplication ADDS to its input (out = a + two products / R' +- p/2): f grows by about 0.6 p per line instead
+        # of contracting, and a routine that had to assume the general 4 p at its entry would reduce every output (six reducing chains per line).
+        # So the multiplication is built per position j in the run of fixed lines, each variant assuming what its predecessor leaves (the first: the
+        # largest bounds the own pair's routines leave); a variant whose output would pass the contract reduces there, and a later position
+        # whose entry bounds an earlier variant covers reuses it.  certify_values() checks every call against the assumed bounds.
+        Fk = [Prog.key(s_) for s_ in self.F]
+        before = ("L2_dblfirst", "L2_dblmul", "L2_addmul", "L2_addmul_last")
+        ent = {k: max(max(self.l2_exit[n].get(k, 0.0) for n in before), 0.51) for k in Fk}
+        line = {Prog.key(s_): max(self.l2_exit[f"L2_fix_{j}"][Prog.key(s_)] for j in range(self.MAX_FIXED)) for s_ in self.LINE[1:]}     # (the scaled coefficients: 0.6 p)
+        variants, self.fsp_variant = [], []
+        for j in range(self.MAX_FIXED):
+            cover = next((v for v in variants if all(ent[k] <= v[1][k] for k in Fk)), None)
+            if cover is None:
+                name = f"L2_fsp1_{len(variants)}"
+                self.l2_routine(name, lambda p: p.mul_by_034_one(self.F, self.LINE[1], self.LINE[2]), tm, entry={**ent, **line})
+                cover = (name, dict(ent), {k: self.l2_exit[name][k] for k in Fk})
+                variants.append(cover)
+            self.fsp_variant.append(cover[0])
+            ent = dict(cover[2])
 
-    def _fixed_lines(self, e, kind):
+    def _fixed_lines(self, e):
         """f *= the current line of every fixed pair (S_K of them); the table cursor moves on by one line"""
         u = self.uid()
         done = self.lab(f"L_fx_done_{u}")
         for j in range(self.MAX_FIXED):
             e.salu(f"s_cmp_gt_u32 s{S_K}, {j}")
             e.salu(f"s_cbranch_scc0 {done}")
-            self.call2(e, f"L2_fix{kind}_{j}")
-            self.call2(e, f"L2_fsp{kind}")
+            self.call2(e, f"L2_fix_{j}")
+            self.call2(e, self.fsp_variant[j])
         e.label(done)
-        e.salu(f"s_add_u32 s{S_TABCUR}, s{S_TABCUR}, {3 * SLOT_BYTES}")
+        e.salu(f"s_add_u32 s{S_TABCUR}, s{S_TABCUR}, {self.FIX_LINE_SLOTS * SLOT_BYTES}")
 
     def miller_main_fixed(self, e, p):
         """g1: 1 + S_K points per group, group-major (the group's own P first, then the P_j of the fixed pairs); g2: the group's own Q;
@@ -3745,7 +3829,7 @@ class KernelBuilder:
         p.reset_tags()
         e.salu(f"s_mov_b32 s{S_TABCUR}, 0")
         self.call2(e, "L2_dblfirst")
-        self._fixed_lines(e, "034")
+        self._fixed_lines(e)
         first = self.naf_first
         assert first == 63
         e.salu(f"s_mov_b32 s{S_I}, {first}")
@@ -3754,49 +3838,79 @@ class KernelBuilder:
         e.salu(f"s_cbranch_scc1 {L('L_mskip')}")
         self.call2(e, "L2_sqr")
         self.call2(e, "L2_dblmul")
-        self._fixed_lines(e, "034")
+        self._fixed_lines(e)
         e.label(L("L_mskip"))
         e.salu(f"s_bitcmp1_b64 {S_NAF_NZ}, s{S_I}")
         e.salu(f"s_cbranch_scc0 {L('L_mnoadd')}")
         self._select_pm_q(e, p)
         self.call2(e, "L2_addmul")
-        self._fixed_lines(e, "235")
+        self._fixed_lines(e)
         e.label(L("L_mnoadd"))
         e.salu(f"s_sub_u32 s{S_I}, s{S_I}, 1")
         e.salu(f"s_cbranch_scc0 {L('L_mloop')}")
         self._frobenius_points(p)                                # + pi(Q), then the line through the result and -pi^2(Q)
         self.call2(e, "L2_addmul")
-        self._fixed_lines(e, "235")
+        self._fixed_lines(e)
         p.reset_tags()
         p.mov(self.SX, self.QX)
         p.mov(self.SY, self.QY)
         self.call2(e, "L2_addmul_last")
-        self._fixed_lines(e, "235")
+        self._fixed_lines(e)
         p.reset_tags()
 
-    # the table's maker: one fixed G2 point per lane (g2: S_N points), out = the table
+    # the table's maker: one fixed G2 point per lane (g2: S_N points), out = the table.  Pass 1 walks the point steps and leaves, per line, the
+    # denominator D (L0, or xi L5), the two numerators and the product of all EARLIER denominators; one Fq2 inversion of the whole product; pass 2
+    # walks the lines backwards (Montgomery's trick) and leaves B = N1 / D, C = N2 / D.
+    LN_ACC, LN_INV = AGPR(0, "lnacc"), AGPR(1, "lninv")          # (no f in this kernel: its AGPR slots are free)
+
     def _lines_routines(self):
-        self.COLD = self.COLD + ("L2_ldbl", "L2_ladd", "L2_ladd_last")
+        self.COLD = self.COLD + ("L2_ldbl", "L2_ladd", "L2_ladd_last", "L2_linv", "L2_lnorm")
         tm = self.miller_temps()
+        step_b = self.FIX_LINE_SLOTS * SLOT_BYTES
 
         def step(kind):
             def body(p):
                 if kind == "dbl":
                     p.dbl_step(self.R, (self.PX, self.PY), self.LINE)
+                    D, N1, N2 = self.LINE
                 else:
                     p.add_step(self.R, (self.SX, self.SY), (self.PX, self.PY), self.LINE, update=(kind == "add"))
-                for i in range(3):
-                    p.A(self.LINE[i]).to(Tab(i))
+                    N1, N2, D = self.LINE
+                    p.A(D).mulxi().to(D)
+                p.A(N1).to(Tab(1))
+                p.A(N2).to(Tab(2))
+                p.A(self.LN_ACC).to(Tab(3))                         # the product of the denominators BEFORE this line
+                p.A(D).to(Tab(0))
+                p.mul(self.LN_ACC).to(self.LN_ACC)
                 p.wait()
-                p.e.salu(f"s_add_u32 s72, s72, {3 * SLOT_BYTES}")
+                p.e.salu(f"s_add_u32 s72, s72, {step_b}")
                 p.e.salu("s_addc_u32 s73, s73, 0")
             return body
         self.l2_routine("L2_ldbl", step("dbl"), tm, local=self.LINE)
         self.l2_routine("L2_ladd", step("add"), tm, local=self.LINE)
         self.l2_routine("L2_ladd_last", step("last"), tm, local=self.LINE)
+        self.l2_routine("L2_fqinv", self._fq_inv, tm)
+        self.l2_routine("L2_linv", lambda p: self._fq2_inv_inline(p, self.LN_ACC, self.LN_INV), tm)
+
+        def norm_line(p):
+            t = p.tmp()
+            p.A(Tab(3)).mul(self.LN_INV).to(t)                      # 1 / D of this line
+            p.A(Tab(0)).mul(self.LN_INV).to(self.LN_INV)            # 1 / (product of the earlier denominators)
+            p.A(Tab(1)).mul(t).to(Tab(1))
+            p.A(Tab(2)).mul(t).to(Tab(2))
+            p.rel(t)
+            p.wait()
+            p.e.salu(f"s_sub_u32 s72, s72, {step_b}")
+            p.e.salu("s_subb_u32 s73, s73, 0")
+        self.l2_routine("L2_lnorm", norm_line, tm)
 
     def lines_main(self, e, p):
         L = self.lab
+        # lanes past the last point would redo it INTO THE SAME PART OF THE TABLE -- harmless for pass 1's plain stores, not for pass 2, which reads
+        # what it overwrites (another wave's lane may have been there already): they sit the whole item out
+        e.emit(f"v_cmp_gt_u32_e32 vcc, s{S_N}, v{V_IDX}", w=["vcc"])
+        e.raw("s_nop 1")
+        e.salu(f"s_and_saveexec_b64 {S_SAVE_EXEC}, vcc")
         self.io_walk_begin(e, S_G2)
         self.io_load_fq2_into_A(e, p)
         p.to(self.QX)
@@ -3809,9 +3923,10 @@ class KernelBuilder:
         p.to(self.R[2])
         p.to(self.PX)                                            # the lines are left WITHOUT an evaluation point: (Px, Py) = (1, 1)
         p.to(self.PY)
+        p.to(self.LN_ACC)
         p.reset_tags()
         e.salu(f"s_mov_b64 {S_TAB}, {S_OUT}")
-        e.salu(f"s_mov_b32 s{S_TMP0}, 0x{self.n_fixed_lines * 3 * SLOT_BYTES:x}")
+        e.salu(f"s_mov_b32 s{S_TMP0}, 0x{self.n_fixed_lines * self.FIX_LINE_SLOTS * SLOT_BYTES:x}")
         e.emit(f"v_lshrrev_b32_e32 v{V_IOOFF}, 3, v{V_IDX8}", vw=[V_IOOFF])       # (clamped) index of this lane's point
         e.emit(f"v_mul_lo_u32 v{V_IOOFF}, v{V_IOOFF}, s{S_TMP0}", vw=[V_IOOFF])   # its part of the table
         self.call2(e, "L2_ldbl")
@@ -3836,6 +3951,18 @@ class KernelBuilder:
         p.mov(self.SY, self.QY)
         self.call2(e, "L2_ladd_last")
         e.raw("s_waitcnt vmcnt(0)")
+        p.reset_tags()
+        # pass 2: one inversion, then the lines backwards (the cursor stands behind the last line)
+        self.call2(e, "L2_linv")
+        e.salu(f"s_sub_u32 s72, s72, {self.FIX_LINE_SLOTS * SLOT_BYTES}")
+        e.salu("s_subb_u32 s73, s73, 0")
+        e.salu(f"s_mov_b32 s{S_I}, {self.n_fixed_lines - 1}")
+        e.label(L("L_lnorm"))
+        self.call2(e, "L2_lnorm")
+        e.salu(f"s_sub_u32 s{S_I}, s{S_I}, 1")
+        e.salu(f"s_cbranch_scc0 {L('L_lnorm')}")
+        e.raw("s_waitcnt vmcnt(0)")
+        e.salu(f"s_mov_b64 exec, {S_SAVE_EXEC}")
         p.reset_tags()
 
     # ---------------------------------------------------------------------------------------------

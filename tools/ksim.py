@@ -490,6 +490,10 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None, start_pc=None, 
                 r = m.vsrc(a[1], False) - m.vsrc(a[2], False)
                 m.sset(a[0], r)
                 m.scc = 1 if r < 0 else 0
+            elif op == "s_subb_u32":
+                r = m.vsrc(a[1], False) - m.vsrc(a[2], False) - m.scc
+                m.sset(a[0], r)
+                m.scc = 1 if r < 0 else 0
             elif op in ("s_add_i32", "s_sub_i32"):                       # SCC = signed overflow
                 x, y = m.vsrc(a[1], False) & M32, m.vsrc(a[2], False) & M32
                 x = x - (1 << 32) if x >> 31 else x
