@@ -280,8 +280,9 @@ int bn254_multi_pairing_check_batch_elems(const uint64_t* g1, const uint64_t* g2
  * bn254_g2_lines_bytes(k_fixed) bytes, in the engine's internal limb form: opaque, valid for the library build that made it); the batch calls then compute,
  * per group g,
  *     final_exp_native(multi_miller_loop_native([(P[g][0], Q0[g]), (P[g][1], Qfix_1), ..., (P[g][k], Qfix_k)]))          (k = k_fixed <= 4)
- * with the fixed pairs reduced to one scaling of a table line by (Px, Py) and one sparse multiplication per step: 5.74 M instructions per group of
- * 1 + 3 pairs against 7.11 M for four free pairs (2^18 groups: 41.8 ms against 52.5 on one MI355X), and no per-lane point state but the group's own.  The same limbs as
+ * with the fixed pairs reduced to one scaling of a table line by (Px, Py) and one sparse multiplication per step (every table line is kept with the constant
+ * coefficient ONE, which makes that multiplication six two-product passes): 5.3 M instructions per group of 1 + 3 pairs against 7.11 M for four free pairs
+ * (2^18 groups: 38.8 ms against 52.2 on one MI355X), and no per-lane point state but the group's own.  The same limbs as
  * bn254_multi_pairing_batch_dev(do_final_exp = 1) on the expanded pairs (the value after the final exponentiation does not see how the Miller value was
  * reached).  g1: n x (1 + k_fixed) G1 points, group-major like every multi-pairing batch (limb-major planes of n (1 + k) points; or element-major for
  * the `_elems` form); g2_var: n G2 points; out: n Fq12.  The `_check` form gives the `== MyFq12::one` verdict byte per group instead
@@ -298,10 +299,10 @@ int bn254_pairing_fixed_g2_batch_elems_dev(const uint64_t* g1, const uint64_t* g
 int bn254_pairing_fixed_g2_check_batch_dev(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* table, size_t k_fixed, uint8_t* verdict, size_t n,
                                            int device, void* stream);
 /* ... against `target` (48 host words, NULL = one; see bn254_multi_pairing_check_target_batch_dev): with gamma, delta fixed and e(alpha, beta) as the
- * target a Groth16 proof costs 1 + 2 pairs, 4.97 M instructions instead of 5.74 M. */
+ * target a Groth16 proof costs 1 + 2 pairs, 4.66 M instructions instead of 5.3 M (2^18 proofs: 34.3 ms). */
 int bn254_pairing_fixed_g2_check_target_batch_dev(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* table, size_t k_fixed, const uint64_t* target,
                                                   uint8_t* verdict, size_t n, int device, void* stream);
-/* host-pointer forms (what a binding uses): g2_fixed = the k_fixed fixed points themselves; the table is made inside the call (1.3 ms).
+/* host-pointer forms (what a binding uses): g2_fixed = the k_fixed fixed points themselves; the table is made inside the call (2.1 ms).
  * `_elems`: every array element-major. */
 int bn254_pairing_fixed_g2_batch(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* g2_fixed, size_t k_fixed, uint64_t* out, size_t n, int device,
                                  void* stream);

@@ -210,7 +210,7 @@ inline std::vector<MyFq12> multi_pairing_batch(const std::vector<G1Affine>& ps, 
 
 // Groups whose LAST k_fixed G2 points are the same for the whole batch (a Groth16 verifier's beta, gamma, delta): ps = n x (1 + k_fixed) G1 points,
 // group-major (the group's own P first), qs = the n groups' own G2 points, fixed = the shared ones.  final_exp_native(multi_miller_loop_native(...))
-// per group, the same limbs as multi_pairing_batch on the expanded pairs, at 0.83 of its cost for 1 + 3 pairs.
+// per group, the same limbs as multi_pairing_batch on the expanded pairs, at 0.74 of its cost for 1 + 3 pairs.
 inline std::vector<MyFq12> pairing_fixed_g2_batch(const std::vector<G1Affine>& ps, const std::vector<G2Affine>& qs, const std::vector<G2Affine>& fixed, int device = 0) {
     const size_t n = qs.size(), kf = fixed.size();
     if (kf == 0 || ps.size() != n * (kf + 1)) throw Panic(BN254_ERR_INVALID_ARG);

@@ -1127,7 +1127,7 @@ int bn254_pairing_fixed_g2_check_batch_dev(const uint64_t* g1, const uint64_t* g
     return bn254_pairing_fixed_g2_check_target_batch_dev(g1, g2_var, table, k_fixed, nullptr, verdict, n, device, stream);
 }
 
-// host-pointer forms: stage, make the table (1.3 ms), launch, copy back.  `elems`: every array element-major (the fixed points too), result in out_order.
+// host-pointer forms: stage, make the table (2.1 ms), launch, copy back.  `elems`: every array element-major (the fixed points too), result in out_order.
 static int fixed_host(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* g2_fixed, size_t k_fixed, uint64_t* out, size_t n, bool elems, int out_order,
                       int device, void* stream) {
     if (n == 0) return BN254_OK;
