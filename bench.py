@@ -486,6 +486,22 @@ def host_path(pkg, torch, g1, g2, n, local_rank, dev):
                     for b in (b1, b2, bo):
                         pkg.free_pinned(b)
         res[label] = row
+    if hasattr(pkg, "pairing_fixed_g2_check_batch_elems"):
+        # a Groth16 verifier's check from host structs: 2^18 proofs of 1 + 2 pairs (gamma, delta fixed, e(alpha, beta) as the target), element-major in,
+        # one verdict byte per proof out -- the fixed-G2 kernel behind the same two-worker pipeline
+        units, kv = n // 4, 2
+        e1 = pkg.layout.to_aos(np.ascontiguousarray(h1.reshape(8, n)[:, :units * (1 + kv)]).reshape(-1), 8)
+        e2 = pkg.layout.to_aos(np.ascontiguousarray(h2.reshape(16, n)[:, :units]).reshape(-1), 16)
+        ef = pkg.layout.to_aos(np.ascontiguousarray(h2.reshape(16, n)[:, units:units + kv]).reshape(-1), 16)
+        target = np.zeros(48, dtype=np.uint64)
+        pkg.pairing_fixed_g2_check_batch_elems(e1, e2, ef, kv, units, target=target, device=local_rank)
+        ts = []
+        for _ in range(2):
+            t0 = _t.perf_counter()
+            pkg.pairing_fixed_g2_check_batch_elems(e1, e2, ef, kv, units, target=target, device=local_rank)
+            ts.append(_t.perf_counter() - t0)
+        res["Groth16 verifier check: 2^18 proofs (1 + 2 pairs, fixed gamma / delta, target), element-major, pageable"] = {
+            "ms": min(ts) * 1e3, "proofs_per_s": units / min(ts), "units_per_s": units / min(ts)}
     return res
 
 

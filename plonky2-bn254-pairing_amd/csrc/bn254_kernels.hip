@@ -231,6 +231,9 @@ struct DeviceCtx {
     std::mutex pipe_mu;        // one host-pointer pipeline at a time per device (its two workers fill the chip anyway)
     hipStream_t pipe_stream[2] = {nullptr, nullptr};   // the workers' private streams: created once, their scratch and staging kept
     hipEvent_t pipe_ev[2] = {nullptr, nullptr};        // ... and the event each worker waits for its chunk on
+    void* pipe_table = nullptr;                         // line table of a fixed-G2 pipeline call (+ room to stage its points): made per call, under pipe_mu
+    hipEvent_t pipe_table_ev = nullptr;
+    std::vector<uint64_t> pipe_table_key;               // the fixed points (and their layout) the table in pipe_table was made from: a verifier calls again with the same key
     std::mutex shard_mu;       // one device-pointer sharded call at a time per device
     std::vector<hipStream_t> shard_streams;            // private streams of bn254_*_sharded_dev (one per shard on this device)
 };
@@ -786,8 +789,16 @@ struct HostFmt {               // how the caller's host arrays are laid out
     bool elems = false;        // element-major (one G1 / G2 / Fq12 after the other) instead of limb-major planes
     int out_order = BN254_FQ12_MYFQ12;
 };
+struct FixedJob {              // a fixed-G2 batch through the pipeline: units of 1 + k_fixed G1 points and ONE G2 point, the fixed points in host memory
+    const uint64_t* g2_fixed = nullptr;   // (limb-major planes of k_fixed points, or element-major with fmt.elems)
+    size_t k_fixed = 0;
+    uint8_t* verdict = nullptr;           // != null: one byte per unit (product == target) instead of the Fq12
+    const uint64_t* target = nullptr;     // 48 host words or null = MyFq12::one
+    const uint64_t* table = nullptr;      // (device: filled in by run_pipeline, with the event recorded behind its making)
+    hipEvent_t table_ready = nullptr;
+};
 static int run_pipeline(const int* devices, int n_dev, const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_units, size_t k,
-                        int do_final_exp, HostFmt fmt = HostFmt());
+                        int do_final_exp, HostFmt fmt = HostFmt(), const FixedJob* fixed = nullptr);
 static bool host_pinned(const void* p, size_t bytes);
 
 int bn254_device_count(void) {
@@ -1131,9 +1142,17 @@ int bn254_pairing_fixed_g2_check_batch_dev(const uint64_t* g1, const uint64_t* g
 static int fixed_host(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* g2_fixed, size_t k_fixed, uint64_t* out, size_t n, bool elems, int out_order,
                       int device, void* stream) {
     if (n == 0) return BN254_OK;
-    if (!g1 || !g2_var || !g2_fixed || !out || k_fixed == 0 || k_fixed > (size_t)BN254_FIXED_MAX || n * (k_fixed + 1) > ((size_t)1 << 23) ||
+    if (!g1 || !g2_var || !g2_fixed || !out || k_fixed == 0 || k_fixed > (size_t)BN254_FIXED_MAX || n * (k_fixed + 1) >= ((size_t)1 << 29) ||
         (out_order != BN254_FQ12_MYFQ12 && out_order != BN254_FQ12_ARK))
         return BN254_ERR_INVALID_ARG;
+    if (n > PIPE_CHUNK) {                 // large batch: chunked, copies overlapped with compute (private streams), the table made once
+        int rc0 = check_device(device);
+        if (rc0) return rc0;
+        HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+        HostFmt fmt; fmt.elems = elems; fmt.out_order = out_order;
+        FixedJob job; job.g2_fixed = g2_fixed; job.k_fixed = k_fixed;
+        return run_pipeline(&device, 1, g1, g2_var, out, n, k_fixed + 1, 1, fmt, &job);
+    }
     Stage s; uint64_t *d1, *d2, *df, *dt, *d3, *dl = nullptr; int rc;
     if ((rc = s.init(device, stream)) || (rc = s.up(g1, 64 * n * (k_fixed + 1), &d1)) || (rc = s.up(g2_var, 128 * n, &d2)) || (rc = s.up(g2_fixed, 128 * k_fixed, &df)) ||
         (rc = s.up(nullptr, bn254_g2_lines_bytes(k_fixed), &dt)) || (rc = s.up(nullptr, 384 * n, &d3)) || (elems && (rc = s.up(nullptr, 128 * k_fixed, &dl))))
@@ -1156,7 +1175,15 @@ int bn254_pairing_fixed_g2_batch_elems(const uint64_t* g1, const uint64_t* g2_va
 int bn254_pairing_fixed_g2_check_batch_elems(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* g2_fixed, size_t k_fixed, const uint64_t* target,
                                              uint8_t* verdict, size_t n, int device, void* stream) {
     if (n == 0) return BN254_OK;
-    if (!g1 || !g2_var || !g2_fixed || !verdict || k_fixed == 0 || k_fixed > (size_t)BN254_FIXED_MAX || n * (k_fixed + 1) > ((size_t)1 << 23)) return BN254_ERR_INVALID_ARG;
+    if (!g1 || !g2_var || !g2_fixed || !verdict || k_fixed == 0 || k_fixed > (size_t)BN254_FIXED_MAX || n * (k_fixed + 1) >= ((size_t)1 << 29)) return BN254_ERR_INVALID_ARG;
+    if (n > PIPE_CHUNK) {
+        int rc0 = check_device(device);
+        if (rc0) return rc0;
+        HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+        HostFmt fmt; fmt.elems = true;
+        FixedJob job; job.g2_fixed = g2_fixed; job.k_fixed = k_fixed; job.verdict = verdict; job.target = target;
+        return run_pipeline(&device, 1, g1, g2_var, nullptr, n, k_fixed + 1, 1, fmt, &job);
+    }
     Stage s; uint64_t *d1, *d2, *df, *dt, *d3, *dl, *dv; int rc;
     if ((rc = s.init(device, stream)) || (rc = s.up(g1, 64 * n * (k_fixed + 1), &d1)) || (rc = s.up(g2_var, 128 * n, &d2)) || (rc = s.up(g2_fixed, 128 * k_fixed, &df)) ||
         (rc = s.up(nullptr, bn254_g2_lines_bytes(k_fixed), &dt)) || (rc = s.up(nullptr, 384 * n, &d3)) || (rc = s.up(nullptr, 128 * k_fixed, &dl)) ||
@@ -1518,28 +1545,59 @@ struct PipeWorker {            // one worker of the host-pointer pipeline: its p
 };
 
 static int run_chunks(int dev, PipeWorker pw, const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_units, size_t k, int do_final_exp,
-                      size_t u0, size_t cnt, size_t chunk, size_t first, size_t step, HostFmt fmt) {
+                      size_t u0, size_t cnt, size_t chunk, size_t first, size_t step, HostFmt fmt, const FixedJob* fx) {
     if (cnt == 0 || first * chunk >= cnt) return BN254_OK;
     if (hipSetDevice(dev) != hipSuccess) return BN254_ERR_INVALID_ARG;
     int rc = BN254_OK;
     hipStream_t st = pw.st;
     {
         Stage s; uint64_t *d1, *d2, *d3, *e1 = nullptr, *e2 = nullptr, *e3 = nullptr;
-        size_t cap = cnt < chunk ? cnt : chunk, np_all = n_units * k;
-        if ((rc = s.init(dev, st)) || (rc = s.up(nullptr, 64 * cap * k, &d1)) || (rc = s.up(nullptr, 128 * cap * k, &d2)) || (rc = s.up(nullptr, 384 * cap, &d3))) goto done;
-        if (fmt.elems && ((rc = s.up(nullptr, 64 * cap * k, &e1)) || (rc = s.up(nullptr, 128 * cap * k, &e2)) || (rc = s.up(nullptr, 384 * cap, &e3)))) goto done;
+        std::vector<uint64_t> hres;                             // (verdict calls: a chunk's Fq12 values on their way to the comparison)
+        const size_t k2 = fx ? 1 : k;                          // G2 points per unit (a fixed-G2 unit brings its own point only)
+        size_t cap = cnt < chunk ? cnt : chunk, np_all = n_units * k, np2_all = n_units * k2;
+        if ((rc = s.init(dev, st)) || (rc = s.up(nullptr, 64 * cap * k, &d1)) || (rc = s.up(nullptr, 128 * cap * k2, &d2)) || (rc = s.up(nullptr, 384 * cap, &d3))) goto done;
+        if (fmt.elems && ((rc = s.up(nullptr, 64 * cap * k, &e1)) || (rc = s.up(nullptr, 128 * cap * k2, &e2)) || (rc = s.up(nullptr, 384 * cap, &e3)))) goto done;
         for (size_t c0 = first * chunk; c0 < cnt; c0 += step * chunk) {
-            size_t m = cnt - c0 < chunk ? cnt - c0 : chunk, np = m * k, base = u0 + c0;
+            size_t m = cnt - c0 < chunk ? cnt - c0 : chunk, np = m * k, np2 = m * k2, base = u0 + c0;
             // a chunk of an element-major array is one contiguous run, and the throughput kernels take it as it is (no transposition pass, which --
             // a kernel -- would wait for the other worker's launch to leave the CUs); the lane-cooperative programs of a small last chunk read
             // planes: those are then made on the device
-            const bool direct = fmt.elems && (do_final_exp ? direct_elems_ok<true, true>(m, k, dev, st) : direct_elems_ok<true, false>(m, k, dev, st));
+            const bool direct = fmt.elems && !fx && (do_final_exp ? direct_elems_ok<true, true>(m, k, dev, st) : direct_elems_ok<true, false>(m, k, dev, st));
             if (fmt.elems) {
                 if (copy_rows(e1, g1 + base * k * 8, np * 64, hipMemcpyHostToDevice, st) != hipSuccess ||
-                    copy_rows(e2, g2 + base * k * 16, np * 128, hipMemcpyHostToDevice, st) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
-                if (!direct && ((rc = launch_layout(true, e1, d1, 8, np, 0, dev, st)) || (rc = launch_layout(true, e2, d2, 16, np, 0, dev, st)))) goto done;
+                    copy_rows(e2, g2 + base * k2 * 16, np2 * 128, hipMemcpyHostToDevice, st) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
+                if (!direct && !fx && ((rc = launch_layout(true, e1, d1, 8, np, 0, dev, st)) || (rc = launch_layout(true, e2, d2, 16, np, 0, dev, st)))) goto done;
             } else if (hipMemcpy2DAsync(d1, np * 8, g1 + base * k, np_all * 8, np * 8, 8, hipMemcpyHostToDevice, st) != hipSuccess ||
-                       hipMemcpy2DAsync(d2, np * 8, g2 + base * k, np_all * 8, np * 8, 16, hipMemcpyHostToDevice, st) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
+                       hipMemcpy2DAsync(d2, np2 * 8, g2 + base * k2, np2_all * 8, np2 * 8, 16, hipMemcpyHostToDevice, st) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
+            if (fx) {
+                // the fixed-G2 kernel reads either layout itself (a small last chunk: launch_fixed expands the pairs for the lane-cooperative program)
+                const bool vd = fx->verdict != nullptr;                      // (verdicts: element-major input only)
+                if (c0 == first * chunk && fx->table_ready && hipStreamWaitEvent(st, fx->table_ready, 0) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
+                const bool last = c0 + chunk >= cnt;                           // nothing is queued behind the job's last launch
+                const bool planes_out = !fmt.elems || (vd && last);
+                const int mode = fmt.elems ? (IO_IN_ELEMS | (planes_out ? 0 : IO_OUT_ELEMS | (!vd && fmt.out_order == BN254_FQ12_ARK ? IO_OUT_ARK : 0))) : 0;
+                if ((rc = launch_fixed(fmt.elems ? e1 : d1, fmt.elems ? e2 : d2, fx->table, fx->k_fixed, planes_out ? d3 : e3, m, mode, dev, st))) goto done;
+                if (vd && last) {
+                    if ((rc = launch_is_equal(d3, fx->target, (uint8_t*)e1, m, st))) goto done;              // (e1: this chunk's inputs, dead behind its launch)
+                    if (hipMemcpy2DAsync(fx->verdict + base, m, e1, m, m, 1, hipMemcpyDeviceToHost, st) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
+                } else if (vd) {
+                    // The comparison is the worker THREAD's: a compare kernel behind this launch would have to wait for the other worker's launch to leave
+                    // the CUs (8 ms), and this worker's next upload with it.  The Fq12 values come back under the other worker's kernel like any
+                    // result; 384 bytes per unit are compared while that kernel runs.  (The job's LAST chunk has no launch behind it: compared on the device.)
+                    hres.resize(48 * cap);
+                    if (copy_rows(hres.data(), e3, m * 384, hipMemcpyDeviceToHost, st) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
+                } else if (fmt.elems) {
+                    if (copy_rows(out + base * 48, e3, m * 384, hipMemcpyDeviceToHost, st) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
+                } else if (hipMemcpy2DAsync(out + base, n_units * 8, d3, m * 8, m * 8, 48, hipMemcpyDeviceToHost, st) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
+                if (hipEventRecord(pw.out_done, st) != hipSuccess || hipEventSynchronize(pw.out_done) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
+                if (vd && !last) {
+                    uint64_t t[48];
+                    const uint64_t one[4] = BN254_FQ_ONE_LIMBS;
+                    for (int w = 0; w < 48; w++) t[w] = fx->target ? fx->target[w] : (w < 4 ? one[w] : 0ull);
+                    for (size_t i = 0; i < m; i++) fx->verdict[base + i] = memcmp(hres.data() + 48 * i, t, 384) == 0 ? 1 : 0;
+                }
+                continue;
+            }
             if (direct) {
                 const int mode = IO_IN_ELEMS | IO_OUT_ELEMS | (fmt.out_order == BN254_FQ12_ARK ? IO_OUT_ARK : 0);
                 rc = do_final_exp ? launch_pairing<true, true>(e1, e2, nullptr, e3, m, k, dev, st, mode) : launch_pairing<true, false>(e1, e2, nullptr, e3, m, k, dev, st, mode);
@@ -1565,7 +1623,7 @@ static int run_chunks(int dev, PipeWorker pw, const uint64_t* g1, const uint64_t
 
 // devices[0..n_dev): the batch is split into n_dev contiguous slices
 static int run_pipeline(const int* devices, int n_dev, const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_units, size_t k,
-                        int do_final_exp, HostFmt fmt) {
+                        int do_final_exp, HostFmt fmt, const FixedJob* fixed) {
     size_t chunk = PIPE_CHUNK;                        // lanes = units (one unit per lane whatever k is)
     // (element-major data passes two small kernels on the way in and one on the way out (k_layout); a pairing launch holds every register of every
     // CU, so they run at the launch boundaries: 0.5 ms per chunk, 8 %.  Launches of one CU less do not help -- the other worker's launch takes the
@@ -1585,6 +1643,35 @@ static int run_pipeline(const int* devices, int n_dev, const uint64_t* g1, const
         for (hipEvent_t& ev : c.pipe_ev)
             if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return BN254_ERR_HIP;
     }
+    std::vector<FixedJob> jobs((size_t)n_dev);
+    if (fixed) {
+        // the line table of this call's fixed points, once per device (2 ms) on the first worker's stream, before the workers start
+        const size_t kf = fixed->k_fixed, tab_max = bn254_g2_lines_bytes(BN254_FIXED_MAX);
+        for (int d = 0; d < n_dev; d++) {
+            DeviceCtx& c = g_ctx[devices[d]];
+            hipStream_t st = c.pipe_stream[0];
+            if (hipSetDevice(devices[d]) != hipSuccess) return BN254_ERR_HIP;
+            if (!c.pipe_table && hipMalloc(&c.pipe_table, tab_max + 2 * 128 * BN254_FIXED_MAX) != hipSuccess) { c.pipe_table = nullptr; return BN254_ERR_ALLOC; }
+            uint64_t* tab = (uint64_t*)c.pipe_table;
+            uint64_t *in = (uint64_t*)((char*)c.pipe_table + tab_max), *planes = in + 16 * BN254_FIXED_MAX;
+            jobs[(size_t)d] = *fixed;
+            jobs[(size_t)d].table = tab;
+            // the table of the previous call stands when the fixed points are the same (a verifier's key does not change between its batches: 2 ms saved)
+            std::vector<uint64_t> key(fixed->g2_fixed, fixed->g2_fixed + 16 * kf);
+            key.push_back(fmt.elems ? 1 : 0);
+            if (key == c.pipe_table_key) continue;
+            c.pipe_table_key.clear();
+            if (hipMemcpyAsync(in, fixed->g2_fixed, 128 * kf, hipMemcpyHostToDevice, st) != hipSuccess) return BN254_ERR_HIP;
+            int rc = BN254_OK;
+            if (fmt.elems && (rc = launch_layout(true, in, planes, 16, kf, 0, devices[d], st))) return rc;
+            if ((rc = bn254_g2_lines_dev(fmt.elems ? planes : in, kf, tab, devices[d], st))) return rc;
+            // (no wait here: worker 0 works on this very stream; worker 1 waits for the event in front of its first LAUNCH, its uploads run meanwhile)
+            if (!c.pipe_table_ev && hipEventCreateWithFlags(&c.pipe_table_ev, hipEventDisableTiming) != hipSuccess) return BN254_ERR_HIP;
+            if (hipEventRecord(c.pipe_table_ev, st) != hipSuccess) return BN254_ERR_HIP;
+            jobs[(size_t)d].table_ready = c.pipe_table_ev;
+            c.pipe_table_key = std::move(key);
+        }
+    }
     std::vector<int> rcs;
     std::vector<std::thread> th;
     rcs.reserve((size_t)n_dev * 2);
@@ -1598,11 +1685,17 @@ static int run_pipeline(const int* devices, int n_dev, const uint64_t* g1, const
             int dev = devices[d];
             DeviceCtx& dc = g_ctx[dev];
             PipeWorker pw{dc.pipe_stream[w], dc.pipe_ev[w]};
-            th.emplace_back([=] { *slot = run_chunks(dev, pw, g1, g2, out, n_units, k, do_final_exp, u0, c, chunk, w, workers, fmt); });
+            const FixedJob* fj = fixed ? &jobs[(size_t)d] : nullptr;
+            th.emplace_back([=] { *slot = run_chunks(dev, pw, g1, g2, out, n_units, k, do_final_exp, u0, c, chunk, w, workers, fmt, fj); });
         }
     }
     for (auto& t : th) t.join();
-    for (int rc : rcs) if (rc) return rc;
+    for (int rc : rcs)
+        if (rc) {
+            if (fixed)              // (a table whose making raised the status must not be taken for good by the next call)
+                for (int d = 0; d < n_dev; d++) g_ctx[devices[d]].pipe_table_key.clear();
+            return rc;
+        }
     return BN254_OK;
 }
 

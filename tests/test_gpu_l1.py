@@ -26,7 +26,7 @@ pytestmark = pytest.mark.gpu
 NV = 248          # v0 .. v247
 OUT = {"mul6": list(range(K4.HOME0 + 6 * K4.SLOT_DW, K4.HOME0 + 7 * K4.SLOT_DW)) + list(range(K4.HOME0 + 2 * K4.SLOT_DW, K4.HOME0 + 3 * K4.SLOT_DW))
        + list(range(K4.A0, K4.A0 + K4.SLOT_DW)) + [K4.V_IDX8, K4.V_IDX, K4.V_TID, K4.V_FLAG],
-       "mul3": list(range(K4.A0, K4.A0 + K4.SLOT_DW)), "mul": list(range(K4.A0, K4.A0 + K4.SLOT_DW)),
+       "mul3": list(range(K4.A0, K4.A0 + K4.SLOT_DW)), "mul": list(range(K4.A0, K4.A0 + K4.SLOT_DW)), "mul2a": list(range(K4.A0, K4.A0 + K4.SLOT_DW)),
        "sqr4c": list(range(K4.A0, K4.B0 + K4.SLOT_DW)), "dblstep": list(range(K4.HOME0, K4.HOME0 + 3 * K4.SLOT_DW))}
 
 
@@ -41,6 +41,7 @@ def _cases(rng):
     Hb = lambda k: K4.HOME0 + K4.SLOT_DW * k
     mags = {"mul6": {**{Hb(k): 2 for k in range(3)}, **{Hb(k): 1 for k in range(3, 6)}},
             "mul3": {K4.A0: 2, K4.B0: 1, Hb(0): 2, Hb(1): 1, Hb(2): 2, Hb(3): 1},
+            "mul2a": {K4.A0: 3.9, Hb(0): 2, Hb(1): 1, Hb(2): 2, Hb(3): 1},
             "mul": {K4.A0: 2.5, K4.B0: 2.5},
             "sqr4c": {K4.A0: 1, K4.B0: 1, Hb(3): 1, Hb(4): 1},
             "dblstep": {Hb(0): 1, Hb(1): 1, Hb(2): 1, K4.B0: 1}}

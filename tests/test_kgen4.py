@@ -125,6 +125,17 @@ def test_l1_routines():
         for h in range(2):
             assert (val(m, h) - w[h] * RPI) % P == 0, ("mul3", t, h)
         assert _is_norm(m, list(range(NL))) and _is_norm(m, list(range(NL, 2 * NL)))
+    # mul2a: A <- A + H0*H1 + H2*H3 (the value in A enters the upper half of the column sums: added AS IT IS, not divided by R')
+    for t in range(12):
+        ops = [(rnd(), rnd()) for _ in range(5)]
+        m = _m4([], rng, 0)
+        for blk, el in zip((K4.A0, K4.HOME0, K4.HOME0 + K4.SLOT_DW, K4.HOME0 + 2 * K4.SLOT_DW, K4.HOME0 + 3 * K4.SLOT_DW), ops):
+            put(m, blk, el)
+        S.run_block(B["mul2a"], m)
+        w = f2a(f2m(ops[1], ops[2]), f2m(ops[3], ops[4]))
+        for h in range(2):
+            assert (val(m, h) - w[h] * RPI - ops[0][h]) % P == 0, ("mul2a", t, h)
+        assert _is_norm(m, list(range(NL))) and _is_norm(m, list(range(NL, 2 * NL)))
     # sqr4c / sqr4cx: Fq4 squaring of the cyclotomic squaring with the Granger-Scott recombination (zc, zd in home blocks 3, 4)
     for t in range(12):
         a, b, zc, zd = [(rnd(), rnd()) for _ in range(4)]
@@ -185,7 +196,8 @@ def test_l1_routines():
     cases = (("mul6", {**{H_(k): 2 for k in range(3)}, **{H_(k): 1 for k in range(3, 6)}}),
              ("sqr4c", {K4.A0: 1, K4.B0: 1, H_(3): 1, H_(4): 1}), ("sqr4cx", {K4.A0: 1, K4.B0: 1, H_(3): 1, H_(4): 1}),
              ("mul", {K4.A0: 2.5, K4.B0: 2.5}), ("mul3", {K4.A0: 1, K4.B0: 1, H_(0): 1, H_(1): 1, H_(2): 1, H_(3): 1}),
-             ("mul3", {K4.A0: 2, K4.B0: 1, H_(0): 2, H_(1): 1, H_(2): 2, H_(3): 1}), ("sqr", {K4.A0: 1.8}))
+             ("mul3", {K4.A0: 2, K4.B0: 1, H_(0): 2, H_(1): 1, H_(2): 2, H_(3): 1}), ("sqr", {K4.A0: 1.8}),
+             ("mul2a", {K4.A0: 3.9, H_(0): 2, H_(1): 1, H_(2): 2, H_(3): 1}))
     for name, mags in cases:
         for pattern in (lambda i: 1, lambda i: -1, lambda i: 1 if i % 2 else -1, lambda i: 1 if (i // 2) % 2 else -1):
             m = _m4([], rng, 0)
