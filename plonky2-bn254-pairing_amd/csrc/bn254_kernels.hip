@@ -195,6 +195,8 @@ struct StreamCtx {
     Buf fx[5];                 // ... and final_exp_native's: m, m^x, m^(x^2), m^(x^3), the y-chain's first part
     Buf sub[4];                // groups of more than MAX_K pairs: sub-group inputs (G1, G2) and the two Miller values in flight
     Buf stage[8];              // device staging of the host-pointer entry points (inputs / outputs), grown on demand
+    Buf fixed_tab;             // host-pointer fixed-G2 calls: the line table of the LAST call's fixed points (+ room to stage them) ...
+    std::vector<uint64_t> fixed_key;   // ... and those points (and their layout): a verifier's key does not change between its calls, the table is then made once
     std::vector<void*> retired;   // buffers that were outgrown while work on them may still be queued: freed once the stream has been
                                   // synchronised (bn254_last_status, bn254_release_stream) -- growing never waits for the stream
     std::vector<NafSlot> naf_ring;
@@ -209,7 +211,7 @@ struct StreamCtx {
     size_t last_pitch = 0;        // scratch geometry of the most recent launch (diagnostic builds read their clock stamps back from it)
     uint32_t last_grid = 0;
     ~StreamCtx() {                // the last holder (bn254_release_stream, after the stream has been synchronised) frees everything
-        for (Buf* b : {&scratch, &naf, &tmp, &mid}) if (b->p) (void)hipFree(b->p);
+        for (Buf* b : {&scratch, &naf, &tmp, &mid, &fixed_tab}) if (b->p) (void)hipFree(b->p);
         for (Buf& b : fx) if (b.p) (void)hipFree(b.p);
         for (Buf& b : stage) if (b.p) (void)hipFree(b.p);
         for (Buf& b : sub) if (b.p) (void)hipFree(b.p);
@@ -1139,6 +1141,31 @@ int bn254_pairing_fixed_g2_check_batch_dev(const uint64_t* g1, const uint64_t* g
 }
 
 // host-pointer forms: stage, make the table (2.1 ms), launch, copy back.  `elems`: every array element-major (the fixed points too), result in out_order.
+// the line table of `g2_fixed` (host memory; element-major if `elems`) on this stream: made (2 ms) unless the stream's last host-pointer call had the same points
+static int host_table(Stage& s, const uint64_t* g2_fixed, size_t k_fixed, bool elems, int device, void* stream, const uint64_t** table) {
+    StreamCtx* sc = s.sc.get();
+    const size_t tab_max = bn254_g2_lines_bytes(BN254_FIXED_MAX);
+    int rc = ensure(sc, sc->fixed_tab, tab_max + 2 * 128 * BN254_FIXED_MAX);
+    if (rc) return rc;
+    uint64_t *tab = (uint64_t*)sc->fixed_tab.p, *in = (uint64_t*)((char*)sc->fixed_tab.p + tab_max), *planes = in + 16 * BN254_FIXED_MAX;
+    *table = tab;
+    std::vector<uint64_t> key(g2_fixed, g2_fixed + 16 * k_fixed);
+    key.push_back(elems ? 1 : 0);
+    if (key == sc->fixed_key) return BN254_OK;
+    sc->fixed_key.clear();
+    if (hipMemcpyAsync(in, g2_fixed, 128 * k_fixed, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) return BN254_ERR_HIP;
+    if (elems && (rc = launch_layout(true, in, planes, 16, k_fixed, 0, device, stream))) return rc;      // (the table kernel reads limb-major planes)
+    if ((rc = bn254_g2_lines_dev(elems ? planes : in, k_fixed, tab, device, stream))) return rc;
+    sc->fixed_key = std::move(key);
+    return BN254_OK;
+}
+// ... which must not outlive a call that raised the status (its making may have been what raised it)
+static int finish_fixed_host(Stage& s, void* h_out, const void* d_out, size_t bytes, int device, void* stream) {
+    int rc = finish_host(h_out, d_out, bytes, device, stream);
+    if (rc) s.sc->fixed_key.clear();
+    return rc;
+}
+
 static int fixed_host(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* g2_fixed, size_t k_fixed, uint64_t* out, size_t n, bool elems, int out_order,
                       int device, void* stream) {
     if (n == 0) return BN254_OK;
@@ -1153,16 +1180,14 @@ static int fixed_host(const uint64_t* g1, const uint64_t* g2_var, const uint64_t
         FixedJob job; job.g2_fixed = g2_fixed; job.k_fixed = k_fixed;
         return run_pipeline(&device, 1, g1, g2_var, out, n, k_fixed + 1, 1, fmt, &job);
     }
-    Stage s; uint64_t *d1, *d2, *df, *dt, *d3, *dl = nullptr; int rc;
-    if ((rc = s.init(device, stream)) || (rc = s.up(g1, 64 * n * (k_fixed + 1), &d1)) || (rc = s.up(g2_var, 128 * n, &d2)) || (rc = s.up(g2_fixed, 128 * k_fixed, &df)) ||
-        (rc = s.up(nullptr, bn254_g2_lines_bytes(k_fixed), &dt)) || (rc = s.up(nullptr, 384 * n, &d3)) || (elems && (rc = s.up(nullptr, 128 * k_fixed, &dl))))
+    Stage s; uint64_t *d1, *d2, *d3; const uint64_t* dt; int rc;
+    if ((rc = s.init(device, stream)) || (rc = s.up(g1, 64 * n * (k_fixed + 1), &d1)) || (rc = s.up(g2_var, 128 * n, &d2)) || (rc = s.up(nullptr, 384 * n, &d3)) ||
+        (rc = host_table(s, g2_fixed, k_fixed, elems, device, stream, &dt)))
         return rc;
-    if (elems && (rc = launch_layout(true, df, dl, 16, k_fixed, 0, device, stream))) return rc;      // (the table kernel reads limb-major planes)
-    if ((rc = bn254_g2_lines_dev(elems ? dl : df, k_fixed, dt, device, stream))) return rc;
     rc = elems ? bn254_pairing_fixed_g2_batch_elems_dev(d1, d2, dt, k_fixed, d3, n, out_order, device, stream)
                : bn254_pairing_fixed_g2_batch_dev(d1, d2, dt, k_fixed, d3, n, device, stream);
     if (rc) return rc;
-    return finish_host(out, d3, 384 * n, device, stream);
+    return finish_fixed_host(s, out, d3, 384 * n, device, stream);
 }
 int bn254_pairing_fixed_g2_batch(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* g2_fixed, size_t k_fixed, uint64_t* out, size_t n, int device, void* stream) {
     return fixed_host(g1, g2_var, g2_fixed, k_fixed, out, n, false, BN254_FQ12_MYFQ12, device, stream);
@@ -1184,15 +1209,12 @@ int bn254_pairing_fixed_g2_check_batch_elems(const uint64_t* g1, const uint64_t*
         FixedJob job; job.g2_fixed = g2_fixed; job.k_fixed = k_fixed; job.verdict = verdict; job.target = target;
         return run_pipeline(&device, 1, g1, g2_var, nullptr, n, k_fixed + 1, 1, fmt, &job);
     }
-    Stage s; uint64_t *d1, *d2, *df, *dt, *d3, *dl, *dv; int rc;
-    if ((rc = s.init(device, stream)) || (rc = s.up(g1, 64 * n * (k_fixed + 1), &d1)) || (rc = s.up(g2_var, 128 * n, &d2)) || (rc = s.up(g2_fixed, 128 * k_fixed, &df)) ||
-        (rc = s.up(nullptr, bn254_g2_lines_bytes(k_fixed), &dt)) || (rc = s.up(nullptr, 384 * n, &d3)) || (rc = s.up(nullptr, 128 * k_fixed, &dl)) ||
-        (rc = s.up(nullptr, (n + 7) & ~(size_t)7, &dv)))
+    Stage s; uint64_t *d1, *d2, *d3, *dv; const uint64_t* dt; int rc;
+    if ((rc = s.init(device, stream)) || (rc = s.up(g1, 64 * n * (k_fixed + 1), &d1)) || (rc = s.up(g2_var, 128 * n, &d2)) || (rc = s.up(nullptr, 384 * n, &d3)) ||
+        (rc = s.up(nullptr, (n + 7) & ~(size_t)7, &dv)) || (rc = host_table(s, g2_fixed, k_fixed, true, device, stream, &dt)))
         return rc;
-    if ((rc = launch_layout(true, df, dl, 16, k_fixed, 0, device, stream)) || (rc = bn254_g2_lines_dev(dl, k_fixed, dt, device, stream)) ||
-        (rc = launch_fixed(d1, d2, dt, k_fixed, d3, n, IO_IN_ELEMS, device, stream)) || (rc = launch_is_equal(d3, target, (uint8_t*)dv, n, stream)))
-        return rc;
-    return finish_host(verdict, dv, n, device, stream);
+    if ((rc = launch_fixed(d1, d2, dt, k_fixed, d3, n, IO_IN_ELEMS, device, stream)) || (rc = launch_is_equal(d3, target, (uint8_t*)dv, n, stream))) return rc;
+    return finish_fixed_host(s, verdict, dv, n, device, stream);
 }
 
 int bn254_release_stream(int device, void* stream) {

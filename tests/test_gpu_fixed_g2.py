@@ -161,6 +161,16 @@ def _host_forms(pk, n, kf, k):
     assert pk.pairing_fixed_g2_check_batch_elems(e1, e2, ef, kf, n).sum() == 0                  # none of the random products is one
     with pytest.raises(pk.Bn254Error):
         pk.pairing_fixed_g2_check_batch_elems(e1, e2, ef[: 16 * 1], 5, n)
+    # the stream keeps the table of its last host-pointer call's fixed points: other points give their own values, the first ones theirs again
+    Qf2 = [R.g2_mul(R.G2_GEN, 11 + j) for j in range(kf)]
+    ef2 = H.g2_aos(Qf2)
+    exp2 = H.g2_aos([Qv[g] if j == 0 else Qf2[j - 1] for g in range(n) for j in range(k)])
+    want2 = pk.multi_pairing_batch(H.to_soa(e1, 8), H.to_soa(exp2, 16), n, k)
+    assert not np.array_equal(want2, want)
+    assert np.array_equal(pk.pairing_fixed_g2_batch(H.to_soa(e1, 8), H.to_soa(e2, 16), H.to_soa(ef2, 16), kf, n), want2)
+    assert np.array_equal(pk.pairing_fixed_g2_batch(H.to_soa(e1, 8), H.to_soa(e2, 16), H.to_soa(ef, 16), kf, n), want)
+    assert np.array_equal(pk.pairing_fixed_g2_batch(H.to_soa(e1, 8), H.to_soa(e2, 16), H.to_soa(ef, 16), kf, n), want)          # (a hit)
+    assert np.array_equal(pk.pairing_fixed_g2_batch(e1, e2, ef, kf, n, elems=True), H.to_aos(want, 48))                           # (the same points, the other layout)
 
 
 @pytest.mark.parametrize("kf", [1, 2, 3, 4])
