@@ -676,7 +676,7 @@ def run_rank(args):
                          "achieved_note": "work-normalised: SURVEY.md 8(d)'s algorithmic mul32 per pairing x pairings/s (kernel time from HIP events), "
                                           "not the multiply-adds the kernel executes (the figure is the REFERENCE's schedule: its digit table of 6x+2 with 25 additions; "
                                           "the kernel walks a 21-addition form of the same number -- the pairing's value does not see the chain, DESIGN.md section 4.2 -- "
-                                          "and executes 2.47 M multiply-adds of 3.475 M instructions per pairing)",
+                                          "and executes 2.43 M multiply-adds of 3.43 M instructions per pairing)",
                          "traffic_note": f"HBM bytes per launch from the committed PMC summary {os.path.relpath(PMC_SUMMARY, ROOT)} (separate --pmc passes of this "
                                          "command; raw and corrected counters there), not measured in this run; algorithmic bytes per launch = 576 B x pairings"
                                          + (f"; DROPPED: {stale}" if stale else ""),
