@@ -3735,6 +3735,8 @@ class KernelBuilder:
     # bring w^2: everything lies in Fq6 and dies in the easy part like the projective lines' own scales.  With the constant coefficient ONE a sparse
     # multiplication is six two-product passes (Prog.mul_by_034_one) instead of six three-product ones, and one routine serves every line.
     def _fixed_routines(self):
+        # (the third waiting result of the multiplication goes through the global scratch: handing it the line's unused constant slot, AGPR 6,
+        # instead was measured 0.7 % SLOWER -- 36 more AGPR moves per line against ten memory instructions whose latency the passes hide)
         tm = self.miller_temps(extra=(self.SX, self.SY))
         n_last = sum(1 for d in self.naf[:1] if d) + 2            # lines behind the last squaring: the digit-0 addition (none: 6x + 2 is even) + the Frobenius pair
         assert n_last % 2 == 0, "an odd number of w factors would survive the easy part"
