@@ -289,7 +289,8 @@ int bn254_multi_pairing_check_batch_elems(const uint64_t* g1, const uint64_t* g2
  * (final_exp_native.rs:245-263).  The G2 points of the table must be in the r-torsion like any other (bn254_check_points_ex).  One launch:
  * n (1 + k_fixed) <= 2^23 points per call.  Small batches (below the latency threshold, bn254_set_latency_threshold; k_fixed <= 3) are a fraction of one
  * grid of that kernel (8 ms whatever n is): the table carries the fixed points behind its lines, and such a call expands the pairs and runs the
- * lane-cooperative k-pair program instead (one group of 1 + 3 pairs: 0.8 ms; the same limbs; its buffers are allocated on first use). */
+ * lane-cooperative k-pair program instead (one group of 1 + 3 pairs: 0.8 ms; the same limbs; its buffers are allocated on first use, or by
+ * bn254_reserve(device, stream, n, 1 + k_fixed): the call is then a sequence of plain launches, capturable like the others). */
 size_t bn254_g2_lines_bytes(size_t k_fixed);
 int bn254_g2_lines_dev(const uint64_t* g2_fixed, size_t k_fixed, uint64_t* table, int device, void* stream);
 int bn254_pairing_fixed_g2_batch_dev(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* table, size_t k_fixed, uint64_t* out, size_t n, int device,

@@ -1341,6 +1341,12 @@ int bn254_reserve(int device, void* stream, size_t n, size_t k) {
                 if ((rc = ensure(sc, b, 384 * split_max))) return rc;
         }
     }
+    if (k >= 2 && k <= (size_t)BN254_FIXED_MAX) {      // a small fixed-G2 batch of 1 + (k - 1) pairs expands its pairs for the lane-cooperative k-pair program (launch_fixed)
+        size_t thr = sc->lat_threshold.load() == (size_t)-1 ? g_latency_threshold.load() : sc->lat_threshold.load();
+        size_t m = cvm_split_max(thr);
+        if (m > n) m = n;
+        if (m && ((rc = ensure(sc, sc->sub[0], 64 * m * k)) || (rc = ensure(sc, sc->sub[1], 128 * m * k)) || (rc = ensure(sc, sc->sub[2], 384 * m)))) return rc;
+    }
     if ((rc = ensure(sc, sc->naf, 65536 + 64))) return rc;                                          // pow_native digits (16-bit length field)
     if (k > MAX_K && ((rc = ensure(sc, sc->sub[0], 64 * n * MAX_K)) || (rc = ensure(sc, sc->sub[1], 128 * n * MAX_K)) ||
                       (rc = ensure(sc, sc->sub[2], 384 * n)) || (rc = ensure(sc, sc->sub[3], 384 * n))))

@@ -257,3 +257,49 @@ def test_fixed_g2_host_forms_above_one_chunk_take_the_pipeline():
     assert np.array_equal(pk.pairing_fixed_g2_batch(h1, h2, h(g2fix_b), kf, n), h(want_b))
     assert np.array_equal(pk.pairing_fixed_g2_batch(h1, h2, hf, kf, n), hw)
     assert np.array_equal(pk.pairing_fixed_g2_batch(h1, h2, hf, kf, n), hw)                      # (a hit)
+
+
+def test_fixed_g2_calls_are_capturable_after_reserve():
+    """After bn254_reserve(n, 1 + k_fixed) the fixed-G2 `_dev` calls are plain launches: the throughput kernel on a large batch, and -- for a batch below
+    the latency threshold -- the pair expansion + the lane-cooperative k-pair program through per-stream buffers; captured into a hipGraph and replayed
+    on new contents of the same buffers (the verdict against a target included: the target travels in the kernel's arguments)."""
+    import torch
+    pk = H.pkg()
+    dev = torch.device("cuda:0")
+    side = torch.cuda.Stream(dev)
+    kf, n_big, n_small = 2, 70000, 300
+    k = 1 + kf
+    with torch.cuda.stream(side):
+        g1, g2var, _, table = _setup(pk, torch, dev, side, n_big, kf, 0x77A0)
+        s1, s2 = g1[: 8 * n_small * k].clone(), g2var[: 16 * n_small].clone()
+        out_big = torch.zeros(48 * n_big, dtype=torch.int64, device=dev)
+        out_small = torch.zeros(48 * n_small, dtype=torch.int64, device=dev)
+        verdict = torch.zeros(n_small, dtype=torch.uint8, device=dev)
+        target = np.zeros(48, dtype=np.uint64)
+        pk.reserve(n_big, k, 0, side)
+        pk.last_status(0, side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            pk.pairing_fixed_g2_batch_dev(g1, g2var, table, kf, out_big, n_big, 0, side)
+            pk.pairing_fixed_g2_batch_dev(s1, s2, table, kf, out_small, n_small, 0, side)
+            pk.pairing_fixed_g2_check_target_batch_dev(s1, s2, table, kf, target, verdict, n_small, 0, side)
+        first = None
+        for seed in (0x77B1, 0x77B2):
+            pk.generate_pairs_dev(seed, g1, torch.zeros(16 * n_big * k, dtype=torch.int64, device=dev), n_big * k, 0, side)
+            s1.copy_(g1[8 * 5: 8 * 5 + 8 * n_small * k])
+            out_big.zero_(); out_small.zero_(); verdict.fill_(7)
+            graph.replay()
+            side.synchronize()
+            got = (out_big.clone(), out_small.clone(), verdict.clone())
+            out_big.zero_(); out_small.zero_(); verdict.fill_(7)
+            pk.pairing_fixed_g2_batch_dev(g1, g2var, table, kf, out_big, n_big, 0, side)
+            pk.pairing_fixed_g2_batch_dev(s1, s2, table, kf, out_small, n_small, 0, side)
+            assert pk.last_kernel(0, side) in (16, 32, 64)
+            pk.pairing_fixed_g2_check_target_batch_dev(s1, s2, table, kf, target, verdict, n_small, 0, side)
+            pk.last_status(0, side)
+            assert torch.equal(got[0], out_big) and torch.equal(got[1], out_small) and torch.equal(got[2], verdict)
+            assert int(out_big.abs().sum()) != 0 and int(out_small.abs().sum()) != 0 and int(verdict.max()) == 0
+            if first is not None:
+                assert not torch.equal(first, got[1])
+            first = got[1]
+    pk.release_stream(0, side)
