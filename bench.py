@@ -393,7 +393,18 @@ def extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n, sample_power=F
             out["Groth16 verifier check: 2^18 proofs, e(A, B) e(L, gamma) e(C, delta) == e(alpha, beta) with gamma, delta fixed (bn254_pairing_fixed_g2_check_target_batch_dev)"] = {
                 "ms": ms_v, "proofs_per_s": groups / (ms_v * 1e-3), "kernels": "k_fpairing + k_is_one", "speedup_over_four_free_pairs": g16["ms"] / ms_v,
                 "verdicts_as_expected": bool(int(verdict[0]) == 1 and int(verdict.sum()) == 1)}
-            del tab2, g1v, verdict
+            # groups whose G2 points are ALL fixed (g2_var = None): a KZG / PLONK opening check e(P_1, [tau] G2) e(P_2, G2) -- no point step at all
+            g1k = g1.view(8, groups, k)[:, :, :kv].contiguous().view(-1)
+            ms_k = timed(lambda: pkg.pairing_fixed_g2_check_target_batch_dev(g1k, None, tab2, kv, None, verdict, groups, device=local_rank, stream=stream), 2)
+            exp2 = g2fix.view(16, kf)[:, :kv].reshape(16, 1, kv).expand(16, groups, kv).contiguous().view(-1)
+            pkg.pairing_fixed_g2_batch_dev(g1k, None, tab2, kv, o3, groups, device=local_rank, stream=stream)
+            o4 = torch.zeros_like(o3)
+            pkg.multi_pairing_batch_dev(g1k, exp2, o4, groups, kv, True, device=local_rank, stream=stream)
+            torch.cuda.synchronize(dev)
+            out["KZG-style opening check: 2^18 groups of 2 pairs, both G2 points fixed for the batch (bn254_pairing_fixed_g2_check_target_batch_dev, g2_var = NULL)"] = {
+                "ms": ms_k, "checks_per_s": groups / (ms_k * 1e-3), "kernels": "k_fpairing (no own pair) + k_is_one",
+                "same_limbs_as_k_mpairing_on_the_expanded_pairs": bool(torch.equal(o3, o4))}
+            del tab2, g1v, verdict, g1k, exp2, o4
         del exp, o3, table
     # data formats either side of the path: element-major <-> limb-major on the device (HBM-bound: every word read once, written once)
     HBM_PEAK = 8.0e12

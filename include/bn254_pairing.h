@@ -287,7 +287,10 @@ int bn254_multi_pairing_check_batch_elems(const uint64_t* g1, const uint64_t* g2
  * reached).  g1: n x (1 + k_fixed) G1 points, group-major like every multi-pairing batch (limb-major planes of n (1 + k) points; or element-major for
  * the `_elems` form); g2_var: n G2 points; out: n Fq12.  The `_check` form gives the `== MyFq12::one` verdict byte per group instead
  * (final_exp_native.rs:245-263).  The G2 points of the table must be in the r-torsion like any other (bn254_check_points_ex).  One launch:
- * n (1 + k_fixed) <= 2^23 points per call.  Small batches (below the latency threshold, bn254_set_latency_threshold; k_fixed <= 3) are a fraction of one
+ * n (1 + k_fixed) <= 2^23 points per call.  g2_var == NULL (every form below): the groups have NO pair of their own -- g1 holds k_fixed points per group,
+ * every G2 point is one of the table's (a KZG / PLONK opening check e(P_1, [tau] G2) e(P_2, G2): two pairings for 3.45 M instructions, what ONE costs with a
+ * free G2 point; 2^18 such checks: 25.4 ms = 10.3 M/s against 34.8 ms for two free pairs; k_fixed = 1, pairing(P_i, Q) with one Q for the whole batch:
+ * 12.6 M pairings/s).  Small batches (below the latency threshold, bn254_set_latency_threshold; k_fixed <= 3) are a fraction of one
  * grid of that kernel (8 ms whatever n is): the table carries the fixed points behind its lines, and such a call expands the pairs and runs the
  * lane-cooperative k-pair program instead (one group of 1 + 3 pairs: 0.8 ms; the same limbs; its buffers are allocated on first use, or by
  * bn254_reserve(device, stream, n, 1 + k_fixed): the call is then a sequence of plain launches, capturable like the others). */

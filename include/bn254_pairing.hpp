@@ -224,10 +224,13 @@ inline std::vector<MyFq12> pairing_fixed_g2_batch(const std::vector<G1Affine>& p
 // MyFq12::one.  With gamma, delta as `fixed` and target = pairing(alpha, beta) a proof costs 1 + 2 pairs.
 inline std::vector<uint8_t> pairing_fixed_g2_check_batch(const std::vector<G1Affine>& ps, const std::vector<G2Affine>& qs, const std::vector<G2Affine>& fixed,
                                                          const MyFq12* target = nullptr, int device = 0) {
-    const size_t n = qs.size(), kf = fixed.size();
-    if (kf == 0 || ps.size() != n * (kf + 1)) throw Panic(BN254_ERR_INVALID_ARG);
+    // qs empty: the groups have no pair of their own -- ps holds fixed.size() points per group (a KZG / PLONK opening check e(P_1, [tau] G2) e(P_2, G2) == 1)
+    const size_t kf = fixed.size(), own = qs.empty() ? 0 : 1;
+    if (kf == 0) throw Panic(BN254_ERR_INVALID_ARG);
+    const size_t n = own ? qs.size() : ps.size() / kf;
+    if (ps.size() != n * (kf + own)) throw Panic(BN254_ERR_INVALID_ARG);
     std::vector<uint8_t> verdict(n);
-    check(bn254_pairing_fixed_g2_check_batch_elems(detail::words(ps.data()), detail::words(qs.data()), detail::words(fixed.data()), kf,
+    check(bn254_pairing_fixed_g2_check_batch_elems(detail::words(ps.data()), own ? detail::words(qs.data()) : nullptr, detail::words(fixed.data()), kf,
                                                    target ? detail::words(target) : nullptr, verdict.data(), n, device, nullptr));
     return verdict;
 }

@@ -428,6 +428,8 @@ def soa_to_elems_dev(soa, elems, words, n, fq12_order=FQ12_MYFQ12, device=0, str
 
 
 def _dev(t):
+    if t is None:
+        return None
     return ctypes.c_void_p(t.data_ptr()) if hasattr(t, "data_ptr") else ctypes.c_void_p(int(t))
 
 
@@ -465,23 +467,29 @@ def pairing_batch_elems_dev(g1, g2, out, n, out_order=FQ12_MYFQ12, device=0, str
 
 
 def pairing_fixed_g2_batch(g1, g2_var, g2_fixed, k_fixed, n, device=0, elems=False, out_order=FQ12_MYFQ12):
-    """host arrays: n groups of (own pair + k_fixed pairs whose G2 points, g2_fixed, are the same for every group); limb-major, or everything element-major"""
+    """host arrays: n groups of (own pair + k_fixed pairs whose G2 points, g2_fixed, are the same for every group); limb-major, or everything element-major.
+    g2_var=None: groups WITHOUT a pair of their own (k_fixed G1 points each: every G2 point is one of the fixed ones)"""
     lib = load_library()
-    g1, g2_var, g2_fixed = _np_in(g1, G1_WORDS, n * (1 + k_fixed)), _np_in(g2_var, G2_WORDS, n), _np_in(g2_fixed, G2_WORDS, k_fixed)
+    own = 0 if g2_var is None else 1
+    g1, g2_fixed = _np_in(g1, G1_WORDS, n * (own + k_fixed)), _np_in(g2_fixed, G2_WORDS, k_fixed)
+    g2_var = _np_in(g2_var, G2_WORDS, n) if own else None
     out = np.empty(FQ12_WORDS * n, dtype=np.uint64)
+    pv = _ptr(g2_var) if own else None
     if elems:
-        _check(lib.bn254_pairing_fixed_g2_batch_elems(_ptr(g1), _ptr(g2_var), _ptr(g2_fixed), k_fixed, _ptr(out), n, out_order, device, None), "pairing (fixed G2)")
+        _check(lib.bn254_pairing_fixed_g2_batch_elems(_ptr(g1), pv, _ptr(g2_fixed), k_fixed, _ptr(out), n, out_order, device, None), "pairing (fixed G2)")
     else:
-        _check(lib.bn254_pairing_fixed_g2_batch(_ptr(g1), _ptr(g2_var), _ptr(g2_fixed), k_fixed, _ptr(out), n, device, None), "pairing (fixed G2)")
+        _check(lib.bn254_pairing_fixed_g2_batch(_ptr(g1), pv, _ptr(g2_fixed), k_fixed, _ptr(out), n, device, None), "pairing (fixed G2)")
     return out
 
 
 def pairing_fixed_g2_check_batch_elems(g1, g2_var, g2_fixed, k_fixed, n, target=None, device=0):
     """HOST element-major arrays (n x (1 + k_fixed) G1 structs, n G2, k_fixed fixed G2) -> n verdict bytes: product == target (48 words; None = one)"""
-    g1, g2_var, g2_fixed = _np_in(g1, 8, n * (1 + k_fixed)), _np_in(g2_var, 16, n), _np_in(g2_fixed, 16, k_fixed)
+    own = 0 if g2_var is None else 1                         # (g2_var=None: groups without a pair of their own)
+    g1, g2_fixed = _np_in(g1, 8, n * (own + k_fixed)), _np_in(g2_fixed, 16, k_fixed)
+    g2_var = _np_in(g2_var, 16, n) if own else None
     verdict = np.zeros(n, dtype=np.uint8)
     keep, tp = _target_words(target)
-    _check(load_library().bn254_pairing_fixed_g2_check_batch_elems(_ptr(g1), _ptr(g2_var), _ptr(g2_fixed), k_fixed, tp, _ptr(verdict), n, device, None),
+    _check(load_library().bn254_pairing_fixed_g2_check_batch_elems(_ptr(g1), _ptr(g2_var) if own else None, _ptr(g2_fixed), k_fixed, tp, _ptr(verdict), n, device, None),
            "pairing check (fixed G2)")
     return verdict
 

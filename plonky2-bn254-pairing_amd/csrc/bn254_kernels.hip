@@ -562,7 +562,7 @@ int launch_fexp_pieces(const uint64_t* f_in, uint64_t* out, size_t n, int device
 
 // I/O layout of a launch of the generated kernels (bits 28..30 of their k argument, tools/kgen4_prog.py: S_MODE): which of the arrays are
 // ELEMENT-major -- one G1Affine / G2Affine / Fq12 after the other, as the reference's callers hold them -- instead of limb-major planes
-enum { IO_IN_ELEMS = 1, IO_OUT_ELEMS = 2, IO_OUT_ARK = 4 };
+enum { IO_IN_ELEMS = 1, IO_OUT_ELEMS = 2, IO_OUT_ARK = 4, IO_NO_OWN = 8 };      // (IO_NO_OWN: k_fpairing only -- groups without a pair of their own, MODE_NO_OWN)
 
 // would launch_pairing<M, F> serve this batch on the lane-cooperative kernel (whose programs read limb-major planes only)?
 template <bool M, bool F>
@@ -1061,10 +1061,10 @@ int bn254_multi_pairing_check_batch_dev(const uint64_t* g1, const uint64_t* g2, 
 // (planes of kf points, the tail of the line table).
 __global__ void __launch_bounds__(256) k_expand_fixed(const uint64_t* __restrict__ var, const uint64_t* __restrict__ fix, uint64_t* __restrict__ dst, size_t n, size_t kf,
                                                       int var_elems) {
-    size_t k = kf + 1, per = n * k;
+    size_t own = var ? 1 : 0, k = kf + own, per = n * k;          // (var == null: groups without a point of their own)
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per * 16; i += (size_t)gridDim.x * blockDim.x) {
         size_t w = i / per, r = i - w * per, g = r / k, j = r - g * k;
-        dst[i] = j ? fix[w * kf + (j - 1)] : (var_elems ? var[g * 16 + w] : var[w * n + g]);
+        dst[i] = (j >= own) ? fix[w * kf + (j - own)] : (var_elems ? var[g * 16 + w] : var[w * n + g]);
     }
 }
 // ---- fixed G2 points (a Groth16 verifier's beta, gamma, delta: the same for every proof).  bn254_g2_lines_dev walks the point steps of each
@@ -1089,16 +1089,19 @@ int bn254_g2_lines_dev(const uint64_t* g2_fixed, size_t k_fixed, uint64_t* table
 
 static int launch_fixed(const uint64_t* g1, const uint64_t* g2, const uint64_t* table, size_t k_fixed, uint64_t* out, size_t n, int io_mode, int device, void* stream) {
     if (n == 0) return BN254_OK;
-    if (!g1 || !g2 || !table || !out || k_fixed == 0 || k_fixed > (size_t)BN254_FIXED_MAX || n * (k_fixed + 1) > ((size_t)1 << 23)) return BN254_ERR_INVALID_ARG;      // (32-bit lane offsets of the element-major form: 384 n < 4 GB)
+    // g2 == null: groups WITHOUT a pair of their own (every G2 point is one of the table's: a KZG-style check e(P_1, Qfix_1) e(P_2, Qfix_2)): g1 holds k_fixed points per group
+    const size_t own = g2 ? 1 : 0;
+    if (!g2) io_mode |= IO_NO_OWN;
+    if (!g1 || !table || !out || k_fixed == 0 || k_fixed > (size_t)BN254_FIXED_MAX || n * (k_fixed + 1) > ((size_t)1 << 23)) return BN254_ERR_INVALID_ARG;      // (32-bit lane offsets of the element-major form: 384 n < 4 GB)
     LaunchCtx c;
     int rc = ctx_get(device, stream, 1, (n + BLOCK - 1) / BLOCK, &c);
     if (rc) return rc;
-    if (takes_latency_kernel<true, true>(n, k_fixed + 1, device, stream)) {
+    if (takes_latency_kernel<true, true>(n, k_fixed + own, device, stream)) {
         // a batch this small is a fraction of one grid of the throughput kernel (8 ms whatever n is): expand the pairs and let the lane-cooperative k-pair
         // program take them (a single group of 1 + 3 pairs: 0.74 ms) -- the same value, hence the same limbs (the final exponentiation does not see how the
         // Miller value was reached)
         StreamCtx* sc = c.s.get();
-        const size_t k = k_fixed + 1, np = n * k;
+        const size_t k = k_fixed + own, np = n * k;
         const bool in_e = io_mode & IO_IN_ELEMS, out_e = io_mode & IO_OUT_ELEMS;
         if ((rc = ensure(sc, sc->sub[1], 128 * np)) || (in_e && (rc = ensure(sc, sc->sub[0], 64 * np))) || (out_e && (rc = ensure(sc, sc->sub[2], 384 * n)))) return rc;
         uint64_t *p1 = (uint64_t*)sc->sub[0].p, *p2 = (uint64_t*)sc->sub[1].p, *p3 = (uint64_t*)sc->sub[2].p;
@@ -1169,19 +1172,20 @@ static int finish_fixed_host(Stage& s, void* h_out, const void* d_out, size_t by
 static int fixed_host(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* g2_fixed, size_t k_fixed, uint64_t* out, size_t n, bool elems, int out_order,
                       int device, void* stream) {
     if (n == 0) return BN254_OK;
-    if (!g1 || !g2_var || !g2_fixed || !out || k_fixed == 0 || k_fixed > (size_t)BN254_FIXED_MAX || n * (k_fixed + 1) >= ((size_t)1 << 29) ||
+    if (!g1 || !g2_fixed || !out || k_fixed == 0 || k_fixed > (size_t)BN254_FIXED_MAX || n * (k_fixed + 1) >= ((size_t)1 << 29) ||
         (out_order != BN254_FQ12_MYFQ12 && out_order != BN254_FQ12_ARK))
         return BN254_ERR_INVALID_ARG;
+    const size_t own = g2_var ? 1 : 0;    // (g2_var == null: groups without a pair of their own, k_fixed G1 points each)
     if (n > PIPE_CHUNK) {                 // large batch: chunked, copies overlapped with compute (private streams), the table made once
         int rc0 = check_device(device);
         if (rc0) return rc0;
         HIPCHK(hipStreamSynchronize((hipStream_t)stream));
         HostFmt fmt; fmt.elems = elems; fmt.out_order = out_order;
         FixedJob job; job.g2_fixed = g2_fixed; job.k_fixed = k_fixed;
-        return run_pipeline(&device, 1, g1, g2_var, out, n, k_fixed + 1, 1, fmt, &job);
+        return run_pipeline(&device, 1, g1, g2_var, out, n, k_fixed + own, 1, fmt, &job);
     }
-    Stage s; uint64_t *d1, *d2, *d3; const uint64_t* dt; int rc;
-    if ((rc = s.init(device, stream)) || (rc = s.up(g1, 64 * n * (k_fixed + 1), &d1)) || (rc = s.up(g2_var, 128 * n, &d2)) || (rc = s.up(nullptr, 384 * n, &d3)) ||
+    Stage s; uint64_t *d1, *d2 = nullptr, *d3; const uint64_t* dt; int rc;
+    if ((rc = s.init(device, stream)) || (rc = s.up(g1, 64 * n * (k_fixed + own), &d1)) || (own && (rc = s.up(g2_var, 128 * n, &d2))) || (rc = s.up(nullptr, 384 * n, &d3)) ||
         (rc = host_table(s, g2_fixed, k_fixed, elems, device, stream, &dt)))
         return rc;
     rc = elems ? bn254_pairing_fixed_g2_batch_elems_dev(d1, d2, dt, k_fixed, d3, n, out_order, device, stream)
@@ -1200,17 +1204,18 @@ int bn254_pairing_fixed_g2_batch_elems(const uint64_t* g1, const uint64_t* g2_va
 int bn254_pairing_fixed_g2_check_batch_elems(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* g2_fixed, size_t k_fixed, const uint64_t* target,
                                              uint8_t* verdict, size_t n, int device, void* stream) {
     if (n == 0) return BN254_OK;
-    if (!g1 || !g2_var || !g2_fixed || !verdict || k_fixed == 0 || k_fixed > (size_t)BN254_FIXED_MAX || n * (k_fixed + 1) >= ((size_t)1 << 29)) return BN254_ERR_INVALID_ARG;
+    if (!g1 || !g2_fixed || !verdict || k_fixed == 0 || k_fixed > (size_t)BN254_FIXED_MAX || n * (k_fixed + 1) >= ((size_t)1 << 29)) return BN254_ERR_INVALID_ARG;
+    const size_t own = g2_var ? 1 : 0;
     if (n > PIPE_CHUNK) {
         int rc0 = check_device(device);
         if (rc0) return rc0;
         HIPCHK(hipStreamSynchronize((hipStream_t)stream));
         HostFmt fmt; fmt.elems = true;
         FixedJob job; job.g2_fixed = g2_fixed; job.k_fixed = k_fixed; job.verdict = verdict; job.target = target;
-        return run_pipeline(&device, 1, g1, g2_var, nullptr, n, k_fixed + 1, 1, fmt, &job);
+        return run_pipeline(&device, 1, g1, g2_var, nullptr, n, k_fixed + own, 1, fmt, &job);
     }
-    Stage s; uint64_t *d1, *d2, *d3, *dv; const uint64_t* dt; int rc;
-    if ((rc = s.init(device, stream)) || (rc = s.up(g1, 64 * n * (k_fixed + 1), &d1)) || (rc = s.up(g2_var, 128 * n, &d2)) || (rc = s.up(nullptr, 384 * n, &d3)) ||
+    Stage s; uint64_t *d1, *d2 = nullptr, *d3, *dv; const uint64_t* dt; int rc;
+    if ((rc = s.init(device, stream)) || (rc = s.up(g1, 64 * n * (k_fixed + own), &d1)) || (own && (rc = s.up(g2_var, 128 * n, &d2))) || (rc = s.up(nullptr, 384 * n, &d3)) ||
         (rc = s.up(nullptr, (n + 7) & ~(size_t)7, &dv)) || (rc = host_table(s, g2_fixed, k_fixed, true, device, stream, &dt)))
         return rc;
     if ((rc = launch_fixed(d1, d2, dt, k_fixed, d3, n, IO_IN_ELEMS, device, stream)) || (rc = launch_is_equal(d3, target, (uint8_t*)dv, n, stream))) return rc;
@@ -1581,10 +1586,10 @@ static int run_chunks(int dev, PipeWorker pw, const uint64_t* g1, const uint64_t
     {
         Stage s; uint64_t *d1, *d2, *d3, *e1 = nullptr, *e2 = nullptr, *e3 = nullptr;
         std::vector<uint64_t> hres;                             // (verdict calls: a chunk's Fq12 values on their way to the comparison)
-        const size_t k2 = fx ? 1 : k;                          // G2 points per unit (a fixed-G2 unit brings its own point only)
+        const size_t k2 = fx ? (g2 ? 1 : 0) : k;               // G2 points per unit (a fixed-G2 unit brings its own point only -- or none)
         size_t cap = cnt < chunk ? cnt : chunk, np_all = n_units * k, np2_all = n_units * k2;
-        if ((rc = s.init(dev, st)) || (rc = s.up(nullptr, 64 * cap * k, &d1)) || (rc = s.up(nullptr, 128 * cap * k2, &d2)) || (rc = s.up(nullptr, 384 * cap, &d3))) goto done;
-        if (fmt.elems && ((rc = s.up(nullptr, 64 * cap * k, &e1)) || (rc = s.up(nullptr, 128 * cap * k2, &e2)) || (rc = s.up(nullptr, 384 * cap, &e3)))) goto done;
+        if ((rc = s.init(dev, st)) || (rc = s.up(nullptr, 64 * cap * k, &d1)) || (rc = s.up(nullptr, 128 * cap * (k2 ? k2 : 1), &d2)) || (rc = s.up(nullptr, 384 * cap, &d3))) goto done;
+        if (fmt.elems && ((rc = s.up(nullptr, 64 * cap * k, &e1)) || (rc = s.up(nullptr, 128 * cap * (k2 ? k2 : 1), &e2)) || (rc = s.up(nullptr, 384 * cap, &e3)))) goto done;
         for (size_t c0 = first * chunk; c0 < cnt; c0 += step * chunk) {
             size_t m = cnt - c0 < chunk ? cnt - c0 : chunk, np = m * k, np2 = m * k2, base = u0 + c0;
             // a chunk of an element-major array is one contiguous run, and the throughput kernels take it as it is (no transposition pass, which --
@@ -1593,10 +1598,10 @@ static int run_chunks(int dev, PipeWorker pw, const uint64_t* g1, const uint64_t
             const bool direct = fmt.elems && !fx && (do_final_exp ? direct_elems_ok<true, true>(m, k, dev, st) : direct_elems_ok<true, false>(m, k, dev, st));
             if (fmt.elems) {
                 if (copy_rows(e1, g1 + base * k * 8, np * 64, hipMemcpyHostToDevice, st) != hipSuccess ||
-                    copy_rows(e2, g2 + base * k2 * 16, np2 * 128, hipMemcpyHostToDevice, st) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
+                    (np2 && copy_rows(e2, g2 + base * k2 * 16, np2 * 128, hipMemcpyHostToDevice, st) != hipSuccess)) { rc = BN254_ERR_HIP; goto done; }
                 if (!direct && !fx && ((rc = launch_layout(true, e1, d1, 8, np, 0, dev, st)) || (rc = launch_layout(true, e2, d2, 16, np, 0, dev, st)))) goto done;
             } else if (hipMemcpy2DAsync(d1, np * 8, g1 + base * k, np_all * 8, np * 8, 8, hipMemcpyHostToDevice, st) != hipSuccess ||
-                       hipMemcpy2DAsync(d2, np2 * 8, g2 + base * k2, np2_all * 8, np2 * 8, 16, hipMemcpyHostToDevice, st) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }
+                       (np2 && hipMemcpy2DAsync(d2, np2 * 8, g2 + base * k2, np2_all * 8, np2 * 8, 16, hipMemcpyHostToDevice, st) != hipSuccess)) { rc = BN254_ERR_HIP; goto done; }
             if (fx) {
                 // the fixed-G2 kernel reads either layout itself (a small last chunk: launch_fixed expands the pairs for the lane-cooperative program)
                 const bool vd = fx->verdict != nullptr;                      // (verdicts: element-major input only)
@@ -1604,7 +1609,7 @@ static int run_chunks(int dev, PipeWorker pw, const uint64_t* g1, const uint64_t
                 const bool last = c0 + chunk >= cnt;                           // nothing is queued behind the job's last launch
                 const bool planes_out = !fmt.elems || (vd && last);
                 const int mode = fmt.elems ? (IO_IN_ELEMS | (planes_out ? 0 : IO_OUT_ELEMS | (!vd && fmt.out_order == BN254_FQ12_ARK ? IO_OUT_ARK : 0))) : 0;
-                if ((rc = launch_fixed(fmt.elems ? e1 : d1, fmt.elems ? e2 : d2, fx->table, fx->k_fixed, planes_out ? d3 : e3, m, mode, dev, st))) goto done;
+                if ((rc = launch_fixed(fmt.elems ? e1 : d1, !k2 ? nullptr : (fmt.elems ? e2 : d2), fx->table, fx->k_fixed, planes_out ? d3 : e3, m, mode, dev, st))) goto done;
                 if (vd && last) {
                     if ((rc = launch_is_equal(d3, fx->target, (uint8_t*)e1, m, st))) goto done;              // (e1: this chunk's inputs, dead behind its launch)
                     if (hipMemcpy2DAsync(fx->verdict + base, m, e1, m, m, 1, hipMemcpyDeviceToHost, st) != hipSuccess) { rc = BN254_ERR_HIP; goto done; }

@@ -272,14 +272,20 @@ pub fn pairing_fixed_g2_batch(ps: &[G1Affine], qs: &[G2Affine], fixed: &[G2Affin
 }
 /// New: a Groth16 verifier's pairing check for a batch of proofs: `product of the group's 1 + fixed.len() pairings == target` (`None`: `MyFq12::one`).
 /// With gamma, delta as `fixed` and `target = pairing(alpha, beta)` a proof costs 1 + 2 pairs.
+/// `qs` empty: the groups have NO pair of their own -- `ps` holds `fixed.len()` points per group, every G2 point is one of `fixed` (a KZG / PLONK opening
+/// check `e(P_1, [tau] G2) e(P_2, G2) == 1`: two pairings for the price of one with a free G2 point).
 pub fn pairing_fixed_g2_check_batch(ps: &[G1Affine], qs: &[G2Affine], fixed: &[G2Affine], target: Option<&MyFq12>) -> Vec<bool> {
-    let (n, kf) = (qs.len(), fixed.len());
-    assert!(kf > 0 && kf <= 4 && ps.len() == n * (kf + 1));
+    let kf = fixed.len();
+    assert!(kf > 0 && kf <= 4);
+    let own = if qs.is_empty() { 0 } else { 1 };
+    let n = if own == 1 { qs.len() } else { ps.len() / kf };
+    assert!(ps.len() == n * (kf + own));
     if n == 0 { return Vec::new(); }
     let (g1, g2, gf) = (elems_g1(ps), elems_g2(qs), elems_g2(fixed)); let mut v = vec![0u8; n];
     let t: Option<[u64; 48]> = target.map(pack_fq12);
     let tp = t.as_ref().map_or(core::ptr::null(), |w| w.as_ptr());
-    ok(unsafe { bn254_pairing_fixed_g2_check_batch_elems(g1.as_ptr(), g2.as_ptr(), gf.as_ptr(), kf, tp, v.as_mut_ptr(), n, 0, core::ptr::null_mut()) });
+    let qp = if own == 1 { g2.as_ptr() } else { core::ptr::null() };
+    ok(unsafe { bn254_pairing_fixed_g2_check_batch_elems(g1.as_ptr(), qp, gf.as_ptr(), kf, tp, v.as_mut_ptr(), n, 0, core::ptr::null_mut()) });
     v.into_iter().map(|b| b != 0).collect()
 }
 #[allow(dead_code)] fn _ark_index(j: i32) -> i32 { unsafe { bn254_myfq12_to_ark_index(j) } }

@@ -303,3 +303,64 @@ def test_fixed_g2_calls_are_capturable_after_reserve():
                 assert not torch.equal(first, got[1])
             first = got[1]
     pk.release_stream(0, side)
+
+
+@pytest.mark.parametrize("kf", [1, 2, 3, 4])
+def test_fixed_g2_groups_without_an_own_pair(kf):
+    """g2_var = NULL: every G2 point of a group is one of the table's (a KZG-style opening check): final_exp_native(multi_miller_loop_native) of the
+    k_fixed pairs -- the same limbs as the k-pair kernel on the expanded pairs, on every lane; small batches through the lane-cooperative programs,
+    element-major / ark order, verdicts, host forms (single shot and pipeline)."""
+    import torch
+    pk = H.pkg()
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev)
+    idx = [pk.load_library().bn254_myfq12_to_ark_index(j) for j in range(12)]
+    g2fix = torch.zeros(16 * kf, dtype=torch.int64, device=dev)
+    pk.generate_pairs_dev(0x4B5A + kf, torch.zeros(8 * kf, dtype=torch.int64, device=dev), g2fix, kf, 0, st)
+    table = torch.zeros(pk.g2_lines_bytes(kf) // 8, dtype=torch.int64, device=dev)
+    pk.g2_lines_dev(g2fix, kf, table, 0, st)
+    for n in (3, 1500 + 13 * kf, 65536 + 300):
+        g1 = torch.zeros(8 * n * kf, dtype=torch.int64, device=dev)
+        pk.generate_pairs_dev(0x4B00 + n, g1, torch.zeros(16 * n * kf, dtype=torch.int64, device=dev), n * kf, 0, st)
+        exp = g2fix.view(16, 1, kf).expand(16, n, kf).contiguous().view(-1)
+        want = torch.zeros(48 * n, dtype=torch.int64, device=dev)
+        if kf == 1:
+            pk.pairing_batch_dev(g1, exp, want, n, 0, st)
+        else:
+            pk.multi_pairing_batch_dev(g1, exp, want, n, kf, True, 0, st)
+        for thr in (0, None):                                   # the throughput kernel at every size; then the default route (small batches: lane-cooperative)
+            if thr is not None:
+                pk.set_stream_latency(thr, -1, 0, st)
+            try:
+                got = torch.full((48 * n + 8,), -7, dtype=torch.int64, device=dev)
+                pk.pairing_fixed_g2_batch_dev(g1, None, table, kf, got, n, 0, st)
+                kern = pk.last_kernel(0, st)
+                e1 = torch.empty_like(g1)
+                pk.soa_to_elems_dev(g1, e1, 8, n * kf, 0, 0, st)
+                eo = torch.full((48 * n + 8,), -7, dtype=torch.int64, device=dev)
+                pk.pairing_fixed_g2_batch_elems_dev(e1, None, table, kf, eo, n, pk.FQ12_ARK, 0, st)
+                v = torch.full((n,), 9, dtype=torch.uint8, device=dev)
+                target = want.view(48, n)[:, n - 1].contiguous().cpu().numpy().view(np.uint64)
+                pk.pairing_fixed_g2_check_target_batch_dev(g1, None, table, kf, target, v, n, 0, st)
+                pk.last_status(0, st)
+            finally:
+                pk.set_stream_latency(pk.LATENCY_INHERIT, -1, 0, st)
+            assert kern == 1 if (thr == 0 or n > 60000) else kern in (16, 32, 64)
+            assert torch.equal(got[: 48 * n], want) and bool((got[48 * n:] == -7).all()) and int(want.abs().sum()) != 0
+            assert torch.equal(eo[: 48 * n].view(n, 12, 4), want.view(48, n).t().contiguous().view(n, 12, 4)[:, idx, :]) and bool((eo[48 * n:] == -7).all())
+            assert v.tolist() == [0] * (n - 1) + [1]
+        h = lambda t: t.cpu().numpy().view(np.uint64).copy()
+        h1, hf, hw = h(g1), h(g2fix), h(want)
+        assert np.array_equal(pk.pairing_fixed_g2_batch(h1, None, hf, kf, n), hw)
+        e1h, efh = H.to_aos(h1, 8), H.to_aos(hf, 16)
+        assert np.array_equal(pk.pairing_fixed_g2_batch(e1h, None, efh, kf, n, elems=True), H.to_aos(hw, 48))
+        vh = pk.pairing_fixed_g2_check_batch_elems(e1h, None, efh, kf, n, target=H.to_aos(hw, 48).reshape(n, 48)[0])
+        assert vh[0] == 1 and vh.sum() == 1
+    # the oracle on two groups of the last batch
+    pos = [1, n - 1]
+    sel = torch.as_tensor([p * kf + j for p in pos for j in range(kf)], device=dev)
+    g1h = g1.view(8, n * kf)[:, sel].cpu().numpy().view(np.uint64).reshape(-1).copy()
+    g2h = exp.view(16, n * kf)[:, sel].cpu().numpy().view(np.uint64).reshape(-1).copy()
+    ora = H.oracle_multi_pairing(pk.layout.to_aos(g1h, 8), pk.layout.to_aos(g2h, 16), len(pos), kf)
+    mine = want.view(48, n)[:, torch.as_tensor(pos, device=dev)].cpu().numpy().view(np.uint64).reshape(-1).copy()
+    assert np.array_equal(pk.layout.to_aos(mine, 48), ora)

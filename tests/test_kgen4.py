@@ -723,3 +723,30 @@ def test_fixed_g2_kernels(vec):
         assert got == want, mode
         assert m.max_acc < (1 << 63) and STAT not in m.gmem
     print("fixed-G2 kernel:", m.count, "instructions for one group of 1 + 2 pairs")
+    # groups WITHOUT a pair of their own (mode bit 3: a KZG-style check, every G2 point one of the table's): f = 1, squarings and table lines only
+    assert kb.certify_values(1, own_pair=False)["max_stored"] <= K4P.V_CAP
+    want = None
+    for pi, qi in zip(grp[lane][1:], fixed_idx):
+        mv = R.miller_loop_native((tuple(HX(vec["g2"][qi])[:2]), tuple(HX(vec["g2"][qi])[2:])), tuple(HX(vec["g1"][pi])))
+        want = mv if want is None else R.fq12_mul(want, mv)
+    want = R.final_exp_native(want)
+    rows1 = [HX(vec["g1"][i]) for g in grp for i in g[1:]]
+    m = S.Machine()
+    m.gmem.update(gmem)
+    for i, w in enumerate(_soa(rows1)):
+        m.gmem[G1B + 8 * i] = w & 0xFFFFFFFF
+        m.gmem[G1B + 8 * i + 4] = (w >> 32) & 0xFFFFFFFF
+    for name, val in (("s[2:3]", G1B), ("s[4:5]", 0), ("s[6:7]", TABB), ("s[8:9]", OUTB), ("s10", n), ("s11", kf | (8 << 28)), ("s[12:13]", SCR),
+                      ("s14", 256 * K4.SLOT_BYTES), ("s[16:17]", STAT), ("s18", 0), ("s19", 1)):
+        m.sset(name, val)
+    m.v[255] = lane
+    S.run(lines_f, m)
+    got = []
+    for c in range(12):
+        v = 0
+        for l in range(4):
+            a = OUTB + ((c * 4 + l) * n + lane) * 8
+            v |= (m.gmem[a] | (m.gmem[a + 4] << 32)) << (64 * l)
+        got.append(R.from_mont(v))
+    assert got == want and m.max_acc < (1 << 63) and STAT not in m.gmem
+    print("fixed-G2 kernel, no own pair:", m.count, "instructions for one group of 2 fixed pairs")

@@ -66,6 +66,7 @@ S_TAB = "s[72:73]"        # fixed-G2 kernels: address of the current line triple
 S_TABCUR = 74
 V_IOOFF = 247             # the lane's byte offset into the array being walked: index * 8 (limb-major) or index * 8 * words per element
 MODE_IN_ELEMS, MODE_OUT_ELEMS, MODE_OUT_ARK = 0, 1, 2      # bit numbers in S_MODE
+MODE_NO_OWN = 3            # fixed-G2 kernel: the groups have NO pair of their own -- every G2 point is one of the table's (a KZG-style check: e(P_1, Qfix_1) e(P_2, Qfix_2))
 BLOCK = 256
 
 
@@ -2291,8 +2292,9 @@ class KernelBuilder:
         assert self.l2_maxv[name] <= V_CAP, f"{name} stores {self.l2_maxv[name]} p"
         return self.l2_maxv[name]
 
-    def certify_values(self, k_pairs=1):
-        """Returns a report dict (call sequence, largest stored bound); raises on any contract violation."""
+    def certify_values(self, k_pairs=1, own_pair=True):
+        """Returns a report dict (call sequence, largest stored bound); raises on any contract violation.
+        own_pair=False: the fixed-G2 kernel on groups without a pair of their own (MODE_NO_OWN): f = 1, then only squarings and table lines."""
         worst, calls, seq = 0.0, 0, []
 
         bound = {}                               # what the walked routines left in the slots (only read where a routine assumes less than the contract)
@@ -2309,9 +2311,12 @@ class KernelBuilder:
             if name in ("L2_descale", "L2_inv"):
                 seq.append("L2_fqinv")           # nested: the Fq inversion (fixed exponent)
             if name in fixed_after:              # the fixed-G2 kernel: the current table line of every fixed pair (the most there can be)
-                for j in range(self.MAX_FIXED):
-                    run(f"L2_fix_{j}")
-                    run(self.fsp_variant[j])
+                lines()
+
+        def lines():
+            for j in range(self.MAX_FIXED):
+                run(f"L2_fix_{j}")
+                run(self.fsp_variant[j])
 
         assert self.main_prog.max_v <= V_STORE, "the main program stores across routine boundaries only"
         fis = self.fission and k_pairs <= FIS_MAX_K
@@ -2343,7 +2348,21 @@ class KernelBuilder:
             for _ in range(k_pairs):
                 run("L2_addmul")
                 run("L2_addmul_last")
-        if self.do_miller and not fis:
+        if self.do_miller and not fis and not own_pair:
+            assert self.fixed
+            bound.update({Prog.key(s_): 1.01 for s_ in self.F})         # f = 1 (the main program's stores)
+            lines()
+            for i in range(self.naf_first, -1, -1):
+                if i != self.naf_first:
+                    run("L2_sqr")
+                    lines()
+                if self.naf[i] != 0:
+                    run("L2_fxred")
+                    lines()
+            for _ in range(2):
+                run("L2_fxred")
+                lines()
+        if self.do_miller and not fis and own_pair:
             run("L2_dblfirst")
             for _ in range(k_pairs - 1):
                 run("L2_dblmul")
@@ -3736,7 +3755,7 @@ class KernelBuilder:
     # multiplication is six two-product passes (Prog.mul_by_034_one) instead of six three-product ones, and one routine serves every line.
     def _fixed_routines(self):
         # (the third waiting result of the multiplication goes through the global scratch: handing it the line's unused constant slot, AGPR 6,
-        # instead was measured 0.7 % SLOWER -- 36 more AGPR moves per line against ten memory instructions whose latency the passes hide)
+        # instead makes no measurable difference -- 36 more AGPR moves per line against ten memory instructions whose latency the passes hide)
         tm = self.miller_temps(extra=(self.SX, self.SY))
         n_last = sum(1 for d in self.naf[:1] if d) + 2            # lines behind the last squaring: the digit-0 addition (none: 6x + 2 is even) + the Frobenius pair
         assert n_last % 2 == 0, "an odd number of w factors would survive the easy part"
@@ -3764,9 +3783,11 @@ class KernelBuilder:
         # So the multiplication is built per position j in the run of fixed lines, each variant assuming what its predecessor leaves (the first: the
         # largest bounds the own pair's routines leave); a variant whose output would pass the contract reduces there, and a later position
         # whose entry bounds an earlier variant covers reuses it.  certify_values() checks every call against the assumed bounds.
+        # (groups without a pair of their own: an addition step's lines follow the doubling step's directly -- f is brought back in between)
+        self.l2_routine("L2_fxred", self._reduce_f, tm)
         Fk = [Prog.key(s_) for s_ in self.F]
-        before = ("L2_dblfirst", "L2_dblmul", "L2_addmul", "L2_addmul_last")
-        ent = {k: max(max(self.l2_exit[n].get(k, 0.0) for n in before), 0.51) for k in Fk}
+        before = ("L2_dblfirst", "L2_dblmul", "L2_addmul", "L2_addmul_last", "L2_sqr", "L2_fxred")   # (L2_sqr, L2_fxred: groups without a pair of their own, MODE_NO_OWN)
+        ent = {k: max(max(self.l2_exit[n].get(k, 0.0) for n in before), 1.01) for k in Fk}               # (1.01: f = 1 at the start of such a group)
         line = {Prog.key(s_): max(self.l2_exit[f"L2_fix_{j}"][Prog.key(s_)] for j in range(self.MAX_FIXED)) for s_ in self.LINE[1:]}     # (the scaled coefficients: 0.6 p)
         variants, self.fsp_variant = [], []
         for j in range(self.MAX_FIXED):
@@ -3793,31 +3814,40 @@ class KernelBuilder:
 
     def miller_main_fixed(self, e, p):
         """g1: 1 + S_K points per group, group-major (the group's own P first, then the P_j of the fixed pairs); g2: the group's own Q;
-        f_in: the line table of the S_K fixed points."""
+        f_in: the line table of the S_K fixed points.  Mode bit MODE_NO_OWN: the groups have no pair of their own -- g1: S_K points per group,
+        g2 unused, f starts at one and only the table lines are multiplied in (the loop's squarings, S_K lines per step, the final exponentiation)."""
         L = self.lab
-        e.salu(f"s_add_u32 s{S_TMP1}, s{S_K}, 1")
+        own = lambda label: (e.salu(f"s_bitcmp1_b32 s{self.s_mode}, {MODE_NO_OWN}"), e.salu(f"s_cbranch_scc1 {label}"))      # skip the own pair's work
+        e.salu(f"s_bitcmp0_b32 s{self.s_mode}, {MODE_NO_OWN}")      # SCC = 1 iff the group has its own pair
+        e.salu(f"s_addc_u32 s{S_TMP1}, s{S_K}, 0")                   # points per group: S_K (+ 1)
         e.salu(f"s_mul_i32 s{S_NSTRIDE}, s{S_N}, s{S_TMP1}")
         e.salu(f"s_lshl_b32 s{S_NSTRIDE}, s{S_NSTRIDE}, 3")          # bytes between limb planes of the G1 batch
         e.emit(f"v_mul_lo_u32 v{V_IDX8}, v{V_IDX8}, s{S_TMP1}", vw=[V_IDX8])   # byte offset of the group's first point
+        own(L("L_fx_noP"))
         self.io_walk_begin(e, S_G1, 8)
         self.io_load_fq2_into_A(e, p, c1_present=False)          # Px
         p.to(self.PX)
         self.io_load_fq2_into_A(e, p, c1_present=False)          # Py
         p.to(self.PY)
+        e.emit(f"v_add_u32_e32 v{V_IDX8}, 8, v{V_IDX8}", vw=[V_IDX8])
+        e.label(L("L_fx_noP"))
+        p.reset_tags()
         skip = L("L_fx_pts")
         for j in range(self.MAX_FIXED):                          # (Px_j, Py_j) packed into one slot: c0 = Px, c1 = Py
             e.salu(f"s_cmp_gt_u32 s{S_K}, {j}")
             e.salu(f"s_cbranch_scc0 {skip}")
-            e.emit(f"v_add_u32_e32 v{V_IDX8}, 8, v{V_IDX8}", vw=[V_IDX8])
             self.io_walk_begin(e, S_G1, 8)
             self.io_load_fq2_into_A(e, p)
             p.to(self.FIX_P[j])
             p.reset_tags()
+            e.emit(f"v_add_u32_e32 v{V_IDX8}, 8, v{V_IDX8}", vw=[V_IDX8])
         e.label(skip)
         e.salu(f"s_lshl_b32 s{S_NSTRIDE}, s{S_N}, 3")                # G2 and the result: one element per group
         e.salu(f"s_sub_u32 s{S_TMP1}, s{S_N}, 1")
         e.emit(f"v_min_u32_e32 v{V_IDX8}, s{S_TMP1}, v{V_IDX}", vw=[V_IDX8])
         e.emit(f"v_lshlrev_b32_e32 v{V_IDX8}, 3, v{V_IDX8}", vw=[V_IDX8])
+        e.salu(f"s_mov_b32 s{S_TABCUR}, 0")
+        own(L("L_fx_noQ"))
         self.io_walk_begin(e, S_G2, 16)
         self.io_load_fq2_into_A(e, p)                            # Q.x
         p.to(self.QX)
@@ -3829,8 +3859,20 @@ class KernelBuilder:
         p.set_A_fresh()
         p.to(self.R[2])
         p.reset_tags()
-        e.salu(f"s_mov_b32 s{S_TABCUR}, 0")
         self.call2(e, "L2_dblfirst")
+        e.salu(f"s_branch {L('L_fx_f0')}")
+        e.label(L("L_fx_noQ"))
+        p.reset_tags()
+        self.one_into_A(e)                                       # f = 1
+        p.set_A_fresh()
+        p.to(self.F[0])
+        p.wait()
+        self.zero_block(e, A0)
+        p.set_A_fresh(0.0)
+        for k_ in range(1, 6):
+            p.to(self.F[k_])
+        p.reset_tags()
+        e.label(L("L_fx_f0"))
         self._fixed_lines(e)
         first = self.naf_first
         assert first == 63
@@ -3839,25 +3881,35 @@ class KernelBuilder:
         e.salu(f"s_cmp_eq_u32 s{S_I}, {first}")
         e.salu(f"s_cbranch_scc1 {L('L_mskip')}")
         self.call2(e, "L2_sqr")
+        own(L("L_fx_nodbl"))
         self.call2(e, "L2_dblmul")
+        e.label(L("L_fx_nodbl"))
         self._fixed_lines(e)
         e.label(L("L_mskip"))
         e.salu(f"s_bitcmp1_b64 {S_NAF_NZ}, s{S_I}")
         e.salu(f"s_cbranch_scc0 {L('L_mnoadd')}")
-        self._select_pm_q(e, p)
-        self.call2(e, "L2_addmul")
+        self._own_or_reduce(e, p, L, "noadd", lambda: (self._select_pm_q(e, p), self.call2(e, "L2_addmul")))
         self._fixed_lines(e)
         e.label(L("L_mnoadd"))
         e.salu(f"s_sub_u32 s{S_I}, s{S_I}, 1")
         e.salu(f"s_cbranch_scc0 {L('L_mloop')}")
-        self._frobenius_points(p)                                # + pi(Q), then the line through the result and -pi^2(Q)
-        self.call2(e, "L2_addmul")
+        # + pi(Q), then the line through the result and -pi^2(Q)
+        self._own_or_reduce(e, p, L, "nofr1", lambda: (self._frobenius_points(p), self.call2(e, "L2_addmul")))
+        self._fixed_lines(e)
+        self._own_or_reduce(e, p, L, "nofr2", lambda: (p.reset_tags(), p.mov(self.SX, self.QX), p.mov(self.SY, self.QY), self.call2(e, "L2_addmul_last")))
         self._fixed_lines(e)
         p.reset_tags()
-        p.mov(self.SX, self.QX)
-        p.mov(self.SY, self.QY)
-        self.call2(e, "L2_addmul_last")
-        self._fixed_lines(e)
+
+    def _own_or_reduce(self, e, p, L, tag, own_work):
+        """the own pair's step in front of a run of table lines -- or, for groups without one (MODE_NO_OWN), f brought back to (-0.51 p, 0.51 p): the
+        previous run's lines have grown it, and the first line's multiplication assumes what the own pair's routines leave"""
+        e.salu(f"s_bitcmp1_b32 s{self.s_mode}, {MODE_NO_OWN}")
+        e.salu(f"s_cbranch_scc1 {L('L_fx_' + tag)}")
+        own_work()
+        e.salu(f"s_branch {L('L_fx_' + tag + '_done')}")
+        e.label(L("L_fx_" + tag))
+        self.call2(e, "L2_fxred")
+        e.label(L("L_fx_" + tag + "_done"))
         p.reset_tags()
 
     # the table's maker: one fixed G2 point per lane (g2: S_N points), out = the table.  Pass 1 walks the point steps and leaves, per line, the

@@ -558,6 +558,8 @@ def run(lines, m, entry=None, max_steps=200_000_000, trace=None, start_pc=None, 
                 m.scc = (m.sget(a[0]) >> (m.vsrc(a[1], False) & 63)) & 1
             elif op == "s_bitcmp1_b32":
                 m.scc = (m.vsrc(a[0], False) >> (m.vsrc(a[1], False) & 31)) & 1
+            elif op == "s_bitcmp0_b32":
+                m.scc = 1 - ((m.vsrc(a[0], False) >> (m.vsrc(a[1], False) & 31)) & 1)
             elif op == "s_cbranch_scc1":
                 if m.scc:
                     pc = labels[a[0]]
