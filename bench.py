@@ -397,14 +397,18 @@ def extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n, sample_power=F
             g1k = g1.view(8, groups, k)[:, :, :kv].contiguous().view(-1)
             ms_k = timed(lambda: pkg.pairing_fixed_g2_check_target_batch_dev(g1k, None, tab2, kv, None, verdict, groups, device=local_rank, stream=stream), 2)
             exp2 = g2fix.view(16, kf)[:, :kv].reshape(16, 1, kv).expand(16, groups, kv).contiguous().view(-1)
-            pkg.pairing_fixed_g2_batch_dev(g1k, None, tab2, kv, o3, groups, device=local_rank, stream=stream)
-            o4 = torch.zeros_like(o3)
-            pkg.multi_pairing_batch_dev(g1k, exp2, o4, groups, kv, True, device=local_rank, stream=stream)
-            torch.cuda.synchronize(dev)
+            same = None
+            if not under_profiler():           # (a k = 2 launch of k_mpairing would be averaged into the profile of the four-pair launches)
+                pkg.pairing_fixed_g2_batch_dev(g1k, None, tab2, kv, o3, groups, device=local_rank, stream=stream)
+                o4 = torch.zeros_like(o3)
+                pkg.multi_pairing_batch_dev(g1k, exp2, o4, groups, kv, True, device=local_rank, stream=stream)
+                torch.cuda.synchronize(dev)
+                same = bool(torch.equal(o3, o4))
+                del o4
             out["KZG-style opening check: 2^18 groups of 2 pairs, both G2 points fixed for the batch (bn254_pairing_fixed_g2_check_target_batch_dev, g2_var = NULL)"] = {
                 "ms": ms_k, "checks_per_s": groups / (ms_k * 1e-3), "kernels": "k_fpairing (no own pair) + k_is_one",
-                "same_limbs_as_k_mpairing_on_the_expanded_pairs": bool(torch.equal(o3, o4))}
-            del tab2, g1v, verdict, g1k, exp2, o4
+                "same_limbs_as_k_mpairing_on_the_expanded_pairs": same}
+            del tab2, g1v, verdict, g1k, exp2
         del exp, o3, table
     # data formats either side of the path: element-major <-> limb-major on the device (HBM-bound: every word read once, written once)
     HBM_PEAK = 8.0e12
