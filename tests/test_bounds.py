@@ -30,6 +30,9 @@ def test_value_contract_of_shipped_kernels(name, kw):
     else:
         for k_pairs in ((1, 2, 3, 8) if kw.get("multi") else (1,)):
             rep = kb.certify_values(k_pairs)
+        if kw.get("fixed"):                   # ... and the groups without a pair of their own: squarings and table lines only (every variant's entry bounds)
+            rep0 = kb.certify_values(1, own_pair=False)
+            assert rep0["max_stored"] <= K4P.V_CAP and {"L2_fxred", "L2_sqr"} <= set(rep0["sequence"]) and "L2_dblmul" not in rep0["sequence"]
     assert rep["max_stored"] <= K4P.V_CAP
     # top limb (weight 2^232) of the largest temporary: within one unit (2^28), inside every limb interval
     assert rep["max_stored"] * P_INT / 2 ** 232 <= 2 ** 28
