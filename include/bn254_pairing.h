@@ -171,6 +171,14 @@ int bn254_final_exp_batch(const uint64_t* f_in, uint64_t* out, size_t n, int dev
  * multi == product, :336-348). */
 int bn254_multi_pairing_batch_dev(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_groups, size_t k,
                                   int do_final_exp, int device, void* stream);
+/* Groups of more than 64 pairs (multi_miller_loop_native takes any Vec): the kernels hold 64 pairs' state per lane, larger groups are composed of
+ * sub-groups (the Miller value of a group is the product of the Miller values of any partition of its pairs: the same limbs).  A batch of MANY groups walks
+ * every group on its own lane, sub-group after sub-group; a batch of FEWER than `max_groups` groups (default 65 536: a full grid) -- one aggregated check over
+ * thousands of pairs -- spreads each group over k / C lanes of C pairs (C: the largest divisor of k up to 64 that still fills a grid, else 1), one launch of
+ * the Miller kernel over all of them, a multiplication tree per group, the final exponentiation of n_groups values: one group of 131 072 pairs 0.14 s
+ * instead of minutes.  0: never. */
+void bn254_set_wide_groups(size_t max_groups);
+size_t bn254_get_wide_groups(void);
 int bn254_multi_pairing_batch(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_groups, size_t k,
                               int do_final_exp, int device, void* stream);
 

@@ -120,6 +120,8 @@ _PROTOS = {
     "bn254_pairing_batch_elems_dev": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "bn254_multi_pairing_batch_elems_dev": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "bn254_g2_lines_bytes": (ctypes.c_size_t, [ctypes.c_size_t]),
+    "bn254_set_wide_groups": (None, [ctypes.c_size_t]),
+    "bn254_get_wide_groups": (ctypes.c_size_t, []),
     "bn254_g2_lines_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "bn254_pairing_fixed_g2_batch_dev": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "bn254_pairing_fixed_g2_batch_elems_dev": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
@@ -628,6 +630,15 @@ def last_kernel(device=0, stream=None):
 def reserve(n, k=1, device=0, stream=None):
     """Sizes the per-(device, stream) buffers for `_dev` calls of up to n lanes x k pairs: no later call of that size allocates."""
     _check(load_library().bn254_reserve(device, _stream(stream), n, k), "reserve")
+
+
+def set_wide_groups(max_groups):
+    """groups of more than 64 pairs: batches of fewer than max_groups groups spread each group over several lanes (default 65536; 0: never)"""
+    load_library().bn254_set_wide_groups(max_groups)
+
+
+def get_wide_groups():
+    return load_library().bn254_get_wide_groups()
 
 
 def set_latency_threshold(n):

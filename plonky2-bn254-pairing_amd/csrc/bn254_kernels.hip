@@ -111,6 +111,18 @@ __global__ void __launch_bounds__(256) k_is_one(const uint64_t* __restrict__ f, 
         verdict[i] = diff == 0 ? 1 : 0;
     }
 }
+// One level of the multiplication tree over the Miller values of a group's chunks (launch_pairing, few groups of many pairs): src holds `cur` Fq12
+// per group ([48][G cur] planes); a[g][i] = src[g][i], b[g][i] = src[g][i + h] for i < h = ceil(cur / 2) -- or MyFq12::one where the group has no
+// such element (cur odd: its middle element is carried through the product unchanged).
+__global__ void __launch_bounds__(256) k_tree_split(const uint64_t* __restrict__ src, uint64_t* __restrict__ a, uint64_t* __restrict__ b, size_t G, size_t cur, size_t h) {
+    const uint64_t one[4] = BN254_FQ_ONE_LIMBS;
+    size_t m = G * h, n = G * cur;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < m * 48; i += (size_t)gridDim.x * blockDim.x) {
+        size_t w = i / m, r = i - w * m, g = r / h, j = r - g * h;
+        a[i] = src[w * n + g * cur + j];
+        b[i] = (j + h < cur) ? src[w * n + g * cur + j + h] : (w < 4 ? one[w] : 0ull);
+    }
+}
 // Pairs [j0, j0 + ks) of every k-pair group, as a contiguous ks-pair batch (groups of more than MAX_K pairs are walked in
 // sub-groups, launch_pairing): plane w of the source has n*k entries, pair j of group g at g*k + j.  HBM-bound, coalesced
 // on the destination side.
@@ -580,6 +592,8 @@ bool direct_elems_ok(size_t n_groups, size_t k, int device, void* stream) {
     return k >= 1 && k <= MAX_K && n_groups * k <= ((size_t)1 << 23) && !takes_latency_kernel<M, F>(n_groups, k, device, stream);
 }
 
+constexpr size_t FULL_GRID_LANES = 65536;          // one 256-lane work item on each of 256 CUs
+std::atomic<size_t> g_wide_groups{FULL_GRID_LANES};   // bn254_set_wide_groups: batches of fewer groups (of more than MAX_K pairs) spread a group over several lanes
 template <bool M, bool F>
 int launch_pairing(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in, uint64_t* out, size_t n_groups, size_t k, int device, void* stream, int io_mode = 0) {
     if (n_groups == 0) return BN254_OK;
@@ -596,6 +610,34 @@ int launch_pairing(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in,
         int rc = ctx_get(device, stream, 1, (n_groups + BLOCK - 1) / BLOCK, &hold);
         if (rc) return rc;
         StreamCtx* sc = hold.s.get();
+        if (n_groups < g_wide_groups.load()) {
+            // FEW groups of MANY pairs (one aggregated check over thousands of pairs): a lane per group would leave the chip empty and walk its group
+            // for minutes.  A group's pairs are contiguous, so the batch IS also n_groups k / C groups of C pairs for any divisor C of k: one launch of the
+            // C-pair Miller kernel over all those lanes, then a multiplication tree over each group's k / C values (MyFq12 Mul; the odd one out is
+            // carried through a level by a multiplication by one), then the final exponentiation of n_groups values.  C: the largest divisor (<= MAX_K)
+            // that still fills a grid, else 1 (every pair its own lane).
+            size_t C = 1;
+            for (size_t d = MAX_K; d > 1; d--)
+                if (k % d == 0 && n_groups * (k / d) >= FULL_GRID_LANES) { C = d; break; }
+            const size_t S = k / C, lanes = n_groups * S;
+            if (lanes < ((size_t)1 << 22)) {
+                const size_t half = n_groups * ((S + 1) / 2);
+                if ((rc = ensure(sc, sc->sub[2], 384 * lanes)) || (rc = ensure(sc, sc->sub[0], 384 * half)) || (rc = ensure(sc, sc->sub[1], 384 * half))) return rc;
+                uint64_t *V = (uint64_t*)sc->sub[2].p, *A = (uint64_t*)sc->sub[0].p, *B = (uint64_t*)sc->sub[1].p;
+                if ((rc = launch_pairing<true, false>(g1, g2, nullptr, V, lanes, C, device, stream))) return rc;
+                for (size_t cur = S; cur > 1;) {
+                    const size_t h = (cur + 1) / 2, m = n_groups * h;
+                    size_t blocks = (m * 48 + 255) / 256;
+                    hipLaunchKernelGGL(k_tree_split, dim3((uint32_t)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0, st, (const uint64_t*)V, A, B, n_groups, cur, h);
+                    HIPCHK(hipGetLastError());
+                    if ((rc = launch_op(OP_MUL, A, B, (h == 1 && !F) ? out : V, m, 0, nullptr, 0, device, stream))) return rc;
+                    cur = h;
+                }
+                if (F) return launch_pairing<false, true>(nullptr, nullptr, V, out, n_groups, 1, device, stream);
+                if (S == 1) HIPCHK(hipMemcpyAsync(out, V, 384 * n_groups, hipMemcpyDeviceToDevice, st));
+                return BN254_OK;
+            }
+        }
         if ((rc = ensure(sc, sc->sub[0], 64 * n_groups * MAX_K)) || (rc = ensure(sc, sc->sub[1], 128 * n_groups * MAX_K)) ||
             (rc = ensure(sc, sc->sub[2], 384 * n_groups)) || (rc = ensure(sc, sc->sub[3], 384 * n_groups)))
             return rc;
@@ -1221,6 +1263,9 @@ int bn254_pairing_fixed_g2_check_batch_elems(const uint64_t* g1, const uint64_t*
     if ((rc = launch_fixed(d1, d2, dt, k_fixed, d3, n, IO_IN_ELEMS, device, stream)) || (rc = launch_is_equal(d3, target, (uint8_t*)dv, n, stream))) return rc;
     return finish_fixed_host(s, verdict, dv, n, device, stream);
 }
+
+void bn254_set_wide_groups(size_t max_groups) { g_wide_groups.store(max_groups); }
+size_t bn254_get_wide_groups(void) { return g_wide_groups.load(); }
 
 int bn254_release_stream(int device, void* stream) {
     int rc = check_device(device);

@@ -24,9 +24,72 @@ def _pairs(n, mul=5, seed=8):
     return H.g1_aos(P), H.g2_aos(Q)
 
 
+@pytest.mark.parametrize("wide", [True, False])
 @pytest.mark.parametrize("k,n_groups", [(65, 3), (130, 2), (200, 1)])
-def test_groups_of_more_than_64_pairs(k, n_groups):
+def test_groups_of_more_than_64_pairs(k, n_groups, wide):
+    """wide: a batch of few groups spreads each group over several lanes (one Miller launch over all chunks, a multiplication tree per group);
+    not wide: every group on its own lane, sub-group after sub-group (what a batch of 65 536 groups or more does).  bn254_set_wide_groups."""
     pk = H.pkg()
+    old = pk.get_wide_groups()
+    pk.set_wide_groups(old if wide else 0)
+    try:
+        _groups_of_more_than_64_pairs(pk, k, n_groups)
+    finally:
+        pk.set_wide_groups(old)
+
+
+def test_one_group_of_very_many_pairs():
+    """One aggregated check: ONE group of 4 096 / 131 072 pairs (a lane per group would walk it for minutes).  The value must be the product of the values
+    of the same pairs taken as 64-pair groups (the k-pair kernel itself, no composition), multiplied here with MyFq12 Mul -- Miller value and final value."""
+    import torch
+    pk = H.pkg()
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev)
+
+    def product(vals, m):                       # [48][m] planes -> [48][1]: halves multiplied until one value is left (m a power of two)
+        while m > 1:
+            h = m // 2
+            a, b = vals.view(48, m)[:, :h].contiguous().view(-1), vals.view(48, m)[:, h:].contiguous().view(-1)
+            vals = torch.zeros(48 * h, dtype=torch.int64, device=dev)
+            pk.fq12_mul_batch_dev(a, b, vals, h, 0, st)
+            m = h
+        return vals
+
+    assert pk.get_wide_groups() == 65536
+    for K in (4096, 131072):
+        g1 = torch.zeros(8 * K, dtype=torch.int64, device=dev)
+        g2 = torch.zeros(16 * K, dtype=torch.int64, device=dev)
+        pk.generate_pairs_dev(0xA66 + K, g1, g2, K, 0, st)
+        parts = torch.zeros(48 * (K // 64), dtype=torch.int64, device=dev)
+        pk.multi_pairing_batch_dev(g1, g2, parts, K // 64, 64, False, 0, st)            # the shared-f Miller values of K / 64 groups of 64 pairs
+        want_m = product(parts, K // 64)
+        want = torch.zeros(48, dtype=torch.int64, device=dev)
+        pk.final_exp_batch_dev(want_m, want, 1, 0, st)
+        got_m = torch.full((48 + 8,), -7, dtype=torch.int64, device=dev)
+        pk.multi_pairing_batch_dev(g1, g2, got_m, 1, K, False, 0, st)
+        got = torch.full((48 + 8,), -7, dtype=torch.int64, device=dev)
+        pk.multi_pairing_batch_dev(g1, g2, got, 1, K, True, 0, st)
+        pk.last_status(0, st)
+        assert torch.equal(got_m[:48], want_m) and torch.equal(got[:48], want) and bool((got[48:] == -7).all()) and bool((got_m[48:] == -7).all())
+        assert int(want.abs().sum()) != 0
+    # three groups of 1 001 pairs (7 x 11 x 13: chunks of 13 pairs would not fill a grid -> every pair its own lane; odd levels in the tree)
+    G, K = 3, 1001
+    g1 = torch.zeros(8 * G * K, dtype=torch.int64, device=dev)
+    g2 = torch.zeros(16 * G * K, dtype=torch.int64, device=dev)
+    pk.generate_pairs_dev(0xA77, g1, g2, G * K, 0, st)
+    got = torch.zeros(48 * G, dtype=torch.int64, device=dev)
+    pk.multi_pairing_batch_dev(g1, g2, got, G, K, True, 0, st)
+    pk.set_wide_groups(0)
+    try:
+        ref = torch.zeros(48 * G, dtype=torch.int64, device=dev)
+        pk.multi_pairing_batch_dev(g1, g2, ref, G, K, True, 0, st)                      # the lane-per-group walk: 16 sub-groups in sequence
+    finally:
+        pk.set_wide_groups(65536)
+    pk.last_status(0, st)
+    assert torch.equal(got, ref) and int(ref.abs().sum()) != 0
+
+
+def _groups_of_more_than_64_pairs(pk, k, n_groups):
     g1a, g2a = _pairs(n_groups * k)
     g1, g2 = H.to_soa(g1a, 8), H.to_soa(g2a, 16)
     want_m = H.oracle_multi_miller(g1a, g2a, n_groups, k)
