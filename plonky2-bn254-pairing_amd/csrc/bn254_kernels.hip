@@ -1401,6 +1401,17 @@ int bn254_reserve(int device, void* stream, size_t n, size_t k) {
     if (k > MAX_K && ((rc = ensure(sc, sc->sub[0], 64 * n * MAX_K)) || (rc = ensure(sc, sc->sub[1], 128 * n * MAX_K)) ||
                       (rc = ensure(sc, sc->sub[2], 384 * n)) || (rc = ensure(sc, sc->sub[3], 384 * n))))
         return rc;
+    if (k > MAX_K && n && n < g_wide_groups.load()) {      // few groups of many pairs: the chunk values and the two operand buffers of the multiplication tree (launch_pairing)
+        size_t C = 1;
+        for (size_t d = MAX_K; d > 1; d--)
+            if (k % d == 0 && n * (k / d) >= FULL_GRID_LANES) { C = d; break; }
+        const size_t S = k / C, lanes = n * S, half = n * ((S + 1) / 2);
+        if (lanes < ((size_t)1 << 22)) {
+            if ((rc = ensure(sc, sc->sub[2], 384 * lanes)) || (rc = ensure(sc, sc->sub[0], 384 * half)) || (rc = ensure(sc, sc->sub[1], 384 * half))) return rc;
+            LaunchCtx cw;                               // ... and the scratch of the Miller launch over all the chunks
+            if ((rc = ctx_get(device, stream, C, (lanes + BLOCK - 1) / BLOCK, &cw))) return rc;
+        }
+    }
     while (sc->naf_ring.size() < 4) {
         NafSlot ns;
         if (hipHostMalloc((void**)&ns.host, 65536, hipHostMallocDefault) != hipSuccess) return BN254_ERR_ALLOC;

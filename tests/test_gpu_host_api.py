@@ -89,6 +89,40 @@ def test_one_group_of_very_many_pairs():
     assert torch.equal(got, ref) and int(ref.abs().sum()) != 0
 
 
+def test_one_group_of_many_pairs_is_capturable_after_reserve():
+    """bn254_reserve(1, k) sizes the chunk values, the tree's operand buffers and the Miller launch's scratch: the aggregated check is then a sequence of
+    plain launches (Miller over the chunks, a split + a multiplication per tree level, the final exponentiation), captured and replayed on new pairs."""
+    import torch
+    pk = H.pkg()
+    dev = torch.device("cuda:0")
+    side = torch.cuda.Stream(dev)
+    K = 4096 + 64
+    with torch.cuda.stream(side):
+        g1 = torch.zeros(8 * K, dtype=torch.int64, device=dev)
+        g2 = torch.zeros(16 * K, dtype=torch.int64, device=dev)
+        out = torch.zeros(48, dtype=torch.int64, device=dev)
+        pk.generate_pairs_dev(0xC4B, g1, g2, K, 0, side)
+        pk.reserve(1, K, 0, side)
+        pk.last_status(0, side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            pk.multi_pairing_batch_dev(g1, g2, out, 1, K, True, 0, side)
+        seen = []
+        for seed in (0xC4C, 0xC4D):
+            pk.generate_pairs_dev(seed, g1, g2, K, 0, side)
+            out.zero_()
+            graph.replay()
+            side.synchronize()
+            got = out.clone()
+            out.zero_()
+            pk.multi_pairing_batch_dev(g1, g2, out, 1, K, True, 0, side)
+            pk.last_status(0, side)
+            assert torch.equal(got, out) and int(out.abs().sum()) != 0
+            seen.append(got)
+        assert not torch.equal(seen[0], seen[1])
+    pk.release_stream(0, side)
+
+
 def _groups_of_more_than_64_pairs(pk, k, n_groups):
     g1a, g2a = _pairs(n_groups * k)
     g1, g2 = H.to_soa(g1a, 8), H.to_soa(g2a, 16)
