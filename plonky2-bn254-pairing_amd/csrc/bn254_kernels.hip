@@ -576,6 +576,17 @@ int launch_fexp_pieces(const uint64_t* f_in, uint64_t* out, size_t n, int device
 // ELEMENT-major -- one G1Affine / G2Affine / Fq12 after the other, as the reference's callers hold them -- instead of limb-major planes
 enum { IO_IN_ELEMS = 1, IO_OUT_ELEMS = 2, IO_OUT_ARK = 4, IO_NO_OWN = 8 };      // (IO_NO_OWN: k_fpairing only -- groups without a pair of their own, MODE_NO_OWN)
 
+constexpr size_t FULL_GRID_LANES = 65536;          // one 256-lane work item on each of 256 CUs
+std::atomic<size_t> g_wide_groups{FULL_GRID_LANES};   // bn254_set_wide_groups: batches of fewer groups (of more than MAX_K pairs) spread a group over several lanes
+constexpr int BN254_ERR_NOT_WIDE = -1000;          // (internal: launch_wide declines, the caller goes on with its own route)
+// FEW groups of MANY pairs (one aggregated check over thousands of pairs): a lane per group would leave the chip empty and walk its group for seconds.
+// More than MAX_K pairs: whenever the batch has less than a grid's worth of groups.  5 .. MAX_K pairs (no lane-cooperative program): when the k-pair
+// kernel would run on less than a quarter of a grid -- its launch is then latency-bound (one group of 64 pairs: 128 ms on one lane).
+inline bool takes_wide_route(size_t n_groups, size_t k) {
+    size_t w = g_wide_groups.load();
+    if (k > MAX_K) return n_groups < w;
+    return k > 4 && n_groups * 4 <= w;
+}
 // would launch_pairing<M, F> serve this batch on the lane-cooperative kernel (whose programs read limb-major planes only)?
 template <bool M, bool F>
 bool takes_latency_kernel(size_t n_groups, size_t k, int device, void* stream) {
@@ -589,18 +600,52 @@ bool takes_latency_kernel(size_t n_groups, size_t k, int device, void* stream) {
 // per Fq12 -- 2^23 units keep the largest (the result's: 3.2 GB) below 4 GB; larger batches take the transposition route (64-bit plane walks)
 template <bool M, bool F>
 bool direct_elems_ok(size_t n_groups, size_t k, int device, void* stream) {
-    return k >= 1 && k <= MAX_K && n_groups * k <= ((size_t)1 << 23) && !takes_latency_kernel<M, F>(n_groups, k, device, stream);
+    return k >= 1 && k <= MAX_K && n_groups * k <= ((size_t)1 << 23) && !takes_latency_kernel<M, F>(n_groups, k, device, stream) && !(M && takes_wide_route(n_groups, k));
 }
 
-constexpr size_t FULL_GRID_LANES = 65536;          // one 256-lane work item on each of 256 CUs
-std::atomic<size_t> g_wide_groups{FULL_GRID_LANES};   // bn254_set_wide_groups: batches of fewer groups (of more than MAX_K pairs) spread a group over several lanes
 template <bool M, bool F>
-int launch_pairing(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in, uint64_t* out, size_t n_groups, size_t k, int device, void* stream, int io_mode = 0) {
+int launch_pairing(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in, uint64_t* out, size_t n_groups, size_t k, int device, void* stream, int io_mode = 0);
+// A group's pairs are contiguous, so the batch IS also n_groups k / C groups of C pairs for any divisor C of k: one launch of the C-pair Miller kernel
+// over all those lanes, then a multiplication tree over each group's k / C values (MyFq12 Mul; the odd one out is carried through a level by a
+// multiplication by one), then the final exponentiation of n_groups values.  C: the largest divisor (<= MAX_K, < k) that still fills a grid, else 1
+// (every pair its own lane).  The same field element as the shared-f loop over the whole group, hence the same limbs.
+template <bool F>
+int launch_wide(StreamCtx* sc, const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_groups, size_t k, int device, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    size_t C = 1;
+    for (size_t d = MAX_K; d > 1; d--)
+        if (d < k && k % d == 0 && n_groups * (k / d) >= FULL_GRID_LANES) { C = d; break; }
+    const size_t S = k / C, lanes = n_groups * S, half = n_groups * ((S + 1) / 2);
+    if (lanes >= ((size_t)1 << 22)) return BN254_ERR_NOT_WIDE;
+    int rc;
+    if ((rc = ensure(sc, sc->sub[2], 384 * lanes)) || (rc = ensure(sc, sc->sub[0], 384 * half)) || (rc = ensure(sc, sc->sub[1], 384 * half))) return rc;
+    uint64_t *V = (uint64_t*)sc->sub[2].p, *A = (uint64_t*)sc->sub[0].p, *B = (uint64_t*)sc->sub[1].p;
+    if ((rc = launch_pairing<true, false>(g1, g2, nullptr, V, lanes, C, device, stream, 0))) return rc;
+    for (size_t cur = S; cur > 1;) {
+        const size_t h = (cur + 1) / 2, m = n_groups * h;
+        size_t blocks = (m * 48 + 255) / 256;
+        hipLaunchKernelGGL(k_tree_split, dim3((uint32_t)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0, st, (const uint64_t*)V, A, B, n_groups, cur, h);
+        HIPCHK(hipGetLastError());
+        if ((rc = launch_op(OP_MUL, A, B, (h == 1 && !F) ? out : V, m, 0, nullptr, 0, device, stream))) return rc;
+        cur = h;
+    }
+    if (F) return launch_pairing<false, true>(nullptr, nullptr, V, out, n_groups, 1, device, stream, 0);
+    return BN254_OK;
+}
+template <bool M, bool F>
+int launch_pairing(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in, uint64_t* out, size_t n_groups, size_t k, int device, void* stream, int io_mode) {
     if (n_groups == 0) return BN254_OK;
     if (io_mode && !direct_elems_ok<M, F>(n_groups, k, device, stream)) return BN254_ERR_INVALID_ARG;      // (callers ask first)
     if (!out || (M && (!g1 || !g2)) || (!M && !f_in) || k == 0 || (!M && k != 1)) return BN254_ERR_INVALID_ARG;
     if (n_groups * k >= (1ull << 29) || n_groups * k / k != n_groups) return BN254_ERR_INVALID_ARG;   // 32-bit byte offsets of the SoA planes in the kernels
     hipStream_t st = (hipStream_t)stream;
+    if (M && !io_mode && k <= MAX_K && takes_wide_route(n_groups, k)) {      // 5 .. MAX_K pairs, a handful of groups: spread over the lanes (launch_wide)
+        LaunchCtx hold;
+        int rc = ctx_get(device, stream, 1, 1, &hold);
+        if (rc) return rc;
+        rc = launch_wide<F>(hold.s.get(), g1, g2, out, n_groups, k, device, stream);
+        if (rc != BN254_ERR_NOT_WIDE) return rc;
+    }
     if (k > MAX_K) {
         // multi_miller_loop_native takes any Vec (miller_loop_native.rs:192-282, :324-326); the k-pair kernels hold at most MAX_K
         // pairs' state.  The shared-f Miller value of a group IS the product of the Miller values of any partition of its pairs
@@ -610,33 +655,9 @@ int launch_pairing(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in,
         int rc = ctx_get(device, stream, 1, (n_groups + BLOCK - 1) / BLOCK, &hold);
         if (rc) return rc;
         StreamCtx* sc = hold.s.get();
-        if (n_groups < g_wide_groups.load()) {
-            // FEW groups of MANY pairs (one aggregated check over thousands of pairs): a lane per group would leave the chip empty and walk its group
-            // for minutes.  A group's pairs are contiguous, so the batch IS also n_groups k / C groups of C pairs for any divisor C of k: one launch of the
-            // C-pair Miller kernel over all those lanes, then a multiplication tree over each group's k / C values (MyFq12 Mul; the odd one out is
-            // carried through a level by a multiplication by one), then the final exponentiation of n_groups values.  C: the largest divisor (<= MAX_K)
-            // that still fills a grid, else 1 (every pair its own lane).
-            size_t C = 1;
-            for (size_t d = MAX_K; d > 1; d--)
-                if (k % d == 0 && n_groups * (k / d) >= FULL_GRID_LANES) { C = d; break; }
-            const size_t S = k / C, lanes = n_groups * S;
-            if (lanes < ((size_t)1 << 22)) {
-                const size_t half = n_groups * ((S + 1) / 2);
-                if ((rc = ensure(sc, sc->sub[2], 384 * lanes)) || (rc = ensure(sc, sc->sub[0], 384 * half)) || (rc = ensure(sc, sc->sub[1], 384 * half))) return rc;
-                uint64_t *V = (uint64_t*)sc->sub[2].p, *A = (uint64_t*)sc->sub[0].p, *B = (uint64_t*)sc->sub[1].p;
-                if ((rc = launch_pairing<true, false>(g1, g2, nullptr, V, lanes, C, device, stream))) return rc;
-                for (size_t cur = S; cur > 1;) {
-                    const size_t h = (cur + 1) / 2, m = n_groups * h;
-                    size_t blocks = (m * 48 + 255) / 256;
-                    hipLaunchKernelGGL(k_tree_split, dim3((uint32_t)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0, st, (const uint64_t*)V, A, B, n_groups, cur, h);
-                    HIPCHK(hipGetLastError());
-                    if ((rc = launch_op(OP_MUL, A, B, (h == 1 && !F) ? out : V, m, 0, nullptr, 0, device, stream))) return rc;
-                    cur = h;
-                }
-                if (F) return launch_pairing<false, true>(nullptr, nullptr, V, out, n_groups, 1, device, stream);
-                if (S == 1) HIPCHK(hipMemcpyAsync(out, V, 384 * n_groups, hipMemcpyDeviceToDevice, st));
-                return BN254_OK;
-            }
+        if (takes_wide_route(n_groups, k)) {
+            rc = launch_wide<F>(sc, g1, g2, out, n_groups, k, device, stream);
+            if (rc != BN254_ERR_NOT_WIDE) return rc;
         }
         if ((rc = ensure(sc, sc->sub[0], 64 * n_groups * MAX_K)) || (rc = ensure(sc, sc->sub[1], 128 * n_groups * MAX_K)) ||
             (rc = ensure(sc, sc->sub[2], 384 * n_groups)) || (rc = ensure(sc, sc->sub[3], 384 * n_groups)))
@@ -1401,10 +1422,10 @@ int bn254_reserve(int device, void* stream, size_t n, size_t k) {
     if (k > MAX_K && ((rc = ensure(sc, sc->sub[0], 64 * n * MAX_K)) || (rc = ensure(sc, sc->sub[1], 128 * n * MAX_K)) ||
                       (rc = ensure(sc, sc->sub[2], 384 * n)) || (rc = ensure(sc, sc->sub[3], 384 * n))))
         return rc;
-    if (k > MAX_K && n && n < g_wide_groups.load()) {      // few groups of many pairs: the chunk values and the two operand buffers of the multiplication tree (launch_pairing)
+    if (n && takes_wide_route(n, k)) {      // few groups of many pairs: the chunk values and the two operand buffers of the multiplication tree (launch_wide)
         size_t C = 1;
         for (size_t d = MAX_K; d > 1; d--)
-            if (k % d == 0 && n * (k / d) >= FULL_GRID_LANES) { C = d; break; }
+            if (d < k && k % d == 0 && n * (k / d) >= FULL_GRID_LANES) { C = d; break; }
         const size_t S = k / C, lanes = n * S, half = n * ((S + 1) / 2);
         if (lanes < ((size_t)1 << 22)) {
             if ((rc = ensure(sc, sc->sub[2], 384 * lanes)) || (rc = ensure(sc, sc->sub[0], 384 * half)) || (rc = ensure(sc, sc->sub[1], 384 * half))) return rc;

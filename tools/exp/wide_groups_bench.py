@@ -6,7 +6,7 @@ sys.path.insert(0, ".")
 import __graft_entry__ as g
 pk = g.build()
 dev = torch.device("cuda:0"); st = torch.cuda.current_stream(dev)
-for K in (256, 1024, 4096, 65536, 131072, 1 << 20):
+for K in (8, 32, 64, 256, 1024, 4096, 65536, 131072, 1 << 20):
     g1 = torch.zeros(8 * K, dtype=torch.int64, device=dev); g2 = torch.zeros(16 * K, dtype=torch.int64, device=dev)
     pk.generate_pairs_dev(0xA66 + K, g1, g2, K, 0, st)
     out = torch.zeros(48, dtype=torch.int64, device=dev)
