@@ -174,10 +174,12 @@ int bn254_multi_pairing_batch_dev(const uint64_t* g1, const uint64_t* g2, uint64
 /* Groups of more than 64 pairs (multi_miller_loop_native takes any Vec): the kernels hold 64 pairs' state per lane, larger groups are composed of
  * sub-groups (the Miller value of a group is the product of the Miller values of any partition of its pairs: the same limbs).  A batch of MANY groups walks
  * every group on its own lane, sub-group after sub-group; a batch of FEWER than `max_groups` groups (default 65 536: a full grid) -- one aggregated check over
- * thousands of pairs -- spreads each group over k / C lanes of C pairs (C: the largest divisor of k up to 64 that still fills a grid, else 1), one launch of
+ * thousands of pairs -- spreads each group over k / C lanes of C pairs (C: a divisor of k up to 64), one launch of
  * the Miller kernel over all of them, a multiplication tree per group, the final exponentiation of n_groups values: one group of 131 072 pairs 0.14 s
- * instead of minutes.  Groups of 5 .. 64 pairs take the same route when the k-pair kernel would run on less than a quarter of a grid (4 n_groups <=
- * max_groups): its launch is then latency-bound -- one group of 64 pairs 128 ms on one lane, 1 ms spread.  0: never. */
+ * instead of minutes.  Groups of 5 .. 64 pairs take the same route when its estimated time (passes over the grid x the cost of a lane of C pairs, the tree,
+ * the final exponentiation) beats one launch of the k-pair kernel, which on a partial grid is latency-bound: one group of 64 pairs 145 ms on one lane, 1 ms
+ * spread; 10 000 groups of 64 pairs 34 ms instead of 146; 16 384 groups of 8 pairs 9 ms instead of 22.  C is the divisor of k with the smallest estimate.
+ * 0: never. */
 void bn254_set_wide_groups(size_t max_groups);
 size_t bn254_get_wide_groups(void);
 int bn254_multi_pairing_batch(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_groups, size_t k,

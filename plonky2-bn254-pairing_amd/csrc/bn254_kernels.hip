@@ -580,12 +580,31 @@ constexpr size_t FULL_GRID_LANES = 65536;          // one 256-lane work item on 
 std::atomic<size_t> g_wide_groups{FULL_GRID_LANES};   // bn254_set_wide_groups: batches of fewer groups (of more than MAX_K pairs) spread a group over several lanes
 constexpr int BN254_ERR_NOT_WIDE = -1000;          // (internal: launch_wide declines, the caller goes on with its own route)
 // FEW groups of MANY pairs (one aggregated check over thousands of pairs): a lane per group would leave the chip empty and walk its group for seconds.
-// More than MAX_K pairs: whenever the batch has less than a grid's worth of groups.  5 .. MAX_K pairs (no lane-cooperative program): when the k-pair
-// kernel would run on less than a quarter of a grid -- its launch is then latency-bound (one group of 64 pairs: 128 ms on one lane).
+// More than MAX_K pairs: whenever the batch has less than a grid's worth of groups.  5 .. MAX_K pairs (no lane-cooperative program): when the spread route's
+// estimated time beats one launch of the k-pair kernel, which on a partial grid is latency-bound (one group of 64 pairs: 145 ms on one lane).
+// Pairs per lane of the spread route, C | k, C < k: the divisor with the smallest estimated time -- passes over the grid x what a lane of C pairs costs
+// (the C-pair Miller kernel: 2.2 ms per pair with the shared f, + 1.5), + the tree and the final exponentiation.  Measured anchors: one lane of 8 / 64 pairs
+// 21.6 / 145 ms, the exact one-pair Miller kernel 3.7 ms per grid.
+inline size_t wide_chunk(size_t n_groups, size_t k, double* est_ms) {
+    size_t best = 1;
+    double best_ms = 1e300;
+    for (size_t d = k < MAX_K ? k - 1 : MAX_K; d >= 1; d--) {
+        if (d >= k || k % d) continue;
+        size_t lanes = n_groups * (k / d);
+        if (lanes >= ((size_t)1 << 22)) continue;
+        double ms = (double)((lanes + FULL_GRID_LANES - 1) / FULL_GRID_LANES) * (2.2 * (double)d + 1.5) + 4.0;
+        if (ms < best_ms) { best_ms = ms; best = d; }
+    }
+    if (est_ms) *est_ms = best_ms;
+    return best;
+}
 inline bool takes_wide_route(size_t n_groups, size_t k) {
-    size_t w = g_wide_groups.load();
-    if (k > MAX_K) return n_groups < w;
-    return k > 4 && n_groups * 4 <= w;
+    if (k <= 4 || n_groups >= g_wide_groups.load()) return false;
+    double wide_ms;
+    (void)wide_chunk(n_groups, k, &wide_ms);
+    if (wide_ms > 1e299) return false;                       // (no divisor keeps the lane count below the kernels' limit)
+    if (k > MAX_K) return true;                              // (the alternative walks every group on one lane, sub-group after sub-group)
+    return wide_ms * 1.15 < 2.2 * (double)k + 4.0;           // 5 .. MAX_K pairs: against one launch of the k-pair kernel, latency-bound on a partial grid
 }
 // would launch_pairing<M, F> serve this batch on the lane-cooperative kernel (whose programs read limb-major planes only)?
 template <bool M, bool F>
@@ -607,14 +626,11 @@ template <bool M, bool F>
 int launch_pairing(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in, uint64_t* out, size_t n_groups, size_t k, int device, void* stream, int io_mode = 0);
 // A group's pairs are contiguous, so the batch IS also n_groups k / C groups of C pairs for any divisor C of k: one launch of the C-pair Miller kernel
 // over all those lanes, then a multiplication tree over each group's k / C values (MyFq12 Mul; the odd one out is carried through a level by a
-// multiplication by one), then the final exponentiation of n_groups values.  C: the largest divisor (<= MAX_K, < k) that still fills a grid, else 1
-// (every pair its own lane).  The same field element as the shared-f loop over the whole group, hence the same limbs.
+// multiplication by one), then the final exponentiation of n_groups values.  C: wide_chunk's choice (1: every pair its own lane).  The same field element as the shared-f loop over the whole group, hence the same limbs.
 template <bool F>
 int launch_wide(StreamCtx* sc, const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n_groups, size_t k, int device, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    size_t C = 1;
-    for (size_t d = MAX_K; d > 1; d--)
-        if (d < k && k % d == 0 && n_groups * (k / d) >= FULL_GRID_LANES) { C = d; break; }
+    const size_t C = wide_chunk(n_groups, k, nullptr);
     const size_t S = k / C, lanes = n_groups * S, half = n_groups * ((S + 1) / 2);
     if (lanes >= ((size_t)1 << 22)) return BN254_ERR_NOT_WIDE;
     int rc;
@@ -1423,9 +1439,7 @@ int bn254_reserve(int device, void* stream, size_t n, size_t k) {
                       (rc = ensure(sc, sc->sub[2], 384 * n)) || (rc = ensure(sc, sc->sub[3], 384 * n))))
         return rc;
     if (n && takes_wide_route(n, k)) {      // few groups of many pairs: the chunk values and the two operand buffers of the multiplication tree (launch_wide)
-        size_t C = 1;
-        for (size_t d = MAX_K; d > 1; d--)
-            if (d < k && k % d == 0 && n * (k / d) >= FULL_GRID_LANES) { C = d; break; }
+        const size_t C = wide_chunk(n, k, nullptr);
         const size_t S = k / C, lanes = n * S, half = n * ((S + 1) / 2);
         if (lanes < ((size_t)1 << 22)) {
             if ((rc = ensure(sc, sc->sub[2], 384 * lanes)) || (rc = ensure(sc, sc->sub[0], 384 * half)) || (rc = ensure(sc, sc->sub[1], 384 * half))) return rc;
