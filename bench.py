@@ -410,6 +410,21 @@ def extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n, sample_power=F
                 "same_limbs_as_k_mpairing_on_the_expanded_pairs": same}
             del tab2, g1v, verdict, g1k, exp2
         del exp, o3, table
+    if hasattr(pkg, "set_wide_groups"):
+        # ONE group of all 2^20 pairs (an aggregated check: multi_miller_loop_native on one Vec, miller_loop_native.rs:324-326, + final_exp_native): the group
+        # is spread over the lanes in chunks, the chunks' Miller values multiplied in a tree, one final exponentiation
+        one = torch.zeros(48, dtype=torch.int64, device=dev)
+        ms_a = timed(lambda: pkg.multi_pairing_batch_dev(g1, g2, one, 1, n, True, device=local_rank, stream=stream), 2)
+        halves = torch.zeros(96, dtype=torch.int64, device=dev)
+        pkg.multi_pairing_batch_dev(g1, g2, halves, 2, n // 2, False, device=local_rank, stream=stream)          # the same pairs as two groups: two Miller values
+        prod, chk = torch.zeros(48, dtype=torch.int64, device=dev), torch.zeros(48, dtype=torch.int64, device=dev)
+        pkg.fq12_mul_batch_dev(halves.view(48, 2)[:, 0].contiguous(), halves.view(48, 2)[:, 1].contiguous(), prod, 1, local_rank, stream)
+        pkg.final_exp_batch_dev(prod, chk, 1, local_rank, stream)
+        torch.cuda.synchronize(dev)
+        out["one group of 2^20 pairs (an aggregated check): final_exp_native(multi_miller_loop_native(all pairs))"] = {
+            "ms": ms_a, "pairs_per_s": n / (ms_a * 1e-3), "kernels": "k_mmiller over 65 536 lanes of 16 pairs + a multiplication tree (k_tree_split, k_op) + k_cvm (final exponentiation)",
+            "equals_the_product_of_its_two_halves": bool(torch.equal(one, chk)) and int(one.abs().sum()) != 0}
+        del one, halves, prod, chk
     # data formats either side of the path: element-major <-> limb-major on the device (HBM-bound: every word read once, written once)
     HBM_PEAK = 8.0e12
     lay = {}
