@@ -422,7 +422,7 @@ def extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n, sample_power=F
         pkg.final_exp_batch_dev(prod, chk, 1, local_rank, stream)
         torch.cuda.synchronize(dev)
         out["one group of 2^20 pairs (an aggregated check): final_exp_native(multi_miller_loop_native(all pairs))"] = {
-            "ms": ms_a, "pairs_per_s": n / (ms_a * 1e-3), "kernels": "k_mmiller over 65 536 lanes of 16 pairs + a multiplication tree (k_tree_split, k_op) + k_cvm (final exponentiation)",
+            "ms": ms_a, "pairs_per_s": n / (ms_a * 1e-3), "kernels": "k_mmiller_u over 65 536 lanes of 16 pairs + a multiplication tree (k_tree_split, k_op) + k_cvm (final exponentiation)",
             "equals_the_product_of_its_two_halves": bool(torch.equal(one, chk)) and int(one.abs().sum()) != 0}
         del one, halves, prod, chk
     # data formats either side of the path: element-major <-> limb-major on the device (HBM-bound: every word read once, written once)

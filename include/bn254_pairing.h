@@ -175,8 +175,8 @@ int bn254_multi_pairing_batch_dev(const uint64_t* g1, const uint64_t* g2, uint64
  * sub-groups (the Miller value of a group is the product of the Miller values of any partition of its pairs: the same limbs).  A batch of MANY groups walks
  * every group on its own lane, sub-group after sub-group; a batch of FEWER than `max_groups` groups (default 65 536: a full grid) -- one aggregated check over
  * thousands of pairs -- spreads each group over k / C lanes of C pairs (C: a divisor of k up to 64), one launch of
- * the Miller kernel over all of them, a multiplication tree per group, the final exponentiation of n_groups values: one group of 131 072 pairs 0.14 s
- * instead of minutes.  Groups of 5 .. 64 pairs take the same route when its estimated time (passes over the grid x the cost of a lane of C pairs, the tree,
+ * the Miller kernel over all of them, a multiplication tree per group, the final exponentiation of n_groups values: one group of 131 072 pairs 7.5 ms
+ * instead of minutes (2^20 pairs: 43 ms).  Groups of 5 .. 64 pairs take the same route when its estimated time (passes over the grid x the cost of a lane of C pairs, the tree,
  * the final exponentiation) beats one launch of the k-pair kernel, which on a partial grid is latency-bound: one group of 64 pairs 145 ms on one lane, 1 ms
  * spread; 10 000 groups of 64 pairs 34 ms instead of 146; 16 384 groups of 8 pairs 9 ms instead of 22.  C is the divisor of k with the smallest estimate.
  * 0: never. */

@@ -74,6 +74,7 @@ BN254_ASM_KERNEL(k_miller, BN254_ASM_MILLER)        // the exact miller_loop_nat
 BN254_ASM_KERNEL(k_fexp, BN254_ASM_FEXP)            // final_exp_native on arbitrary Fq12                        final_exp_native.rs:209
 BN254_ASM_KERNEL(k_mpairing, BN254_ASM_MPAIRING)    // k pairs per lane, shared f (multi_miller_loop_native, :324) + final exp
 BN254_ASM_KERNEL(k_mmiller, BN254_ASM_MMILLER)      // k pairs per lane, exact multi_miller_loop_native value
+BN254_ASM_KERNEL(k_mmiller_u, BN254_ASM_MMILLER_U)  // ... without the line scale, on the short chain: a value only a final exponentiation may follow (the spread route's chunks)
 BN254_ASM_KERNEL(k_op, BN254_ASM_OP)                // MyFq12 Mul / frobenius_map_native / pow_native (k = op | power << 8 | naf_len << 16)
 BN254_ASM_KERNEL(k_generate, BN254_ASM_GENERATE)    // synthetic subgroup points: g1 / g2 = outputs, f_in = table, out = seed
 BN254_ASM_KERNEL(k_g2lines, BN254_ASM_G2LINES)      // line table of FIXED G2 points (one point per lane): g2 = points, out = table
@@ -337,7 +338,7 @@ int ctx_get(int device, void* stream, size_t k, size_t n_items, LaunchCtx* out, 
             c.n_cu = prop.multiProcessorCount;
             const void* kernels[] = {(const void*)k_pairing, (const void*)k_miller, (const void*)k_fexp, (const void*)k_mpairing,
                                      (const void*)k_mmiller, (const void*)k_op, (const void*)k_generate, (const void*)k_subcheck,
-                                     (const void*)k_g2lines, (const void*)k_fpairing};
+                                     (const void*)k_g2lines, (const void*)k_fpairing, (const void*)k_mmiller_u};
             for (const void* f : kernels) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
             c.init = true;
         }
@@ -636,7 +637,15 @@ int launch_wide(StreamCtx* sc, const uint64_t* g1, const uint64_t* g2, uint64_t*
     int rc;
     if ((rc = ensure(sc, sc->sub[2], 384 * lanes)) || (rc = ensure(sc, sc->sub[0], 384 * half)) || (rc = ensure(sc, sc->sub[1], 384 * half))) return rc;
     uint64_t *V = (uint64_t*)sc->sub[2].p, *A = (uint64_t*)sc->sub[0].p, *B = (uint64_t*)sc->sub[1].p;
-    if ((rc = launch_pairing<true, false>(g1, g2, nullptr, V, lanes, C, device, stream, 0))) return rc;
+    if (F && C >= 2 && !takes_latency_kernel<true, false>(lanes, C, device, stream)) {
+        // a final exponentiation follows: the chunks' values need not be the exact multi_miller_loop_native values -- no line scale, the short chain
+        // (k_mmiller_u: 2^20 pairs in chunks of 16 41 ms instead of 46)
+        LaunchCtx c;
+        if ((rc = ctx_get(device, stream, C, (lanes + BLOCK - 1) / BLOCK, &c))) return rc;
+        hipLaunchKernelGGL(k_mmiller_u, dim3(c.grid), dim3(BLOCK), LDS_BYTES, st, g1, g2, (const uint64_t*)nullptr, V, (uint32_t)lanes, (uint32_t)C, c.scratch, c.stride, c.status);
+        HIPCHK(hipGetLastError());
+        c.s->last_kernel = 1;
+    } else if ((rc = launch_pairing<true, false>(g1, g2, nullptr, V, lanes, C, device, stream, 0))) return rc;
     for (size_t cur = S; cur > 1;) {
         const size_t h = (cur + 1) / 2, m = n_groups * h;
         size_t blocks = (m * 48 + 255) / 256;

@@ -364,6 +364,19 @@ def test_multi_pairing_kernel_untracked_with_final_exp(vec):
     assert out == R.final_exp_native(HX(g["miller"])) and STAT not in m.gmem
 
 
+def test_multi_miller_kernel_untracked(vec):
+    """k_mmiller_u: the k-pair Miller loop WITHOUT the line scale and without a final exponentiation (the chunks of the spread route, whose values are
+    multiplied and exponentiated later): its value differs from multi_miller_loop_native's by a factor the final exponentiation kills -- and it walks the
+    short chain.  final_exp_native of it must be final_exp_native of the golden Miller value."""
+    g = [x for x in vec["groups"] if x["k"] == 3][0]
+    k, idx = g["k"], g["idx"]
+    kb = K4P.KernelBuilder(do_miller=True, do_fexp=False, track=False, multi=True)
+    assert kb.naf == K4P.SIX_U_PLUS_2_SHORT
+    g1, g2 = _soa([HX(vec["g1"][i]) for i in idx]), _soa([HX(vec["g2"][i]) for i in idx])
+    out, m = run_kernel(kb, g1, g2, k=k)
+    assert out != HX(g["miller"]) and R.final_exp_native(out) == R.final_exp_native(HX(g["miller"])) and STAT not in m.gmem
+
+
 def test_multi_pairing_kernel_streamed_points(vec):
     """k = 5: more pairs than stay on chip -- P travels with R through the prefetch buffer, Q is fetched in the addition steps.
     Expected value: the product of the single Miller values (the reference's own T1, miller_loop_native.rs:336-348)."""

@@ -1856,7 +1856,9 @@ class KernelBuilder:
                 d.append(z)
                 n = (n - z) // 2
             return d + [0] * (66 - len(d))
-        if SHORT_CHAIN and ((self.do_miller and self.do_fexp and not self.track and not FISSION) or self.lines):
+        # (an untracked Miller value is only ever the input of a final exponentiation -- in the same kernel or, for the Miller-only k-pair kernel of the
+        # spread route, in a later one -- and that does not see the chain)
+        if SHORT_CHAIN and ((self.do_miller and not self.track and not FISSION) or self.lines):
             return SIX_U_PLUS_2_SHORT
         return SIX_U_PLUS_2_NAF
 
