@@ -625,6 +625,20 @@ bool direct_elems_ok(size_t n_groups, size_t k, int device, void* stream) {
 
 template <bool M, bool F>
 int launch_pairing(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in, uint64_t* out, size_t n_groups, size_t k, int device, void* stream, int io_mode = 0);
+// The Miller value of n groups of k pairs as ONE FACTOR of a value that a final exponentiation follows (the chunks of a spread group, the sub-groups of
+// a long one): it need not be the exact multi_miller_loop_native value -- no line scale, the short chain (k_mmiller_u: 2^20 pairs in chunks of 16
+// 41 ms instead of 46).  One pair per lane, or a batch the lane-cooperative programs serve: the exact kernels.
+int launch_miller_part(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n, size_t k, int device, void* stream) {
+    if (k < 2 || k > MAX_K || takes_latency_kernel<true, false>(n, k, device, stream)) return launch_pairing<true, false>(g1, g2, nullptr, out, n, k, device, stream, 0);
+    LaunchCtx c;
+    int rc = ctx_get(device, stream, k, (n + BLOCK - 1) / BLOCK, &c);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_mmiller_u, dim3(c.grid), dim3(BLOCK), LDS_BYTES, (hipStream_t)stream, g1, g2, (const uint64_t*)nullptr, out, (uint32_t)n, (uint32_t)k, c.scratch, c.stride,
+                       c.status);
+    HIPCHK(hipGetLastError());
+    c.s->last_kernel = 1;
+    return BN254_OK;
+}
 // A group's pairs are contiguous, so the batch IS also n_groups k / C groups of C pairs for any divisor C of k: one launch of the C-pair Miller kernel
 // over all those lanes, then a multiplication tree over each group's k / C values (MyFq12 Mul; the odd one out is carried through a level by a
 // multiplication by one), then the final exponentiation of n_groups values.  C: wide_chunk's choice (1: every pair its own lane).  The same field element as the shared-f loop over the whole group, hence the same limbs.
@@ -637,15 +651,7 @@ int launch_wide(StreamCtx* sc, const uint64_t* g1, const uint64_t* g2, uint64_t*
     int rc;
     if ((rc = ensure(sc, sc->sub[2], 384 * lanes)) || (rc = ensure(sc, sc->sub[0], 384 * half)) || (rc = ensure(sc, sc->sub[1], 384 * half))) return rc;
     uint64_t *V = (uint64_t*)sc->sub[2].p, *A = (uint64_t*)sc->sub[0].p, *B = (uint64_t*)sc->sub[1].p;
-    if (F && C >= 2 && !takes_latency_kernel<true, false>(lanes, C, device, stream)) {
-        // a final exponentiation follows: the chunks' values need not be the exact multi_miller_loop_native values -- no line scale, the short chain
-        // (k_mmiller_u: 2^20 pairs in chunks of 16 41 ms instead of 46)
-        LaunchCtx c;
-        if ((rc = ctx_get(device, stream, C, (lanes + BLOCK - 1) / BLOCK, &c))) return rc;
-        hipLaunchKernelGGL(k_mmiller_u, dim3(c.grid), dim3(BLOCK), LDS_BYTES, st, g1, g2, (const uint64_t*)nullptr, V, (uint32_t)lanes, (uint32_t)C, c.scratch, c.stride, c.status);
-        HIPCHK(hipGetLastError());
-        c.s->last_kernel = 1;
-    } else if ((rc = launch_pairing<true, false>(g1, g2, nullptr, V, lanes, C, device, stream, 0))) return rc;
+    if ((rc = F ? launch_miller_part(g1, g2, V, lanes, C, device, stream) : launch_pairing<true, false>(g1, g2, nullptr, V, lanes, C, device, stream, 0))) return rc;
     for (size_t cur = S; cur > 1;) {
         const size_t h = (cur + 1) / 2, m = n_groups * h;
         size_t blocks = (m * 48 + 255) / 256;
@@ -698,7 +704,7 @@ int launch_pairing(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in,
             HIPCHK(hipGetLastError());
             bool last = s + 1 == n_sub;
             uint64_t* dst = s == 0 ? acc : val;
-            if ((rc = launch_pairing<true, false>(s1, s2, nullptr, dst, n_groups, ks, device, stream))) return rc;
+            if ((rc = F ? launch_miller_part(s1, s2, dst, n_groups, ks, device, stream) : launch_pairing<true, false>(s1, s2, nullptr, dst, n_groups, ks, device, stream))) return rc;
             // acc <- acc * val; the last product lands in `out` when no final exponentiation follows
             if (s > 0 && (rc = launch_op(OP_MUL, acc, val, (last && !F) ? out : acc, n_groups, 0, nullptr, 0, device, stream))) return rc;
         }
