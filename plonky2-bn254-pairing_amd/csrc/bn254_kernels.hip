@@ -599,8 +599,9 @@ inline size_t wide_chunk(size_t n_groups, size_t k, double* est_ms) {
     if (est_ms) *est_ms = best_ms;
     return best;
 }
+thread_local bool tl_in_wide = false;               // (the spread route's own Miller launch never spreads again: its buffers are in use -- by the choice of C it would not anyway)
 inline bool takes_wide_route(size_t n_groups, size_t k) {
-    if (k <= 4 || n_groups >= g_wide_groups.load()) return false;
+    if (tl_in_wide || k <= 4 || n_groups >= g_wide_groups.load()) return false;
     double wide_ms;
     (void)wide_chunk(n_groups, k, &wide_ms);
     if (wide_ms > 1e299) return false;                       // (no divisor keeps the lane count below the kernels' limit)
@@ -651,7 +652,10 @@ int launch_wide(StreamCtx* sc, const uint64_t* g1, const uint64_t* g2, uint64_t*
     int rc;
     if ((rc = ensure(sc, sc->sub[2], 384 * lanes)) || (rc = ensure(sc, sc->sub[0], 384 * half)) || (rc = ensure(sc, sc->sub[1], 384 * half))) return rc;
     uint64_t *V = (uint64_t*)sc->sub[2].p, *A = (uint64_t*)sc->sub[0].p, *B = (uint64_t*)sc->sub[1].p;
-    if ((rc = F ? launch_miller_part(g1, g2, V, lanes, C, device, stream) : launch_pairing<true, false>(g1, g2, nullptr, V, lanes, C, device, stream, 0))) return rc;
+    tl_in_wide = true;
+    rc = F ? launch_miller_part(g1, g2, V, lanes, C, device, stream) : launch_pairing<true, false>(g1, g2, nullptr, V, lanes, C, device, stream, 0);
+    tl_in_wide = false;
+    if (rc) return rc;
     for (size_t cur = S; cur > 1;) {
         const size_t h = (cur + 1) / 2, m = n_groups * h;
         size_t blocks = (m * 48 + 255) / 256;
@@ -704,7 +708,10 @@ int launch_pairing(const uint64_t* g1, const uint64_t* g2, const uint64_t* f_in,
             HIPCHK(hipGetLastError());
             bool last = s + 1 == n_sub;
             uint64_t* dst = s == 0 ? acc : val;
-            if ((rc = F ? launch_miller_part(s1, s2, dst, n_groups, ks, device, stream) : launch_pairing<true, false>(s1, s2, nullptr, dst, n_groups, ks, device, stream))) return rc;
+            tl_in_wide = true;                          // (the walk's sub-group launches never spread: sub[] is in use here)
+            rc = F ? launch_miller_part(s1, s2, dst, n_groups, ks, device, stream) : launch_pairing<true, false>(s1, s2, nullptr, dst, n_groups, ks, device, stream);
+            tl_in_wide = false;
+            if (rc) return rc;
             // acc <- acc * val; the last product lands in `out` when no final exponentiation follows
             if (s > 0 && (rc = launch_op(OP_MUL, acc, val, (last && !F) ? out : acc, n_groups, 0, nullptr, 0, device, stream))) return rc;
         }
