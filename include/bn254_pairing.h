@@ -317,8 +317,8 @@ int bn254_pairing_fixed_g2_check_batch_dev(const uint64_t* g1, const uint64_t* g
  * target a Groth16 proof costs 1 + 2 pairs, 4.66 M instructions instead of 5.3 M (2^18 proofs: 34.3 ms). */
 int bn254_pairing_fixed_g2_check_target_batch_dev(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* table, size_t k_fixed, const uint64_t* target,
                                                   uint8_t* verdict, size_t n, int device, void* stream);
-/* host-pointer forms (what a binding uses): g2_fixed = the k_fixed fixed points themselves; the table is made inside the call (2.1 ms) -- unless the
- * stream's previous host-pointer call had the same fixed points (a verifier's key does not change between its calls): its table is kept.  One proof's
+/* host-pointer forms (what a binding uses): g2_fixed = the k_fixed fixed points themselves; the table is made inside the call (2.1 ms) -- unless one of the
+ * stream's last four distinct sets of fixed points is the same (a verifier's keys do not change between its calls): their tables are kept.  One proof's
  * check (1 + 2 pairs against a target) from host structs, verdict read back: 0.71 ms; 65 536: 9.2 ms.
  * `_elems`: every array element-major.  More than 65 536 groups go through the two-worker chunked pipeline of the other host-pointer calls (copies under
  * the kernels; any n with n (1 + k_fixed) < 2^29); the pipeline keeps the table of its last call and makes none when the fixed points are the same

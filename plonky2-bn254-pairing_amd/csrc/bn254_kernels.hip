@@ -208,8 +208,13 @@ struct StreamCtx {
     Buf fx[5];                 // ... and final_exp_native's: m, m^x, m^(x^2), m^(x^3), the y-chain's first part
     Buf sub[4];                // groups of more than MAX_K pairs: sub-group inputs (G1, G2) and the two Miller values in flight
     Buf stage[8];              // device staging of the host-pointer entry points (inputs / outputs), grown on demand
-    Buf fixed_tab;             // host-pointer fixed-G2 calls: the line table of the LAST call's fixed points (+ room to stage them) ...
-    std::vector<uint64_t> fixed_key;   // ... and those points (and their layout): a verifier's key does not change between its calls, the table is then made once
+    // host-pointer fixed-G2 calls: the line tables of the last FIXED_TABLES distinct sets of fixed points (+ room to stage them) and those points (and their
+    // layout) -- a verifier's keys do not change between its calls, a table is then made once; the least recently used entry makes room
+    static constexpr int FIXED_TABLES = 4;
+    Buf fixed_tab[FIXED_TABLES];
+    std::vector<uint64_t> fixed_key[FIXED_TABLES];
+    uint64_t fixed_used[FIXED_TABLES] = {0, 0, 0, 0}, fixed_clock = 0;
+    int fixed_last = -1;       // the entry the running call uses (dropped if the call raises the status: its making may have been what raised it)
     std::vector<void*> retired;   // buffers that were outgrown while work on them may still be queued: freed once the stream has been
                                   // synchronised (bn254_last_status, bn254_release_stream) -- growing never waits for the stream
     std::vector<NafSlot> naf_ring;
@@ -224,7 +229,8 @@ struct StreamCtx {
     size_t last_pitch = 0;        // scratch geometry of the most recent launch (diagnostic builds read their clock stamps back from it)
     uint32_t last_grid = 0;
     ~StreamCtx() {                // the last holder (bn254_release_stream, after the stream has been synchronised) frees everything
-        for (Buf* b : {&scratch, &naf, &tmp, &mid, &fixed_tab}) if (b->p) (void)hipFree(b->p);
+        for (Buf* b : {&scratch, &naf, &tmp, &mid}) if (b->p) (void)hipFree(b->p);
+        for (Buf& b : fixed_tab) if (b.p) (void)hipFree(b.p);
         for (Buf& b : fx) if (b.p) (void)hipFree(b.p);
         for (Buf& b : stage) if (b.p) (void)hipFree(b.p);
         for (Buf& b : sub) if (b.p) (void)hipFree(b.p);
@@ -1249,24 +1255,33 @@ int bn254_pairing_fixed_g2_check_batch_dev(const uint64_t* g1, const uint64_t* g
 static int host_table(Stage& s, const uint64_t* g2_fixed, size_t k_fixed, bool elems, int device, void* stream, const uint64_t** table) {
     StreamCtx* sc = s.sc.get();
     const size_t tab_max = bn254_g2_lines_bytes(BN254_FIXED_MAX);
-    int rc = ensure(sc, sc->fixed_tab, tab_max + 2 * 128 * BN254_FIXED_MAX);
-    if (rc) return rc;
-    uint64_t *tab = (uint64_t*)sc->fixed_tab.p, *in = (uint64_t*)((char*)sc->fixed_tab.p + tab_max), *planes = in + 16 * BN254_FIXED_MAX;
-    *table = tab;
     std::vector<uint64_t> key(g2_fixed, g2_fixed + 16 * k_fixed);
     key.push_back(elems ? 1 : 0);
-    if (key == sc->fixed_key) return BN254_OK;
-    sc->fixed_key.clear();
+    int slot = -1, lru = 0;
+    for (int i = 0; i < StreamCtx::FIXED_TABLES; i++) {
+        if (!sc->fixed_key[i].empty() && sc->fixed_key[i] == key) { slot = i; break; }
+        if (sc->fixed_used[i] < sc->fixed_used[lru]) lru = i;
+    }
+    const bool hit = slot >= 0;
+    if (!hit) slot = lru;
+    sc->fixed_used[slot] = ++sc->fixed_clock;
+    sc->fixed_last = slot;
+    int rc = ensure(sc, sc->fixed_tab[slot], tab_max + 2 * 128 * BN254_FIXED_MAX);
+    if (rc) return rc;
+    uint64_t *tab = (uint64_t*)sc->fixed_tab[slot].p, *in = (uint64_t*)((char*)tab + tab_max), *planes = in + 16 * BN254_FIXED_MAX;
+    *table = tab;
+    if (hit) return BN254_OK;
+    sc->fixed_key[slot].clear();
     if (hipMemcpyAsync(in, g2_fixed, 128 * k_fixed, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) return BN254_ERR_HIP;
     if (elems && (rc = launch_layout(true, in, planes, 16, k_fixed, 0, device, stream))) return rc;      // (the table kernel reads limb-major planes)
     if ((rc = bn254_g2_lines_dev(elems ? planes : in, k_fixed, tab, device, stream))) return rc;
-    sc->fixed_key = std::move(key);
+    sc->fixed_key[slot] = std::move(key);
     return BN254_OK;
 }
 // ... which must not outlive a call that raised the status (its making may have been what raised it)
 static int finish_fixed_host(Stage& s, void* h_out, const void* d_out, size_t bytes, int device, void* stream) {
     int rc = finish_host(h_out, d_out, bytes, device, stream);
-    if (rc) s.sc->fixed_key.clear();
+    if (rc && s.sc->fixed_last >= 0) s.sc->fixed_key[s.sc->fixed_last].clear();
     return rc;
 }
 

@@ -171,6 +171,16 @@ def _host_forms(pk, n, kf, k):
     assert np.array_equal(pk.pairing_fixed_g2_batch(H.to_soa(e1, 8), H.to_soa(e2, 16), H.to_soa(ef, 16), kf, n), want)
     assert np.array_equal(pk.pairing_fixed_g2_batch(H.to_soa(e1, 8), H.to_soa(e2, 16), H.to_soa(ef, 16), kf, n), want)          # (a hit)
     assert np.array_equal(pk.pairing_fixed_g2_batch(e1, e2, ef, kf, n, elems=True), H.to_aos(want, 48))                           # (the same points, the other layout)
+    # six keys in turn, twice: more than the four tables a stream keeps -- every call still gives its own key's values
+    sets = []
+    for t_ in range(6):
+        Qt = [R.g2_mul(R.G2_GEN, 100 + 7 * t_ + j) for j in range(kf)]
+        ex = H.g2_aos([Qv[g] if j == 0 else Qt[j - 1] for g in range(n) for j in range(k)])
+        sets.append((H.to_soa(H.g2_aos(Qt), 16), pk.multi_pairing_batch(H.to_soa(e1, 8), H.to_soa(ex, 16), n, k)))
+    for _ in range(2):
+        for fx, wt in sets:
+            assert np.array_equal(pk.pairing_fixed_g2_batch(H.to_soa(e1, 8), H.to_soa(e2, 16), fx, kf, n), wt)
+    assert len({w.tobytes() for _, w in sets}) == 6
 
 
 @pytest.mark.parametrize("kf", [1, 2, 3, 4])
