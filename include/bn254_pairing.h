@@ -331,6 +331,10 @@ int bn254_pairing_fixed_g2_batch_elems(const uint64_t* g1, const uint64_t* g2_va
  * MyFq12 order; NULL = MyFq12::one); one byte per group comes back instead of 384 */
 int bn254_pairing_fixed_g2_check_batch_elems(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* g2_fixed, size_t k_fixed, const uint64_t* target,
                                              uint8_t* verdict, size_t n, int device, void* stream);
+/* ... spread over the first n_devices GPUs of this process (contiguous slices of the groups, the two-worker pipeline and its own line table on each): what
+ * bn254_pairing_sharded_elems is to bn254_pairing_batch_elems */
+int bn254_pairing_fixed_g2_check_sharded_elems(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* g2_fixed, size_t k_fixed, const uint64_t* target,
+                                               uint8_t* verdict, size_t n, int n_devices);
 
 /* ---- input validation (optional) ----------------------------------------------------------
  * The reference never checks for the point at infinity: its line functions read raw x / y (src/miller_loop_native.rs:10-44) and

@@ -127,6 +127,7 @@ _PROTOS = {
     "bn254_pairing_fixed_g2_batch_elems_dev": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "bn254_pairing_fixed_g2_check_batch_dev": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "bn254_pairing_fixed_g2_check_batch_elems": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "bn254_pairing_fixed_g2_check_sharded_elems": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]),
     "bn254_pairing_fixed_g2_check_target_batch_dev": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "bn254_multi_pairing_check_target_batch_dev": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "bn254_pairing_fixed_g2_batch": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
@@ -493,6 +494,18 @@ def pairing_fixed_g2_check_batch_elems(g1, g2_var, g2_fixed, k_fixed, n, target=
     keep, tp = _target_words(target)
     _check(load_library().bn254_pairing_fixed_g2_check_batch_elems(_ptr(g1), _ptr(g2_var) if own else None, _ptr(g2_fixed), k_fixed, tp, _ptr(verdict), n, device, None),
            "pairing check (fixed G2)")
+    return verdict
+
+
+def pairing_fixed_g2_check_sharded_elems(g1, g2_var, g2_fixed, k_fixed, n, n_devices, target=None):
+    """pairing_fixed_g2_check_batch_elems over the first n_devices GPUs of this process (contiguous slices of the groups per device)"""
+    own = 0 if g2_var is None else 1
+    g1, g2_fixed = _np_in(g1, 8, n * (own + k_fixed)), _np_in(g2_fixed, 16, k_fixed)
+    g2_var = _np_in(g2_var, 16, n) if own else None
+    verdict = np.zeros(n, dtype=np.uint8)
+    keep, tp = _target_words(target)
+    _check(load_library().bn254_pairing_fixed_g2_check_sharded_elems(_ptr(g1), _ptr(g2_var) if own else None, _ptr(g2_fixed), k_fixed, tp, _ptr(verdict), n, n_devices),
+           "pairing check (fixed G2, sharded)")
     return verdict
 
 

@@ -1883,6 +1883,21 @@ int bn254_pairing_sharded_elems(const uint64_t* g1, const uint64_t* g2, uint64_t
     return bn254_multi_pairing_sharded_elems(g1, g2, out, n, 1, 1, out_order, n_devices);
 }
 
+// the fixed-G2 verdicts over the first n_devices GPUs of this process: contiguous slices of the groups per device, each device makes its own line table
+int bn254_pairing_fixed_g2_check_sharded_elems(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* g2_fixed, size_t k_fixed, const uint64_t* target,
+                                               uint8_t* verdict, size_t n, int n_devices) {
+    if (n == 0) return BN254_OK;
+    if (!g1 || !g2_fixed || !verdict || k_fixed == 0 || k_fixed > (size_t)BN254_FIXED_MAX || n * (k_fixed + 1) >= ((size_t)1 << 29) || n_devices <= 0) return BN254_ERR_INVALID_ARG;
+    int cnt = bn254_device_count();
+    if (cnt <= 0) return BN254_ERR_NO_DEVICE;
+    if (n_devices > cnt) return BN254_ERR_INVALID_ARG;
+    std::vector<int> devs((size_t)n_devices);
+    for (int d = 0; d < n_devices; d++) devs[(size_t)d] = d;
+    HostFmt fmt; fmt.elems = true;
+    FixedJob job; job.g2_fixed = g2_fixed; job.k_fixed = k_fixed; job.verdict = verdict; job.target = target;
+    return run_pipeline(devs.data(), n_devices, g1, g2_var, nullptr, n, k_fixed + (g2_var ? 1 : 0), 1, fmt, &job);
+}
+
 int bn254_pairing_sharded(const uint64_t* g1, const uint64_t* g2, uint64_t* out, size_t n, int n_devices) {
     return bn254_multi_pairing_sharded(g1, g2, out, n, 1, 1, n_devices);
 }

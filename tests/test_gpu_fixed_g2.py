@@ -251,6 +251,9 @@ def test_fixed_g2_host_forms_above_one_chunk_take_the_pipeline():
     pos = [0, 65535, 65536, 2 * 65536 + 776]
     v = pk.pairing_fixed_g2_check_batch_elems(e1, e2, ef, kf, n, target=w[pos[2]].reshape(-1))
     assert v.sum() == 1 and v[pos[2]] == 1
+    vs = pk.pairing_fixed_g2_check_sharded_elems(e1, e2, ef, kf, n, pk.device_count() if hasattr(pk, "device_count") else 1, target=w[pos[2]].reshape(-1))
+    assert np.array_equal(vs, v)                              # (every GPU of the process; one here)
+    assert np.array_equal(pk.pairing_fixed_g2_check_sharded_elems(e1[: 8 * k * 300], e2[: 16 * 300], ef, kf, 300, 1, target=w[7].reshape(-1)), v[:300] * 0 + (np.arange(300) == 7))
     ora = H.oracle_multi_pairing(pk.layout.to_aos(h(g1.view(8, n * k)[:, torch.as_tensor([p * k + j for p in pos[:2] for j in range(k)], device=dev)].contiguous()), 8),
                                  pk.layout.to_aos(h(g2exp.view(16, n * k)[:, torch.as_tensor([p * k + j for p in pos[:2] for j in range(k)], device=dev)].contiguous()), 16), 2, k)
     assert np.array_equal(np.concatenate([w[p].reshape(-1) for p in pos[:2]]), ora)
