@@ -377,3 +377,56 @@ def test_fixed_g2_groups_without_an_own_pair(kf):
     ora = H.oracle_multi_pairing(pk.layout.to_aos(g1h, 8), pk.layout.to_aos(g2h, 16), len(pos), kf)
     mine = want.view(48, n)[:, torch.as_tensor(pos, device=dev)].cpu().numpy().view(np.uint64).reshape(-1).copy()
     assert np.array_equal(pk.layout.to_aos(mine, 48), ora)
+
+
+def test_fixed_g2_and_spread_calls_from_three_host_threads():
+    """Three host threads on the null stream at once: a small fixed-G2 check (one key), a pipeline-sized one (another key), one group of 300 pairs through the
+    spread route -- each call must give what it gives alone (per-stream tables and buffers are guarded by the stream's lock, the pipeline by the device's)."""
+    import threading
+    import torch
+    pk = H.pkg()
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev)
+    h = lambda t: t.cpu().numpy().view(np.uint64).copy()
+
+    def fixed_case(n, kf, seed):
+        k = 1 + kf
+        g1 = torch.zeros(8 * n * k, dtype=torch.int64, device=dev); g2a = torch.zeros(16 * n * k, dtype=torch.int64, device=dev)
+        pk.generate_pairs_dev(seed, g1, g2a, n * k, 0, st)
+        fx = g2a.view(16, n * k)[:, 1:1 + kf].contiguous().view(-1)
+        var = g2a.view(16, n, k)[:, :, 0].contiguous().view(-1)
+        e1, e2, ef = H.to_aos(h(g1), 8), H.to_aos(h(var), 16), H.to_aos(h(fx), 16)
+        ref = pk.pairing_fixed_g2_batch(e1, e2, ef, kf, n, elems=True).reshape(n, 48)
+        pos = n // 3
+        return (e1, e2, ef, kf, n, ref[pos].copy(), pos)
+
+    small, big = fixed_case(200, 2, 0x7E01), fixed_case(70000, 1, 0x7E02)
+    K = 300
+    g1 = torch.zeros(8 * K, dtype=torch.int64, device=dev); g2 = torch.zeros(16 * K, dtype=torch.int64, device=dev)
+    pk.generate_pairs_dev(0x7E03, g1, g2, K, 0, st)
+    w1, w2 = h(g1), h(g2)
+    want_w = pk.multi_pairing_batch(w1, w2, 1, K)
+    errors = []
+
+    def fixed_worker(case):
+        e1, e2, ef, kf, n, target, pos = case
+        try:
+            for _ in range(4):
+                v = pk.pairing_fixed_g2_check_batch_elems(e1, e2, ef, kf, n, target=target)
+                assert v[pos] == 1 and v.sum() == 1
+        except BaseException as ex:      # noqa: BLE001
+            errors.append(repr(ex))
+
+    def wide_worker():
+        try:
+            for _ in range(6):
+                assert np.array_equal(pk.multi_pairing_batch(w1, w2, 1, K), want_w)
+        except BaseException as ex:      # noqa: BLE001
+            errors.append(repr(ex))
+
+    th = [threading.Thread(target=fixed_worker, args=(small,)), threading.Thread(target=fixed_worker, args=(big,)), threading.Thread(target=wide_worker)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
