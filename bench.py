@@ -775,8 +775,15 @@ def run_rank(args):
                 print("bench.py: gathered outputs differ from the whole-batch recomputation", file=sys.stderr)
                 rc = 3
         if rc == 0 and on_gpu and not multi and not args.no_extra and log2 == LOG2_SINGLE:
-            rec["extra"] = extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n, sample_power=power is not None,
-                                           scalar_latency=not args.no_scalar_latency, calib_peak=calib_peak, host=not args.no_host_path)
+            # (the other configurations and consumer shapes are measured beside the headline, never instead of it: a failure there -- an allocation on a
+            # crowded box, say -- is reported in the line, the headline measurement above stands)
+            try:
+                rec["extra"] = extra_configs(pkg, torch, dev, local_rank, stream, g1, g2, n, sample_power=power is not None,
+                                               scalar_latency=not args.no_scalar_latency, calib_peak=calib_peak, host=not args.no_host_path)
+            except Exception as e:      # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                rec["extra"] = {"error": f"{type(e).__name__}: {e}"}
         if rc == 0 and on_gpu and not multi and not args.no_cpu_baseline:
             m = min(n, 1 << 15)
             g1h = g1.view(8, n)[:, :m].cpu().numpy().view(np.uint64).reshape(-1).copy()
