@@ -788,7 +788,12 @@ def run_rank(args):
             m = min(n, 1 << 15)
             g1h = g1.view(8, n)[:, :m].cpu().numpy().view(np.uint64).reshape(-1).copy()
             g2h = g2.view(16, n)[:, :m].cpu().numpy().view(np.uint64).reshape(-1).copy()
-            rec["cpu_baseline"] = cpu_baseline(pkg, g1h, g2h, m, args.cpu_seconds)
+            try:
+                rec["cpu_baseline"] = cpu_baseline(pkg, g1h, g2h, m, args.cpu_seconds)
+            except Exception as e:      # noqa: BLE001 -- (a reported baseline, not the measurement: its failure must not cost the line)
+                import traceback
+                traceback.print_exc()
+                rec["cpu_baseline"] = {"value": None, "unit": "pairings/s", "cores": 0, "kind": "port", "sample": "", "error": f"{type(e).__name__}: {e}"}
         if multi:
             # what the peers sit through in the verdict broadcast below: must stay well inside the collective timeout
             tmo_s = float(os.environ.get("BENCH_DIST_TIMEOUT_S", "120"))
